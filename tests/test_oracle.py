@@ -1,0 +1,142 @@
+"""Pins the CPU oracle (oracle/lmm_oracle.py) with the reference's own relational tests
+(test/ilmm.jl:10-14,23-26; test/oilmm.jl:10-14,23-26; test/independent_mogp.jl:40-60) and the
+six literal numbers of the reference notebook (tests/golden/notebook_literals.json)."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from oracle import lmm_oracle as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def toy(seed, m, p=3, orth=False, n_train=3, n_test=2):
+    """Shape of test/test_utils.jl:1-35 (5 points on [0,10], 3 outputs, 3/2 split)."""
+    rng = np.random.default_rng(seed)
+    x = np.linspace(0.0, 10.0, n_train + n_test)
+    perm = rng.permutation(n_train + n_test)
+    xtr, xte = x[perm[:n_train]], x[perm[n_train:]]
+    kinds = ["se", "matern32", "matern32"][:m]
+    gps = [{"kind": k, "variance": 1.0, "lengthscale": 1.0, "mean": 0.0} for k in kinds]
+    A = rng.uniform(size=(p, m))
+    if orth:
+        U, S, _ = np.linalg.svd(A, full_matrices=False)
+    else:
+        U = S = None
+    ytr, yte = rng.standard_normal(n_train * p), rng.standard_normal(n_test * p)
+    return gps, A, U, S, xtr, xte, ytr, yte
+
+
+def test_notebook_literals():
+    g = json.load(open(os.path.join(HERE, "golden", "notebook_literals.json")))
+    x = np.linspace(0.0, 20.0, 576)
+    assert x[1] - x[0] == pytest.approx(g["spacing"], rel=1e-15)
+    gp = {"kind": "matern52", "variance": 1.0, "lengthscale": 1.0}
+    k = lambda r: float(O.kernel_eval("matern52", 1.0, 1.0, np.array([r]))[0])
+    assert k(g["spacing"]) == pytest.approx(g["K_21"], rel=1e-14)
+    assert k(20.0) == pytest.approx(g["K_n1_at_20"], rel=1e-13)
+    assert k(20.0 - g["spacing"]) == pytest.approx(g["K_nm1_1_at_20_minus_spacing"], rel=1e-12)
+    # First 2x2 of the Cholesky with the projected noise s = U11^2 - 1 on the diagonal.
+    s = g["U_11"] ** 2 - 1.0
+    K = O.kernelmatrix(gp, x[:2]) + s * np.eye(2)
+    Uf = np.linalg.cholesky(K).T
+    assert Uf[0, 0] == pytest.approx(g["U_11"], rel=1e-15)
+    assert Uf[0, 1] == pytest.approx(g["U_12"], rel=1e-14)
+    assert Uf[1, 1] == pytest.approx(g["U_22"], rel=1e-9)     # cancellation-limited
+
+
+@pytest.mark.parametrize("m", [3, 2, 1])
+def test_ilmm_equals_naive(m):
+    """test/ilmm.jl:10-14,23-26 with sigma^2 = 1e-6."""
+    gps, H, _, _, xtr, xte, ytr, yte = toy(10 + m, m)
+    s2 = 1e-6
+    assert O.ilmm_logpdf(gps, H, xtr, s2, ytr) == pytest.approx(O.naive_logpdf(gps, H, xtr, s2, ytr), rel=1e-6)
+    M, C = O.ilmm_mean_cov(gps, H, xtr, s2)
+    np.testing.assert_allclose(M, O.naive_mean(gps, H, xtr), atol=1e-12)
+    np.testing.assert_allclose(C, O.naive_cov(gps, H, xtr) + s2 * np.eye(len(M)), rtol=1e-8, atol=1e-12)
+    post = O.ilmm_posterior(gps, H, xtr, s2, ytr)
+    Mp, Cp = O.ilmm_mean_cov(post, H, xte, s2)
+    Mn, Cn = O.naive_posterior_mean_cov(gps, H, xtr, s2, ytr, xte)
+    np.testing.assert_allclose(Mp, Mn, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(Cp, Cn + s2 * np.eye(len(Mn)), rtol=1e-5, atol=1e-6)
+    lp = O.ilmm_logpdf(post, H, xte, s2, yte)
+    ln = O.gaussian_logpdf(Mn, Cn + s2 * np.eye(len(Mn)), yte)
+    assert lp == pytest.approx(ln, rel=1e-6)
+
+
+@pytest.mark.parametrize("m", [3, 2, 1])
+def test_oilmm_equals_ilmm_and_naive(m):
+    """test/oilmm.jl:10-14,23-26 with sigma^2 = 0.1."""
+    gps, _, U, S, xtr, xte, ytr, yte = toy(20 + m, m, orth=True)
+    H = O.orthogonal_dense(U, S)
+    s2 = 0.1
+    lo = O.oilmm_logpdf(gps, U, S, xtr, s2, ytr)
+    assert lo == pytest.approx(O.ilmm_logpdf(gps, H, xtr, s2, ytr), rel=1e-8)
+    assert lo == pytest.approx(O.naive_logpdf(gps, H, xtr, s2, ytr), rel=1e-12)
+    Mo, Vo = O.oilmm_mean_var(gps, U, S, xtr, s2)
+    Mi, Vi = O.ilmm_mean_var(gps, H, xtr, s2)
+    np.testing.assert_allclose(Mo, Mi, atol=1e-12)
+    np.testing.assert_allclose(Vo, Vi, rtol=1e-10)
+    po = O.oilmm_posterior(gps, U, S, xtr, s2, ytr)
+    pi = O.ilmm_posterior(gps, H, xtr, s2, ytr)
+    Mo, Vo = O.oilmm_mean_var(po, U, S, xte, s2)
+    Mi, Vi = O.ilmm_mean_var(pi, H, xte, s2)
+    np.testing.assert_allclose(Mo, Mi, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(Vo, Vi, rtol=1e-6, atol=1e-8)
+    Mn, Cn = O.naive_posterior_mean_cov(gps, H, xtr, s2, ytr, xte)
+    np.testing.assert_allclose(Mo, Mn, rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(Vo, np.diag(Cn) + s2, rtol=1e-9, atol=1e-10)
+    assert O.oilmm_logpdf(po, U, S, xte, s2, yte) == pytest.approx(O.ilmm_logpdf(pi, H, xte, s2, yte), rel=1e-6)
+    assert O.oilmm_logpdf(po, U, S, xte, s2, yte) == pytest.approx(
+        O.gaussian_logpdf(Mn, Cn + s2 * np.eye(len(Mn)), yte), rel=1e-9)
+
+
+def test_mogp_equals_singles():
+    """test/independent_mogp.jl:40-43,53-60."""
+    rng = np.random.default_rng(5)
+    x, xs = np.linspace(1, 2, 5)[:3], np.linspace(1, 2, 5)[3:]
+    f1 = {"kind": "matern32", "variance": 1.0, "lengthscale": 1.0, "mean": 30.0}
+    f2 = {"kind": "se", "variance": 1.0, "lengthscale": 1.0, "mean": 10.0}
+    y = rng.standard_normal(6) + np.repeat([30.0, 10.0], 3)
+    assert O.mogp_logpdf([f1, f2], x, 0.1, y) == pytest.approx(
+        O.gp_logpdf(f1, x, 0.1, y[:3]) + O.gp_logpdf(f2, x, 0.1, y[3:]), rel=1e-14)
+    # H = I, U = I, S = 1 makes the OILMM an IndependentMOGP (test/independent_mogp.jl:126-128 idea)
+    assert O.mogp_logpdf([f1, f2], x, 0.1, y) == pytest.approx(
+        O.oilmm_logpdf([f1, f2], np.eye(2), np.ones(2), x, 0.1, y), rel=1e-12)
+    post = O.mogp_posterior([f1, f2], x, 0.1, y)
+    m, v = O.mogp_mean_var(post, xs)
+    m1, v1 = O.gp_mean_var(O.gp_posterior(f1, x, 0.1, y[:3]), xs)
+    np.testing.assert_allclose(m[:2], m1)
+    np.testing.assert_allclose(v[:2], v1)
+
+
+def test_rand_matches_cov_structure():
+    """rand with caller-supplied normals: the linear map z -> sample has covariance = model cov."""
+    gps, _, U, S, xtr, *_ = toy(3, 2, orth=True)
+    n, p, m = 3, 3, 2
+    H = O.orthogonal_dense(U, S)
+    cols = []
+    for k in range(m * n + n * p):
+        e = np.zeros(m * n + n * p); e[k] = 1.0
+        cols.append(O.oilmm_rand(gps, U, S, xtr, 0.1, e[:m * n], e[m * n:]))
+    A = np.stack(cols, axis=1)
+    np.testing.assert_allclose(A @ A.T, O.naive_cov(gps, H, xtr) + 0.1 * np.eye(n * p), rtol=1e-9, atol=1e-12)
+    A2 = np.stack([O.ilmm_rand(gps, H, xtr, 0.1, np.eye(m * n + n * p)[k][:m * n], np.eye(m * n + n * p)[k][m * n:])
+                   for k in range(m * n + n * p)], axis=1)
+    np.testing.assert_allclose(A2 @ A2.T, O.naive_cov(gps, H, xtr) + 0.1 * np.eye(n * p), rtol=1e-9, atol=1e-9)
+
+
+def test_helpers():
+    """test/ilmm.jl:55-71, test/orthogonal_matrix.jl:1-14."""
+    assert O.reshape_y(np.arange(16.0), 8).shape == (2, 8)
+    assert O.reshape_y(np.arange(16.0), 2).shape == (8, 2)
+    with pytest.raises(ValueError):
+        O.orthogonal_validate(np.random.default_rng(0).uniform(size=(5, 3)))
+    U, S, _ = np.linalg.svd(np.random.default_rng(0).uniform(size=(5, 3)), full_matrices=False)
+    O.orthogonal_validate(U)
+    np.testing.assert_allclose(O.orthogonal_dense(U, S), U @ np.diag(np.sqrt(S)))
+    with pytest.raises(RuntimeError, match="out dim"):
+        O.oilmm_logpdf([{"kind": "se"}], U[:, :1], S[:1], np.arange(3.0), 0.1, np.zeros(3 * 4))
