@@ -1,0 +1,164 @@
+/*
+ * lmm_hip.h -- C ABI of liblmm_hip.so: MI355X (gfx950) ILMM / OILMM inference hot path.
+ *
+ * The reference (LinearMixingModels.jl 0.1.11) has no FFI; its boundary is Julia multiple dispatch
+ * on AbstractGPs' generic functions.  Each entry point below is what ONE reference method body
+ * becomes after `ccall`; the method it replaces is cited as  file:line  relative to the reference
+ * repository.  INTEGRATION.md shows the Julia-side stubs.
+ *
+ * Conventions (all entry points)
+ *   - Float64, column-major, dense, contiguous (Julia `Array` layout).
+ *   - x   : d x n input locations (`Vector{Float64}` => d = 1; `ColVecs(X)` => X).
+ *   - y   : length n*p "by-outputs" vector == n x p column-major (MOInputIsotopicByOutputs order,
+ *           reference src/ilmm.jl:43 `reshape_y`).
+ *   - x, y, xs, z, eps and every OUTPUT array may be HOST or DEVICE (HIP) pointers; the library
+ *     detects which (hipPointerGetAttributes).  Small model arrays (U, S, H, gps) are host.
+ *   - latents are described by lmm_gp_t (ConstMean + variance * kernel(|x-x'| / lengthscale)).
+ *   - `latent_begin, latent_end` select the shard [begin, end) of latent processes this process
+ *     (one process per GPU) evaluates; partial results are summed by the caller (RCCL all-reduce
+ *     in the Python/Julia host layer).  Use 0, m for the whole model.
+ *   - return value: LMM_OK or an lmm_status code; lmm_last_error_string() gives the message,
+ *     lmm_last_error_detail() the failing latent and LAPACK-style pivot `info`
+ *     (-> Julia `PosDefException(info)`).  Nothing is ever NaN-and-continue.
+ *   - calls are blocking; the library never keeps a caller pointer after returning.
+ */
+#ifndef LMM_HIP_H
+#define LMM_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  LMM_OK = 0,
+  LMM_ERR_DIM = 1,             /* "out dim of x != out dim of f."   (reference src/ilmm.jl:52)          */
+  LMM_ERR_NOT_ORTHOGONAL = 2,  /* "`U` is not an orthogonal matrix" (reference src/orthogonal_matrix.jl:22) */
+  LMM_ERR_NOT_PD = 3,          /* PosDefException from cholesky                                         */
+  LMM_ERR_HIP = 4,
+  LMM_ERR_ARG = 5,
+  LMM_ERR_UNSUPPORTED = 6
+} lmm_status;
+
+typedef enum { LMM_KERNEL_SE = 0, LMM_KERNEL_MATERN32 = 1, LMM_KERNEL_MATERN52 = 2 } lmm_kernel_kind;
+
+/* One latent GP: GP(mean, variance * Kernel o ScaleTransform(1/lengthscale)). */
+typedef struct {
+  int kind;            /* lmm_kernel_kind */
+  double variance;
+  double lengthscale;
+  double mean;         /* ConstMean / ZeroMean */
+} lmm_gp_t;
+
+/* The reference's hard-coded numerics constants, passed explicitly so that fp32 callers can
+ * widen them (SURVEY.md section 7 "jitter hazards"); pass NULL for the reference values. */
+typedef struct {
+  double project_jitter;   /* 1e-9  : reference src/ilmm.jl:63                                 */
+  double ilmm_rand_jitter; /* 1e-12 : reference src/ilmm.jl:84                                 */
+  double default_jitter;   /* 1e-18 : AbstractGPs f(x) default, reference src/oilmm.jl:47,61   */
+} lmm_jitters_t;
+
+typedef struct lmm_post lmm_post_t;   /* opaque posterior state (device resident) */
+
+/* ---- lifetime -------------------------------------------------------------------------- */
+int lmm_init(int device);                 /* bind this process to HIP device `device`, create streams */
+int lmm_shutdown(void);
+const char* lmm_last_error_string(void);
+int lmm_last_error_detail(int* latent, int* info);
+int lmm_device_synchronize(void);
+
+/* ---- Orthogonal(U, S) validation: reference src/orthogonal_matrix.jl:21-23 -------------- */
+int lmm_orthogonal_validate(const double* U, int p, int m);
+
+/* ---- logpdf ------------------------------------------------------------------------------ */
+/* logpdf(fx::FiniteGP{<:OILMM}, y): reference src/oilmm.jl:79-93 (+ project :20-30, regulariser
+ * :101-113, per-latent generic logpdf).  *out = sum_{l in shard} lml_l + (with_regulariser ? reg : 0). */
+int lmm_oilmm_logpdf(const double* x, int d, int n, const double* y, int p,
+                     const double* U, const double* S, int m, double sigma2,
+                     const lmm_gp_t* gps, int latent_begin, int latent_end, int with_regulariser,
+                     double* out);
+
+/* logpdf(fx::FiniteGP{<:ILMM}, y), dense H (p x m): reference src/ilmm.jl:150-163 (+ project :61-68,
+ * regulariser :171-181; cov(::IndependentMOGP) src/independent_mogp.jl:60-63): ONE (mn) x (mn)
+ * factorisation.  Does not shard (replicas only). */
+int lmm_ilmm_logpdf(const double* x, int d, int n, const double* y, int p,
+                    const double* H, int m, double sigma2, const lmm_gp_t* gps,
+                    const lmm_jitters_t* jit, double* out);
+
+/* logpdf(ft::FiniteGP{<:IndependentMOGP,<:MOInputIsotopicByOutputs,<:Diagonal{<:Real,<:Fill}}, y):
+ * reference src/independent_mogp.jl:74-80.  y is n x m. */
+int lmm_mogp_logpdf(const double* x, int d, int n, const double* y, int m, double sigma2,
+                    const lmm_gp_t* gps, int latent_begin, int latent_end, double* out);
+
+/* ---- posterior ---------------------------------------------------------------------------- */
+/* posterior(fx::FiniteGP{<:OILMM}, y): reference src/oilmm.jl:116-134.  Keeps, per latent of the
+ * shard, the Cholesky factor C_l, alpha_l = C_l \ delta_l and x on the device. */
+int lmm_oilmm_posterior_create(const double* x, int d, int n, const double* y, int p,
+                               const double* U, const double* S, int m, double sigma2,
+                               const lmm_gp_t* gps, int latent_begin, int latent_end,
+                               lmm_post_t** out);
+/* posterior(ft::IsotropicByOutputsFiniteIndependentMOGP, y): reference src/independent_mogp.jl:119-126. */
+int lmm_mogp_posterior_create(const double* x, int d, int n, const double* y, int m, double sigma2,
+                              const lmm_gp_t* gps, int latent_begin, int latent_end, lmm_post_t** out);
+/* posterior(fx::FiniteGP{<:ILMM}, y), dense H: reference src/ilmm.jl:184-198. */
+int lmm_ilmm_posterior_create(const double* x, int d, int n, const double* y, int p,
+                              const double* H, int m, double sigma2, const lmm_gp_t* gps,
+                              const lmm_jitters_t* jit, lmm_post_t** out);
+int lmm_post_destroy(lmm_post_t* post);
+
+/* Latent marginals of the (prior if post == NULL, else posterior) latent processes of the shard at xs:
+ * mean_lat, var_lat are (m_shard x ns) row-per-latent, i.e. ns x m_shard column-major.  No jitter, no
+ * mixing.  AbstractGPs PosteriorGP mean/var reached from reference
+ * src/oilmm.jl:61 and src/independent_mogp.jl:50,55. */
+int lmm_latent_marginals(const lmm_post_t* post, const lmm_gp_t* gps, int m_shard,
+                         const double* xs, int d, int ns, double* mean_lat, double* var_lat);
+
+/* mean_and_var(fx::FiniteGP{<:OILMM}) => marginals / mean / var: reference src/oilmm.jl:57-76.
+ * H = U sqrt(S) (pass S == NULL to give a dense H in U: the diagonal-covariance mixing of an ILMM whose
+ * latents are independent).  Outputs are the shard's PARTIAL sums over its latents, length ns*p,
+ * by-outputs; sigma2 (+ default jitter per latent) is added iff add_noise != 0.
+ * post == NULL => prior latents `gps` (m_shard of them, starting at latent_begin). */
+int lmm_oilmm_mean_and_var(const lmm_post_t* post, const lmm_gp_t* gps,
+                           const double* U, const double* S, int p, int m,
+                           int latent_begin, int latent_end, double sigma2, int add_noise,
+                           const double* xs, int d, int ns, const lmm_jitters_t* jit,
+                           double* mean_out, double* var_out);
+
+/* logpdf(po(xs, sigma2), ys) where po is the posterior OILMM (reference test/oilmm.jl:25; the posterior
+ * is again an OILMM with the same H, reference src/oilmm.jl:133): per-latent posterior covariance at
+ * xs (Schur complement) + the reference src/oilmm.jl:79-93 algorithm. */
+int lmm_oilmm_post_logpdf(const lmm_post_t* post, const double* U, const double* S, int p, int m,
+                          double sigma2, const double* xs, int d, int ns, const double* ys,
+                          int with_regulariser, double* out);
+
+/* ---- rand ----------------------------------------------------------------------------------- */
+/* rand(rng, fx::FiniteGP{<:OILMM}): reference src/oilmm.jl:40-54.  The caller supplies the standard
+ * normals in the reference's draw order: z_lat = m blocks of ns (latent order), eps = ns*p (by-outputs),
+ * so a Julia shim passing randn(rng, ...) reproduces the reference sample-for-sample.
+ * H = U sqrt(S), or dense H in U with S == NULL and latent jitter `ilmm_rand_jitter`
+ * (rand(rng, fx::FiniteGP{<:ILMM}): reference src/ilmm.jl:78-87 + src/independent_mogp.jl:83-86).
+ * post == NULL => prior latents.  Output: PARTIAL sum over the shard's latents (length ns*p); the
+ * noise term sqrt(sigma2)*eps is added iff add_noise != 0. */
+int lmm_lmm_rand(const lmm_post_t* post, const lmm_gp_t* gps,
+                 const double* U, const double* S, int p, int m,
+                 int latent_begin, int latent_end, double sigma2, int add_noise,
+                 const double* xs, int d, int ns, const double* z_lat, const double* eps,
+                 const lmm_jitters_t* jit, double* out);
+
+/* ---- building blocks exported for tests / profiling (device pointers only) ------------------ */
+/* In-place lower Cholesky of the leading ncols columns of an nrows x ncols column-major matrix (ld),
+ * rows >= ncols ride along (become A21 * L11^-T).  nrows, ncols multiples of 64.  Winv: ncols/64 dense
+ * 64x64 inverse diagonal blocks (scratch / output).  info: device int (0 = ok, k = pivot k failed). */
+int lmm_dev_potrf(double* A, int nrows, int ncols, int ld, double* Winv, int n_real, int* info_dev);
+/* C[MxN] -= A[MxK] * B[NxK]^T (column-major, device). lower != 0: only tiles on/below the diagonal. */
+int lmm_dev_gemm_nt_sub(double* C, int ldc, const double* A, int lda, const double* B, int ldb,
+                        int M, int N, int K, int lower);
+/* Gram assembly of one latent into a padded factor matrix (lower triangle + pad identity). */
+int lmm_dev_gram(double* A, int ld, int nrows, int ncols, const double* x, int d, int n,
+                 const lmm_gp_t* gp, double diag_add);
+/* f64 MFMA issue-rate microbenchmark: returns measured TFLOP/s of v_mfma_f64_16x16x4_f64. */
+int lmm_dev_mfma_f64_peak(double* tflops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LMM_HIP_H */

@@ -1,0 +1,16 @@
+"""MI355X-native ILMM/OILMM inference hot path: host-side mirror of the LinearMixingModels.jl interface over
+liblmm_hip.so (hand-written gfx950 HIP kernels behind the C ABI of include/lmm_hip.h).
+
+The directory name contains a dot, so import it through the root-level loader:  `import lmm_amd`."""
+from ._lib import LMMError, PosDefException, init, load, LIB_PATH, SYMBOLS
+from .model import (GP, ILMM, OILMM, FiniteGP, IndependentMOGP, Matern32Kernel, Matern52Kernel,
+                    MOInputIsotopicByOutputs, Normal, Orthogonal, SEKernel, get_latent_gp, independent_mogp, logpdf,
+                    marginals, mean, mean_and_var, noise_var, posterior, rand, reshape_y, unpack, var)
+from .parallel import latent_shard, sharded_logpdf, sharded_mean_and_var
+
+__all__ = [
+    "ILMM", "IndependentMOGP", "independent_mogp", "Orthogonal", "OILMM", "get_latent_gp",   # the reference's 6 exports
+    "GP", "SEKernel", "Matern32Kernel", "Matern52Kernel", "MOInputIsotopicByOutputs", "FiniteGP", "Normal",
+    "logpdf", "posterior", "rand", "marginals", "mean_and_var", "mean", "var", "noise_var", "reshape_y", "unpack",
+    "latent_shard", "sharded_logpdf", "sharded_mean_and_var", "init", "load", "PosDefException", "LMMError",
+]

@@ -1,0 +1,155 @@
+"""ctypes binding of liblmm_hip.so (include/lmm_hip.h).  No fallback: if the HIP library or a GPU is
+missing every compute entry point raises -- the product path never routes through a CPU implementation."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblmm_hip.so")
+
+LMM_OK, LMM_ERR_DIM, LMM_ERR_NOT_ORTHOGONAL, LMM_ERR_NOT_PD, LMM_ERR_HIP, LMM_ERR_ARG, LMM_ERR_UNSUPPORTED = range(7)
+KERNEL_KINDS = {"se": 0, "matern32": 1, "matern52": 2}
+
+# Every symbol include/lmm_hip.h declares (tests/test_abi.py checks the library exports each one).
+SYMBOLS = [
+    "lmm_init", "lmm_shutdown", "lmm_last_error_string", "lmm_last_error_detail", "lmm_device_synchronize",
+    "lmm_orthogonal_validate", "lmm_oilmm_logpdf", "lmm_ilmm_logpdf", "lmm_mogp_logpdf",
+    "lmm_oilmm_posterior_create", "lmm_mogp_posterior_create", "lmm_ilmm_posterior_create", "lmm_post_destroy",
+    "lmm_latent_marginals", "lmm_oilmm_mean_and_var", "lmm_oilmm_post_logpdf", "lmm_lmm_rand",
+    "lmm_dev_potrf", "lmm_dev_gemm_nt_sub", "lmm_dev_gram", "lmm_dev_mfma_f64_peak",
+]
+
+
+class GpT(C.Structure):
+    _fields_ = [("kind", C.c_int), ("variance", C.c_double), ("lengthscale", C.c_double), ("mean", C.c_double)]
+
+
+class JittersT(C.Structure):
+    _fields_ = [("project_jitter", C.c_double), ("ilmm_rand_jitter", C.c_double), ("default_jitter", C.c_double)]
+
+
+class PosDefException(ArithmeticError):
+    """Julia's LinearAlgebra.PosDefException(info)."""
+
+    def __init__(self, msg: str, latent: int, info: int):
+        super().__init__(msg)
+        self.latent, self.info = latent, info
+
+
+class LMMError(RuntimeError):
+    pass
+
+
+_lib = None
+_initialised_device: Optional[int] = None
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LMMError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        # PyTorch-ROCm bundles its own libamdhip64 (same SONAME as /opt/rocm's).  A process must hold ONE HIP
+        # runtime, so when torch is present load it first: the dynamic linker then binds liblmm_hip.so's
+        # libamdhip64.so.7 dependency to the copy torch already mapped (device pointers, streams and RCCL of
+        # both sides then live in the same runtime).  Without torch the system ROCm runtime is used.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        _lib = C.CDLL(LIB_PATH)
+        _lib.lmm_last_error_string.restype = C.c_char_p
+    return _lib
+
+
+def init(device: Optional[int] = None) -> int:
+    """lmm_init: one process per GPU.  device defaults to LOCAL_RANK (torch.distributed launch) or 0."""
+    global _initialised_device
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    lib = load()
+    check(lib.lmm_init(C.c_int(device)))
+    _initialised_device = device
+    return device
+
+
+def ensure_init() -> None:
+    if _initialised_device is None:
+        init()
+
+
+def check(rc: int) -> None:
+    if rc == LMM_OK:
+        return
+    lib = load()
+    msg = lib.lmm_last_error_string().decode()
+    if rc == LMM_ERR_DIM:
+        raise RuntimeError(msg)                      # Julia: ErrorException("out dim of x != out dim of f.")
+    if rc == LMM_ERR_NOT_ORTHOGONAL:
+        raise ValueError(msg)                        # Julia: ArgumentError
+    if rc == LMM_ERR_NOT_PD:
+        lat, info = C.c_int(), C.c_int()
+        lib.lmm_last_error_detail(C.byref(lat), C.byref(info))
+        raise PosDefException(msg, lat.value, info.value)
+    if rc == LMM_ERR_ARG:
+        raise ValueError(msg)
+    if rc == LMM_ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise LMMError(msg)
+
+
+def _is_torch(a) -> bool:
+    return type(a).__module__.startswith("torch")
+
+
+class Arr:
+    """A Float64 array handed to the C ABI: a NumPy array (host pointer) or a CUDA/HIP torch tensor
+    (device pointer).  Keeps the owner alive for the duration of the call."""
+
+    def __init__(self, a, writable: bool = False):
+        if _is_torch(a):
+            import torch
+            if a.dtype != torch.float64:
+                raise TypeError("expected a float64 tensor")
+            if not a.is_contiguous():
+                if writable:
+                    raise ValueError("output tensor must be contiguous")
+                a = a.contiguous()
+            self.owner = a
+            self.ptr = C.c_void_p(a.data_ptr())
+            self.size = a.numel()
+        else:
+            if writable:
+                if not (isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags.c_contiguous):
+                    raise ValueError("output array must be a C-contiguous float64 ndarray")
+            else:
+                a = np.ascontiguousarray(a, dtype=np.float64)
+            self.owner = a
+            self.ptr = a.ctypes.data_as(C.c_void_p)
+            self.size = a.size
+
+
+def gps_array(gps: Sequence[dict]):
+    arr = (GpT * max(len(gps), 1))()
+    for l, g in enumerate(gps):
+        arr[l].kind = KERNEL_KINDS[g["kind"]]
+        arr[l].variance = float(g.get("variance", 1.0))
+        arr[l].lengthscale = float(g.get("lengthscale", 1.0))
+        arr[l].mean = float(g.get("mean", 0.0))
+    return arr
+
+
+def jitters(j: Optional[Tuple[float, float, float]]):
+    if j is None:
+        return None
+    return C.byref(JittersT(*map(float, j)))
+
+
+def colmajor(a: np.ndarray) -> np.ndarray:
+    """Column-major (Julia Array) image of a 2-D host matrix as a flat float64 vector."""
+    return np.asarray(a, dtype=np.float64).flatten(order="F")

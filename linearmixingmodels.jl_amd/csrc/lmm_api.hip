@@ -1,0 +1,1026 @@
+// lmm_api.hip -- host orchestration + C ABI (include/lmm_hip.h) of liblmm_hip.so.
+//
+// One process drives ONE MI355X (one process per GPU; the multi-GPU layer above shards latents and
+// sums partial results with one RCCL all-reduce).  Latent problems are independent, so each latent of the
+// shard gets a slot = (factor-matrix buffer, HIP stream); slots run concurrently so one latent's
+// latency-bound 64x64 diagonal-block step overlaps the other latents' MFMA trailing updates.
+//
+// Blocked Cholesky: recursive halving on column ranges,
+//     potrf(j0, w):  potrf(j0, h);  C[j0+h:, j0+h:j0+w] -= A[j0+h:, j0:j0+h] A[j0+h:j0+w, j0:j0+h]';  potrf(j0+h, w-h)
+// so that >95 % of the n^3/3 flops run in large-K f64-MFMA updates that read/write each trailing tile once
+// per level (log2(n/64) levels) instead of once per panel.  Leaves (64 columns): diag64 (factor + inverse
+// of the diagonal block) then TRSM as a GEMM with the inverse.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "lmm_internal.h"
+
+namespace {
+
+constexpr double kLog2Pi = 1.8378770664093453;
+constexpr int kMaxStreams = 16;
+
+struct Ctx {
+  bool init = false;
+  int device = -1;
+  int nstreams = 4;
+  hipStream_t streams[kMaxStreams];
+  hipEvent_t ev_main;
+  hipEvent_t ev_slot[kMaxStreams];
+  std::multimap<size_t, void*> pool;   // cached device blocks (size -> ptr)
+  std::map<void*, size_t> live;
+  std::string err;
+  int err_latent = -1, err_info = 0;
+};
+Ctx g;
+std::mutex g_mu;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g.err = buf;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess) throw fail(LMM_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                                     __FILE__, __LINE__);                                         \
+  } while (0)
+
+void* dev_alloc(size_t bytes) {
+  if (bytes == 0) bytes = 256;
+  bytes = (bytes + 255) & ~size_t(255);
+  auto it = g.pool.find(bytes);
+  void* p = nullptr;
+  if (it != g.pool.end()) {
+    p = it->second;
+    g.pool.erase(it);
+  } else {
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {   // release the cache and retry once
+      for (auto& kv : g.pool) (void)hipFree(kv.second);
+      g.pool.clear();
+      (void)hipGetLastError();
+      e = hipMalloc(&p, bytes);
+      if (e != hipSuccess) throw fail(LMM_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    }
+  }
+  g.live[p] = bytes;
+  return p;
+}
+
+void dev_free(void* p) {
+  if (!p) return;
+  auto it = g.live.find(p);
+  if (it == g.live.end()) return;
+  g.pool.insert({it->second, p});
+  g.live.erase(it);
+}
+
+template <typename T>
+struct Buf {   // RAII device buffer from the caching pool
+  T* p = nullptr;
+  size_t n = 0;
+  Buf() = default;
+  explicit Buf(size_t count) : p(static_cast<T*>(dev_alloc(count * sizeof(T)))), n(count) {}
+  Buf(const Buf&) = delete;
+  Buf& operator=(const Buf&) = delete;
+  Buf(Buf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+  Buf& operator=(Buf&& o) noexcept { if (this != &o) { dev_free(p); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
+  ~Buf() { dev_free(p); }
+};
+
+bool is_device_ptr(const void* p) {
+  hipPointerAttribute_t a;
+  hipError_t e = hipPointerGetAttributes(&a, p);
+  if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+  return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+// A read-only input that may live on host or device: gives a device pointer valid on stream st.
+struct DevIn {
+  const double* p = nullptr;
+  Buf<double> own;
+  DevIn(const double* src, size_t count, hipStream_t st) {
+    if (src == nullptr) return;
+    if (is_device_ptr(src)) { p = src; return; }
+    own = Buf<double>(count);
+    HIPCHK(hipMemcpyAsync(own.p, src, count * sizeof(double), hipMemcpyHostToDevice, st));
+    p = own.p;
+  }
+};
+
+// An output that may live on host or device.
+struct DevOut {
+  double* dst; double* p; size_t count; Buf<double> own; bool direct;
+  DevOut(double* dst_, size_t count_) : dst(dst_), p(nullptr), count(count_), direct(false) {
+    if (dst == nullptr) return;
+    if (is_device_ptr(dst)) { p = dst; direct = true; }
+    else { own = Buf<double>(count); p = own.p; }
+  }
+  void finish(hipStream_t st) {
+    if (dst && !direct) HIPCHK(hipMemcpyAsync(dst, p, count * sizeof(double), hipMemcpyDeviceToHost, st));
+  }
+};
+
+inline int rup(int v, int m) { return (v + m - 1) / m * m; }
+
+struct Dims {
+  int n, NC, NR, ld;
+  Dims(int n_, int nrider) : n(n_) {
+    NC = rup(std::max(n, 1), 64);
+    NR = rup(NC + std::max(nrider, 0), 64);
+    ld = NR;
+    if ((ld % 512) == 0) ld += 16;   // keep column starts off the same HBM channel / L2 set
+  }
+  size_t elems() const { return (size_t)ld * NC; }
+};
+
+LatentDev to_dev(const lmm_gp_t& gp) {
+  LatentDev d;
+  d.kind = gp.kind; d.var = gp.variance; d.inv_ls = 1.0 / gp.lengthscale; d.mean = gp.mean;
+  return d;
+}
+
+int check_gps(const lmm_gp_t* gps, int m) {
+  if (!gps) return fail(LMM_ERR_ARG, "gps is NULL");
+  for (int l = 0; l < m; ++l) {
+    if (gps[l].kind < 0 || gps[l].kind > 2) return fail(LMM_ERR_UNSUPPORTED, "latent %d: unsupported kernel kind %d", l, gps[l].kind);
+    if (!(gps[l].variance > 0.0) || !(gps[l].lengthscale > 0.0)) return fail(LMM_ERR_ARG, "latent %d: variance and lengthscale must be > 0", l);
+  }
+  return LMM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// blocked factorisation drivers
+// ------------------------------------------------------------------------------------------------
+inline int split(int w) {            // left width of the recursive split (multiple of 64; of 128 when w >= 256)
+  if (w >= 256) return rup(w / 2, 128);
+  return (w == 192) ? 128 : 64;
+}
+
+// Factor columns [j0, j0+w) of A (rows j0..NR-1 participate).  W: NC/64 inverse diagonal blocks.
+void potrf_rec(double* A, int ld, int NR, int j0, int w, double* W, int n_real, int* info, hipStream_t st) {
+  if (w <= 64) {
+    double* blk = A + (size_t)j0 * ld + j0;
+    double* Wb = W + (size_t)(j0 / 64) * 4096;
+    launch_diag64(blk, ld, Wb, j0, n_real, info, st);
+    const int M = NR - (j0 + 64);
+    if (M > 0) {
+      double* pan = A + (size_t)j0 * ld + (j0 + 64);
+      launch_gemm_nt(pan, ld, pan, ld, Wb, 64, M, 64, 64, 0, true, st);
+    }
+    return;
+  }
+  const int h = split(w);
+  potrf_rec(A, ld, NR, j0, h, W, n_real, info, st);
+  const int r0 = j0 + h;
+  launch_gemm_nt(A + (size_t)r0 * ld + r0, ld, A + (size_t)j0 * ld + r0, ld, A + (size_t)j0 * ld + r0, ld,
+                 NR - r0, w - h, h, 1, false, st);
+  potrf_rec(A, ld, NR, r0, w - h, W, n_real, info, st);
+}
+
+// R (nr x NC, ldr) <- R * L^-T for an already factored L (ld) with inverse diagonal blocks W.
+void trsm_rec(double* R, int ldr, int nr, const double* L, int ld, const double* W, int j0, int w, hipStream_t st) {
+  if (w <= 64) {
+    double* pan = R + (size_t)j0 * ldr;
+    launch_gemm_nt(pan, ldr, pan, ldr, W + (size_t)(j0 / 64) * 4096, 64, nr, 64, 64, 0, true, st);
+    return;
+  }
+  const int h = split(w);
+  trsm_rec(R, ldr, nr, L, ld, W, j0, h, st);
+  launch_gemm_nt(R + (size_t)(j0 + h) * ldr, ldr, R + (size_t)j0 * ldr, ldr, L + (size_t)j0 * ld + (j0 + h), ld,
+                 nr, w - h, h, 0, false, st);
+  trsm_rec(R, ldr, nr, L, ld, W, j0 + h, w - h, st);
+}
+
+struct Slot {
+  Buf<double> A, W;
+  hipStream_t st;
+};
+
+void make_slots(std::vector<Slot>& slots, int count, size_t a_elems, int NC) {
+  slots.resize(count);
+  for (int s = 0; s < count; ++s) {
+    slots[s].A = Buf<double>(a_elems);
+    slots[s].W = Buf<double>((size_t)(NC / 64) * 4096);
+    slots[s].st = g.streams[s];
+  }
+}
+
+void fork_slots(int count) {       // slot streams wait for everything queued on the main stream
+  HIPCHK(hipEventRecord(g.ev_main, g.streams[0]));
+  for (int s = 1; s < count; ++s) HIPCHK(hipStreamWaitEvent(g.streams[s], g.ev_main, 0));
+}
+
+void join_slots(int count) {       // main stream waits for every slot stream
+  for (int s = 1; s < count; ++s) {
+    HIPCHK(hipEventRecord(g.ev_slot[s], g.streams[s]));
+    HIPCHK(hipStreamWaitEvent(g.streams[0], g.ev_slot[s], 0));
+  }
+}
+
+int check_info(const std::vector<int>& info, int latent_begin) {
+  for (size_t k = 0; k < info.size(); ++k) {
+    if (info[k] != 0) {
+      g.err_latent = latent_begin + (int)k;
+      g.err_info = info[k];
+      return fail(LMM_ERR_NOT_PD, "PosDefException: matrix is not positive definite; Cholesky factorization failed "
+                                  "(latent %d, pivot %d)", g.err_latent, g.err_info);
+    }
+  }
+  return LMM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side small dense algebra (m, p <= a few hundred): projections and regulariser scalars
+// ------------------------------------------------------------------------------------------------
+// reference src/oilmm.jl:20-30:  T = sqrt(S) \ U'  (m x p, column-major), SigmaT = sigma2 ./ S
+void project_orthogonal(const double* U, const double* S, int p, int m, double s2, std::vector<double>& T,
+                        std::vector<double>& ST, std::vector<double>& H) {
+  T.assign((size_t)m * p, 0.0); ST.assign(m, 0.0); H.assign((size_t)p * m, 0.0);
+  for (int l = 0; l < m; ++l) {
+    const double rs = std::sqrt(S[l]);
+    ST[l] = s2 / S[l];
+    for (int o = 0; o < p; ++o) {
+      T[l + (size_t)o * m] = U[o + (size_t)l * p] / rs;
+      H[o + (size_t)l * p] = U[o + (size_t)l * p] * rs;   // reference src/orthogonal_matrix.jl:27-30
+    }
+  }
+}
+
+bool host_cholesky(std::vector<double>& A, int m) {   // lower, in place, column-major
+  for (int j = 0; j < m; ++j) {
+    double d = A[j + (size_t)j * m];
+    for (int k = 0; k < j; ++k) d -= A[j + (size_t)k * m] * A[j + (size_t)k * m];
+    if (!(d > 0.0)) return false;
+    d = std::sqrt(d);
+    A[j + (size_t)j * m] = d;
+    for (int i = j + 1; i < m; ++i) {
+      double s = A[i + (size_t)j * m];
+      for (int k = 0; k < j; ++k) s -= A[i + (size_t)k * m] * A[j + (size_t)k * m];
+      A[i + (size_t)j * m] = s / d;
+    }
+  }
+  return true;
+}
+
+// reference src/ilmm.jl:61-68.  T m x p, ST m x m (column-major); also logdet(ST) for src/ilmm.jl:179.
+int project_dense(const double* H, int p, int m, double s2, double jitter, std::vector<double>& T,
+                  std::vector<double>& ST, double* logdetST) {
+  std::vector<double> G((size_t)m * m, 0.0);
+  for (int a = 0; a < m; ++a)
+    for (int b = 0; b < m; ++b) {
+      double s = 0.0;
+      for (int o = 0; o < p; ++o) s += H[o + (size_t)a * p] * H[o + (size_t)b * p];
+      G[a + (size_t)b * m] = s / s2 + (a == b ? jitter : 0.0);
+    }
+  if (!host_cholesky(G, m)) return fail(LMM_ERR_NOT_PD, "PosDefException in project(H, sigma2): H'H/sigma2 + 1e-9 I not PD");
+  T.assign((size_t)m * p, 0.0);
+  for (int o = 0; o < p; ++o) {     // solve (L L') t = H[o,:]' / s2
+    std::vector<double> v(m);
+    for (int a = 0; a < m; ++a) {
+      double s = H[o + (size_t)a * p] / s2;
+      for (int k = 0; k < a; ++k) s -= G[a + (size_t)k * m] * v[k];
+      v[a] = s / G[a + (size_t)a * m];
+    }
+    for (int a = m - 1; a >= 0; --a) {
+      double s = v[a];
+      for (int k = a + 1; k < m; ++k) s -= G[k + (size_t)a * m] * v[k];
+      v[a] = s / G[a + (size_t)a * m];
+    }
+    for (int a = 0; a < m; ++a) T[a + (size_t)o * m] = v[a];
+  }
+  ST.assign((size_t)m * m, 0.0);
+  for (int a = 0; a < m; ++a)
+    for (int b = 0; b < m; ++b) {
+      double s = 0.0;
+      for (int o = 0; o < p; ++o) s += T[a + (size_t)o * m] * T[b + (size_t)o * m];
+      ST[a + (size_t)b * m] = s2 * s;
+    }
+  if (logdetST) {
+    std::vector<double> C = ST;
+    if (!host_cholesky(C, m)) return fail(LMM_ERR_NOT_PD, "PosDefException: SigmaT not PD");
+    double ld = 0.0;
+    for (int a = 0; a < m; ++a) ld += std::log(C[a + (size_t)a * m]);
+    *logdetST = 2.0 * ld;
+  }
+  return LMM_OK;
+}
+
+struct Uploaded {   // small host arrays staged on the device
+  Buf<double> buf;
+  Uploaded() = default;
+  Uploaded(const std::vector<double>& v, hipStream_t st) : buf(v.size()) {
+    HIPCHK(hipMemcpyAsync(buf.p, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice, st));
+  }
+};
+
+// Ty (n x C, ld n) = In (n x K) * Mx' - sub;  optionally residual sum of squares |Ref - Ty * Hm'|_F^2.
+void project_on_device(const double* Y, int n, int p, const Buf<double>& Td, int m, int c0, int C,
+                       const double* sub_dev, double* Ty, hipStream_t st) {
+  launch_tall_skinny(Y, n, n, p, Td.p + c0, m, C, Ty, n, sub_dev, nullptr, 0, nullptr, 0, st);
+}
+
+void residual_on_device(const double* Y, int n, int p, const double* Ty_all, int m, const Buf<double>& Hd,
+                        double* partial, double* out1, hipStream_t st) {
+  launch_tall_skinny(Ty_all, n, n, m, Hd.p, p, p, nullptr, 0, nullptr, Y, n, partial, 1, st);
+  launch_sum_partials(partial, tall_skinny_partials(n, p), out1, st);
+}
+
+// Core: per-latent log marginal likelihoods for latents [l0, l1) given the device rider vectors
+// delta (n x (l1-l0), ld n) and per-latent noise.  Returns lml per latent (host).
+int latent_lmls(const double* xd, int d, int n, const lmm_gp_t* gps, const double* noise, int l0, int l1,
+                const double* delta, std::vector<double>& lml) {
+  const int ms = l1 - l0;
+  lml.assign(ms, 0.0);
+  if (ms == 0) return LMM_OK;
+  Dims D(n, 1);
+  const int nslots = std::min(ms, g.nstreams);
+  std::vector<Slot> slots;
+  make_slots(slots, nslots, D.elems(), D.NC);
+  Buf<double> out(ms);
+  Buf<int> info(ms);
+  HIPCHK(hipMemsetAsync(info.p, 0, ms * sizeof(int), g.streams[0]));
+  fork_slots(nslots);
+  for (int k = 0; k < ms; ++k) {
+    Slot& s = slots[k % nslots];
+    const lmm_gp_t& gp = gps[l0 + k];
+    GramArgs a{};
+    a.A = s.A.p; a.ld = D.ld; a.nrows = D.NR; a.ncols = D.NC; a.row_tile0 = 0; a.row_shift = 0; a.full = 0;
+    a.x = xd; a.d = d; a.n = n; a.kind = gp.kind; a.var = gp.variance; a.inv_ls = 1.0 / gp.lengthscale;
+    a.diag_add = noise[l0 + k]; a.pad_diag = 1.0;
+    a.rider = delta + (size_t)k * n; a.rider_ld = n; a.nrider = 1; a.xs = nullptr; a.ns = 0;
+    launch_gram(a, s.st);
+    potrf_rec(s.A.p, D.ld, D.NR, 0, D.NC, s.W.p, n, info.p + k, s.st);
+    launch_lml_reduce(s.A.p, D.ld, n, D.NC, 1, out.p + k, s.st);
+  }
+  join_slots(nslots);
+  std::vector<int> hinfo(ms);
+  HIPCHK(hipMemcpyAsync(lml.data(), out.p, ms * sizeof(double), hipMemcpyDeviceToHost, g.streams[0]));
+  HIPCHK(hipMemcpyAsync(hinfo.data(), info.p, ms * sizeof(int), hipMemcpyDeviceToHost, g.streams[0]));
+  HIPCHK(hipStreamSynchronize(g.streams[0]));
+  return check_info(hinfo, l0);
+}
+
+const lmm_jitters_t kDefaultJit = {1e-9, 1e-12, 1e-18};
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// posterior handle
+// ------------------------------------------------------------------------------------------------
+struct lmm_post {
+  int kind = 0;               // 0: per-latent (OILMM / MOGP), 1: dense ILMM
+  int n = 0, d = 0, l0 = 0, l1 = 0, m = 0;
+  int NC = 0, NR = 0, ld = 0;
+  std::vector<lmm_gp_t> gps;  // all m latents (host)
+  Buf<double> x;              // d x n
+  std::vector<Buf<double>> L; // per latent of the shard: factor matrix (NR x NC, ld)
+  std::vector<Buf<double>> W; // inverse diagonal blocks
+  std::vector<Buf<double>> alpha;
+};
+
+#define LMM_TRY try {
+#define LMM_CATCH                                   \
+  }                                                 \
+  catch (int code) { return code; }                 \
+  catch (const std::exception& e) { return fail(LMM_ERR_HIP, "exception: %s", e.what()); }
+
+#define REQUIRE_INIT() \
+  if (!g.init) return fail(LMM_ERR_ARG, "lmm_init() has not been called")
+
+extern "C" {
+
+int lmm_init(int device) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  LMM_TRY
+  if (g.init) {
+    if (g.device == device) return LMM_OK;
+    return fail(LMM_ERR_ARG, "already initialised on device %d (one process per GPU)", g.device);
+  }
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count == 0) return fail(LMM_ERR_HIP, "no HIP device available (%s)", hipGetErrorString(e));
+  if (device < 0 || device >= count) return fail(LMM_ERR_ARG, "device %d out of range (0..%d)", device, count - 1);
+  HIPCHK(hipSetDevice(device));
+  const char* ns = getenv("LMM_NSTREAMS");
+  g.nstreams = ns ? std::max(1, std::min(kMaxStreams, atoi(ns))) : 4;
+  for (int s = 0; s < kMaxStreams; ++s) {
+    HIPCHK(hipStreamCreateWithFlags(&g.streams[s], hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&g.ev_slot[s], hipEventDisableTiming));
+  }
+  HIPCHK(hipEventCreateWithFlags(&g.ev_main, hipEventDisableTiming));
+  g.device = device;
+  g.init = true;
+  return LMM_OK;
+  LMM_CATCH
+}
+
+int lmm_shutdown(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g.init) return LMM_OK;
+  (void)hipDeviceSynchronize();
+  for (auto& kv : g.pool) (void)hipFree(kv.second);
+  g.pool.clear();
+  for (int s = 0; s < kMaxStreams; ++s) { (void)hipStreamDestroy(g.streams[s]); (void)hipEventDestroy(g.ev_slot[s]); }
+  (void)hipEventDestroy(g.ev_main);
+  g.init = false;
+  return LMM_OK;
+}
+
+const char* lmm_last_error_string(void) { return g.err.c_str(); }
+
+int lmm_last_error_detail(int* latent, int* info) {
+  if (latent) *latent = g.err_latent;
+  if (info) *info = g.err_info;
+  return LMM_OK;
+}
+
+int lmm_device_synchronize(void) {
+  REQUIRE_INIT();
+  LMM_TRY
+  HIPCHK(hipDeviceSynchronize());
+  return LMM_OK;
+  LMM_CATCH
+}
+
+// reference src/orthogonal_matrix.jl:21-23: isapprox(U'U, I) (Frobenius norm, rtol = sqrt(eps)).
+int lmm_orthogonal_validate(const double* U, int p, int m) {
+  if (!U || p <= 0 || m <= 0) return fail(LMM_ERR_ARG, "bad arguments");
+  double diff2 = 0.0, g2 = 0.0;
+  for (int a = 0; a < m; ++a)
+    for (int b = 0; b < m; ++b) {
+      double s = 0.0;
+      for (int o = 0; o < p; ++o) s += U[o + (size_t)a * p] * U[o + (size_t)b * p];
+      g2 += s * s;
+      const double dlt = s - (a == b ? 1.0 : 0.0);
+      diff2 += dlt * dlt;
+    }
+  const double rtol = std::sqrt(2.220446049250313e-16);
+  if (!(std::sqrt(diff2) <= rtol * std::max(std::sqrt(g2), std::sqrt((double)m))))
+    return fail(LMM_ERR_NOT_ORTHOGONAL, "`U` is not an orthogonal matrix");
+  return LMM_OK;
+}
+
+int lmm_oilmm_logpdf(const double* x, int d, int n, const double* y, int p, const double* U, const double* S, int m,
+                     double sigma2, const lmm_gp_t* gps, int latent_begin, int latent_end, int with_regulariser,
+                     double* out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  REQUIRE_INIT();
+  LMM_TRY
+  if (!x || !y || !U || !S || !out || d <= 0 || n <= 0 || p <= 0 || m <= 0) return fail(LMM_ERR_ARG, "bad arguments");
+  if (m > p) return fail(LMM_ERR_DIM, "out dim of x != out dim of f.");
+  if (latent_begin < 0 || latent_end > m || latent_begin > latent_end) return fail(LMM_ERR_ARG, "bad latent shard");
+  if (int rc = check_gps(gps, m)) return rc;
+  if (!(sigma2 > 0.0)) return fail(LMM_ERR_ARG, "sigma2 must be > 0");
+  hipStream_t st0 = g.streams[0];
+  std::vector<double> T, ST, H;
+  project_orthogonal(U, S, p, m, sigma2, T, ST, H);
+  DevIn xd(x, (size_t)d * n, st0), yd(y, (size_t)n * p, st0);
+  Uploaded Td(T, st0);
+  std::vector<double> means(m);
+  for (int l = 0; l < m; ++l) means[l] = gps[l].mean;
+  Uploaded meansd(means, st0);
+  const int l0 = latent_begin, l1 = latent_end, ms = l1 - l0;
+  // projection (+ residual for the regulariser, which needs T*Y for all m latents)
+  const int c0 = with_regulariser ? 0 : l0, C = with_regulariser ? m : ms;
+  Buf<double> Ty((size_t)n * std::max(C, 1));
+  double resid = 0.0;
+  Buf<double> resid_dev(1);
+  if (C > 0) project_on_device(yd.p, n, p, Td.buf, m, c0, C, nullptr, Ty.p, st0);
+  if (with_regulariser) {
+    Uploaded Hd(H, st0);
+    Buf<double> partial(tall_skinny_partials(n, p));
+    // reference src/oilmm.jl:112: sum(abs2, (I - U U') Y)  ==  |Y - H T Y|_F^2 since H T = U U'
+    residual_on_device(yd.p, n, p, Ty.p, m, Hd.buf, partial.p, resid_dev.p, st0);
+    HIPCHK(hipMemcpyAsync(&resid, resid_dev.p, sizeof(double), hipMemcpyDeviceToHost, st0));
+    HIPCHK(hipStreamSynchronize(st0));
+  }
+  // delta_l = (T y)_l - mean_l
+  Buf<double> delta((size_t)n * std::max(ms, 1));
+  if (ms > 0) project_on_device(yd.p, n, p, Td.buf, m, l0, ms, meansd.buf.p + l0, delta.p, st0);
+  std::vector<double> lml;
+  if (int rc = latent_lmls(xd.p, d, n, gps, ST.data(), l0, l1, delta.p, lml)) return rc;
+  double total = 0.0;
+  for (int k = 0; k < ms; ++k) total += lml[k];
+  if (with_regulariser) {
+    // reference src/oilmm.jl:101-113
+    double logdetS = 0.0;
+    for (int l = 0; l < m; ++l) logdetS += std::log(S[l]);
+    total += -((double)n * (logdetS + (double)(p - m) * std::log(2.0 * M_PI * sigma2)) + resid / sigma2) / 2.0;
+  }
+  *out = total;
+  return LMM_OK;
+  LMM_CATCH
+}
+
+int lmm_mogp_logpdf(const double* x, int d, int n, const double* y, int m, double sigma2, const lmm_gp_t* gps,
+                    int latent_begin, int latent_end, double* out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  REQUIRE_INIT();
+  LMM_TRY
+  if (!x || !y || !out || d <= 0 || n <= 0 || m <= 0) return fail(LMM_ERR_ARG, "bad arguments");
+  if (latent_begin < 0 || latent_end > m || latent_begin > latent_end) return fail(LMM_ERR_ARG, "bad latent shard");
+  if (int rc = check_gps(gps, m)) return rc;
+  hipStream_t st0 = g.streams[0];
+  const int l0 = latent_begin, l1 = latent_end, ms = l1 - l0;
+  DevIn xd(x, (size_t)d * n, st0), yd(y, (size_t)n * m, st0);
+  // delta_l = y_l - mean_l  via the projection kernel with T = I restricted to the shard
+  std::vector<double> T((size_t)m * m, 0.0), means(m), noise(m, sigma2);
+  for (int l = 0; l < m; ++l) { T[l + (size_t)l * m] = 1.0; means[l] = gps[l].mean; }
+  Uploaded Td(T, st0), meansd(means, st0);
+  Buf<double> delta((size_t)n * std::max(ms, 1));
+  if (ms > 0) project_on_device(yd.p, n, m, Td.buf, m, l0, ms, meansd.buf.p + l0, delta.p, st0);
+  std::vector<double> lml;
+  if (int rc = latent_lmls(xd.p, d, n, gps, noise.data(), l0, l1, delta.p, lml)) return rc;
+  double total = 0.0;
+  for (int k = 0; k < ms; ++k) total += lml[k];
+  *out = total;
+  return LMM_OK;
+  LMM_CATCH
+}
+
+int lmm_ilmm_logpdf(const double* x, int d, int n, const double* y, int p, const double* H, int m, double sigma2,
+                    const lmm_gp_t* gps, const lmm_jitters_t* jit, double* out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  REQUIRE_INIT();
+  LMM_TRY
+  if (!x || !y || !H || !out || d <= 0 || n <= 0 || p <= 0 || m <= 0) return fail(LMM_ERR_ARG, "bad arguments");
+  if (int rc = check_gps(gps, m)) return rc;
+  if (!jit) jit = &kDefaultJit;
+  if ((long long)m * n > 2000000000LL / 64) return fail(LMM_ERR_UNSUPPORTED, "m*n too large for the dense path");
+  hipStream_t st0 = g.streams[0];
+  std::vector<double> T, ST;
+  double logdetST = 0.0;
+  if (int rc = project_dense(H, p, m, sigma2, jit->project_jitter, T, ST, &logdetST)) return rc;
+  DevIn xd(x, (size_t)d * n, st0), yd(y, (size_t)n * p, st0);
+  Uploaded Td(T, st0), STd(ST, st0);
+  std::vector<double> Hv(H, H + (size_t)p * m), means(m);
+  std::vector<LatentDev> lat(m);
+  for (int l = 0; l < m; ++l) { means[l] = gps[l].mean; lat[l] = to_dev(gps[l]); }
+  Uploaded Hd(Hv, st0), meansd(means, st0);
+  Buf<LatentDev> latd(m);
+  HIPCHK(hipMemcpyAsync(latd.p, lat.data(), m * sizeof(LatentDev), hipMemcpyHostToDevice, st0));
+  // projection, residual, rider = vec(T Y) - mean
+  Buf<double> Ty((size_t)n * m), delta((size_t)n * m), partial(tall_skinny_partials(n, p)), resid_dev(1);
+  project_on_device(yd.p, n, p, Td.buf, m, 0, m, nullptr, Ty.p, st0);
+  residual_on_device(yd.p, n, p, Ty.p, m, Hd.buf, partial.p, resid_dev.p, st0);
+  project_on_device(yd.p, n, p, Td.buf, m, 0, m, meansd.buf.p, delta.p, st0);
+  // one dense (mn) x (mn) factorisation: reference src/ilmm.jl:160-162
+  const int N = m * n;
+  Dims D(N, 1);
+  Buf<double> A(D.elems()), W((size_t)(D.NC / 64) * 4096), lml_dev(1);
+  Buf<int> info(1);
+  HIPCHK(hipMemsetAsync(info.p, 0, sizeof(int), st0));
+  DenseArgs a{};
+  a.A = A.p; a.ld = D.ld; a.nrows = D.NR; a.ncols = D.NC; a.x = xd.p; a.d = d; a.n = n; a.m = m;
+  a.lat = latd.p; a.sigmaT = STd.buf.p; a.rider = delta.p; a.rider_ld = N; a.nrider = 1;
+  launch_dense_assemble(a, st0);
+  potrf_rec(A.p, D.ld, D.NR, 0, D.NC, W.p, N, info.p, st0);
+  launch_lml_reduce(A.p, D.ld, N, D.NC, 1, lml_dev.p, st0);
+  double lml = 0.0, resid = 0.0;
+  int hinfo = 0;
+  HIPCHK(hipMemcpyAsync(&lml, lml_dev.p, sizeof(double), hipMemcpyDeviceToHost, st0));
+  HIPCHK(hipMemcpyAsync(&resid, resid_dev.p, sizeof(double), hipMemcpyDeviceToHost, st0));
+  HIPCHK(hipMemcpyAsync(&hinfo, info.p, sizeof(int), hipMemcpyDeviceToHost, st0));
+  HIPCHK(hipStreamSynchronize(st0));
+  if (int rc = check_info(std::vector<int>{hinfo}, 0)) return rc;
+  // reference src/ilmm.jl:171-181
+  const double reg = -((double)n * ((double)(p - m) * kLog2Pi + ((double)p * std::log(sigma2) - logdetST)) + resid / sigma2) / 2.0;
+  *out = lml + reg;
+  return LMM_OK;
+  LMM_CATCH
+}
+
+// ------------------------------------------------------------------------------------------------
+// posterior
+// ------------------------------------------------------------------------------------------------
+static int posterior_create_common(const double* xd, int d, int n, const lmm_gp_t* gps, int m, const double* noise,
+                                   int l0, int l1, const double* delta, lmm_post_t** out) {
+  const int ms = l1 - l0;
+  lmm_post* P = new lmm_post();
+  try {
+    Dims D(n, 1);
+    P->kind = 0; P->n = n; P->d = d; P->l0 = l0; P->l1 = l1; P->m = m;
+    P->NC = D.NC; P->NR = D.NR; P->ld = D.ld;
+    P->gps.assign(gps, gps + m);
+    P->x = Buf<double>((size_t)d * n);
+    HIPCHK(hipMemcpyAsync(P->x.p, xd, (size_t)d * n * sizeof(double), hipMemcpyDeviceToDevice, g.streams[0]));
+    Buf<int> info(std::max(ms, 1));
+    HIPCHK(hipMemsetAsync(info.p, 0, std::max(ms, 1) * sizeof(int), g.streams[0]));
+    const int nslots = std::max(1, std::min(ms, g.nstreams));
+    fork_slots(nslots);
+    for (int k = 0; k < ms; ++k) {
+      hipStream_t st = g.streams[k % nslots];
+      P->L.emplace_back((size_t)D.elems());
+      P->W.emplace_back((size_t)(D.NC / 64) * 4096);
+      P->alpha.emplace_back((size_t)D.NC);
+      const lmm_gp_t& gp = gps[l0 + k];
+      GramArgs a{};
+      a.A = P->L[k].p; a.ld = D.ld; a.nrows = D.NR; a.ncols = D.NC; a.x = P->x.p; a.d = d; a.n = n;
+      a.kind = gp.kind; a.var = gp.variance; a.inv_ls = 1.0 / gp.lengthscale; a.diag_add = noise[l0 + k]; a.pad_diag = 1.0;
+      a.rider = delta + (size_t)k * n; a.rider_ld = n; a.nrider = 1;
+      launch_gram(a, st);
+      potrf_rec(P->L[k].p, D.ld, D.NR, 0, D.NC, P->W[k].p, n, info.p + k, st);
+      // alpha = L^-T (L^-1 delta): the rider row is z = L^-1 delta
+      HIPCHK(hipMemsetAsync(P->alpha[k].p, 0, (size_t)D.NC * sizeof(double), st));
+      launch_extract_row(P->L[k].p, D.ld, D.NC, n, P->alpha[k].p, st);
+      launch_backsolve(P->L[k].p, D.ld, P->W[k].p, D.NC / 64, P->alpha[k].p, st);
+    }
+    join_slots(nslots);
+    std::vector<int> hinfo(std::max(ms, 1), 0);
+    HIPCHK(hipMemcpyAsync(hinfo.data(), info.p, std::max(ms, 1) * sizeof(int), hipMemcpyDeviceToHost, g.streams[0]));
+    HIPCHK(hipStreamSynchronize(g.streams[0]));
+    if (int rc = check_info(hinfo, l0)) { delete P; return rc; }
+  } catch (int code) { delete P; return code; }
+  *out = P;
+  return LMM_OK;
+}
+
+int lmm_oilmm_posterior_create(const double* x, int d, int n, const double* y, int p, const double* U, const double* S,
+                               int m, double sigma2, const lmm_gp_t* gps, int latent_begin, int latent_end,
+                               lmm_post_t** out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  REQUIRE_INIT();
+  LMM_TRY
+  if (!x || !y || !U || !S || !out || d <= 0 || n <= 0 || p <= 0 || m <= 0) return fail(LMM_ERR_ARG, "bad arguments");
+  if (m > p) return fail(LMM_ERR_DIM, "out dim of x != out dim of f.");
+  if (latent_begin < 0 || latent_end > m || latent_begin > latent_end) return fail(LMM_ERR_ARG, "bad latent shard");
+  if (int rc = check_gps(gps, m)) return rc;
+  hipStream_t st0 = g.streams[0];
+  std::vector<double> T, ST, H;
+  project_orthogonal(U, S, p, m, sigma2, T, ST, H);
+  DevIn xd(x, (size_t)d * n, st0), yd(y, (size_t)n * p, st0);
+  Uploaded Td(T, st0);
+  std::vector<double> means(m);
+  for (int l = 0; l < m; ++l) means[l] = gps[l].mean;
+  Uploaded meansd(means, st0);
+  const int ms = latent_end - latent_begin;
+  Buf<double> delta((size_t)n * std::max(ms, 1));
+  if (ms > 0) project_on_device(yd.p, n, p, Td.buf, m, latent_begin, ms, meansd.buf.p + latent_begin, delta.p, st0);
+  return posterior_create_common(xd.p, d, n, gps, m, ST.data(), latent_begin, latent_end, delta.p, out);
+  LMM_CATCH
+}
+
+int lmm_mogp_posterior_create(const double* x, int d, int n, const double* y, int m, double sigma2, const lmm_gp_t* gps,
+                              int latent_begin, int latent_end, lmm_post_t** out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  REQUIRE_INIT();
+  LMM_TRY
+  if (!x || !y || !out || d <= 0 || n <= 0 || m <= 0) return fail(LMM_ERR_ARG, "bad arguments");
+  if (latent_begin < 0 || latent_end > m || latent_begin > latent_end) return fail(LMM_ERR_ARG, "bad latent shard");
+  if (int rc = check_gps(gps, m)) return rc;
+  hipStream_t st0 = g.streams[0];
+  DevIn xd(x, (size_t)d * n, st0), yd(y, (size_t)n * m, st0);
+  std::vector<double> T((size_t)m * m, 0.0), means(m), noise(m, sigma2);
+  for (int l = 0; l < m; ++l) { T[l + (size_t)l * m] = 1.0; means[l] = gps[l].mean; }
+  Uploaded Td(T, st0), meansd(means, st0);
+  const int ms = latent_end - latent_begin;
+  Buf<double> delta((size_t)n * std::max(ms, 1));
+  if (ms > 0) project_on_device(yd.p, n, m, Td.buf, m, latent_begin, ms, meansd.buf.p + latent_begin, delta.p, st0);
+  return posterior_create_common(xd.p, d, n, gps, m, noise.data(), latent_begin, latent_end, delta.p, out);
+  LMM_CATCH
+}
+
+int lmm_ilmm_posterior_create(const double*, int, int, const double*, int, const double*, int, double, const lmm_gp_t*,
+                              const lmm_jitters_t*, lmm_post_t**) {
+  return fail(LMM_ERR_UNSUPPORTED, "dense-H ILMM posterior handle is not built yet (SURVEY.md 8a row A11); "
+                                   "use the OILMM path or lmm_ilmm_logpdf");
+}
+
+int lmm_post_destroy(lmm_post_t* post) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (post) {
+    if (g.init) (void)hipDeviceSynchronize();
+    delete post;
+  }
+  return LMM_OK;
+}
+
+// Latent marginals (mean, var) of latents [l0, l1) at xs into device arrays (ns per latent).
+// post != NULL: posterior latents; else prior latents gps[l0..l1).  Caller holds g_mu.
+static int latent_marginals_dev(const lmm_post* P, const lmm_gp_t* gps_shard, int ms, const double* xsd, int d, int ns,
+                                double* mean_lat, double* var_lat) {
+  if (ms == 0) return LMM_OK;
+  if (P == nullptr) {
+    fork_slots(1);
+    for (int k = 0; k < ms; ++k) {
+      LatentDev gd = to_dev(gps_shard[k]);
+      launch_post_mean(xsd, ns, nullptr, 0, d, nullptr, gd, mean_lat + (size_t)k * ns, g.streams[0]);
+      // prior variance kappa(0) = variance: base - 0
+      launch_rider_var(nullptr, 0, ns, 0, gps_shard[k].variance, var_lat + (size_t)k * ns, g.streams[0]);
+    }
+    return LMM_OK;
+  }
+  if (P->d != d) return fail(LMM_ERR_DIM, "input dimension mismatch: posterior has d=%d, xs has d=%d", P->d, d);
+  const int nsr = rup(ns, 64);
+  const int nslots = std::min(ms, g.nstreams);
+  int ldr = nsr; if ((ldr % 512) == 0) ldr += 16;
+  std::vector<Buf<double>> R;
+  for (int s = 0; s < nslots; ++s) R.emplace_back((size_t)ldr * P->NC);
+  fork_slots(nslots);
+  for (int k = 0; k < ms; ++k) {
+    hipStream_t st = g.streams[k % nslots];
+    double* Rk = R[k % nslots].p;
+    const lmm_gp_t& gp = P->gps[P->l0 + k];
+    LatentDev gd = to_dev(gp);
+    launch_post_mean(xsd, ns, P->x.p, P->n, d, P->alpha[k].p, gd, mean_lat + (size_t)k * ns, st);
+    GramArgs a{};
+    a.A = Rk; a.ld = ldr; a.nrows = P->NC + nsr; a.ncols = P->NC; a.row_tile0 = P->NC / 64; a.row_shift = P->NC; a.full = 1;
+    a.x = P->x.p; a.d = d; a.n = P->n; a.kind = gp.kind; a.var = gp.variance; a.inv_ls = 1.0 / gp.lengthscale;
+    a.diag_add = 0.0; a.pad_diag = 0.0; a.xs = xsd; a.ns = ns;
+    launch_gram(a, st);
+    trsm_rec(Rk, ldr, nsr, P->L[k].p, P->ld, P->W[k].p, 0, P->NC, st);
+    launch_rider_var(Rk, ldr, ns, P->n, gp.variance, var_lat + (size_t)k * ns, st);
+  }
+  join_slots(nslots);
+  HIPCHK(hipStreamSynchronize(g.streams[0]));   // R buffers are released on return
+  return LMM_OK;
+}
+
+int lmm_latent_marginals(const lmm_post_t* post, const lmm_gp_t* gps, int m_shard, const double* xs, int d, int ns,
+                         double* mean_lat, double* var_lat) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  REQUIRE_INIT();
+  LMM_TRY
+  if (!xs || !mean_lat || !var_lat || d <= 0 || ns <= 0) return fail(LMM_ERR_ARG, "bad arguments");
+  const int ms = post ? (post->l1 - post->l0) : m_shard;
+  if (!post) { if (int rc = check_gps(gps, m_shard)) return rc; }
+  hipStream_t st0 = g.streams[0];
+  DevIn xsd(xs, (size_t)d * ns, st0);
+  DevOut mo(mean_lat, (size_t)ns * ms), vo(var_lat, (size_t)ns * ms);
+  if (int rc = latent_marginals_dev(post, gps, ms, xsd.p, d, ns, mo.p, vo.p)) return rc;
+  mo.finish(st0); vo.finish(st0);
+  HIPCHK(hipStreamSynchronize(st0));
+  return LMM_OK;
+  LMM_CATCH
+}
+
+int lmm_oilmm_mean_and_var(const lmm_post_t* post, const lmm_gp_t* gps, const double* U, const double* S, int p, int m,
+                           int latent_begin, int latent_end, double sigma2, int add_noise, const double* xs, int d,
+                           int ns, const lmm_jitters_t* jit, double* mean_out, double* var_out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  REQUIRE_INIT();
+  LMM_TRY
+  if (!U || !xs || !mean_out || !var_out || d <= 0 || ns <= 0 || p <= 0 || m <= 0) return fail(LMM_ERR_ARG, "bad arguments");
+  if (!jit) jit = &kDefaultJit;
+  int l0 = latent_begin, l1 = latent_end;
+  if (post) { l0 = post->l0; l1 = post->l1; if (post->m != m) return fail(LMM_ERR_DIM, "posterior has %d latents, H has %d", post->m, m); }
+  else if (int rc = check_gps(gps, m)) return rc;
+  if (l0 < 0 || l1 > m || l0 > l1) return fail(LMM_ERR_ARG, "bad latent shard");
+  const int ms = l1 - l0;
+  hipStream_t st0 = g.streams[0];
+  // H columns of the shard (p x ms)
+  std::vector<double> Hs((size_t)p * std::max(ms, 1), 0.0);
+  for (int k = 0; k < ms; ++k)
+    for (int o = 0; o < p; ++o) Hs[o + (size_t)k * p] = U[o + (size_t)(l0 + k) * p] * (S ? std::sqrt(S[l0 + k]) : 1.0);
+  Uploaded Hd(Hs, st0);
+  DevIn xsd(xs, (size_t)d * ns, st0);
+  Buf<double> ml((size_t)ns * std::max(ms, 1)), vl((size_t)ns * std::max(ms, 1));
+  if (int rc = latent_marginals_dev(post, post ? nullptr : gps + l0, ms, xsd.p, d, ns, ml.p, vl.p)) return rc;
+  DevOut mo(mean_out, (size_t)ns * p), vo(var_out, (size_t)ns * p);
+  // reference src/oilmm.jl:69,72: M = H M_latent;  V = abs2.(H) V_latent .+ sigma2   (V_latent carries the 1e-18 jitter)
+  launch_mix(ml.p, ns, ms, Hd.buf.p, p, 1, 0.0, 0.0, nullptr, 0.0, mo.p, st0);
+  launch_mix(vl.p, ns, ms, Hd.buf.p, p, 2, jit->default_jitter, add_noise ? sigma2 : 0.0, nullptr, 0.0, vo.p, st0);
+  mo.finish(st0); vo.finish(st0);
+  HIPCHK(hipStreamSynchronize(st0));
+  return LMM_OK;
+  LMM_CATCH
+}
+
+// Per-latent posterior (or prior) covariance at xs as a factor matrix B (NRs x NCs): gram(xs) + diag_add
+// - R R' (posterior), rider row = rider_vec.  Factorises it.  Caller holds g_mu.  st: stream.
+static void build_and_factor_at_xs(const lmm_post* P, int k, const lmm_gp_t& gp, const double* xsd, int d, int ns,
+                                   double diag_add, const double* rider_vec, const Dims& Ds, double* B, double* WB,
+                                   double* Rk, int ldr, int nsr, int* info, hipStream_t st) {
+  GramArgs a{};
+  a.A = B; a.ld = Ds.ld; a.nrows = Ds.NR; a.ncols = Ds.NC; a.x = xsd; a.d = d; a.n = ns;
+  a.kind = gp.kind; a.var = gp.variance; a.inv_ls = 1.0 / gp.lengthscale; a.diag_add = diag_add; a.pad_diag = 1.0;
+  a.rider = rider_vec; a.rider_ld = ns; a.nrider = rider_vec ? 1 : 0;
+  launch_gram(a, st);
+  if (P != nullptr) {
+    GramArgs r{};
+    r.A = Rk; r.ld = ldr; r.nrows = P->NC + nsr; r.ncols = P->NC; r.row_tile0 = P->NC / 64; r.row_shift = P->NC; r.full = 1;
+    r.x = P->x.p; r.d = d; r.n = P->n; r.kind = gp.kind; r.var = gp.variance; r.inv_ls = 1.0 / gp.lengthscale;
+    r.xs = xsd; r.ns = ns;
+    launch_gram(r, st);
+    trsm_rec(Rk, ldr, nsr, P->L[k].p, P->ld, P->W[k].p, 0, P->NC, st);
+    // Schur complement on the leading NCs x NCs block (rows of R beyond ns are zero)
+    launch_gemm_nt(B, Ds.ld, Rk, ldr, Rk, ldr, Ds.NC, Ds.NC, P->NC, 1, false, st);
+  }
+  potrf_rec(B, Ds.ld, Ds.NR, 0, Ds.NC, WB, ns, info, st);
+}
+
+int lmm_oilmm_post_logpdf(const lmm_post_t* post, const double* U, const double* S, int p, int m, double sigma2,
+                          const double* xs, int d, int ns, const double* ys, int with_regulariser, double* out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  REQUIRE_INIT();
+  LMM_TRY
+  if (!post || !U || !S || !xs || !ys || !out || d <= 0 || ns <= 0) return fail(LMM_ERR_ARG, "bad arguments");
+  const lmm_post* P = post;
+  if (P->m != m) return fail(LMM_ERR_DIM, "posterior has %d latents, H has %d", P->m, m);
+  if (P->d != d) return fail(LMM_ERR_DIM, "input dimension mismatch");
+  hipStream_t st0 = g.streams[0];
+  const int l0 = P->l0, l1 = P->l1, ms = l1 - l0;
+  std::vector<double> T, ST, H;
+  project_orthogonal(U, S, p, m, sigma2, T, ST, H);
+  DevIn xsd(xs, (size_t)d * ns, st0), ysd(ys, (size_t)ns * p, st0);
+  Uploaded Td(T, st0);
+  const int C = with_regulariser ? m : ms, c0 = with_regulariser ? 0 : l0;
+  Buf<double> Ty((size_t)ns * std::max(C, 1)), resid_dev(1);
+  double resid = 0.0;
+  if (C > 0) project_on_device(ysd.p, ns, p, Td.buf, m, c0, C, nullptr, Ty.p, st0);
+  if (with_regulariser) {
+    Uploaded Hd(H, st0);
+    Buf<double> partial(tall_skinny_partials(ns, p));
+    residual_on_device(ysd.p, ns, p, Ty.p, m, Hd.buf, partial.p, resid_dev.p, st0);
+    HIPCHK(hipMemcpyAsync(&resid, resid_dev.p, sizeof(double), hipMemcpyDeviceToHost, st0));
+    HIPCHK(hipStreamSynchronize(st0));
+  }
+  const double* Ty_shard = Ty.p + (size_t)(l0 - c0) * ns;
+  Dims Ds(ns, 1);
+  const int nsr = rup(ns, 64);
+  int ldr = nsr; if ((ldr % 512) == 0) ldr += 16;
+  const int nslots = std::max(1, std::min(ms, g.nstreams));
+  std::vector<Buf<double>> Bm, WB, R, dl, mu;
+  for (int s = 0; s < nslots; ++s) {
+    Bm.emplace_back(Ds.elems()); WB.emplace_back((size_t)(Ds.NC / 64) * 4096); R.emplace_back((size_t)ldr * P->NC);
+    dl.emplace_back((size_t)ns); mu.emplace_back((size_t)ns);
+  }
+  Buf<double> outd(std::max(ms, 1));
+  Buf<int> info(std::max(ms, 1));
+  HIPCHK(hipMemsetAsync(info.p, 0, std::max(ms, 1) * sizeof(int), st0));
+  fork_slots(nslots);
+  for (int k = 0; k < ms; ++k) {
+    const int s = k % nslots;
+    hipStream_t st = g.streams[s];
+    const lmm_gp_t& gp = P->gps[l0 + k];
+    launch_post_mean(xsd.p, ns, P->x.p, P->n, d, P->alpha[k].p, to_dev(gp), mu[s].p, st);
+    launch_vec_lin(Ty_shard + (size_t)k * ns, mu[s].p, -1.0, ns, dl[s].p, st);
+    build_and_factor_at_xs(P, k, gp, xsd.p, d, ns, ST[l0 + k], dl[s].p, Ds, Bm[s].p, WB[s].p, R[s].p, ldr, nsr,
+                           info.p + k, st);
+    launch_lml_reduce(Bm[s].p, Ds.ld, ns, Ds.NC, 1, outd.p + k, st);
+  }
+  join_slots(nslots);
+  std::vector<double> lml(std::max(ms, 1), 0.0);
+  std::vector<int> hinfo(std::max(ms, 1), 0);
+  HIPCHK(hipMemcpyAsync(lml.data(), outd.p, std::max(ms, 1) * sizeof(double), hipMemcpyDeviceToHost, st0));
+  HIPCHK(hipMemcpyAsync(hinfo.data(), info.p, std::max(ms, 1) * sizeof(int), hipMemcpyDeviceToHost, st0));
+  HIPCHK(hipStreamSynchronize(st0));
+  if (int rc = check_info(hinfo, l0)) return rc;
+  double total = 0.0;
+  for (int k = 0; k < ms; ++k) total += lml[k];
+  if (with_regulariser) {
+    double logdetS = 0.0;
+    for (int l = 0; l < m; ++l) logdetS += std::log(S[l]);
+    total += -((double)ns * (logdetS + (double)(p - m) * std::log(2.0 * M_PI * sigma2)) + resid / sigma2) / 2.0;
+  }
+  *out = total;
+  return LMM_OK;
+  LMM_CATCH
+}
+
+int lmm_lmm_rand(const lmm_post_t* post, const lmm_gp_t* gps, const double* U, const double* S, int p, int m,
+                 int latent_begin, int latent_end, double sigma2, int add_noise, const double* xs, int d, int ns,
+                 const double* z_lat, const double* eps, const lmm_jitters_t* jit, double* out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  REQUIRE_INIT();
+  LMM_TRY
+  if (!U || !xs || !z_lat || !out || d <= 0 || ns <= 0 || p <= 0 || m <= 0) return fail(LMM_ERR_ARG, "bad arguments");
+  if (add_noise && !eps) return fail(LMM_ERR_ARG, "eps is NULL");
+  if (!jit) jit = &kDefaultJit;
+  const lmm_post* P = post;
+  int l0 = latent_begin, l1 = latent_end;
+  if (P) { l0 = P->l0; l1 = P->l1; if (P->m != m) return fail(LMM_ERR_DIM, "posterior has %d latents, H has %d", P->m, m); }
+  else if (int rc = check_gps(gps, m)) return rc;
+  if (l0 < 0 || l1 > m || l0 > l1) return fail(LMM_ERR_ARG, "bad latent shard");
+  const int ms = l1 - l0;
+  // OILMM: f(x) default jitter 1e-18 (reference src/oilmm.jl:47); dense-H ILMM: 1e-12 (src/ilmm.jl:84)
+  const double jitter = S ? jit->default_jitter : jit->ilmm_rand_jitter;
+  hipStream_t st0 = g.streams[0];
+  std::vector<double> Hs((size_t)p * std::max(ms, 1), 0.0);
+  for (int k = 0; k < ms; ++k)
+    for (int o = 0; o < p; ++o) Hs[o + (size_t)k * p] = U[o + (size_t)(l0 + k) * p] * (S ? std::sqrt(S[l0 + k]) : 1.0);
+  Uploaded Hd(Hs, st0);
+  DevIn xsd(xs, (size_t)d * ns, st0), zd(z_lat + (size_t)l0 * ns, (size_t)ns * std::max(ms, 1), st0);
+  DevIn epsd(add_noise ? eps : nullptr, (size_t)ns * p, st0);
+  Dims Ds(ns, 0);
+  const int nsr = rup(ns, 64);
+  int ldr = nsr; if ((ldr % 512) == 0) ldr += 16;
+  const int nslots = std::max(1, std::min(ms, g.nstreams));
+  std::vector<Buf<double>> Bm, WB, R, mu, part;
+  for (int s = 0; s < nslots; ++s) {
+    Bm.emplace_back(Ds.elems()); WB.emplace_back((size_t)(Ds.NC / 64) * 4096);
+    R.emplace_back(P ? (size_t)ldr * P->NC : 1); mu.emplace_back((size_t)ns);
+    part.emplace_back((size_t)ns * trmv_chunks(ns));
+  }
+  Buf<double> X((size_t)ns * std::max(ms, 1));
+  Buf<int> info(std::max(ms, 1));
+  HIPCHK(hipMemsetAsync(info.p, 0, std::max(ms, 1) * sizeof(int), st0));
+  fork_slots(nslots);
+  for (int k = 0; k < ms; ++k) {
+    const int s = k % nslots;
+    hipStream_t st = g.streams[s];
+    const lmm_gp_t& gp = P ? P->gps[l0 + k] : gps[l0 + k];
+    build_and_factor_at_xs(P, k, gp, xsd.p, d, ns, jitter, nullptr, Ds, Bm[s].p, WB[s].p, R[s].p, ldr, nsr, info.p + k, st);
+    double mu_const = gp.mean;
+    if (P) {   // posterior mean vector: sample = mean(xs) + L z
+      launch_post_mean(xsd.p, ns, P->x.p, P->n, d, P->alpha[k].p, to_dev(gp), mu[s].p, st);
+      mu_const = 0.0;
+    }
+    launch_trmv_lower(Bm[s].p, Ds.ld, ns, zd.p + (size_t)k * ns, mu_const, part[s].p, X.p + (size_t)k * ns, st);
+    if (P) launch_vec_lin(X.p + (size_t)k * ns, mu[s].p, 1.0, ns, X.p + (size_t)k * ns, st);
+  }
+  join_slots(nslots);
+  DevOut od(out, (size_t)ns * p);
+  // reference src/oilmm.jl:50-53 / src/ilmm.jl:86: F = vec((H X')') + sqrt(sigma2) eps
+  launch_mix(X.p, ns, ms, Hd.buf.p, p, 1, 0.0, 0.0, add_noise ? epsd.p : nullptr, std::sqrt(sigma2), od.p, st0);
+  od.finish(st0);
+  std::vector<int> hinfo(std::max(ms, 1), 0);
+  HIPCHK(hipMemcpyAsync(hinfo.data(), info.p, std::max(ms, 1) * sizeof(int), hipMemcpyDeviceToHost, st0));
+  HIPCHK(hipStreamSynchronize(st0));
+  return check_info(hinfo, l0);
+  LMM_CATCH
+}
+
+// ------------------------------------------------------------------------------------------------
+// building blocks (device pointers) for tests / profiling
+// ------------------------------------------------------------------------------------------------
+int lmm_dev_potrf(double* A, int nrows, int ncols, int ld, double* Winv, int n_real, int* info_dev) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  REQUIRE_INIT();
+  LMM_TRY
+  if (!A || !Winv || !info_dev || nrows % 64 || ncols % 64 || nrows < ncols || ld < nrows || (ld & 1))
+    return fail(LMM_ERR_ARG, "bad arguments");
+  potrf_rec(A, ld, nrows, 0, ncols, Winv, n_real, info_dev, g.streams[0]);
+  HIPCHK(hipStreamSynchronize(g.streams[0]));
+  return LMM_OK;
+  LMM_CATCH
+}
+
+int lmm_dev_gemm_nt_sub(double* C, int ldc, const double* A, int lda, const double* B, int ldb, int M, int N, int K,
+                        int lower) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  REQUIRE_INIT();
+  LMM_TRY
+  if (!C || !A || !B || M % 64 || N % 64 || K % 16 || (ldc & 1) || (lda & 1) || (ldb & 1)) return fail(LMM_ERR_ARG, "bad arguments");
+  launch_gemm_nt(C, ldc, A, lda, B, ldb, M, N, K, lower, false, g.streams[0]);
+  HIPCHK(hipStreamSynchronize(g.streams[0]));
+  return LMM_OK;
+  LMM_CATCH
+}
+
+int lmm_dev_gram(double* A, int ld, int nrows, int ncols, const double* x, int d, int n, const lmm_gp_t* gp,
+                 double diag_add) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  REQUIRE_INIT();
+  LMM_TRY
+  if (!A || !x || !gp || nrows % 64 || ncols % 64 || (ld & 1) || ld < nrows) return fail(LMM_ERR_ARG, "bad arguments");
+  GramArgs a{};
+  a.A = A; a.ld = ld; a.nrows = nrows; a.ncols = ncols; a.x = x; a.d = d; a.n = n;
+  a.kind = gp->kind; a.var = gp->variance; a.inv_ls = 1.0 / gp->lengthscale; a.diag_add = diag_add; a.pad_diag = 1.0;
+  launch_gram(a, g.streams[0]);
+  HIPCHK(hipStreamSynchronize(g.streams[0]));
+  return LMM_OK;
+  LMM_CATCH
+}
+
+int lmm_dev_mfma_f64_peak(double* tflops) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  REQUIRE_INIT();
+  LMM_TRY
+  const int blocks = 256 * 4, iters = 20000;
+  Buf<double> out((size_t)blocks * 256);
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  launch_mfma_peak(out.p, blocks, 100, g.streams[0]);
+  HIPCHK(hipEventRecord(e0, g.streams[0]));
+  launch_mfma_peak(out.p, blocks, iters, g.streams[0]);
+  HIPCHK(hipEventRecord(e1, g.streams[0]));
+  HIPCHK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  const double flops = (double)blocks * 4 /*waves*/ * iters * 8.0 * 2048.0;
+  *tflops = flops / (ms * 1e-3) / 1e12;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return LMM_OK;
+  LMM_CATCH
+}
+
+}  // extern "C"

@@ -1,0 +1,54 @@
+// lmm_internal.h -- shared between lmm_kernels.hip (device) and lmm_api.hip (host orchestration).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/lmm_hip.h"
+
+struct LatentDev {
+  int kind;
+  double var, inv_ls, mean;
+};
+
+// Gram / factor-matrix assembly arguments (see gram_kernel).
+struct GramArgs {
+  double* A;            // factor matrix base (row 0 = matrix row `row_shift`)
+  int ld, nrows, ncols; // nrows = rows covered by the launch (multiple of 64), ncols multiple of 64
+  int row_tile0;        // first 64-row tile of the launch (rider-only launches start at ncols/64)
+  int row_shift;        // row index stored at A[0]
+  int full;             // 1: no lower-triangle skip (rectangular rider matrix)
+  const double* x; int d, n;
+  int kind; double var, inv_ls, diag_add, pad_diag;
+  const double* rider; int rider_ld, nrider;   // rows ncols + r  <- rider[r*rider_ld + j]
+  const double* xs; int ns;                    // rows ncols + r  <- kappa(xs_r, x_j)
+};
+
+struct DenseArgs {
+  double* A; int ld, nrows, ncols;
+  const double* x; int d, n, m;
+  const LatentDev* lat;      // device, m entries
+  const double* sigmaT;      // device, m x m column-major
+  const double* rider; int rider_ld, nrider;
+};
+
+void launch_gram(const GramArgs& a, hipStream_t st);
+void launch_dense_assemble(const DenseArgs& a, hipStream_t st);
+void launch_diag64(double* Ablk, int ld, double* Wblk, int gcol0, int n_real, int* info, hipStream_t st);
+void launch_gemm_nt(double* C, int ldc, const double* A, int lda, const double* B, int ldb, int M, int N, int K,
+                    int lower, bool set, hipStream_t st);
+void launch_lml_reduce(const double* A, int ld, int n, int rider_row0, int nrhs, double* out, hipStream_t st);
+void launch_extract_row(const double* A, int ld, int row, int n, double* out, hipStream_t st);
+void launch_rider_var(const double* R, int ld, int nr, int n, double base, double* out, hipStream_t st);
+void launch_backsolve(const double* L, int ld, const double* W, int nblk, double* z, hipStream_t st);
+void launch_tall_skinny(const double* In, int ldi, int n, int K, const double* Mx, int ldm, int C, double* Out, int ldo,
+                        const double* sub, const double* Ref, int ldr, double* partial, int mode, hipStream_t st);
+int tall_skinny_partials(int n, int C);
+void launch_sum_partials(const double* partial, int count, double* out, hipStream_t st);
+void launch_post_mean(const double* xs, int ns, const double* x, int n, int d, const double* alpha, LatentDev g,
+                      double* out, hipStream_t st);
+void launch_mix(const double* lat, int ns, int ml, const double* Hm, int p, int pw, double lat_add, double out_add,
+                const double* eps, double eps_scale, double* out, hipStream_t st);
+int trmv_chunks(int n);
+void launch_trmv_lower(const double* L, int ld, int n, const double* z, double mu, double* partial, double* out,
+                       hipStream_t st);
+void launch_add_diag(double* A, int ld, int n, double v, hipStream_t st);
+void launch_vec_lin(const double* a, const double* b, double sb, int n, double* out, hipStream_t st);  // out = a + sb*b
+void launch_mfma_peak(double* out, int blocks, int iters, hipStream_t st);

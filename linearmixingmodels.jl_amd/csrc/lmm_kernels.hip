@@ -1,0 +1,729 @@
+// lmm_kernels.hip -- CDNA4 (gfx950) device kernels for the ILMM/OILMM inference hot path.
+//
+// Everything is Float64 and column-major.  A latent's "factor matrix" is an NR x NC panel (leading
+// dimension ld) whose first n columns hold the lower triangle of K_l + noise*I, columns n..NC-1 are an
+// identity pad (NC = roundup(n, 64)), and rows >= NC are "rider" rows: right-hand sides (delta, or
+// cross-Gram rows K(x*, x)) that ride along the factorisation and come out as  rider * L^-T, i.e. the
+// forward-substituted vectors  (L^-1 delta)'  -- the triangular solve costs no extra kernel.
+//
+// Kernels:
+//   K1 gram_kernel / ilmm_dense_assemble_kernel   HBM-write bound   (A17, A6, A7)
+//   K2 diag64_kernel + gemm_nt_kernel<.., SET> (TRSM by inverse) + gemm_nt_kernel<.., SUB>
+//      (v_mfma_f64_16x16x4_f64 SYRK/GEMM trailing update)        MFMA-f64 bound (A6, A7, A10, A11, A14)
+//   K3/K6 lml_reduce_kernel (logdet + quadratic form, wavefront shuffles), backsolve_step_kernel
+//   K4/K5 tall_skinny_kernel (T*Y projection, H*T*Y residual norm), mix_kernel (H unprojection)
+//   K7 trmv_lower_kernel (sample transform), axpy noise
+#include <hip/hip_runtime.h>
+#include "lmm_internal.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+#define LOG2PI 1.8378770664093453
+
+// ---------------------------------------------------------------------------------------------------
+// math helpers
+// ---------------------------------------------------------------------------------------------------
+// exp(x) for x <= 0, Float64, < 1 ulp-ish: Cody-Waite reduction + degree-13 Taylor on |r| <= ln2/2
+// (truncation 4e-18) + v_ldexp_f64 (handles the subnormal tail; exp(-inf) -> 0).
+__device__ __forceinline__ double exp_nonpos(double x) {
+  x = fmax(x, -800.0);
+  const double k = __builtin_rint(x * 1.4426950408889634);
+  double r = __builtin_fma(-k, 6.93147180369123816490e-01, x);
+  r = __builtin_fma(-k, 1.90821492927058770002e-10, r);
+  double p = 1.6059043836821613e-10;            // 1/13!
+  p = __builtin_fma(p, r, 2.08767569878681e-09);    // 1/12!
+  p = __builtin_fma(p, r, 2.505210838544172e-08);   // 1/11!
+  p = __builtin_fma(p, r, 2.755731922398589e-07);   // 1/10!
+  p = __builtin_fma(p, r, 2.7557319223985893e-06);  // 1/9!
+  p = __builtin_fma(p, r, 2.48015873015873e-05);    // 1/8!
+  p = __builtin_fma(p, r, 1.984126984126984e-04);   // 1/7!
+  p = __builtin_fma(p, r, 1.388888888888889e-03);   // 1/6!
+  p = __builtin_fma(p, r, 8.333333333333333e-03);   // 1/5!
+  p = __builtin_fma(p, r, 4.1666666666666664e-02);  // 1/4!
+  p = __builtin_fma(p, r, 1.6666666666666666e-01);  // 1/3!
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  return __builtin_ldexp(p, (int)k);
+}
+
+// kappa(r) of KernelFunctions' SEKernel / Matern32Kernel / Matern52Kernel,
+// r = |x - x'| / lengthscale, r2 = r^2.
+__device__ __forceinline__ double kappa(int kind, double var, double r, double r2) {
+  if (kind == LMM_KERNEL_SE) return var * exp_nonpos(-0.5 * r2);
+  if (kind == LMM_KERNEL_MATERN32) {
+    const double s = 1.7320508075688772 * r;
+    return var * (1.0 + s) * exp_nonpos(-s);
+  }
+  const double s = 2.23606797749979 * r;
+  return var * (1.0 + s + (5.0 / 3.0) * r2) * exp_nonpos(-s);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// Block-wide sum for 256-thread blocks; result valid in thread 0.
+__device__ __forceinline__ double block_sum_256(double v, double* sh4) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) sh4[w] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0) r = sh4[0] + sh4[1] + sh4[2] + sh4[3];
+  __syncthreads();
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K1: Gram assembly (lower triangle of K + diag_add*I, identity pad, rider rows).  HBM-write bound:
+// each thread produces two consecutive rows (one 16-byte store) for 8 columns of a 64x64 tile.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double scaled_dist2(const double* __restrict__ a, const double* __restrict__ b,
+                                               int d, double inv_ls) {
+  double s = 0.0;
+  for (int k = 0; k < d; ++k) {
+    const double t = (a[k] - b[k]) * inv_ls;
+    s = __builtin_fma(t, t, s);
+  }
+  return s;
+}
+
+__global__ __launch_bounds__(256) void gram_kernel(GramArgs a) {
+  const int ti = blockIdx.x + a.row_tile0, tj = blockIdx.y;
+  if (!a.full && ti < tj) return;                          // lower tiles only
+  const int t = threadIdx.x;
+  const int i0 = ti * 64 + 2 * (t & 31);
+  const int cg = t >> 5;
+  // Classify the two rows this thread owns (constant over the column loop).
+  // type 0: data point of x; 1: zero row (pad); 2: rider from buffer; 3: cross-Gram row of xs.
+  int rtype[2];
+  const double* rpt[2];
+  double rx[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int i = i0 + e;
+    rtype[e] = 1; rpt[e] = nullptr; rx[e] = 0.0;
+    if (i < a.n) { rtype[e] = 0; rpt[e] = a.x + (size_t)i * a.d; }
+    else if (i >= a.ncols) {
+      const int r = i - a.ncols;
+      if (a.xs != nullptr && r < a.ns) { rtype[e] = 3; rpt[e] = a.xs + (size_t)r * a.d; }
+      else if (a.rider != nullptr && r < a.nrider) { rtype[e] = 2; rpt[e] = a.rider + (size_t)r * a.rider_ld; }
+    }
+    if ((rtype[e] == 0 || rtype[e] == 3) && a.d == 1) rx[e] = rpt[e][0];
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int j = tj * 64 + cg + 8 * q;
+    d2 v;
+    if (j >= a.n) {                                        // identity pad column
+      v.x = (i0 == j) ? a.pad_diag : 0.0;
+      v.y = (i0 + 1 == j) ? a.pad_diag : 0.0;
+    } else {
+      double xj = 0.0;
+      if (a.d == 1) xj = a.x[j];
+      double out[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        double val = 0.0;
+        if (rtype[e] == 0 || rtype[e] == 3) {
+          double r, r2;
+          if (a.d == 1) { r = fabs(rx[e] - xj) * a.inv_ls; r2 = r * r; }
+          else { r2 = scaled_dist2(rpt[e], a.x + (size_t)j * a.d, a.d, a.inv_ls); r = sqrt(r2); }
+          val = kappa(a.kind, a.var, r, r2);
+          if (rtype[e] == 0 && i0 + e == j) val += a.diag_add;
+        } else if (rtype[e] == 2) {
+          val = rpt[e][j];
+        }
+        out[e] = val;
+      }
+      v.x = out[0]; v.y = out[1];
+    }
+    *reinterpret_cast<d2*>(a.A + (size_t)j * a.ld + (i0 - a.row_shift)) = v;
+  }
+}
+
+// K8: dense ILMM latent covariance  blockdiag(K_1..K_m) + SigmaT (x) I_n  (+ mean-free rider row):
+// element (i, j), i = li*n + ii, j = lj*n + jj  ->  [li == lj] kappa_li(x_ii, x_jj) + [ii == jj] SigmaT[li, lj].
+// Reference: src/ilmm.jl:160 kron(SigmaT, I) + src/independent_mogp.jl:60-63 BlockDiagonal.
+__global__ __launch_bounds__(256) void ilmm_dense_assemble_kernel(DenseArgs a) {
+  const int ti = blockIdx.x, tj = blockIdx.y;
+  if (ti < tj) return;
+  const int t = threadIdx.x;
+  const int i0 = ti * 64 + 2 * (t & 31);
+  const int cg = t >> 5;
+  const int N = a.m * a.n;
+  int li[2], ii[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) { li[e] = (i0 + e) / a.n; ii[e] = (i0 + e) - li[e] * a.n; }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int j = tj * 64 + cg + 8 * q;
+    double out[2] = {0.0, 0.0};
+    if (j >= N) {
+      out[0] = (i0 == j) ? 1.0 : 0.0;
+      out[1] = (i0 + 1 == j) ? 1.0 : 0.0;
+    } else {
+      const int lj = j / a.n, jj = j - lj * a.n;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int i = i0 + e;
+        double val = 0.0;
+        if (i < N) {
+          if (li[e] == lj) {
+            const LatentDev g = a.lat[lj];
+            double r, r2;
+            if (a.d == 1) { r = fabs(a.x[ii[e]] - a.x[jj]) * g.inv_ls; r2 = r * r; }
+            else { r2 = scaled_dist2(a.x + (size_t)ii[e] * a.d, a.x + (size_t)jj * a.d, a.d, g.inv_ls); r = sqrt(r2); }
+            val = kappa(g.kind, g.var, r, r2);
+          }
+          if (ii[e] == jj) val += a.sigmaT[li[e] + lj * a.m];
+        } else if (i >= a.ncols) {
+          const int r = i - a.ncols;
+          if (a.rider != nullptr && r < a.nrider) val = a.rider[(size_t)r * a.rider_ld + j];
+        }
+        out[e] = val;
+      }
+    }
+    d2 v; v.x = out[0]; v.y = out[1];
+    *reinterpret_cast<d2*>(a.A + (size_t)j * a.ld + i0) = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K2a: 64x64 diagonal block: Cholesky factor L and its inverse W = L^-1 in one symmetric Gaussian
+// elimination of [A | I] held in LDS (one barrier per pivot).  One workgroup, latency bound.
+//   after eliminating column j with multipliers A_ij/d_j:  [A | I] -> [D L1' | L1^-1];
+//   L = L1 D^1/2,  W = D^-1/2 L1^-1.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void diag64_kernel(double* __restrict__ A, int ld, double* __restrict__ W,
+                                                     int gcol0, int n_real, int* __restrict__ info) {
+  constexpr int S = 65;
+  __shared__ double z[128 * S];
+  const int t = threadIdx.x;
+  for (int idx = t; idx < 64 * 64; idx += 256) {
+    const int r = idx & 63, c = idx >> 6;
+    z[c * S + r] = (r >= c) ? A[(size_t)c * ld + r] : 0.0;
+    z[(64 + c) * S + r] = (r == c) ? 1.0 : 0.0;
+  }
+  const int i = t & 63, cs = t >> 6;
+  for (int j = 0; j < 63; ++j) {
+    __syncthreads();
+    const double dj = z[j * S + j];
+    if (t == 0 && !(dj > 0.0) && gcol0 + j < n_real) atomicCAS(info, 0, gcol0 + j + 1);
+    if (i > j) {
+      const double mult = z[j * S + i] / dj;
+      const int ns = 63 - j;                                // S-part columns j+1..63, then W-part 0..j
+      for (int s = cs; s < 64; s += 4) {
+        if (s < ns) {
+          const int k = j + 1 + s;
+          if (i >= k) z[k * S + i] -= mult * z[j * S + k];
+        } else {
+          const int c = s - ns;
+          z[(64 + c) * S + i] -= mult * z[(64 + c) * S + j];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (t == 0) {
+    const double dl = z[63 * S + 63];
+    if (!(dl > 0.0) && gcol0 + 63 < n_real) atomicCAS(info, 0, gcol0 + 64);
+  }
+  for (int idx = t; idx < 64 * 64; idx += 256) {
+    const int r = idx & 63, c = idx >> 6;
+    double w = 0.0;
+    if (r >= c) {
+      const double dc = z[c * S + c];
+      const double lc = sqrt(dc);
+      A[(size_t)c * ld + r] = (r == c) ? lc : z[c * S + r] / lc;
+      w = z[(64 + c) * S + r] / sqrt(z[r * S + r]);
+    }
+    W[c * 64 + r] = w;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K2b: C (M x N) {-=, =} A (M x K) * B (N x K)^T  on v_mfma_f64_16x16x4_f64.
+//   128 x BN block tile, 4 waves (2 x 2), wave tile 64 x BN/2 = (4 x BN/32) MFMA 16x16 tiles,
+//   BK = 16 k-columns per LDS stage, two LDS stages, one barrier per stage.
+//   LDS image is k-major ([k][row], row stride BM+16 doubles): a k-column of the tile is one contiguous
+//   1-KiB global segment (coalesced 16-B loads) and the MFMA operand read (lane l: row l&15, k l>>4) is
+//   one conflict-free ds_read_b64.
+//   MFMA A-operand <- B tile (C's column index), MFMA B-operand <- A tile (C's row index), so lane&15 of
+//   the f64 C/D map (col = lane&15, row = (lane>>4) + 4*reg) runs along C's contiguous rows.
+//   M, N multiples of 64; K multiple of 16.  lower != 0: tiles strictly above the diagonal of the
+//   (common-origin) region are skipped (SYRK on the lower triangle).
+// ---------------------------------------------------------------------------------------------------
+template <int BN, bool SET>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(double* C, int ldc,
+                                                          const double* A, int lda,
+                                                          const double* __restrict__ B, int ldb,
+                                                          int M, int N, int K, int lower) {
+  constexpr int BM = 128, BK = 16;
+  constexpr int WN = BN / 2;
+  constexpr int TM = 4, TN = WN / 16;
+  constexpr int SA = BM + 16, SB = BN + 16;
+  constexpr int NLA = (BM * BK / 2) / 256;     // 16-byte loads per thread for the A tile (4)
+  constexpr int NLB = (BN * BK / 2) / 256;     // (4 or 2)
+  __shared__ double As[2][BK * SA];
+  __shared__ double Bs[2][BK * SB];
+
+  const int bm = blockIdx.x * BM, bn = blockIdx.y * BN;
+  if (lower && bm + BM - 1 < bn) return;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int wr = (w & 1) * 64, wc = (w >> 1) * WN;
+  const bool active = (bm + wr < M) && (bn + wc < N) && !(lower && bm + wr + 63 < bn + wc);
+
+  // global -> register staging addresses (clamped: out-of-range rows re-read valid memory, unused)
+  const double* ga[NLA];
+  const double* gb[NLB];
+  int sa[NLA], sb[NLB];
+#pragma unroll
+  for (int q = 0; q < NLA; ++q) {
+    const int u = t + 256 * q, rp = u % (BM / 2), k = u / (BM / 2);
+    int row = bm + 2 * rp; if (row > M - 2) row = M - 2;
+    ga[q] = A + (size_t)k * lda + row;
+    sa[q] = k * SA + 2 * rp;
+  }
+#pragma unroll
+  for (int q = 0; q < NLB; ++q) {
+    const int u = t + 256 * q, rp = u % (BN / 2), k = u / (BN / 2);
+    int row = bn + 2 * rp; if (row > N - 2) row = N - 2;
+    gb[q] = B + (size_t)k * ldb + row;
+    sb[q] = k * SB + 2 * rp;
+  }
+  d2 ra[NLA], rb[NLB];
+#pragma unroll
+  for (int q = 0; q < NLA; ++q) ra[q] = *reinterpret_cast<const d2*>(ga[q]);
+#pragma unroll
+  for (int q = 0; q < NLB; ++q) rb[q] = *reinterpret_cast<const d2*>(gb[q]);
+#pragma unroll
+  for (int q = 0; q < NLA; ++q) *reinterpret_cast<d2*>(&As[0][sa[q]]) = ra[q];
+#pragma unroll
+  for (int q = 0; q < NLB; ++q) *reinterpret_cast<d2*>(&Bs[0][sb[q]]) = rb[q];
+  __syncthreads();
+
+  d4 acc[TN][TM];
+#pragma unroll
+  for (int jj = 0; jj < TN; ++jj)
+#pragma unroll
+    for (int ii = 0; ii < TM; ++ii) acc[jj][ii] = (d4){0.0, 0.0, 0.0, 0.0};
+
+  const int nk = K / BK;
+  const int fr = lane & 15, fk = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) {
+      const size_t offa = (size_t)(kt + 1) * BK * lda, offb = (size_t)(kt + 1) * BK * ldb;
+#pragma unroll
+      for (int q = 0; q < NLA; ++q) ra[q] = *reinterpret_cast<const d2*>(ga[q] + offa);
+#pragma unroll
+      for (int q = 0; q < NLB; ++q) rb[q] = *reinterpret_cast<const d2*>(gb[q] + offb);
+    }
+    if (active) {
+      const double* as = &As[buf][0];
+      const double* bs = &Bs[buf][0];
+#pragma unroll
+      for (int s = 0; s < BK / 4; ++s) {
+        double fa[TN], fb[TM];
+#pragma unroll
+        for (int jj = 0; jj < TN; ++jj) fa[jj] = bs[(4 * s + fk) * SB + wc + jj * 16 + fr];
+#pragma unroll
+        for (int ii = 0; ii < TM; ++ii) fb[ii] = as[(4 * s + fk) * SA + wr + ii * 16 + fr];
+#pragma unroll
+        for (int jj = 0; jj < TN; ++jj)
+#pragma unroll
+          for (int ii = 0; ii < TM; ++ii)
+            acc[jj][ii] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[jj], fb[ii], acc[jj][ii], 0, 0, 0);
+      }
+    }
+    if (kt + 1 < nk) {
+#pragma unroll
+      for (int q = 0; q < NLA; ++q) *reinterpret_cast<d2*>(&As[buf ^ 1][sa[q]]) = ra[q];
+#pragma unroll
+      for (int q = 0; q < NLB; ++q) *reinterpret_cast<d2*>(&Bs[buf ^ 1][sb[q]]) = rb[q];
+    }
+    __syncthreads();
+  }
+
+  if (!active) return;
+  // epilogue: lane holds C[row = ii*16 + (lane&15), col = jj*16 + (lane>>4) + 4*reg]
+#pragma unroll
+  for (int jj = 0; jj < TN; ++jj) {
+#pragma unroll
+    for (int ii = 0; ii < TM; ++ii) {
+      const int row = bm + wr + ii * 16 + fr;
+      const int col0 = bn + wc + jj * 16 + fk;
+      if (lower && (bm + wr + ii * 16 + 15 < bn + wc + jj * 16)) continue;   // 16x16 tile above diagonal
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double* p = C + (size_t)(col0 + 4 * r) * ldc + row;
+        if (SET) *p = acc[jj][ii][r];
+        else *p -= acc[jj][ii][r];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K3/K6: per-latent log marginal likelihood from the factor:  -(n log 2pi + 2 sum log L_kk + |z|^2)/2,
+// z = rider row `rider_row` (= (L^-1 delta)').  One workgroup; wavefront shuffle reductions.
+// Also used with nrhs > 1 riders (matrix-Y): out[r].
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lml_reduce_kernel(const double* __restrict__ A, int ld, int n,
+                                                         int rider_row0, int nrhs, double* __restrict__ out) {
+  __shared__ double sh[4];
+  double sl = 0.0;
+  for (int k = threadIdx.x; k < n; k += 256) sl += log(A[(size_t)k * ld + k]);
+  const double sumlog = block_sum_256(sl, sh);
+  __shared__ double bc;
+  if (threadIdx.x == 0) bc = sumlog;
+  __syncthreads();
+  for (int r = 0; r < nrhs; ++r) {
+    double q = 0.0;
+    for (int k = threadIdx.x; k < n; k += 256) {
+      const double v = A[(size_t)k * ld + rider_row0 + r];
+      q = __builtin_fma(v, v, q);
+    }
+    const double quad = block_sum_256(q, sh);
+    if (threadIdx.x == 0) out[r] = -0.5 * ((double)n * LOG2PI + 2.0 * bc + quad);
+  }
+}
+
+// Extract rider row r (length n) of a factor matrix into a contiguous vector.
+__global__ void extract_row_kernel(const double* __restrict__ A, int ld, int row, int n, double* __restrict__ out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) out[k] = A[(size_t)k * ld + row];
+}
+
+// Column sum of squares over a rider block: out[r] = base[r] - sum_k R[r + k*ld]^2  (posterior variance:
+// k(x*,x*) - colsumsq(C.U' \ K(x,x*)); AbstractGPs PosteriorGP var).
+__global__ __launch_bounds__(256) void rider_var_kernel(const double* __restrict__ R, int ld, int nr, int n,
+                                                        double base, double* __restrict__ out) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= nr) return;
+  double q = 0.0;
+  for (int k = 0; k < n; ++k) {
+    const double v = R[(size_t)k * ld + r];
+    q = __builtin_fma(v, v, q);
+  }
+  out[r] = base - q;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Back substitution  L' alpha = z  (alpha = C \ delta second half), one launch per 64-block, from the
+// last block to the first.  Step b: alpha_b = W_bb' z_b (recomputed by every workgroup), then
+// z_i -= sum_{j in b} L[j, i] alpha_j for the columns i < 64 b owned by this workgroup.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void backsolve_step_kernel(const double* __restrict__ L, int ld,
+                                                             const double* __restrict__ W, int b,
+                                                             double* __restrict__ z) {
+  __shared__ double zb[64];
+  __shared__ double ab[64];
+  const int t = threadIdx.x;
+  if (t < 64) zb[t] = z[b * 64 + t];
+  __syncthreads();
+  if (t < 64) {
+    const double* Wb = W + (size_t)b * 4096;
+    double s = 0.0;
+    for (int j = t; j < 64; ++j) s = __builtin_fma(Wb[t * 64 + j], zb[j], s);   // (W')[t,j] = W[j,t]
+    ab[t] = s;
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && t < 64) z[b * 64 + t] = ab[t];
+  const int i = blockIdx.x * 256 + t;
+  if (i < b * 64) {
+    const double* col = L + (size_t)i * ld + b * 64;
+    double s = 0.0;
+#pragma unroll 8
+    for (int j = 0; j < 64; ++j) s = __builtin_fma(col[j], ab[j], s);
+    z[i] -= s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K4/K5: tall-skinny products with a thread per row i of an n-row operand.
+//   val[i, c] = sum_k Mx[c + k*ldm] * In[i + k*ldi]            (c in this block's chunk of CH outputs)
+//   mode 0: Out[i + c*ldo] = val - sub[c]                       (T*Y projection, minus latent mean)
+//   mode 1: partial[block] = sum (Ref[i + c*ldr] - val)^2       (regulariser residual |Y - H T Y|_F^2)
+// ---------------------------------------------------------------------------------------------------
+template <int CH>
+__global__ __launch_bounds__(256) void tall_skinny_kernel(const double* __restrict__ In, int ldi, int n, int K,
+                                                          const double* __restrict__ Mx, int ldm, int C,
+                                                          double* __restrict__ Out, int ldo,
+                                                          const double* __restrict__ sub,
+                                                          const double* __restrict__ Ref, int ldr,
+                                                          double* __restrict__ partial, int mode) {
+  __shared__ double sh[4];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int c0 = blockIdx.y * CH;
+  double acc[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) acc[c] = 0.0;
+  if (i < n) {
+    for (int k = 0; k < K; ++k) {
+      const double v = In[(size_t)k * ldi + i];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int cc = (c0 + c < C) ? (c0 + c) : (C - 1);
+        acc[c] = __builtin_fma(Mx[(size_t)k * ldm + cc], v, acc[c]);
+      }
+    }
+  }
+  if (mode == 0) {
+    if (i < n) {
+#pragma unroll
+      for (int c = 0; c < CH; ++c)
+        if (c0 + c < C) Out[(size_t)(c0 + c) * ldo + i] = acc[c] - (sub ? sub[c0 + c] : 0.0);
+    }
+  } else {
+    double s = 0.0;
+    if (i < n) {
+#pragma unroll
+      for (int c = 0; c < CH; ++c)
+        if (c0 + c < C) {
+          const double r = Ref[(size_t)(c0 + c) * ldr + i] - acc[c];
+          s = __builtin_fma(r, r, s);
+        }
+    }
+    const double tot = block_sum_256(s, sh);
+    if (threadIdx.x == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = tot;
+  }
+}
+
+// Deterministic final sum of `count` partials into out[0] (+ add).
+__global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ partial, int count,
+                                                           double* __restrict__ out) {
+  __shared__ double sh[4];
+  double s = 0.0;
+  for (int k = threadIdx.x; k < count; k += 256) s += partial[k];
+  const double tot = block_sum_256(s, sh);
+  if (threadIdx.x == 0) out[0] = tot;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Posterior / prior latent mean at xs:  mean[s] = mu + sum_i kappa(xs_s, x_i) alpha_i   (cross-Gram fused
+// with the GEMV; never materialised).  alpha == nullptr -> prior mean.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void post_mean_kernel(const double* __restrict__ xs, int ns,
+                                                        const double* __restrict__ x, int n, int d,
+                                                        const double* __restrict__ alpha, LatentDev g,
+                                                        double* __restrict__ out) {
+  __shared__ double xa[256 * 2];
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  double acc = 0.0;
+  if (alpha != nullptr) {
+    if (d == 1) {
+      const double xv = (s < ns) ? xs[s] : 0.0;
+      for (int i0 = 0; i0 < n; i0 += 256) {
+        __syncthreads();
+        const int i = i0 + threadIdx.x;
+        xa[threadIdx.x] = (i < n) ? x[i] : 0.0;
+        xa[256 + threadIdx.x] = (i < n) ? alpha[i] : 0.0;
+        __syncthreads();
+        const int lim = (n - i0 < 256) ? (n - i0) : 256;
+        for (int k = 0; k < lim; ++k) {
+          const double r = fabs(xv - xa[k]) * g.inv_ls;
+          acc = __builtin_fma(kappa(g.kind, g.var, r, r * r), xa[256 + k], acc);
+        }
+      }
+    } else if (s < ns) {
+      for (int i = 0; i < n; ++i) {
+        const double r2 = scaled_dist2(xs + (size_t)s * d, x + (size_t)i * d, d, g.inv_ls);
+        acc = __builtin_fma(kappa(g.kind, g.var, sqrt(r2), r2), alpha[i], acc);
+      }
+    }
+  }
+  if (s < ns) out[s] = g.mean + acc;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K4: H unprojection of latent marginals / samples.  out[s + o*ns] (+)= sum_l Hm[o,l]^pw * lat[s + l*ns] (+ add)
+//   pw = 1: means / samples;  pw = 2: variances (abs2.(H) * V).   Reference src/oilmm.jl:69,72, src/ilmm.jl:86.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mix_kernel(const double* __restrict__ lat, int ns, int ml,
+                                                  const double* __restrict__ Hm, int p, int pw,
+                                                  double lat_add, double out_add,
+                                                  const double* __restrict__ eps, double eps_scale,
+                                                  double* __restrict__ out) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  const int o = blockIdx.y;
+  if (s >= ns) return;
+  double acc = out_add;
+  for (int l = 0; l < ml; ++l) {
+    double h = Hm[o + (size_t)l * p];
+    if (pw == 2) h = h * h;
+    acc = __builtin_fma(h, lat[(size_t)l * ns + s] + lat_add, acc);
+  }
+  if (eps != nullptr) acc = __builtin_fma(eps_scale, eps[(size_t)o * ns + s], acc);
+  out[(size_t)o * ns + s] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K7: sample transform  out = mu + L z  (lower-triangular, column-major).  Thread per row, k-split over
+// blockIdx.y with deterministic two-pass partials.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void trmv_lower_kernel(const double* __restrict__ L, int ld, int n,
+                                                         const double* __restrict__ zv, int kchunk,
+                                                         double* __restrict__ partial) {
+  __shared__ double zs[256];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int k0 = blockIdx.y * kchunk;
+  int k1 = k0 + kchunk; if (k1 > n) k1 = n;
+  const int rowmax = blockIdx.x * 256 + 255;
+  double acc = 0.0;
+  for (int kb = k0; kb < k1 && kb <= rowmax; kb += 256) {
+    __syncthreads();
+    zs[threadIdx.x] = (kb + threadIdx.x < k1) ? zv[kb + threadIdx.x] : 0.0;
+    __syncthreads();
+    const int lim = (k1 - kb < 256) ? (k1 - kb) : 256;
+    if (i < n) {
+      for (int k = 0; k < lim; ++k) {
+        const int kk = kb + k;
+        if (kk <= i) acc = __builtin_fma(L[(size_t)kk * ld + i], zs[k], acc);
+      }
+    }
+  }
+  if (i < n) partial[(size_t)blockIdx.y * n + i] = acc;
+}
+
+__global__ void trmv_finish_kernel(const double* __restrict__ partial, int n, int nchunks, double mu,
+                                   double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = mu;
+  for (int c = 0; c < nchunks; ++c) s += partial[(size_t)c * n + i];
+  out[i] = s;
+}
+
+__global__ void vec_lin_kernel(const double* a, const double* b, double sb, int n, double* out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) out[k] = a[k] + sb * b[k];
+}
+
+// Add a constant to the first n diagonal entries (noise / jitter on a Schur complement).
+__global__ void add_diag_kernel(double* A, int ld, int n, double v) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) A[(size_t)k * ld + k] += v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// f64 MFMA issue-rate microbenchmark (the guide gives no FP64 matrix peak).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mfma_f64_peak_kernel(double* out, int iters) {
+  d4 acc[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) acc[q] = (d4){0.0, 0.0, 0.0, 0.0};
+  double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[q], 0, 0, 0);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) s += acc[q][0] + acc[q][1] + acc[q][2] + acc[q][3];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// launch wrappers (host)
+// ---------------------------------------------------------------------------------------------------
+void launch_gram(const GramArgs& a, hipStream_t st) {
+  dim3 grid(a.nrows / 64 - a.row_tile0, a.ncols / 64);
+  hipLaunchKernelGGL(gram_kernel, grid, dim3(256), 0, st, a);
+}
+
+void launch_dense_assemble(const DenseArgs& a, hipStream_t st) {
+  dim3 grid(a.nrows / 64, a.ncols / 64);
+  hipLaunchKernelGGL(ilmm_dense_assemble_kernel, grid, dim3(256), 0, st, a);
+}
+
+void launch_diag64(double* Ablk, int ld, double* Wblk, int gcol0, int n_real, int* info, hipStream_t st) {
+  hipLaunchKernelGGL(diag64_kernel, dim3(1), dim3(256), 0, st, Ablk, ld, Wblk, gcol0, n_real, info);
+}
+
+void launch_gemm_nt(double* C, int ldc, const double* A, int lda, const double* B, int ldb, int M, int N, int K,
+                    int lower, bool set, hipStream_t st) {
+  if (M <= 0 || N <= 0 || K <= 0) return;
+  const bool narrow = (N <= 64);
+  dim3 grid((M + 127) / 128, narrow ? 1 : (N + 127) / 128);
+  if (set) {
+    // in-place TRSM-by-inverse needs the full column extent in one block column
+    hipLaunchKernelGGL((gemm_nt_kernel<64, true>), dim3((M + 127) / 128, (N + 63) / 64), dim3(256), 0, st, C, ldc, A, lda, B,
+                       ldb, M, N, K, 0);
+  } else if (narrow) {
+    hipLaunchKernelGGL((gemm_nt_kernel<64, false>), grid, dim3(256), 0, st, C, ldc, A, lda, B, ldb, M, N, K, lower);
+  } else {
+    hipLaunchKernelGGL((gemm_nt_kernel<128, false>), grid, dim3(256), 0, st, C, ldc, A, lda, B, ldb, M, N, K, lower);
+  }
+}
+
+void launch_lml_reduce(const double* A, int ld, int n, int rider_row0, int nrhs, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(lml_reduce_kernel, dim3(1), dim3(256), 0, st, A, ld, n, rider_row0, nrhs, out);
+}
+
+void launch_extract_row(const double* A, int ld, int row, int n, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(extract_row_kernel, dim3((n + 255) / 256), dim3(256), 0, st, A, ld, row, n, out);
+}
+
+void launch_rider_var(const double* R, int ld, int nr, int n, double base, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(rider_var_kernel, dim3((nr + 255) / 256), dim3(256), 0, st, R, ld, nr, n, base, out);
+}
+
+void launch_backsolve(const double* L, int ld, const double* W, int nblk, double* z, hipStream_t st) {
+  for (int b = nblk - 1; b >= 0; --b) {
+    int grid = (b * 64 + 255) / 256; if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(backsolve_step_kernel, dim3(grid), dim3(256), 0, st, L, ld, W, b, z);
+  }
+}
+
+void launch_tall_skinny(const double* In, int ldi, int n, int K, const double* Mx, int ldm, int C, double* Out, int ldo,
+                        const double* sub, const double* Ref, int ldr, double* partial, int mode, hipStream_t st) {
+  dim3 grid((n + 255) / 256, (C + 15) / 16);
+  hipLaunchKernelGGL((tall_skinny_kernel<16>), grid, dim3(256), 0, st, In, ldi, n, K, Mx, ldm, C, Out, ldo, sub, Ref, ldr,
+                     partial, mode);
+}
+
+int tall_skinny_partials(int n, int C) { return ((n + 255) / 256) * ((C + 15) / 16); }
+
+void launch_sum_partials(const double* partial, int count, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, partial, count, out);
+}
+
+void launch_post_mean(const double* xs, int ns, const double* x, int n, int d, const double* alpha, LatentDev g,
+                      double* out, hipStream_t st) {
+  hipLaunchKernelGGL(post_mean_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, xs, ns, x, n, d, alpha, g, out);
+}
+
+void launch_mix(const double* lat, int ns, int ml, const double* Hm, int p, int pw, double lat_add, double out_add,
+                const double* eps, double eps_scale, double* out, hipStream_t st) {
+  dim3 grid((ns + 255) / 256, p);
+  hipLaunchKernelGGL(mix_kernel, grid, dim3(256), 0, st, lat, ns, ml, Hm, p, pw, lat_add, out_add, eps, eps_scale, out);
+}
+
+int trmv_chunks(int n) { int c = (n + 2047) / 2048; return c < 1 ? 1 : c; }
+
+void launch_trmv_lower(const double* L, int ld, int n, const double* z, double mu, double* partial, double* out,
+                       hipStream_t st) {
+  const int nch = trmv_chunks(n);
+  const int kchunk = ((n + nch - 1) / nch + 255) / 256 * 256;
+  dim3 grid((n + 255) / 256, nch);
+  hipLaunchKernelGGL(trmv_lower_kernel, grid, dim3(256), 0, st, L, ld, n, z, kchunk, partial);
+  hipLaunchKernelGGL(trmv_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, st, partial, n, nch, mu, out);
+}
+
+void launch_add_diag(double* A, int ld, int n, double v, hipStream_t st) {
+  hipLaunchKernelGGL(add_diag_kernel, dim3((n + 255) / 256), dim3(256), 0, st, A, ld, n, v);
+}
+
+void launch_vec_lin(const double* a, const double* b, double sb, int n, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(vec_lin_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a, b, sb, n, out);
+}
+
+void launch_mfma_peak(double* out, int blocks, int iters, hipStream_t st) {
+  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, st, out, iters);
+}

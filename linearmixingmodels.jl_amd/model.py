@@ -1,0 +1,393 @@
+"""Host-side mirror of the LinearMixingModels.jl interface for the ILMM/OILMM inference hot path.
+
+Julia is not available in the build image, so this module plays the role of the
+Julia shim for tests and benchmarks: the same type names (`ILMM`, `IndependentMOGP`, `independent_mogp`,
+`Orthogonal`, `get_latent_gp`; reference src/LinearMixingModels.jl:21-24) and the AbstractGPs verbs the
+reference adds methods to (`logpdf`, `posterior`, `rand`, `marginals`, `mean_and_var`, `mean`, `var`),
+each body being ONE call into liblmm_hip.so -- exactly what the `ccall` shim in
+`linearmixingmodels.jl_amd/julia/LinearMixingModelsHIP.jl` does.  No arithmetic happens here.
+
+Arrays may be NumPy (host) or float64 CUDA/HIP torch tensors (device pointers are passed straight
+through the C ABI).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib as L
+
+
+# ---- kernels / GPs (KernelFunctions.jl + AbstractGPs.jl names) ------------------------------------
+class _Kernel:
+    kind = ""
+
+    def __init__(self, variance: float = 1.0, lengthscale: float = 1.0):
+        self.variance, self.lengthscale = float(variance), float(lengthscale)
+
+    def __eq__(self, o):
+        return type(self) is type(o) and (self.variance, self.lengthscale) == (o.variance, o.lengthscale)
+
+    def __repr__(self):
+        return f"{type(self).__name__}(variance={self.variance}, lengthscale={self.lengthscale})"
+
+
+class SEKernel(_Kernel):
+    kind = "se"
+
+
+class Matern32Kernel(_Kernel):
+    kind = "matern32"
+
+
+class Matern52Kernel(_Kernel):
+    kind = "matern52"
+
+
+class GP:
+    """GP(kernel) or GP(mean_const, kernel)."""
+
+    def __init__(self, *args):
+        if len(args) == 1:
+            self.mean, self.kernel = 0.0, args[0]
+        else:
+            self.mean, self.kernel = float(args[0]), args[1]
+
+    def desc(self) -> dict:
+        return {"kind": self.kernel.kind, "variance": self.kernel.variance, "lengthscale": self.kernel.lengthscale,
+                "mean": self.mean}
+
+    def __eq__(self, o):
+        return isinstance(o, GP) and self.mean == o.mean and self.kernel == o.kernel
+
+
+class IndependentMOGP:
+    """reference src/independent_mogp.jl:10-12."""
+
+    def __init__(self, fs: Sequence[GP], _post: Optional["_PostHandle"] = None):
+        self.fs = list(fs)
+        self._post = _post
+
+    def __call__(self, x: "MOInputIsotopicByOutputs", sigma2: float = 1e-18) -> "FiniteGP":
+        return FiniteGP(self, x, float(sigma2))
+
+    def __eq__(self, o):
+        return isinstance(o, IndependentMOGP) and self.fs == o.fs and self._post is o._post
+
+
+def independent_mogp(fs: Sequence[GP]) -> IndependentMOGP:
+    """reference src/independent_mogp.jl:31."""
+    return IndependentMOGP(fs)
+
+
+class Orthogonal:
+    """reference src/orthogonal_matrix.jl:11-34: H = U * sqrt(S); validates U'U ~ I."""
+
+    def __init__(self, U, S, validate_fields: bool = True):
+        self.U = np.asarray(U, dtype=np.float64)
+        self.S = np.asarray(S, dtype=np.float64).reshape(-1)      # the Diagonal's diag
+        if self.U.ndim != 2 or self.U.shape[1] != self.S.shape[0]:
+            raise ValueError("U must be p x m and S of length m")
+        if validate_fields:
+            p, m = self.U.shape
+            L.check(L.load().lmm_orthogonal_validate(L.Arr(L.colmajor(self.U)).ptr, C.c_int(p), C.c_int(m)))
+
+    @property
+    def shape(self) -> Tuple[int, int]:
+        return self.U.shape
+
+    def collect(self) -> np.ndarray:
+        """reference src/orthogonal_matrix.jl:27-30 (materialised H)."""
+        return self.U * np.sqrt(self.S)[None, :]
+
+    def __array__(self, dtype=None, copy=None):
+        return self.collect()
+
+
+class MOInputIsotopicByOutputs:
+    """KernelFunctions.MOInputIsotopicByOutputs(x, out_dim): x is (n,) or ColVecs-style (d, n)."""
+
+    def __init__(self, x, out_dim: int):
+        self.x, self.out_dim = x, int(out_dim)
+
+    @property
+    def dim(self) -> int:
+        return 1 if len(self.x.shape) == 1 else int(self.x.shape[0])
+
+    @property
+    def n(self) -> int:
+        return int(self.x.shape[-1])
+
+    def carr(self) -> L.Arr:
+        x = self.x
+        if len(x.shape) == 2:          # (d, n) -> d x n column-major == (n, d) C-order
+            x = x.T.contiguous() if L._is_torch(x) else np.ascontiguousarray(np.asarray(x, dtype=np.float64).T)
+        return L.Arr(x)
+
+    def __len__(self):
+        return self.n * self.out_dim
+
+
+class _PostHandle:
+    """Owns an lmm_post_t* (device-resident posterior state); freed with the Python object, as the Julia
+    shim does with a finalizer."""
+
+    def __init__(self, ptr: C.c_void_p, l0: int, l1: int):
+        self.ptr, self.l0, self.l1 = ptr, l0, l1
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                L.load().lmm_post_destroy(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+class ILMM:
+    """reference src/ilmm.jl:16-19.  `ILMM(f, H)` with H a dense p x m matrix or an `Orthogonal` (=> OILMM,
+    reference src/oilmm.jl:13).  `shard=(begin, end)` restricts this process to a block of latents
+    (one process per GPU); partial results are combined by `parallel.py`."""
+
+    def __init__(self, f: IndependentMOGP, H, shard: Optional[Tuple[int, int]] = None):
+        self.f, self.H = f, H if isinstance(H, Orthogonal) else np.asarray(H, dtype=np.float64)
+        m = len(f.fs)
+        if self.H.shape[1] != m:
+            raise ValueError(f"H has {self.H.shape[1]} columns but there are {m} latent processes")
+        self.shard = (0, m) if shard is None else (int(shard[0]), int(shard[1]))
+
+    @property
+    def is_oilmm(self) -> bool:
+        return isinstance(self.H, Orthogonal)
+
+    def __call__(self, x: MOInputIsotopicByOutputs, sigma2: float = 1e-18) -> "FiniteGP":
+        return FiniteGP(self, x, float(sigma2))
+
+
+def OILMM(f: IndependentMOGP, H: Orthogonal, **kw) -> ILMM:
+    if not isinstance(H, Orthogonal):
+        raise TypeError("OILMM needs an Orthogonal mixing matrix")
+    return ILMM(f, H, **kw)
+
+
+def get_latent_gp(f: ILMM) -> IndependentMOGP:
+    """reference src/ilmm.jl:39."""
+    return f.f
+
+
+class Normal:
+    def __init__(self, mu, sigma):
+        self.mu, self.sigma = mu, sigma
+
+
+class FiniteGP:
+    """AbstractGPs.FiniteGP(f, x, Diagonal(Fill(sigma2, n*p)))."""
+
+    def __init__(self, f, x: MOInputIsotopicByOutputs, sigma2: float):
+        self.f, self.x, self.sigma2 = f, x, sigma2
+
+    def __len__(self):
+        return len(self.x)
+
+
+# ---- helpers ----------------------------------------------------------------------------------------
+def noise_var(sigma2):
+    """reference src/ilmm.jl:41."""
+    return sigma2
+
+
+def reshape_y(y, n: int):
+    """reference src/ilmm.jl:43: reshape(y, N, :)'."""
+    return np.asarray(y).reshape(-1, n)
+
+
+def unpack(fx: FiniteGP):
+    """reference src/ilmm.jl:45-54."""
+    f = fx.f
+    if fx.x.out_dim != f.H.shape[0]:
+        raise RuntimeError("out dim of x != out dim of f.")
+    return f.f, f.H, fx.sigma2, fx.x.x
+
+
+def _H_args(H):
+    """(U or dense-H pointer, S pointer or None, p, m) for the C ABI."""
+    if isinstance(H, Orthogonal):
+        return L.Arr(L.colmajor(H.U)), L.Arr(H.S), H.U.shape[0], H.U.shape[1]
+    return L.Arr(L.colmajor(H)), None, H.shape[0], H.shape[1]
+
+
+def _alloc_like(ref, count: int):
+    """Output buffer on the same side (host / device) as `ref`."""
+    if L._is_torch(ref) and ref.is_cuda:
+        import torch
+        return torch.empty(count, dtype=torch.float64, device=ref.device)
+    return np.empty(count, dtype=np.float64)
+
+
+# ---- the AbstractGPs verbs ----------------------------------------------------------------------------
+def logpdf(fx: FiniteGP, y, with_regulariser: bool = True) -> float:
+    """logpdf(fx, y).  ILMM/OILMM: reference src/oilmm.jl:79-93, src/ilmm.jl:150-163; IndependentMOGP:
+    src/independent_mogp.jl:74-80.  Returns this process's shard of the sum (the whole value when the model
+    is not sharded)."""
+    L.ensure_init()
+    lib = L.load()
+    f, x, s2 = fx.f, fx.x, fx.sigma2
+    out = C.c_double()
+    xa, ya = x.carr(), L.Arr(y)
+    if isinstance(f, IndependentMOGP):
+        if x.out_dim != len(f.fs):
+            raise RuntimeError("out dim of x != out dim of f.")
+        if ya.size != x.n * x.out_dim:
+            raise ValueError("length(y) != n * out_dim")
+        if f._post is not None:
+            return _post_logpdf(f._post, [g.desc() for g in f.fs], np.eye(len(f.fs)), np.ones(len(f.fs)), x, s2, ya, False)
+        gps = L.gps_array([g.desc() for g in f.fs])
+        L.check(lib.lmm_mogp_logpdf(xa.ptr, x.dim, x.n, ya.ptr, len(f.fs), C.c_double(s2), gps, 0, len(f.fs), C.byref(out)))
+        return out.value
+    unpack(fx)
+    if ya.size != x.n * x.out_dim:
+        raise ValueError("length(y) != n * out_dim")
+    descs = [g.desc() for g in f.f.fs]
+    gps = L.gps_array(descs)
+    Ua, Sa, p, m = _H_args(f.H)
+    l0, l1 = f.shard
+    if f.f._post is not None:
+        if not f.is_oilmm:
+            raise NotImplementedError("logpdf on a dense-H posterior ILMM (SURVEY 8a row A11/A13)")
+        return _post_logpdf(f.f._post, descs, f.H.U, f.H.S, x, s2, ya, with_regulariser)
+    if f.is_oilmm:
+        L.check(lib.lmm_oilmm_logpdf(xa.ptr, x.dim, x.n, ya.ptr, p, Ua.ptr, Sa.ptr, m, C.c_double(s2), gps, l0, l1,
+                                     int(with_regulariser), C.byref(out)))
+    else:
+        if (l0, l1) != (0, m):
+            raise NotImplementedError("dense-H ILMM does not shard (SURVEY.md 8e: replicas only)")
+        L.check(lib.lmm_ilmm_logpdf(xa.ptr, x.dim, x.n, ya.ptr, p, Ua.ptr, m, C.c_double(s2), gps, None, C.byref(out)))
+    return out.value
+
+
+def _post_logpdf(post: _PostHandle, descs, U, S, x, s2, ya, with_reg) -> float:
+    lib = L.load()
+    out = C.c_double()
+    Ua, Sa = L.Arr(L.colmajor(U)), L.Arr(S)
+    xa = x.carr()
+    L.check(lib.lmm_oilmm_post_logpdf(post.ptr, Ua.ptr, Sa.ptr, U.shape[0], U.shape[1], C.c_double(s2), xa.ptr, x.dim,
+                                      x.n, ya.ptr, int(with_reg), C.byref(out)))
+    return out.value
+
+
+def posterior(fx: FiniteGP, y):
+    """posterior(fx, y): reference src/oilmm.jl:116-134 (returns ILMM(independent_mogp(posteriors), H) -- again
+    an OILMM with the same H) and src/independent_mogp.jl:119-126."""
+    L.ensure_init()
+    lib = L.load()
+    f, x, s2 = fx.f, fx.x, fx.sigma2
+    xa, ya = x.carr(), L.Arr(y)
+    handle = C.c_void_p()
+    if isinstance(f, IndependentMOGP):
+        if f._post is not None:
+            raise NotImplementedError("sequential conditioning (SURVEY.md 8f next #4)")
+        gps = L.gps_array([g.desc() for g in f.fs])
+        m = len(f.fs)
+        L.check(lib.lmm_mogp_posterior_create(xa.ptr, x.dim, x.n, ya.ptr, m, C.c_double(s2), gps, 0, m, C.byref(handle)))
+        return IndependentMOGP(f.fs, _PostHandle(handle, 0, m))
+    unpack(fx)
+    if f.f._post is not None:
+        raise NotImplementedError("sequential conditioning (SURVEY.md 8f next #4)")
+    gps = L.gps_array([g.desc() for g in f.f.fs])
+    Ua, Sa, p, m = _H_args(f.H)
+    l0, l1 = f.shard
+    if f.is_oilmm:
+        L.check(lib.lmm_oilmm_posterior_create(xa.ptr, x.dim, x.n, ya.ptr, p, Ua.ptr, Sa.ptr, m, C.c_double(s2), gps, l0,
+                                               l1, C.byref(handle)))
+    else:
+        L.check(lib.lmm_ilmm_posterior_create(xa.ptr, x.dim, x.n, ya.ptr, p, Ua.ptr, m, C.c_double(s2), gps, None,
+                                              C.byref(handle)))
+    return ILMM(IndependentMOGP(f.f.fs, _PostHandle(handle, l0, l1)), f.H, shard=f.shard)
+
+
+def mean_and_var(fx: FiniteGP, add_noise: bool = True):
+    """mean_and_var(fx): reference src/oilmm.jl:57-76 (OILMM) and src/independent_mogp.jl:50,55.  For a sharded
+    model the outputs are this shard's partial sums (add_noise only on one rank)."""
+    L.ensure_init()
+    lib = L.load()
+    f, x, s2 = fx.f, fx.x, fx.sigma2
+    xa = x.carr()
+    if isinstance(f, IndependentMOGP):
+        m = len(f.fs)
+        if x.out_dim != m:
+            raise RuntimeError("out dim of x != out dim of f.")
+        mean, var = _alloc_like(x.x, x.n * m), _alloc_like(x.x, x.n * m)
+        ma, va = L.Arr(mean, True), L.Arr(var, True)
+        post = f._post.ptr if f._post is not None else None
+        gps = L.gps_array([g.desc() for g in f.fs])
+        L.check(lib.lmm_latent_marginals(post, gps, m, xa.ptr, x.dim, x.n, ma.ptr, va.ptr))
+        return mean, var + s2                      # var(f, x) + Sigma_y diagonal
+    unpack(fx)
+    if not f.is_oilmm:
+        raise NotImplementedError("mean_and_var for dense-H ILMM (SURVEY.md 8a row A13): use Orthogonal H, or the "
+                                  "oracle's dense kron path at small n")
+    Ua, Sa, p, m = _H_args(f.H)
+    l0, l1 = f.shard
+    mean, var = _alloc_like(x.x, x.n * p), _alloc_like(x.x, x.n * p)
+    ma, va = L.Arr(mean, True), L.Arr(var, True)
+    post = f.f._post.ptr if f.f._post is not None else None
+    gps = L.gps_array([g.desc() for g in f.f.fs])
+    L.check(lib.lmm_oilmm_mean_and_var(post, gps, Ua.ptr, Sa.ptr, p, m, l0, l1, C.c_double(s2), int(add_noise), xa.ptr,
+                                       x.dim, x.n, None, ma.ptr, va.ptr))
+    return mean, var
+
+
+def mean(fx: FiniteGP):
+    """reference src/ilmm.jl:142."""
+    return mean_and_var(fx)[0]
+
+
+def var(fx: FiniteGP):
+    """reference src/ilmm.jl:145."""
+    return mean_and_var(fx)[1]
+
+
+def marginals(fx: FiniteGP) -> Normal:
+    """AbstractGPs.marginals(fx) = Normal.(mean, sqrt.(var)) (vectorised)."""
+    m, v = mean_and_var(fx)
+    return Normal(m, v ** 0.5)
+
+
+def rand(rng, fx: FiniteGP, N: Optional[int] = None, jitters=None, add_noise: bool = True):
+    """rand(rng, fx[, N]): reference src/oilmm.jl:40-54, src/ilmm.jl:78-92, src/independent_mogp.jl:83-96.
+    `rng` is a numpy Generator; standard normals are drawn on the host in the reference's order (m blocks of n
+    latent normals, then n*p noise normals) and handed to the device, as the Julia shim does with randn(rng, ...)."""
+    if N is not None:
+        return np.stack([rand(rng, fx, None, jitters, add_noise) for _ in range(N)], axis=1)   # src/ilmm.jl:90-92
+    L.ensure_init()
+    lib = L.load()
+    f, x, s2 = fx.f, fx.x, fx.sigma2
+    xa = x.carr()
+    n = x.n
+    if isinstance(f, IndependentMOGP):
+        # vcat(rand(rng, f_l(x, s2))): latent jitter = s2, H = I, no extra noise term
+        m = len(f.fs)
+        z = rng.standard_normal(m * n)
+        out = np.empty(n * m)
+        gps = L.gps_array([g.desc() for g in f.fs])
+        post = f._post.ptr if f._post is not None else None
+        Ua = L.Arr(L.colmajor(np.eye(m)))
+        jit = L.jitters((1e-9, s2, s2))
+        L.check(lib.lmm_lmm_rand(post, gps, Ua.ptr, None, m, m, 0, m, C.c_double(s2), 0, xa.ptr, x.dim, n, L.Arr(z).ptr,
+                                 None, jit, L.Arr(out, True).ptr))
+        return out
+    unpack(fx)
+    Ua, Sa, p, m = _H_args(f.H)
+    z = rng.standard_normal(m * n)
+    eps = rng.standard_normal(n * p)
+    out = np.empty(n * p)
+    gps = L.gps_array([g.desc() for g in f.f.fs])
+    post = f.f._post.ptr if f.f._post is not None else None
+    l0, l1 = f.shard
+    L.check(lib.lmm_lmm_rand(post, gps, Ua.ptr, Sa.ptr if Sa is not None else None, p, m, l0, l1, C.c_double(s2),
+                             int(add_noise), xa.ptr, x.dim, n, L.Arr(z).ptr, L.Arr(eps).ptr, L.jitters(jitters),
+                             L.Arr(out, True).ptr))
+    return out

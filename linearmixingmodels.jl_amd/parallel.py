@@ -1,0 +1,73 @@
+"""Multi-GPU layer: one process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm, "gloo" in CPU
+tests).  The reference has no parallelism; the latent processes of an OILMM are
+independent, so rank r owns a contiguous block of latents, evaluates its partial sum through the C ABI with no
+data-path collective, and ONE scalar all-reduce over xGMI finishes logpdf."""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+from . import model as M
+
+
+def latent_shard(m: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block partition of m latents: the first m % world ranks get one extra."""
+    base, extra = divmod(m, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist if dist.is_available() and dist.is_initialized() else None
+
+
+def _world() -> Tuple[int, int]:
+    d = _dist()
+    return (d.get_rank(), d.get_world_size()) if d else (0, 1)
+
+
+def _all_reduce_sum(t):
+    d = _dist()
+    if d is not None and d.get_world_size() > 1:
+        d.all_reduce(t, op=d.ReduceOp.SUM)
+    return t
+
+
+def _reduce_device():
+    import torch
+    d = _dist()
+    if d is not None and d.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def sharded_logpdf(f: M.ILMM, x: M.MOInputIsotopicByOutputs, sigma2: float, y,
+                   local_fn: Optional[Callable] = None, reduce: bool = True) -> float:
+    """logpdf of an OILMM FiniteGP with the latents sharded over the ranks of the default process group.
+    Rank 0 adds the regulariser.  `local_fn(fx_shard, y, with_regulariser)` defaults to the HIP path
+    (model.logpdf); tests inject a checker to exercise the sharding + all-reduce on CPU/gloo."""
+    import torch
+    rank, world = _world()
+    m = len(f.f.fs)
+    shard = latent_shard(m, rank, world)
+    fx = M.ILMM(f.f, f.H, shard=shard)(x, sigma2)
+    fn = local_fn or M.logpdf
+    part = fn(fx, y, rank == 0)
+    if not reduce:
+        return part
+    t = torch.tensor([part], dtype=torch.float64, device=_reduce_device())
+    return float(_all_reduce_sum(t)[0])
+
+
+def sharded_mean_and_var(fx_shard: M.FiniteGP, local_fn: Optional[Callable] = None):
+    """mean_and_var of a (posterior) OILMM whose latents are sharded: each rank mixes its latents through its
+    columns of H, then ONE all-reduce of the p*n* partial means and variances (form (ii));
+    sigma2 is added by rank 0 only."""
+    import torch
+    rank, _ = _world()
+    fn = local_fn or M.mean_and_var
+    mean, var = fn(fx_shard, rank == 0)
+    dev = _reduce_device()
+    t = torch.stack([torch.as_tensor(mean, dtype=torch.float64), torch.as_tensor(var, dtype=torch.float64)]).to(dev)
+    _all_reduce_sum(t)
+    return t[0], t[1]

@@ -1,0 +1,355 @@
+"""-m gpu parity tests: the HIP path (through the C ABI / the host mirror) against the CPU oracle on the same
+seeded inputs.  Bar: rtol 1e-6 in Float64 (BASELINE.json north_star); most checks are far tighter."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+from oracle import lmm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-6     # the north-star tolerance (Float64)
+
+
+@pytest.fixture(scope="module")
+def lmm():
+    import lmm_amd
+    lmm_amd.init(0)
+    return lmm_amd
+
+
+def _gps(kinds, rng=None):
+    out = []
+    for k in kinds:
+        g = {"kind": k, "variance": 1.0, "lengthscale": 1.0, "mean": 0.0}
+        if rng is not None:
+            g.update(variance=float(rng.uniform(0.5, 2.0)), lengthscale=float(rng.uniform(0.5, 2.0)),
+                     mean=float(rng.normal()))
+        out.append(g)
+    return out
+
+
+def _to_model(lmm, gps):
+    K = {"se": lmm.SEKernel, "matern32": lmm.Matern32Kernel, "matern52": lmm.Matern52Kernel}
+    return lmm.independent_mogp([lmm.GP(g["mean"], K[g["kind"]](g["variance"], g["lengthscale"])) for g in gps])
+
+
+def _orth(rng, p, m):
+    U, S, _ = np.linalg.svd(rng.uniform(size=(p, m)), full_matrices=False)
+    return np.ascontiguousarray(U), S
+
+
+# ---------------------------------------------------------------------------------------------------
+# building blocks
+# ---------------------------------------------------------------------------------------------------
+def test_mfma_gemm_nt_sub(lmm):
+    """f64 MFMA tile kernel vs torch (asymmetric operands: catches a swapped C/D map)."""
+    import torch
+    lib = lmm.load()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for (M, N, K, lower) in [(128, 128, 64, 0), (192, 64, 16, 0), (320, 192, 208, 0), (256, 256, 128, 1), (448, 320, 64, 1)]:
+        ldc, lda, ldb = M + 16, M + 2, N + 4
+        Ct = torch.randn(N, ldc, generator=g, device="cuda", dtype=torch.float64)     # column-major: [col][row]
+        At = torch.randn(K, lda, generator=g, device="cuda", dtype=torch.float64)
+        Bt = torch.randn(K, ldb, generator=g, device="cuda", dtype=torch.float64)
+        C0 = Ct.clone()
+        rc = lib.lmm_dev_gemm_nt_sub(C.c_void_p(Ct.data_ptr()), ldc, C.c_void_p(At.data_ptr()), lda,
+                                     C.c_void_p(Bt.data_ptr()), ldb, M, N, K, lower)
+        assert rc == 0, lib.lmm_last_error_string()
+        A = At[:, :M].T; B = Bt[:, :N].T                      # M x K, N x K
+        ref = C0[:, :M].T - A @ B.T                           # M x N
+        got = Ct[:, :M].T
+        if lower:
+            mask = torch.tril(torch.ones(M, N, device="cuda", dtype=torch.bool))
+            # 16x16 tiles straddling the diagonal are computed in full; only the lower triangle is contractual
+            assert torch.allclose(got[mask], ref[mask], rtol=1e-12, atol=1e-11)
+        else:
+            assert torch.allclose(got, ref, rtol=1e-12, atol=1e-11)
+        assert torch.equal(Ct[:, M:], C0[:, M:])              # padding rows untouched
+
+
+@pytest.mark.parametrize("n,riders", [(64, 0), (100, 1), (200, 1), (700, 3), (1500, 1)])
+def test_potrf_vs_lapack(lmm, n, riders):
+    import torch
+    lib = lmm.load()
+    rng = np.random.default_rng(n)
+    NC = (n + 63) // 64 * 64
+    NR = (NC + riders + 63) // 64 * 64
+    ld = NR + 2
+    G = rng.standard_normal((n, n + 8))
+    Kmat = G @ G.T / n + 0.5 * np.eye(n)
+    full = np.zeros((NR, NC))
+    full[:n, :n] = np.tril(Kmat)
+    full[np.arange(n, NC), np.arange(n, NC)] = 1.0
+    rhs = rng.standard_normal((riders, n))
+    full[NC:NC + riders, :n] = rhs
+    A = torch.zeros(NC, ld, dtype=torch.float64, device="cuda")
+    A[:, :NR] = torch.from_numpy(full.T.copy()).cuda()
+    W = torch.zeros(NC // 64 * 4096, dtype=torch.float64, device="cuda")
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    rc = lib.lmm_dev_potrf(C.c_void_p(A.data_ptr()), NR, NC, ld, C.c_void_p(W.data_ptr()), n, C.c_void_p(info.data_ptr()))
+    assert rc == 0, lib.lmm_last_error_string()
+    assert int(info.item()) == 0
+    got = A[:, :NR].T.cpu().numpy()
+    Lref = np.linalg.cholesky(Kmat)
+    np.testing.assert_allclose(np.tril(got[:n, :n]), Lref, rtol=1e-9, atol=1e-11)
+    if riders:
+        import scipy.linalg as sla
+        zref = sla.solve_triangular(Lref, rhs.T, lower=True).T
+        np.testing.assert_allclose(got[NC:NC + riders, :n], zref, rtol=1e-8, atol=1e-10)
+    # inverse diagonal blocks
+    Wh = W.cpu().numpy().reshape(NC // 64, 64, 64)
+    b = 0
+    Lb = np.tril(got[:64, :64]) if n >= 64 else None
+    if Lb is not None:
+        np.testing.assert_allclose(Wh[b].T @ Lb, np.eye(64), atol=1e-9)
+
+
+def test_potrf_reports_not_pd(lmm):
+    import torch
+    lib = lmm.load()
+    n = 128
+    M = np.eye(n); M[70, 70] = -1.0
+    A = torch.from_numpy(M.copy()).cuda()
+    W = torch.zeros(2 * 4096, dtype=torch.float64, device="cuda")
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    assert lib.lmm_dev_potrf(C.c_void_p(A.data_ptr()), n, n, n, C.c_void_p(W.data_ptr()), n, C.c_void_p(info.data_ptr())) == 0
+    assert int(info.item()) == 71          # LAPACK-style 1-based failing pivot
+
+
+@pytest.mark.parametrize("kind", ["se", "matern32", "matern52"])
+@pytest.mark.parametrize("d", [1, 3])
+def test_gram_vs_oracle(lmm, kind, d):
+    import torch
+    lib = lmm.load()
+    rng = np.random.default_rng(7)
+    n = 150
+    x = rng.uniform(0, 5, size=(n,) if d == 1 else (d, n))
+    gp = {"kind": kind, "variance": 1.7, "lengthscale": 0.8, "mean": 0.0}
+    NC = NR = 192
+    ld = NR
+    A = torch.full((NC, ld), float("nan"), dtype=torch.float64, device="cuda")
+    xd = torch.from_numpy(np.ascontiguousarray(x.T if d > 1 else x)).cuda()
+    from lmm_amd import _lib as L
+    garr = L.gps_array([gp])
+    assert lib.lmm_dev_gram(C.c_void_p(A.data_ptr()), ld, NR, NC, C.c_void_p(xd.data_ptr()), d, n, garr, C.c_double(0.25)) == 0
+    got = A.T.cpu().numpy()
+    ref = O.kernelmatrix(gp, x) + 0.25 * np.eye(n)
+    il = np.tril_indices(n)
+    np.testing.assert_allclose(got[:n, :n][il], ref[il], rtol=2e-13, atol=1e-300)
+    np.testing.assert_array_equal(np.tril(got[n:, n:]), np.eye(NC - n))
+    assert np.all(got[n:, :n] == 0.0)
+
+
+# ---------------------------------------------------------------------------------------------------
+# the reference's relational tests at its own shapes, HIP path vs oracle (test/oilmm.jl, test/ilmm.jl)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m", [3, 2, 1])
+def test_oilmm_toy_shapes(lmm, m):
+    """test/oilmm.jl:44-63 shapes: p=3, n_train=3, n_test=2, sigma2=0.1, kernels SE/Matern32."""
+    rng = np.random.default_rng(100 + m)
+    x = np.linspace(0, 10, 5); perm = rng.permutation(5)
+    xtr, xte = x[perm[:3]], x[perm[3:]]
+    gps = _gps(["se", "matern32", "matern32"][:m])
+    U, S = _orth(rng, 3, m)
+    ytr, yte = rng.standard_normal(9), rng.standard_normal(6)
+    f = lmm.ILMM(_to_model(lmm, gps), lmm.Orthogonal(U, S))
+    fx = f(lmm.MOInputIsotopicByOutputs(xtr, 3), 0.1)
+    ref = O.oilmm_logpdf(gps, U, S, xtr, 0.1, ytr)
+    assert lmm.logpdf(fx, ytr) == pytest.approx(ref, rel=1e-11)
+    assert lmm.logpdf(fx, ytr) == pytest.approx(O.naive_logpdf(gps, O.orthogonal_dense(U, S), xtr, 0.1, ytr), rel=1e-11)
+    # prior marginals
+    mu, v = lmm.mean_and_var(fx)
+    mo, vo = O.oilmm_mean_var(gps, U, S, xtr, 0.1)
+    np.testing.assert_allclose(mu, mo, atol=1e-13); np.testing.assert_allclose(v, vo, rtol=1e-13)
+    # posterior
+    post = lmm.posterior(fx, ytr)
+    pox = post(lmm.MOInputIsotopicByOutputs(xte, 3), 0.1)
+    po = O.oilmm_posterior(gps, U, S, xtr, 0.1, ytr)
+    mo, vo = O.oilmm_mean_var(po, U, S, xte, 0.1)
+    mu, v = lmm.mean_and_var(pox)
+    np.testing.assert_allclose(mu, mo, rtol=1e-9, atol=1e-11); np.testing.assert_allclose(v, vo, rtol=1e-9)
+    assert lmm.logpdf(pox, yte) == pytest.approx(O.oilmm_logpdf(po, U, S, xte, 0.1, yte), rel=1e-9)
+    mg = lmm.marginals(pox)
+    np.testing.assert_allclose(mg.sigma, np.sqrt(vo), rtol=1e-9)
+    assert len(lmm.rand(np.random.default_rng(0), pox)) == 3 * 2
+
+
+@pytest.mark.parametrize("m", [3, 2, 1])
+def test_ilmm_dense_toy_shapes(lmm, m):
+    """test/ilmm.jl:44-78 shapes: dense H 3 x m, sigma2 = 1e-6."""
+    rng = np.random.default_rng(200 + m)
+    x = np.linspace(0, 10, 5); perm = rng.permutation(5)
+    xtr = x[perm[:3]]
+    gps = _gps(["se", "matern32", "matern32"][:m])
+    H = rng.uniform(size=(3, m))
+    ytr = rng.standard_normal(9)
+    fx = lmm.ILMM(_to_model(lmm, gps), H)(lmm.MOInputIsotopicByOutputs(xtr, 3), 1e-6)
+    got = lmm.logpdf(fx, ytr)
+    assert got == pytest.approx(O.ilmm_logpdf(gps, H, xtr, 1e-6, ytr), rel=RTOL)
+    assert got == pytest.approx(O.naive_logpdf(gps, H, xtr, 1e-6, ytr), rel=RTOL)
+
+
+def test_mogp_toy(lmm):
+    """test/independent_mogp.jl:33-60."""
+    rng = np.random.default_rng(5)
+    x = np.linspace(1, 2, 5); xtr, xte = x[:3], x[3:]
+    gps = [{"kind": "matern32", "variance": 1.0, "lengthscale": 1.0, "mean": 30.0},
+           {"kind": "se", "variance": 1.0, "lengthscale": 1.0, "mean": 10.0}]
+    y = rng.standard_normal(6) + np.repeat([30.0, 10.0], 3)
+    ys = rng.standard_normal(4) + np.repeat([30.0, 10.0], 2)
+    f = _to_model(lmm, gps)
+    fx = f(lmm.MOInputIsotopicByOutputs(xtr, 2), 0.1)
+    assert lmm.logpdf(fx, y) == pytest.approx(O.mogp_logpdf(gps, xtr, 0.1, y), rel=1e-11)
+    post = lmm.posterior(fx, y)
+    pfx = post(lmm.MOInputIsotopicByOutputs(xte, 2), 0.1)
+    po = O.mogp_posterior(gps, xtr, 0.1, y)
+    mo, vo = O.mogp_mean_var(po, xte)
+    mu, v = lmm.mean_and_var(pfx)
+    np.testing.assert_allclose(mu, mo, rtol=1e-10); np.testing.assert_allclose(v, vo + 0.1, rtol=1e-10)
+    assert lmm.logpdf(pfx, ys) == pytest.approx(O.mogp_logpdf(po, xte, 0.1, ys), rel=1e-9)
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE configs and mid sizes
+# ---------------------------------------------------------------------------------------------------
+def test_c0_oilmm_logpdf_posterior(lmm):
+    """BASELINE configs[0]: OILMM, 3 SE latents, p=5, n=200, Float64."""
+    P = O.synthetic_problem(3, 5, 200, "se", True, s2=0.1, seed=0)
+    f = lmm.ILMM(_to_model(lmm, P["gps"]), lmm.Orthogonal(P["U"], P["S"]))
+    fx = f(lmm.MOInputIsotopicByOutputs(P["x"], 5), 0.1)
+    ref = O.oilmm_logpdf(P["gps"], P["U"], P["S"], P["x"], 0.1, P["y"])
+    assert lmm.logpdf(fx, P["y"]) == pytest.approx(ref, rel=1e-10)
+    xs = P["x"][:50] + 0.011
+    po = O.oilmm_posterior(P["gps"], P["U"], P["S"], P["x"], 0.1, P["y"])
+    mo, vo = O.oilmm_mean_var(po, P["U"], P["S"], xs, 0.1)
+    mu, v = lmm.mean_and_var(lmm.posterior(fx, P["y"])(lmm.MOInputIsotopicByOutputs(xs, 5), 0.1))
+    np.testing.assert_allclose(mu, mo, rtol=1e-7, atol=1e-9); np.testing.assert_allclose(v, vo, rtol=1e-7)
+
+
+@pytest.mark.parametrize("kind,n,m,p,d", [("matern52", 1000, 4, 6, 1), ("matern32", 777, 5, 5, 2), ("se", 513, 2, 3, 1)])
+def test_oilmm_mid_sizes(lmm, kind, n, m, p, d):
+    rng = np.random.default_rng(n)
+    x = np.arange(n) * (20.0 / 575.0) if d == 1 else rng.uniform(0, 8, size=(d, n))
+    gps = _gps([kind] * m, rng)
+    U, S = _orth(rng, p, m)
+    S = np.linspace(2.0, 1.0, m)
+    y = rng.standard_normal(n * p)
+    fx = lmm.ILMM(_to_model(lmm, gps), lmm.Orthogonal(U, S))(lmm.MOInputIsotopicByOutputs(x, p), 0.1)
+    assert lmm.logpdf(fx, y) == pytest.approx(O.oilmm_logpdf(gps, U, S, x, 0.1, y), rel=1e-9)
+
+
+def test_oilmm_device_resident_inputs(lmm):
+    """x and y handed over as device (torch) tensors: same answer as host arrays."""
+    import torch
+    P = O.synthetic_problem(4, 8, 640, "matern52", True, seed=3)
+    f = lmm.ILMM(_to_model(lmm, P["gps"]), lmm.Orthogonal(P["U"], P["S"]))
+    a = lmm.logpdf(f(lmm.MOInputIsotopicByOutputs(P["x"], 8), 0.1), P["y"])
+    b = lmm.logpdf(f(lmm.MOInputIsotopicByOutputs(torch.from_numpy(P["x"]).cuda(), 8), 0.1), torch.from_numpy(P["y"]).cuda())
+    assert a == b
+    assert a == pytest.approx(O.oilmm_logpdf(P["gps"], P["U"], P["S"], P["x"], 0.1, P["y"]), rel=1e-9)
+
+
+def test_sharded_partials_sum_to_whole(lmm):
+    """Latent shards (as on 2 and 3 GPUs) add up to the unsharded logpdf exactly as the all-reduce would."""
+    P = O.synthetic_problem(5, 7, 300, "matern52", True, seed=4)
+    H = lmm.Orthogonal(P["U"], P["S"])
+    x = lmm.MOInputIsotopicByOutputs(P["x"], 7)
+    whole = lmm.logpdf(lmm.ILMM(_to_model(lmm, P["gps"]), H)(x, 0.1), P["y"])
+    for world in (2, 3):
+        parts = [lmm.logpdf(lmm.ILMM(_to_model(lmm, P["gps"]), H, shard=lmm.latent_shard(5, r, world))(x, 0.1), P["y"], r == 0)
+                 for r in range(world)]
+        assert sum(parts) == pytest.approx(whole, rel=1e-13)
+
+
+def test_ilmm_dense_mid(lmm):
+    """Dense-H ILMM: one (mn) x (mn) factorisation (reference src/ilmm.jl:150-163), m=3, n=150 -> 450."""
+    P = O.synthetic_problem(3, 5, 150, "se", False, seed=5)
+    P["gps"][1]["kind"] = "matern32"; P["gps"][2]["lengthscale"] = 0.7
+    fx = lmm.ILMM(_to_model(lmm, P["gps"]), P["H"])(lmm.MOInputIsotopicByOutputs(P["x"], 5), 0.1)
+    assert lmm.logpdf(fx, P["y"]) == pytest.approx(O.ilmm_logpdf(P["gps"], P["H"], P["x"], 0.1, P["y"]), rel=1e-8)
+
+
+def test_rand_matches_oracle_given_normals(lmm):
+    """Same standard normals in the reference's draw order => same sample (reference src/oilmm.jl:40-54)."""
+    rng = np.random.default_rng(11)
+    n, p, m = 40, 4, 2
+    x = np.sort(rng.uniform(0, 10, n))
+    gps = _gps(["matern32", "matern52"], rng)
+    U, S = _orth(rng, p, m)
+    f = lmm.ILMM(_to_model(lmm, gps), lmm.Orthogonal(U, S))
+    fx = f(lmm.MOInputIsotopicByOutputs(x, p), 0.1)
+    jit = (1e-9, 1e-6, 1e-6)            # widened latent jitter: 1e-18 is not PD in Float64 for smooth kernels
+    got = lmm.rand(np.random.default_rng(99), fx, jitters=jit)
+    g2 = np.random.default_rng(99); z = g2.standard_normal(m * n); eps = g2.standard_normal(n * p)
+    X = np.stack([O.gp_rand(g, x, 1e-6, z[l * n:(l + 1) * n]) for l, g in enumerate(gps)])
+    ref = (O.orthogonal_dense(U, S) @ X).reshape(-1) + math.sqrt(0.1) * eps
+    np.testing.assert_allclose(got, ref, rtol=1e-7, atol=1e-8)
+    # posterior sample, dense-H mixing
+    y = rng.standard_normal(n * p)
+    post = lmm.posterior(fx, y)
+    xs = x[:16] + 0.05
+    s = lmm.rand(np.random.default_rng(5), post(lmm.MOInputIsotopicByOutputs(xs, p), 0.1), jitters=jit)
+    g2 = np.random.default_rng(5); z = g2.standard_normal(m * 16); eps = g2.standard_normal(16 * p)
+    po = O.oilmm_posterior(gps, U, S, x, 0.1, y)
+    X = np.stack([O.gp_rand(g, xs, 1e-6, z[l * 16:(l + 1) * 16]) for l, g in enumerate(po)])
+    ref = (O.orthogonal_dense(U, S) @ X).reshape(-1) + math.sqrt(0.1) * eps
+    np.testing.assert_allclose(s, ref, rtol=1e-6, atol=1e-8)
+
+
+def test_sampling_consistency(lmm):
+    """test/test_utils.jl:41-48: sample from the prior at tiny noise, condition, recover the sample."""
+    rng = np.random.default_rng(3)
+    x = np.linspace(0, 10, 5)[:3]
+    gps = _gps(["matern32", "matern52"])
+    U, S = _orth(rng, 3, 2)
+    f = lmm.ILMM(_to_model(lmm, gps), lmm.Orthogonal(U, S))
+    xin = lmm.MOInputIsotopicByOutputs(x, 3)
+    jit = (1e-9, 1e-12, 1e-12)
+    # sample noise-free-ish from the model so y lies (almost) in the column space of H
+    y = lmm.rand(np.random.default_rng(1), f(xin, 1e-6), jitters=jit)
+    post = lmm.posterior(f(xin, 1e-6), y)
+    mu, v = lmm.mean_and_var(post(xin, 1e-18))
+    # posterior mean reproduces the projection of y onto span(H); variance collapses
+    Y = y.reshape(3, 3)
+    proj = (U @ (U.T @ Y)).reshape(-1)
+    np.testing.assert_allclose(mu, proj, rtol=1e-2, atol=1e-2)
+    assert np.all(np.abs(v) < 1e-2)
+
+
+def test_errors(lmm):
+    rng = np.random.default_rng(0)
+    U, S = _orth(rng, 3, 2)
+    f = lmm.ILMM(_to_model(lmm, _gps(["se", "se"])), lmm.Orthogonal(U, S))
+    with pytest.raises(RuntimeError, match="out dim of x != out dim of f"):        # src/ilmm.jl:52
+        lmm.logpdf(f(lmm.MOInputIsotopicByOutputs(np.arange(4.0), 4), 0.1), np.zeros(16))
+    with pytest.raises(ValueError, match="not an orthogonal matrix"):             # src/orthogonal_matrix.jl:22
+        lmm.Orthogonal(rng.uniform(size=(5, 3)), np.ones(3))
+    # duplicate inputs + (numerically) zero noise: Cholesky must report the failing pivot, not return NaN
+    x = np.array([0.0, 1.0, 1.0, 2.0])
+    fbad = lmm.ILMM(_to_model(lmm, _gps(["se"])), lmm.Orthogonal(np.array([[1.0], [0.0]]), np.array([1.0])))
+    with pytest.raises(lmm.PosDefException) as ei:
+        lmm.logpdf(fbad(lmm.MOInputIsotopicByOutputs(x, 2), 1e-300), np.zeros(8))
+    assert ei.value.latent == 0 and ei.value.info == 3
+
+
+def test_full_size_properties(lmm):
+    """Size-independent properties at a size the oracle cannot reach quickly (n = 4096):
+    (i) shards add up; (ii) logpdf is quadratic in y: l(a*y) - l(0) = a^2 (l(y) - l(0)); (iii) mogp == oilmm with U = I."""
+    import torch
+    n, m, p = 4096, 2, 2
+    x = np.arange(n) * (20.0 / 575.0)
+    gps = _gps(["matern52"] * m)
+    rng = np.random.default_rng(8)
+    y = rng.standard_normal(n * p)
+    f = lmm.ILMM(_to_model(lmm, gps), lmm.Orthogonal(np.eye(2), np.ones(2)))
+    xin = lmm.MOInputIsotopicByOutputs(x, p)
+    l1 = lmm.logpdf(f(xin, 0.1), y); l0 = lmm.logpdf(f(xin, 0.1), np.zeros(n * p)); l2 = lmm.logpdf(f(xin, 0.1), 2.0 * y)
+    assert (l2 - l0) == pytest.approx(4.0 * (l1 - l0), rel=1e-10)
+    assert lmm.logpdf(_to_model(lmm, gps)(xin, 0.1), y) == pytest.approx(l1, rel=1e-12)
+    # against LAPACK on one latent (scipy on the host: 4096^3/3 flops, seconds)
+    ref = O.gp_logpdf(gps[0], x, 0.1, y[:n])
+    one = lmm.logpdf(lmm.independent_mogp([lmm.GP(lmm.Matern52Kernel())])(lmm.MOInputIsotopicByOutputs(x, 1), 0.1), y[:n])
+    assert one == pytest.approx(ref, rel=1e-9)
