@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py -- logpdf evaluations/s of the ILMM/OILMM hot path on N MI355X (BASELINE.json metric).
+
+A "step" is ONE logpdf evaluation of the workload (all n x p observations) with x and y already resident in
+HBM.  Default workload = BASELINE.json configs[2] (the configuration north_star quotes its scaling target on):
+OILMM, Orthogonal(U,S) 64x32, 32 Matern52 latents, n = 16384, Float64.  It fits one GPU, so the same problem is
+run at every N with the 32 latents sharded over the ranks (strong scaling; one scalar all-reduce per step).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c1|c0|small]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for the field definitions).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+WORKLOADS = {
+    # name: (m, p, n, kernel, orthogonal, BASELINE.json config it is)
+    "c2": (32, 64, 16384, "matern52", True, "configs[2]: OILMM, Orthogonal(U,S) 64x32, 32 Matern52 latents, n=16384, f64"),
+    "c1": (8, 16, 4096, "se", False, "configs[1]: ILMM, dense H 16x8, 8 SEKernel latents, n=4096, f64 (dense (mn)x(mn) path)"),
+    "c0": (3, 5, 200, "se", True, "configs[0]: OILMM, 3 SEKernel latents, p=5, n=200, f64"),
+    "small": (8, 16, 2048, "matern52", True, "reduced smoke workload (NOT a BASELINE config)"),
+}
+FP64_MFMA_PEAK_TFLOPS = 78.6      # AMD MI355X datasheet FP64 matrix (= vector) peak; not in the local guide
+HBM_PEAK_GBS = 8000.0             # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def build_model(lmm, P):
+    K = {"se": lmm.SEKernel, "matern32": lmm.Matern32Kernel, "matern52": lmm.Matern52Kernel}
+    fs = lmm.independent_mogp([lmm.GP(g["mean"], K[g["kind"]](g["variance"], g["lengthscale"])) for g in P["gps"]])
+    H = lmm.Orthogonal(P["U"], P["S"]) if "U" in P else P["H"]
+    return fs, H
+
+
+def cpu_baseline(P, orthogonal, budget_latents=2):
+    """The oracle (a NumPy/SciPy port of the reference algorithm: per-latent Gram -> LAPACK dpotrf -> dtrtrs) timed
+    on the host cores on a bounded sample of the SAME workload: `budget_latents` of the m latents at full n,
+    extrapolated linearly to m latents (latents are independent and equally sized)."""
+    from oracle import lmm_oracle as O
+    m, n = P["m"], P["n"]
+    cores = os.cpu_count() or 1
+    if not orthogonal:
+        # dense ILMM: (mn)^3/3 does not subsample by latents; time a reduced n and scale by the cubic flop count
+        ns = max(64, n // 8)
+        Ps = O.synthetic_problem(m, P["p"], ns, P["gps"][0]["kind"], False, P["s2"], seed=0)
+        t0 = time.perf_counter(); O.ilmm_logpdf(Ps["gps"], Ps["H"], Ps["x"], Ps["s2"], Ps["y"]); dt = time.perf_counter() - t0
+        est = dt * (n / ns) ** 3
+        return {"value": 1.0 / est, "unit": "evals/s", "cores": cores, "kind": "port",
+                "sample": f"oracle ilmm_logpdf at n={ns} ({dt:.2f} s), scaled by (n/{ns})^3 to n={n}"}
+    k = min(budget_latents, m)
+    T, ST = O.project_orthogonal(P["U"], P["S"], P["s2"])
+    Ty = T @ O.reshape_y(P["y"], n)
+    t0 = time.perf_counter()
+    for l in range(k):
+        O.gp_logpdf(P["gps"][l], P["x"], ST[l], Ty[l])
+    dt = time.perf_counter() - t0
+    est = dt / k * m
+    return {"value": 1.0 / est, "unit": "evals/s", "cores": cores, "kind": "port",
+            "sample": f"oracle per-latent logpdf (NumPy Gram + LAPACK potrf/trtrs) for {k} of {m} latents at n={n}: "
+                      f"{dt:.2f} s, extrapolated x{m}/{k}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+
+    import lmm_amd
+    from lmm_amd import _lib as L
+    from oracle import lmm_oracle as O      # synthetic problem generator + cpu_baseline leg only
+    lmm_amd.init(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    m, p, n, kind, orth, desc = WORKLOADS[args.workload]
+    P = O.synthetic_problem(m, p, n, kind, orth, s2=0.1, seed=0)
+    fs, H = build_model(lmm_amd, P)
+    xd = torch.from_numpy(P["x"]).to(dev)
+    yd = torch.from_numpy(P["y"]).to(dev)
+    xin = lmm_amd.MOInputIsotopicByOutputs(xd, p)
+    if orth:
+        shard = lmm_amd.latent_shard(m, rank, world)
+        f = lmm_amd.ILMM(fs, H, shard=shard)
+    else:
+        shard = (0, m)                       # dense ILMM does not shard: replicas only
+        f = lmm_amd.ILMM(fs, H)
+    fx = f(xin, 0.1)
+    red = torch.zeros(1, dtype=torch.float64, device=dev)
+
+    def step():
+        part = lmm_amd.logpdf(fx, yd, rank == 0)
+        if world > 1 and orth:
+            red[0] = part
+            dist.all_reduce(red)             # ONE scalar RCCL all-reduce per evaluation
+            return float(red[0])
+        return part
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    val = None
+    for _ in range(args.warmup):
+        val = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        val = step()
+    fence()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt[0])
+    steps = max(args.steps, 1)
+    evals_per_s = (steps * (world if not orth else 1)) / dt     # replicas: every rank evaluates the whole job
+
+    roof = None
+    extra = {}
+    if rank == 0 and not args.no_roofline:
+        # Roofline leg: one more evaluation of (a few latents of) the same workload with every launch of the hot
+        # kernels bracketed by HIP events on its own stream, latents forced onto ONE stream so that an event pair
+        # times its kernel alone (DESIGN.md "Measurement").
+        lib = lmm_amd.load()
+        nprof = min(2, shard[1] - shard[0]) if orth else m
+        fprof = lmm_amd.ILMM(fs, H, shard=(shard[0], shard[0] + nprof))(xin, 0.1) if orth else fx
+        L.check(lib.lmm_profile_begin(1))
+        lmm_amd.logpdf(fprof, yd, False)
+        ent = (L.ProfEntryT * len(L.PROF_CLASSES))()
+        L.check(lib.lmm_profile_end(ent))
+        prof = {c: {"launches": int(ent[i].launches), "ms": float(ent[i].ms), "work": float(ent[i].work)}
+                for i, c in enumerate(L.PROF_CLASSES)}
+        up = prof["update"]
+        if up["launches"] and up["ms"] > 0:
+            ach = up["work"] / (up["ms"] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "gemm_nt_kernel<128,SUB> (f64 MFMA SYRK/GEMM trailing update)",
+                    "achieved": round(ach, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "launches": up["launches"], "avg_launch_ms": round(up["ms"] / up["launches"], 4),
+                    "flops_per_launch": up["work"] / up["launches"],
+                    "mode": f"serial-stream instrumented pass over {nprof} latent(s)"}
+        gr = prof["gram"]
+        if gr["launches"] and gr["ms"] > 0:
+            gbs = gr["work"] / (gr["ms"] * 1e-3) / 1e9
+            extra["roofline_gram"] = {"bound": "hbm", "kernel": "gram_kernel (lower-triangular f64 write)",
+                                      "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                                      "launches": gr["launches"], "avg_launch_ms": round(gr["ms"] / gr["launches"], 4)}
+        extra["kernel_classes_ms"] = {c: round(v["ms"], 3) for c, v in prof.items()}
+        tf = C.c_double()
+        if lib.lmm_dev_mfma_f64_peak(C.byref(tf)) == 0:
+            extra["mfma_f64_issue_rate_measured_tflops"] = round(tf.value, 2)
+        fl = m * n ** 3 / 3.0 if orth else (m * n) ** 3 / 3.0
+        extra["end_to_end_cholesky_tflops"] = round(fl * evals_per_s / 1e12 / (1 if orth else world), 3)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(P, orth)
+
+    if rank == 0:
+        line = {
+            "metric": "logpdf evals/sec", "value": evals_per_s, "unit": "evals/s",
+            "obs_per_s": evals_per_s * n * p,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / steps * 1e3,
+            "higher_is_better": True, "scaling": "strong" if orth else "replicas", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": desc, "m": m, "p": p, "n": n, "kernel": kind, "sigma2": 0.1,
+                       "latents_per_gpu": (shard[1] - shard[0]), "parallelism": f"latent-shard x{world}" if orth else "replicas"},
+            "logpdf": val,
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        line.update(extra)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

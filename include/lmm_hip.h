@@ -155,6 +155,23 @@ int lmm_dev_gemm_nt_sub(double* C, int ldc, const double* A, int lda, const doub
 /* Gram assembly of one latent into a padded factor matrix (lower triangle + pad identity). */
 int lmm_dev_gram(double* A, int ld, int nrows, int ncols, const double* x, int d, int n,
                  const lmm_gp_t* gp, double diag_add);
+/* ---- measurement hooks (bench.py roofline leg) ------------------------------------------------ */
+/* Between lmm_profile_begin and lmm_profile_end every launch of the classes below is bracketed by HIP events
+ * on the stream it is launched on.  serial != 0 forces all latents onto ONE stream, so an event pair times its
+ * kernel alone (the production path runs latents on concurrent streams, where durations overlap).
+ * work = algorithmic flops (MFMA classes) or algorithmic HBM bytes (Gram assembly) summed over launches. */
+typedef enum {
+  LMM_PROF_GRAM = 0,          /* gram_kernel: lower-triangular f64 write, bytes                        */
+  LMM_PROF_UPDATE = 1,        /* gemm_nt_kernel<128,SUB>: SYRK/GEMM trailing update, flops              */
+  LMM_PROF_UPDATE_NARROW = 2, /* gemm_nt_kernel<64,SUB>: 64-column update inside a 128 panel, flops     */
+  LMM_PROF_TRSM = 3,          /* gemm_nt_kernel<64,SET>: panel TRSM by inverse diagonal block, flops    */
+  LMM_PROF_DIAG = 4,          /* diag64_kernel: 64x64 factor + inverse, flops                           */
+  LMM_PROF_COUNT = 5
+} lmm_prof_class;
+typedef struct { long long launches; double ms; double work; } lmm_prof_entry_t;
+int lmm_profile_begin(int serial);
+int lmm_profile_end(lmm_prof_entry_t* out /* LMM_PROF_COUNT entries */);
+
 /* f64 MFMA issue-rate microbenchmark: returns measured TFLOP/s of v_mfma_f64_16x16x4_f64. */
 int lmm_dev_mfma_f64_peak(double* tflops);
 

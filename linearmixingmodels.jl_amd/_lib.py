@@ -20,6 +20,7 @@ SYMBOLS = [
     "lmm_orthogonal_validate", "lmm_oilmm_logpdf", "lmm_ilmm_logpdf", "lmm_mogp_logpdf",
     "lmm_oilmm_posterior_create", "lmm_mogp_posterior_create", "lmm_ilmm_posterior_create", "lmm_post_destroy",
     "lmm_latent_marginals", "lmm_oilmm_mean_and_var", "lmm_oilmm_post_logpdf", "lmm_lmm_rand",
+    "lmm_profile_begin", "lmm_profile_end",
     "lmm_dev_potrf", "lmm_dev_gemm_nt_sub", "lmm_dev_gram", "lmm_dev_mfma_f64_peak",
 ]
 
@@ -30,6 +31,13 @@ class GpT(C.Structure):
 
 class JittersT(C.Structure):
     _fields_ = [("project_jitter", C.c_double), ("ilmm_rand_jitter", C.c_double), ("default_jitter", C.c_double)]
+
+
+class ProfEntryT(C.Structure):
+    _fields_ = [("launches", C.c_longlong), ("ms", C.c_double), ("work", C.c_double)]
+
+
+PROF_CLASSES = ["gram", "update", "update_narrow", "trsm", "diag"]
 
 
 class PosDefException(ArithmeticError):

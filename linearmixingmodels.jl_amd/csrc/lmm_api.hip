@@ -41,6 +41,11 @@ struct Ctx {
   std::map<void*, size_t> live;
   std::string err;
   int err_latent = -1, err_info = 0;
+  // measurement hooks
+  bool prof = false, prof_serial = false;
+  struct ProfRec { int cls; double work; hipEvent_t e0, e1; };
+  std::vector<ProfRec> prof_recs;
+  std::vector<hipEvent_t> ev_pool;
 };
 Ctx g;
 std::mutex g_mu;
@@ -140,6 +145,25 @@ struct DevOut {
 
 inline int rup(int v, int m) { return (v + m - 1) / m * m; }
 
+// Brackets one launch with events when profiling is on (lmm_profile_begin); otherwise just launches.
+struct ProfScope {
+  bool on; hipStream_t st; size_t idx;
+  ProfScope(int cls, double work, hipStream_t st_) : on(g.prof), st(st_), idx(0) {
+    if (!on) return;
+    Ctx::ProfRec r; r.cls = cls; r.work = work;
+    for (hipEvent_t* e : {&r.e0, &r.e1}) {
+      if (!g.ev_pool.empty()) { *e = g.ev_pool.back(); g.ev_pool.pop_back(); }
+      else HIPCHK(hipEventCreate(e));
+    }
+    HIPCHK(hipEventRecord(r.e0, st));
+    idx = g.prof_recs.size();
+    g.prof_recs.push_back(r);
+  }
+  ~ProfScope() { if (on) (void)hipEventRecord(g.prof_recs[idx].e1, st); }
+};
+
+inline int eff_streams() { return (g.prof && g.prof_serial) ? 1 : g.nstreams; }
+
 struct Dims {
   int n, NC, NR, ld;
   Dims(int n_, int nrider) : n(n_) {
@@ -179,10 +203,11 @@ void potrf_rec(double* A, int ld, int NR, int j0, int w, double* W, int n_real, 
   if (w <= 64) {
     double* blk = A + (size_t)j0 * ld + j0;
     double* Wb = W + (size_t)(j0 / 64) * 4096;
-    launch_diag64(blk, ld, Wb, j0, n_real, info, st);
+    { ProfScope ps(LMM_PROF_DIAG, 2.0 * 64.0 * 64.0 * 64.0 / 3.0, st); launch_diag64(blk, ld, Wb, j0, n_real, info, st); }
     const int M = NR - (j0 + 64);
     if (M > 0) {
       double* pan = A + (size_t)j0 * ld + (j0 + 64);
+      ProfScope ps(LMM_PROF_TRSM, (double)M * 64.0 * 64.0, st);   // triangular solve: M * 64^2 flops
       launch_gemm_nt(pan, ld, pan, ld, Wb, 64, M, 64, 64, 0, true, st);
     }
     return;
@@ -190,8 +215,12 @@ void potrf_rec(double* A, int ld, int NR, int j0, int w, double* W, int n_real, 
   const int h = split(w);
   potrf_rec(A, ld, NR, j0, h, W, n_real, info, st);
   const int r0 = j0 + h;
-  launch_gemm_nt(A + (size_t)r0 * ld + r0, ld, A + (size_t)j0 * ld + r0, ld, A + (size_t)j0 * ld + r0, ld,
-                 NR - r0, w - h, h, 1, false, st);
+  {
+    const double Mr = NR - r0, Nc = w - h;     // lower trapezoid: Nc(Nc+1)/2 + (Mr-Nc)Nc outputs, 2h flops each
+    ProfScope ps(Nc <= 64 ? LMM_PROF_UPDATE_NARROW : LMM_PROF_UPDATE, 2.0 * h * (Nc * (Nc + 1.0) / 2.0 + (Mr - Nc) * Nc), st);
+    launch_gemm_nt(A + (size_t)r0 * ld + r0, ld, A + (size_t)j0 * ld + r0, ld, A + (size_t)j0 * ld + r0, ld,
+                   NR - r0, w - h, h, 1, false, st);
+  }
   potrf_rec(A, ld, NR, r0, w - h, W, n_real, info, st);
 }
 
@@ -351,7 +380,7 @@ int latent_lmls(const double* xd, int d, int n, const lmm_gp_t* gps, const doubl
   lml.assign(ms, 0.0);
   if (ms == 0) return LMM_OK;
   Dims D(n, 1);
-  const int nslots = std::min(ms, g.nstreams);
+  const int nslots = std::min(ms, eff_streams());
   std::vector<Slot> slots;
   make_slots(slots, nslots, D.elems(), D.NC);
   Buf<double> out(ms);
@@ -366,7 +395,7 @@ int latent_lmls(const double* xd, int d, int n, const lmm_gp_t* gps, const doubl
     a.x = xd; a.d = d; a.n = n; a.kind = gp.kind; a.var = gp.variance; a.inv_ls = 1.0 / gp.lengthscale;
     a.diag_add = noise[l0 + k]; a.pad_diag = 1.0;
     a.rider = delta + (size_t)k * n; a.rider_ld = n; a.nrider = 1; a.xs = nullptr; a.ns = 0;
-    launch_gram(a, s.st);
+    { ProfScope ps(LMM_PROF_GRAM, (double)n * ((double)n + 1.0) / 2.0 * 8.0, s.st); launch_gram(a, s.st); }
     potrf_rec(s.A.p, D.ld, D.NR, 0, D.NC, s.W.p, n, info.p + k, s.st);
     launch_lml_reduce(s.A.p, D.ld, n, D.NC, 1, out.p + k, s.st);
   }
@@ -997,6 +1026,33 @@ int lmm_dev_gram(double* A, int ld, int nrows, int ncols, const double* x, int d
   a.kind = gp->kind; a.var = gp->variance; a.inv_ls = 1.0 / gp->lengthscale; a.diag_add = diag_add; a.pad_diag = 1.0;
   launch_gram(a, g.streams[0]);
   HIPCHK(hipStreamSynchronize(g.streams[0]));
+  return LMM_OK;
+  LMM_CATCH
+}
+
+int lmm_profile_begin(int serial) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  REQUIRE_INIT();
+  g.prof = true; g.prof_serial = serial != 0;
+  g.prof_recs.clear();
+  return LMM_OK;
+}
+
+int lmm_profile_end(lmm_prof_entry_t* out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  REQUIRE_INIT();
+  LMM_TRY
+  if (!out) return fail(LMM_ERR_ARG, "out is NULL");
+  HIPCHK(hipDeviceSynchronize());
+  for (int c = 0; c < LMM_PROF_COUNT; ++c) { out[c].launches = 0; out[c].ms = 0.0; out[c].work = 0.0; }
+  for (auto& r : g.prof_recs) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, r.e0, r.e1));
+    out[r.cls].launches += 1; out[r.cls].ms += ms; out[r.cls].work += r.work;
+    g.ev_pool.push_back(r.e0); g.ev_pool.push_back(r.e1);
+  }
+  g.prof_recs.clear();
+  g.prof = false; g.prof_serial = false;
   return LMM_OK;
   LMM_CATCH
 }
