@@ -201,48 +201,64 @@ __global__ __launch_bounds__(256) void ilmm_dense_assemble_kernel(DenseArgs a) {
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void diag64_kernel(double* __restrict__ A, int ld, double* __restrict__ W,
                                                      int gcol0, int n_real, int* __restrict__ info) {
-  constexpr int S = 65;
-  __shared__ double z[128 * S];
-  const int t = threadIdx.x;
-  for (int idx = t; idx < 64 * 64; idx += 256) {
-    const int r = idx & 63, c = idx >> 6;
-    z[c * S + r] = (r >= c) ? A[(size_t)c * ld + r] : 0.0;
-    z[(64 + c) * S + r] = (r == c) ? 1.0 : 0.0;
+  // Register-resident elimination: thread (i = t & 63, q = t >> 6) owns row i, columns 16q..16q+15 of both the
+  // S part (the block being factored) and the W part (identity -> L1^-1).  Per pivot j the owners publish, through
+  // double-buffered LDS, column j (colb: every row's multiplier numerator; cmsk: the same masked to rows > j, which by
+  // symmetry is the pivot row of the S part) and row j of the W part; one barrier per pivot; all register indices are
+  // compile-time (inner 16 pivots unrolled), so nothing spills to scratch.
+  __shared__ __attribute__((aligned(16))) double colb[2][64];
+  __shared__ __attribute__((aligned(16))) double cmsk[2][64];
+  __shared__ __attribute__((aligned(16))) double roww[2][64];
+  __shared__ double dd[64];
+  const int t = threadIdx.x, i = t & 63, q = t >> 6;
+  double s[16], w[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    const int k = 16 * q + c;
+    s[c] = (i >= k) ? A[(size_t)k * ld + i] : 0.0;
+    w[c] = (i == k) ? 1.0 : 0.0;
   }
-  const int i = t & 63, cs = t >> 6;
-  for (int j = 0; j < 63; ++j) {
-    __syncthreads();
-    const double dj = z[j * S + j];
-    if (t == 0 && !(dj > 0.0) && gcol0 + j < n_real) atomicCAS(info, 0, gcol0 + j + 1);
-    if (i > j) {
-      const double mult = z[j * S + i] / dj;
-      const int ns = 63 - j;                                // S-part columns j+1..63, then W-part 0..j
-      for (int s = cs; s < 64; s += 4) {
-        if (s < ns) {
-          const int k = j + 1 + s;
-          if (i >= k) z[k * S + i] -= mult * z[j * S + k];
-        } else {
-          const int c = s - ns;
-          z[(64 + c) * S + i] -= mult * z[(64 + c) * S + j];
-        }
+  for (int jb = 0; jb < 4; ++jb) {
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+      const int j = 16 * jb + jj, b = jj & 1;
+      if (q == jb) {                       // owners of column j (wave-uniform)
+        colb[b][i] = s[jj];
+        cmsk[b][i] = (i > j) ? s[jj] : 0.0;
+      }
+      if (i == j) {                        // owners of row j of the W part
+#pragma unroll
+        for (int c = 0; c < 16; ++c) roww[b][16 * q + c] = w[c];
+      }
+      __syncthreads();
+      const double dj = colb[b][j];
+      if (t == 0) {
+        dd[j] = dj;
+        if (!(dj > 0.0) && gcol0 + j < n_real) atomicCAS(info, 0, gcol0 + j + 1);
+      }
+      const double mult = (i > j) ? colb[b][i] / dj : 0.0;
+      const d2* rs = reinterpret_cast<const d2*>(&cmsk[b][16 * q]);
+      const d2* rw = reinterpret_cast<const d2*>(&roww[b][16 * q]);
+#pragma unroll
+      for (int c2 = 0; c2 < 8; ++c2) {
+        const d2 ps = rs[c2], pw = rw[c2];
+        s[2 * c2] = __builtin_fma(-mult, ps.x, s[2 * c2]);
+        s[2 * c2 + 1] = __builtin_fma(-mult, ps.y, s[2 * c2 + 1]);
+        w[2 * c2] = __builtin_fma(-mult, pw.x, w[2 * c2]);
+        w[2 * c2 + 1] = __builtin_fma(-mult, pw.y, w[2 * c2 + 1]);
       }
     }
   }
   __syncthreads();
-  if (t == 0) {
-    const double dl = z[63 * S + 63];
-    if (!(dl > 0.0) && gcol0 + 63 < n_real) atomicCAS(info, 0, gcol0 + 64);
-  }
-  for (int idx = t; idx < 64 * 64; idx += 256) {
-    const int r = idx & 63, c = idx >> 6;
-    double w = 0.0;
-    if (r >= c) {
-      const double dc = z[c * S + c];
-      const double lc = sqrt(dc);
-      A[(size_t)c * ld + r] = (r == c) ? lc : z[c * S + r] / lc;
-      w = z[(64 + c) * S + r] / sqrt(z[r * S + r]);
+  const double rsi = 1.0 / sqrt(dd[i]);           // row scale of W = D^-1/2 L1^-1
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    const int k = 16 * q + c;
+    if (i >= k) {
+      const double lk = sqrt(dd[k]);
+      A[(size_t)k * ld + i] = (i == k) ? lk : s[c] / lk;
     }
-    W[c * 64 + r] = w;
+    W[k * 64 + i] = (i >= k) ? w[c] * rsi : 0.0;
   }
 }
 

@@ -327,8 +327,8 @@ def mean_and_var(fx: FiniteGP, add_noise: bool = True):
         return mean, var + s2                      # var(f, x) + Sigma_y diagonal
     unpack(fx)
     if not f.is_oilmm:
-        raise NotImplementedError("mean_and_var for dense-H ILMM (SURVEY.md 8a row A13): use Orthogonal H, or the "
-                                  "oracle's dense kron path at small n")
+        raise NotImplementedError("mean_and_var for dense-H ILMM (SURVEY.md 8a row A13) is not built yet; "
+                                  "use an Orthogonal mixing matrix")
     Ua, Sa, p, m = _H_args(f.H)
     l0, l1 = f.shard
     mean, var = _alloc_like(x.x, x.n * p), _alloc_like(x.x, x.n * p)

@@ -1,0 +1,91 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol include/lmm_hip.h declares,
+the host-only entry point works without a GPU, and compute entry points fail loudly (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import lmm_amd
+from lmm_amd import _lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "lmm_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(lmm_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_all_exported():
+    lib = lmm_amd.load()
+    decl = declared_symbols()
+    assert len(decl) >= 20
+    for s in decl:
+        assert hasattr(lib, s), f"liblmm_hip.so does not export {s}"
+    assert sorted(L.SYMBOLS) == decl, "SYMBOLS list in _lib.py is out of sync with include/lmm_hip.h"
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(L.GpT) == 32 and L.GpT.variance.offset == 8 and L.GpT.mean.offset == 24
+    assert C.sizeof(L.JittersT) == 24
+    assert C.sizeof(L.ProfEntryT) == 24
+
+
+def test_orthogonal_validate_host_only():
+    """reference test/orthogonal_matrix.jl:1-14."""
+    rng = np.random.default_rng(0)
+    with pytest.raises(ValueError, match="`U` is not an orthogonal matrix"):
+        lmm_amd.Orthogonal(rng.uniform(size=(5, 3)), rng.uniform(size=3))
+    U, S, _ = np.linalg.svd(rng.uniform(size=(5, 3)), full_matrices=False)
+    H = lmm_amd.Orthogonal(U, S)
+    assert H.shape == U.shape
+    np.testing.assert_array_equal(H.S, S)
+    np.testing.assert_array_equal(H.U, U)
+    np.testing.assert_allclose(H.collect(), U @ np.diag(np.sqrt(S)))
+    lmm_amd.Orthogonal(rng.uniform(size=(5, 3)), S, validate_fields=False)     # validate_fields kwarg
+
+
+def test_helpers_match_reference_utils():
+    """reference test/ilmm.jl:55-71."""
+    assert lmm_amd.noise_var(2) == 2
+    y = np.random.default_rng(1).uniform(size=16)
+    assert lmm_amd.reshape_y(y, 8).shape == (2, 8)
+    assert lmm_amd.reshape_y(y, 2).shape == (8, 2)
+    fs = lmm_amd.independent_mogp([lmm_amd.GP(lmm_amd.Matern32Kernel())])
+    H = np.random.default_rng(2).uniform(size=(2, 1))
+    x = lmm_amd.MOInputIsotopicByOutputs(np.random.default_rng(3).uniform(size=(2, 2)), 2)   # ColVecs(rand(2,2))
+    ilmm = lmm_amd.ILMM(fs, H)
+    f, H2, s2, xx = lmm_amd.unpack(ilmm(x, 0.1))
+    assert f is fs and H2 is ilmm.H and s2 == 0.1 and xx is x.x
+    assert lmm_amd.get_latent_gp(ilmm) == fs
+    assert lmm_amd.independent_mogp([lmm_amd.GP(lmm_amd.SEKernel())]) == lmm_amd.IndependentMOGP([lmm_amd.GP(lmm_amd.SEKernel())])
+    with pytest.raises(RuntimeError, match="out dim of x != out dim of f"):
+        lmm_amd.unpack(ilmm(lmm_amd.MOInputIsotopicByOutputs(np.zeros(3), 3), 0.1))
+
+
+def test_no_cpu_fallback():
+    """Without a GPU every compute entry point must raise; nothing routes through the oracle."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    fs = lmm_amd.independent_mogp([lmm_amd.GP(lmm_amd.SEKernel())])
+    fx = lmm_amd.ILMM(fs, lmm_amd.Orthogonal(np.array([[1.0], [0.0]]), np.array([1.0])))(
+        lmm_amd.MOInputIsotopicByOutputs(np.arange(4.0), 2), 0.1)
+    with pytest.raises(lmm_amd.LMMError, match="no HIP device"):
+        lmm_amd.logpdf(fx, np.zeros(8))
+    src = "".join(open(os.path.join(ROOT, "linearmixingmodels.jl_amd", f)).read()
+                  for f in ("__init__.py", "_lib.py", "model.py", "parallel.py"))
+    assert "import oracle" not in src and "from oracle" not in src and "lmm_oracle" not in src
+
+
+def test_latent_shard_partition():
+    for m in (1, 3, 8, 32, 33):
+        for world in (1, 2, 3, 4, 8):
+            blocks = [lmm_amd.latent_shard(m, r, world) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == m
+            assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+            sizes = [b - a for a, b in blocks]
+            assert max(sizes) - min(sizes) <= 1
