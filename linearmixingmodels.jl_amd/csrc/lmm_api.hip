@@ -43,7 +43,7 @@ struct Ctx {
   int err_latent = -1, err_info = 0;
   // measurement hooks
   bool prof = false, prof_serial = false;
-  struct ProfRec { int cls; double work; hipEvent_t e0, e1; };
+  struct ProfRec { int cls; double work; hipEvent_t e0, e1; int M, N, K; };
   std::vector<ProfRec> prof_recs;
   std::vector<hipEvent_t> ev_pool;
 };
@@ -148,9 +148,9 @@ inline int rup(int v, int m) { return (v + m - 1) / m * m; }
 // Brackets one launch with events when profiling is on (lmm_profile_begin); otherwise just launches.
 struct ProfScope {
   bool on; hipStream_t st; size_t idx;
-  ProfScope(int cls, double work, hipStream_t st_) : on(g.prof), st(st_), idx(0) {
+  ProfScope(int cls, double work, hipStream_t st_, int M = 0, int N = 0, int K = 0) : on(g.prof), st(st_), idx(0) {
     if (!on) return;
-    Ctx::ProfRec r; r.cls = cls; r.work = work;
+    Ctx::ProfRec r; r.cls = cls; r.work = work; r.M = M; r.N = N; r.K = K;
     for (hipEvent_t* e : {&r.e0, &r.e1}) {
       if (!g.ev_pool.empty()) { *e = g.ev_pool.back(); g.ev_pool.pop_back(); }
       else HIPCHK(hipEventCreate(e));
@@ -217,7 +217,7 @@ void potrf_rec(double* A, int ld, int NR, int j0, int w, double* W, int n_real, 
   const int r0 = j0 + h;
   {
     const double Mr = NR - r0, Nc = w - h;     // lower trapezoid: Nc(Nc+1)/2 + (Mr-Nc)Nc outputs, 2h flops each
-    ProfScope ps(Nc <= 64 ? LMM_PROF_UPDATE_NARROW : LMM_PROF_UPDATE, 2.0 * h * (Nc * (Nc + 1.0) / 2.0 + (Mr - Nc) * Nc), st);
+    ProfScope ps(Nc <= 64 ? LMM_PROF_UPDATE_NARROW : LMM_PROF_UPDATE, 2.0 * h * (Nc * (Nc + 1.0) / 2.0 + (Mr - Nc) * Nc), st, NR - r0, w - h, h);
     launch_gemm_nt(A + (size_t)r0 * ld + r0, ld, A + (size_t)j0 * ld + r0, ld, A + (size_t)j0 * ld + r0, ld,
                    NR - r0, w - h, h, 1, false, st);
   }
@@ -1049,6 +1049,8 @@ int lmm_profile_end(lmm_prof_entry_t* out) {
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, r.e0, r.e1));
     out[r.cls].launches += 1; out[r.cls].ms += ms; out[r.cls].work += r.work;
+    if (getenv("LMM_PROF_DUMP") && r.M > 0)
+      fprintf(stderr, "[prof] cls=%d M=%d N=%d K=%d ms=%.4f tflops=%.2f\n", r.cls, r.M, r.N, r.K, ms, r.work / (ms * 1e-3) / 1e12);
     g.ev_pool.push_back(r.e0); g.ev_pool.push_back(r.e1);
   }
   g.prof_recs.clear();

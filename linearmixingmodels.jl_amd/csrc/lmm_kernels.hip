@@ -14,6 +14,7 @@
 //   K4/K5 tall_skinny_kernel (T*Y projection, H*T*Y residual norm), mix_kernel (H unprojection)
 //   K7 trmv_lower_kernel (sample transform), axpy noise
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "lmm_internal.h"
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -386,6 +387,169 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(double* C, int ldc,
 }
 
 // ---------------------------------------------------------------------------------------------------
+// K2c: the same product on v_mfma_f64_4x4x4_4b_f64 -- the FP64 MFMA form that issues at the full FP64 rate on
+// gfx950 (measured tools/mfma_probe3: 76.8 TFLOP/s vs 36-47 for the 16x16x4 form).  The instruction computes 4
+// independent 4x4x4 products; measured lane map (tools/mfma_map):
+//     A[blk][i][k] : lane 16k + 4 blk + i      B[blk][k][j] : lane 16k + 4 blk + j      D[blk][i][j] : lane 16i + 4 blk + j
+// A wave's 64 x WN tile is covered by fragments  fa[u] (rows 16u + (lane&15), k = lane>>4 -- the same LDS read as the
+// 16x16x4 operand) and fb[v][s] (columns 16v + ((lane&15) + 4s) mod 16: the 4-row groups rotated by s), so that block
+// blk of MFMA (u, v, s) is the 4x4 product of row group blk with column group (blk + s) mod 4: 4 rotations cover a
+// 16 x 16 tile.  Per k-step of 4: 4 + 4 TN ds_read_b64 feed 16 TN MFMAs (16 cycles each).
+// ---------------------------------------------------------------------------------------------------
+template <int BN, bool SET>
+__global__ __launch_bounds__(256, 2) void gemm44_kernel(double* C, int ldc, const double* A, int lda,
+                                                         const double* __restrict__ B, int ldb,
+                                                         int M, int N, int K, int lower, int MT, int full_items,
+                                                         int splitk) {
+  constexpr int BM = 128, BK = 16;
+  constexpr int WN = BN / 2;
+  constexpr int TM = 4, TN = WN / 16;
+  constexpr int SA = BM + 16, SB = BN + 16;
+  constexpr int NLA = (BM * BK / 2) / 256;     // 4: thread t stages rows 2(t%64).. of k-columns t/64 + 4q
+  constexpr int NLB = (BN * BK / 2) / 256;     // 4 (BN=128) or 2 (BN=64)
+  constexpr int KSB = 256 / (BN / 2);          // k-columns covered per pass of the B staging (4 or 8)
+  constexpr int STAGE = 2 * BK * SA + 2 * BK * SB, EPI = 4 * 32 * 65;
+  __shared__ __attribute__((aligned(16))) double smem[STAGE > EPI ? STAGE : EPI];   // staging, then epilogue transpose
+  double (*As)[BK * SA] = reinterpret_cast<double (*)[BK * SA]>(smem);
+  double (*Bs)[BK * SB] = reinterpret_cast<double (*)[BK * SB]>(smem + 2 * BK * SA);
+
+  // Work item -> (tile, k-part).  Tiles on/below the diagonal are enumerated column by column; the first
+  // `full_items` tiles run their whole K range, the remaining ones (the last, partial round of workgroups over the
+  // chip) are split `splitk`-ways along K and combined with f64 atomics, so the launch ends without a long tail.
+  int tile = blockIdx.x, part = 0, nparts = 1;
+  if (tile >= full_items) {
+    const int r = tile - full_items;
+    tile = full_items + r / splitk; part = r - (r / splitk) * splitk; nparts = splitk;
+  }
+  int tj = 0, ti;
+  if (lower) {
+    int rem = tile;
+    for (;;) {
+      const int first = (tj * BN) / BM;
+      const int cnt = MT - first;
+      if (rem < cnt) { ti = first + rem; break; }
+      rem -= cnt; ++tj;
+    }
+  } else {
+    tj = tile / MT; ti = tile - tj * MT;
+  }
+  const int bm = ti * BM, bn = tj * BN;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int wr = (w & 1) * 64, wc = (w >> 1) * WN;
+  const bool active = (bm + wr < M) && (bn + wc < N) && !(lower && bm + wr + 63 < bn + wc);
+  const int nk_all = K / BK;
+  const int kc0 = (int)((long long)nk_all * part / nparts), kc1 = (int)((long long)nk_all * (part + 1) / nparts);
+  A += (size_t)kc0 * BK * lda;
+  B += (size_t)kc0 * BK * ldb;
+
+  // staging addresses: one base pointer per operand; the NLA / NLB passes differ by a uniform k offset
+  int rowa = bm + 2 * (t % (BM / 2)); if (rowa > M - 2) rowa = M - 2;
+  int rowb = bn + 2 * (t % (BN / 2)); if (rowb > N - 2) rowb = N - 2;
+  const double* ga0 = A + (size_t)(t / (BM / 2)) * lda + rowa;
+  const double* gb0 = B + (size_t)(t / (BN / 2)) * ldb + rowb;
+  const int sa0 = (t / (BM / 2)) * SA + 2 * (t % (BM / 2));
+  const int sb0 = (t / (BN / 2)) * SB + 2 * (t % (BN / 2));
+  d2 ra[NLA], rb[NLB];
+#pragma unroll
+  for (int q = 0; q < NLA; ++q) ra[q] = *reinterpret_cast<const d2*>(ga0 + (size_t)(4 * q) * lda);
+#pragma unroll
+  for (int q = 0; q < NLB; ++q) rb[q] = *reinterpret_cast<const d2*>(gb0 + (size_t)(KSB * q) * ldb);
+#pragma unroll
+  for (int q = 0; q < NLA; ++q) *reinterpret_cast<d2*>(&As[0][sa0 + 4 * q * SA]) = ra[q];
+#pragma unroll
+  for (int q = 0; q < NLB; ++q) *reinterpret_cast<d2*>(&Bs[0][sb0 + KSB * q * SB]) = rb[q];
+  __syncthreads();
+
+  double acc[TM][TN][4];
+#pragma unroll
+  for (int u = 0; u < TM; ++u)
+#pragma unroll
+    for (int v = 0; v < TN; ++v)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc[u][v][s] = 0.0;
+
+  const int l15 = lane & 15, lk = lane >> 4;
+  const int offA = lk * SA + wr + l15;
+  int offB[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) offB[s] = lk * SB + wc + ((l15 + 4 * s) & 15);
+
+  const int nk = kc1 - kc0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+#ifndef LMM_ABLATE_NOLOAD
+    if (kt + 1 < nk) {
+      const double* pa = ga0 + (size_t)(kt + 1) * BK * lda;
+      const double* pb = gb0 + (size_t)(kt + 1) * BK * ldb;
+#pragma unroll
+      for (int q = 0; q < NLA; ++q) ra[q] = *reinterpret_cast<const d2*>(pa + (size_t)(4 * q) * lda);
+#pragma unroll
+      for (int q = 0; q < NLB; ++q) rb[q] = *reinterpret_cast<const d2*>(pb + (size_t)(KSB * q) * ldb);
+    }
+#endif
+#ifndef LMM_ABLATE_NOMFMA
+    if (active) {
+      const double* as = &As[buf][0];
+      const double* bs = &Bs[buf][0];
+#pragma unroll
+      for (int s4 = 0; s4 < BK / 4; ++s4) {
+        double fa[TM];
+#pragma unroll
+        for (int u = 0; u < TM; ++u) fa[u] = as[offA + 4 * s4 * SA + 16 * u];
+#pragma unroll
+        for (int v = 0; v < TN; ++v) {
+          double fb[4];
+#pragma unroll
+          for (int s = 0; s < 4; ++s) fb[s] = bs[offB[s] + 4 * s4 * SB + 16 * v];
+#pragma unroll
+          for (int u = 0; u < TM; ++u)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+              acc[u][v][s] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[u], fb[s], acc[u][v][s], 0, 0, 0);
+        }
+      }
+    }
+#endif
+    if (kt + 1 < nk) {
+#pragma unroll
+      for (int q = 0; q < NLA; ++q) *reinterpret_cast<d2*>(&As[buf ^ 1][sa0 + 4 * q * SA]) = ra[q];
+#pragma unroll
+      for (int q = 0; q < NLB; ++q) *reinterpret_cast<d2*>(&Bs[buf ^ 1][sb0 + KSB * q * SB]) = rb[q];
+    }
+    __syncthreads();
+  }
+
+  if (!active) return;
+  // epilogue: lane (i = lane>>4, blk = (lane>>2)&3, j = lane&3) holds C[row 16u + 4 blk + i, col 16v + 4((blk+s)&3) + j].
+  // Transposed through a wave-private LDS region (32 columns x 64 rows at a time) so that every global access of the
+  // read-modify-write (or f64 atomic) is one contiguous 512-byte row segment per wave instruction.
+  constexpr int ES = 65;
+  double* ep = smem + w * (32 * ES);
+  const int li = lane >> 4, lb = (lane >> 2) & 3, lj = lane & 3;
+#pragma unroll
+  for (int h = 0; h < TN / 2; ++h) {
+#pragma unroll
+    for (int u = 0; u < TM; ++u)
+#pragma unroll
+      for (int vv = 0; vv < 2; ++vv)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          ep[(16 * vv + 4 * ((lb + s) & 3) + lj) * ES + 16 * u + 4 * lb + li] = acc[u][2 * h + vv][s];
+    __builtin_amdgcn_wave_barrier();
+    double* cp = C + (size_t)(bn + wc + 32 * h) * ldc + bm + wr + lane;
+#pragma unroll 8
+    for (int c = 0; c < 32; ++c) {
+      const double val = ep[c * ES + lane];
+      double* p = cp + (size_t)c * ldc;
+      if (SET) *p = val;
+      else if (nparts == 1) *p -= val;
+      else unsafeAtomicAdd(p, -val);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // K3/K6: per-latent log marginal likelihood from the factor:  -(n log 2pi + 2 sum log L_kk + |z|^2)/2,
 // z = rider row `rider_row` (= (L^-1 delta)').  One workgroup; wavefront shuffle reductions.
 // Also used with nrhs > 1 riders (matrix-Y): out[r].
@@ -662,10 +826,44 @@ void launch_diag64(double* Ablk, int ld, double* Wblk, int gcol0, int n_real, in
   hipLaunchKernelGGL(diag64_kernel, dim3(1), dim3(256), 0, st, Ablk, ld, Wblk, gcol0, n_real, info);
 }
 
+static int g_use_mfma16 = -1;   // LMM_MFMA16=1 selects the 16x16x4 MFMA kernels (A/B comparisons)
+
 void launch_gemm_nt(double* C, int ldc, const double* A, int lda, const double* B, int ldb, int M, int N, int K,
                     int lower, bool set, hipStream_t st) {
   if (M <= 0 || N <= 0 || K <= 0) return;
+  if (g_use_mfma16 < 0) { const char* e = getenv("LMM_MFMA16"); g_use_mfma16 = (e && atoi(e) != 0) ? 1 : 0; }
   const bool narrow = (N <= 64);
+  if (!g_use_mfma16) {
+    const int MT = (M + 127) / 128;
+    if (set) {   // in-place TRSM by inverse: one block column, no K split
+      hipLaunchKernelGGL((gemm44_kernel<64, true>), dim3(MT), dim3(256), 0, st, C, ldc, A, lda, B, ldb, M, N, K, 0, MT, MT, 1);
+      return;
+    }
+    const int BNsel = narrow ? 64 : 128;
+    const int NT = narrow ? 1 : (N + 127) / 128;
+    long long T = 0;
+    for (int tj = 0; tj < NT; ++tj) T += lower ? (MT - (tj * BNsel) / 128) : MT;
+    static int slots = 0;
+    if (slots == 0) {
+      int dev = 0, cus = 256;
+      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      slots = cus;    // the MFMA pipe, not residency, is the resource: one workgroup per CU already runs at ~80 % of the
+                      // CU's f64 rate (tools/stream_overlap), so a round is one tile per CU
+    }
+    const int nk = K / 16;
+    int full_items = (int)(T / slots) * slots, splitk = 1;
+    const int R = (int)(T - full_items);
+    static int deterministic = -1;          // LMM_DETERMINISTIC=1: no split-K atomics (bitwise reproducible, slower tail)
+    if (deterministic < 0) { const char* e = getenv("LMM_DETERMINISTIC"); deterministic = (e && atoi(e) != 0) ? 1 : 0; }
+    if (!deterministic && R > 0 && R <= slots / 2 && nk >= 8) {   // a thin last round: split its tiles along K to fill the chip
+      splitk = slots / R; if (splitk > nk / 4) splitk = nk / 4; if (splitk < 1) splitk = 1;
+    }
+    if (splitk == 1) full_items = (int)T;
+    const int items = full_items + (int)(T - full_items) * splitk;
+    if (narrow) hipLaunchKernelGGL((gemm44_kernel<64, false>), dim3(items), dim3(256), 0, st, C, ldc, A, lda, B, ldb, M, N, K, lower, MT, full_items, splitk);
+    else hipLaunchKernelGGL((gemm44_kernel<128, false>), dim3(items), dim3(256), 0, st, C, ldc, A, lda, B, ldb, M, N, K, lower, MT, full_items, splitk);
+    return;
+  }
   dim3 grid((M + 127) / 128, narrow ? 1 : (N + 127) / 128);
   if (set) {
     // in-place TRSM-by-inverse needs the full column extent in one block column

@@ -248,7 +248,7 @@ def test_oilmm_device_resident_inputs(lmm):
     f = lmm.ILMM(_to_model(lmm, P["gps"]), lmm.Orthogonal(P["U"], P["S"]))
     a = lmm.logpdf(f(lmm.MOInputIsotopicByOutputs(P["x"], 8), 0.1), P["y"])
     b = lmm.logpdf(f(lmm.MOInputIsotopicByOutputs(torch.from_numpy(P["x"]).cuda(), 8), 0.1), torch.from_numpy(P["y"]).cuda())
-    assert a == b
+    assert a == pytest.approx(b, rel=1e-13)      # split-K tail uses f64 atomics: last-bit run-to-run differences
     assert a == pytest.approx(O.oilmm_logpdf(P["gps"], P["U"], P["S"], P["x"], 0.1, P["y"]), rel=1e-9)
 
 

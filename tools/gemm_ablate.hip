@@ -1,0 +1,33 @@
+// Times the trailing-update kernel alone (and its ablations: -DLMM_ABLATE_NOLOAD / -DLMM_ABLATE_NOMFMA).
+#include "../linearmixingmodels.jl_amd/csrc/lmm_kernels.hip"
+#include <cstdio>
+__global__ void fill_rand(double* p, size_t n, unsigned seed) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  for (; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned long long z = (i + 1) * 0x9E3779B97F4A7C15ull + seed; z ^= z >> 29; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 32;
+    p[i] = ((double)(z & 0xFFFFFFFFFFFFFull) / 4503599627370496.0) - 0.5;
+  }
+}
+int main(int argc, char** argv) {
+  const int M = argc > 1 ? atoi(argv[1]) : 8192, N = argc > 2 ? atoi(argv[2]) : 8192, K = argc > 3 ? atoi(argv[3]) : 8192;
+  const int lower = argc > 4 ? atoi(argv[4]) : 1;
+  const int ld = M + 16;
+  double *C, *A;
+  hipMalloc(&C, (size_t)ld * N * 8); hipMalloc(&A, (size_t)ld * K * 8);
+  const int rnd = argc > 5 ? atoi(argv[5]) : 1;
+  hipMemset(C, 0, (size_t)ld * N * 8); hipMemset(A, 0, (size_t)ld * K * 8);
+  if (rnd) { fill_rand<<<2048, 256>>>(A, (size_t)ld * K, 1u); fill_rand<<<2048, 256>>>(C, (size_t)ld * N, 2u); }
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int which = 0; which < 2; ++which) {
+    setenv("LMM_MFMA16", which ? "1" : "0", 1); g_use_mfma16 = -1;
+    launch_gemm_nt(C, ld, A, ld, A, ld, M, N, K, lower, false, 0);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int r = 0; r < 3; ++r) launch_gemm_nt(C, ld, A, ld, A, ld, M, N, K, lower, false, 0);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 3;
+    double fl = lower ? 2.0 * K * ((double)N * (N + 1) / 2 + (double)(M - N) * N) : 2.0 * M * N * (double)K;
+    printf("%s rnd=%d M=%d N=%d K=%d lower=%d: %.3f ms  %.2f TFLOP/s (algorithmic)\n", which ? "mfma16x16x4" : "mfma4x4x4_4b", rnd, M, N, K, lower, ms, fl / ms / 1e9);
+  }
+  return 0;
+}
