@@ -104,6 +104,10 @@ int lmm_ilmm_posterior_create(const double* x, int d, int n, const double* y, in
                               const double* H, int m, double sigma2, const lmm_gp_t* gps,
                               const lmm_jitters_t* jit, lmm_post_t** out);
 int lmm_post_destroy(lmm_post_t* post);
+/* mean_and_var / marginals of the dense-H posterior ILMM at xs: reference src/ilmm.jl:108-129,142-145 applied to the
+ * PosteriorGP latent of src/ilmm.jl:196-197.  Outputs length ns*p, by-outputs; sigma2 included. */
+int lmm_ilmm_post_mean_and_var(const lmm_post_t* post, double sigma2, const double* xs, int d, int ns,
+                               const lmm_jitters_t* jit, double* mean_out, double* var_out);
 
 /* Latent marginals of the (prior if post == NULL, else posterior) latent processes of the shard at xs:
  * mean_lat, var_lat are (m_shard x ns) row-per-latent, i.e. ns x m_shard column-major.  No jitter, no

@@ -423,6 +423,10 @@ struct lmm_post {
   std::vector<Buf<double>> L; // per latent of the shard: factor matrix (NR x NC, ld)
   std::vector<Buf<double>> W; // inverse diagonal blocks
   std::vector<Buf<double>> alpha;
+  // dense ILMM (kind 1): L[0] is the (mn) x (mn) factor, alpha[0] the (mn) weights
+  int p = 0;
+  std::vector<double> H;        // p x m column-major (host)
+  Buf<LatentDev> latd;          // device latent descriptors
 };
 
 #define LMM_TRY try {
@@ -727,10 +731,96 @@ int lmm_mogp_posterior_create(const double* x, int d, int n, const double* y, in
   LMM_CATCH
 }
 
-int lmm_ilmm_posterior_create(const double*, int, int, const double*, int, const double*, int, double, const lmm_gp_t*,
-                              const lmm_jitters_t*, lmm_post_t**) {
-  return fail(LMM_ERR_UNSUPPORTED, "dense-H ILMM posterior handle is not built yet (SURVEY.md 8a row A11); "
-                                   "use the OILMM path or lmm_ilmm_logpdf");
+// posterior(fx::FiniteGP{<:ILMM}, y), dense H: reference src/ilmm.jl:184-198.  One (mn) x (mn) factorisation kept on the
+// device with alpha = C \ (Yproj - mean).
+int lmm_ilmm_posterior_create(const double* x, int d, int n, const double* y, int p, const double* H, int m, double sigma2,
+                              const lmm_gp_t* gps, const lmm_jitters_t* jit, lmm_post_t** out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  REQUIRE_INIT();
+  LMM_TRY
+  if (!x || !y || !H || !out || d <= 0 || n <= 0 || p <= 0 || m <= 0) return fail(LMM_ERR_ARG, "bad arguments");
+  if (int rc = check_gps(gps, m)) return rc;
+  if (!jit) jit = &kDefaultJit;
+  if ((long long)m * n > 2000000000LL / 64) return fail(LMM_ERR_UNSUPPORTED, "m*n too large for the dense path");
+  hipStream_t st0 = g.streams[0];
+  std::vector<double> T, ST;
+  if (int rc = project_dense(H, p, m, sigma2, jit->project_jitter, T, ST, nullptr)) return rc;
+  DevIn xd(x, (size_t)d * n, st0), yd(y, (size_t)n * p, st0);
+  Uploaded Td(T, st0), STd(ST, st0);
+  std::vector<double> means(m);
+  std::vector<LatentDev> lat(m);
+  for (int l = 0; l < m; ++l) { means[l] = gps[l].mean; lat[l] = to_dev(gps[l]); }
+  Uploaded meansd(means, st0);
+  const int N = m * n;
+  Dims D(N, 1);
+  lmm_post* P = new lmm_post();
+  try {
+    P->kind = 1; P->n = n; P->d = d; P->l0 = 0; P->l1 = m; P->m = m; P->p = p;
+    P->NC = D.NC; P->NR = D.NR; P->ld = D.ld;
+    P->gps.assign(gps, gps + m);
+    P->H.assign(H, H + (size_t)p * m);
+    P->x = Buf<double>((size_t)d * n);
+    HIPCHK(hipMemcpyAsync(P->x.p, xd.p, (size_t)d * n * sizeof(double), hipMemcpyDeviceToDevice, st0));
+    P->latd = Buf<LatentDev>(m);
+    HIPCHK(hipMemcpyAsync(P->latd.p, lat.data(), m * sizeof(LatentDev), hipMemcpyHostToDevice, st0));
+    Buf<double> delta((size_t)n * m);
+    project_on_device(yd.p, n, p, Td.buf, m, 0, m, meansd.buf.p, delta.p, st0);
+    P->L.emplace_back(D.elems());
+    P->W.emplace_back((size_t)(D.NC / 64) * 4096);
+    P->alpha.emplace_back((size_t)D.NC);
+    Buf<int> info(1);
+    HIPCHK(hipMemsetAsync(info.p, 0, sizeof(int), st0));
+    DenseArgs a{};
+    a.A = P->L[0].p; a.ld = D.ld; a.nrows = D.NR; a.ncols = D.NC; a.x = P->x.p; a.d = d; a.n = n; a.m = m;
+    a.lat = P->latd.p; a.sigmaT = STd.buf.p; a.rider = delta.p; a.rider_ld = N; a.nrider = 1;
+    launch_dense_assemble(a, st0);
+    potrf_rec(P->L[0].p, D.ld, D.NR, 0, D.NC, P->W[0].p, N, info.p, st0);
+    HIPCHK(hipMemsetAsync(P->alpha[0].p, 0, (size_t)D.NC * sizeof(double), st0));
+    launch_extract_row(P->L[0].p, D.ld, D.NC, N, P->alpha[0].p, st0);
+    launch_backsolve(P->L[0].p, D.ld, P->W[0].p, D.NC / 64, P->alpha[0].p, st0);
+    int hinfo = 0;
+    HIPCHK(hipMemcpyAsync(&hinfo, info.p, sizeof(int), hipMemcpyDeviceToHost, st0));
+    HIPCHK(hipStreamSynchronize(st0));
+    if (int rc = check_info(std::vector<int>{hinfo}, 0)) { delete P; return rc; }
+  } catch (int code) { delete P; return code; }
+  *out = P;
+  return LMM_OK;
+  LMM_CATCH
+}
+
+// mean_and_var(fx::FiniteGP{<:ILMM}) on the dense-H posterior: reference src/ilmm.jl:108-129 with the latent
+// PosteriorGP{IndependentMOGP} of src/ilmm.jl:196-197.  The same numbers as H_full * mu and
+// diag_Xt_A_X(cholesky(latent_cov), H_full') + sigma2, computed without the Cholesky of the 1e-18-jittered latent
+// covariance:  V = sum_l H^2 (k_l(0) + jitter) + sigma2 - rowsumsq((H (x) I) Kxs' L^-T).
+int lmm_ilmm_post_mean_and_var(const lmm_post_t* post, double sigma2, const double* xs, int d, int ns,
+                               const lmm_jitters_t* jit, double* mean_out, double* var_out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  REQUIRE_INIT();
+  LMM_TRY
+  if (!post || !xs || !mean_out || !var_out || d <= 0 || ns <= 0) return fail(LMM_ERR_ARG, "bad arguments");
+  const lmm_post* P = post;
+  if (P->kind != 1) return fail(LMM_ERR_ARG, "not a dense-H ILMM posterior");
+  if (P->d != d) return fail(LMM_ERR_DIM, "input dimension mismatch");
+  if (!jit) jit = &kDefaultJit;
+  hipStream_t st0 = g.streams[0];
+  const int m = P->m, p = P->p, n = P->n, N = m * n;
+  DevIn xsd(xs, (size_t)d * ns, st0);
+  Uploaded Hd(P->H, st0);
+  Buf<double> ml((size_t)ns * m);
+  for (int l = 0; l < m; ++l)
+    launch_post_mean(xsd.p, ns, P->x.p, n, d, P->alpha[0].p + (size_t)l * n, to_dev(P->gps[l]), ml.p + (size_t)l * ns, st0);
+  const int nr = rup(m * ns, 64);
+  int ldr = nr; if ((ldr % 512) == 0) ldr += 16;
+  Buf<double> R((size_t)ldr * P->NC);
+  launch_dense_cross(R.p, ldr, nr, P->NC, xsd.p, ns, P->x.p, n, d, m, P->latd.p, st0);
+  trsm_rec(R.p, ldr, nr, P->L[0].p, P->ld, P->W[0].p, 0, P->NC, st0);
+  DevOut mo(mean_out, (size_t)ns * p), vo(var_out, (size_t)ns * p);
+  launch_mix(ml.p, ns, m, Hd.buf.p, p, 1, 0.0, 0.0, nullptr, 0.0, mo.p, st0);
+  launch_dense_var(R.p, ldr, ns, m, N, Hd.buf.p, p, P->latd.p, jit->default_jitter, sigma2, vo.p, st0);
+  mo.finish(st0); vo.finish(st0);
+  HIPCHK(hipStreamSynchronize(st0));
+  return LMM_OK;
+  LMM_CATCH
 }
 
 int lmm_post_destroy(lmm_post_t* post) {
@@ -1063,7 +1153,7 @@ int lmm_dev_mfma_f64_peak(double* tflops) {
   std::lock_guard<std::mutex> lk(g_mu);
   REQUIRE_INIT();
   LMM_TRY
-  const int blocks = 256 * 4, iters = 20000;
+  const int blocks = 256 * 2, iters = 4000;
   Buf<double> out((size_t)blocks * 256);
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
@@ -1074,7 +1164,7 @@ int lmm_dev_mfma_f64_peak(double* tflops) {
   HIPCHK(hipEventSynchronize(e1));
   float ms = 0.f;
   HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-  const double flops = (double)blocks * 4 /*waves*/ * iters * 8.0 * 2048.0;
+  const double flops = (double)blocks * 4 /*waves*/ * iters * 64.0 * 512.0;
   *tflops = flops / (ms * 1e-3) / 1e12;
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return LMM_OK;

@@ -31,6 +31,10 @@ struct DenseArgs {
 
 void launch_gram(const GramArgs& a, hipStream_t st);
 void launch_dense_assemble(const DenseArgs& a, hipStream_t st);
+void launch_dense_cross(double* R, int ldr, int nrows, int ncols, const double* xs, int ns, const double* x, int n, int d,
+                        int m, const LatentDev* lat, hipStream_t st);
+void launch_dense_var(const double* R, int ldr, int ns, int m, int Ncols, const double* Hm, int p, const LatentDev* lat,
+                      double jitter, double sigma2, double* out, hipStream_t st);
 void launch_diag64(double* Ablk, int ld, double* Wblk, int gcol0, int n_real, int* info, hipStream_t st);
 void launch_gemm_nt(double* C, int ldc, const double* A, int lda, const double* B, int ldb, int M, int N, int K,
                     int lower, bool set, hipStream_t st);

@@ -194,6 +194,49 @@ __global__ __launch_bounds__(256) void ilmm_dense_assemble_kernel(DenseArgs a) {
   }
 }
 
+// Dense-ILMM cross-covariance riders: row (l, s) of R (m*ns rows) is K_l(xs_s, x) placed in the column block of
+// latent l (reference src/independent_mogp.jl:66-71: block-diagonal cov(f, x, y)); zero elsewhere and in the pad.
+__global__ __launch_bounds__(256) void dense_cross_kernel(double* __restrict__ R, int ldr, int nrows, int ncols,
+                                                          const double* __restrict__ xs, int ns,
+                                                          const double* __restrict__ x, int n, int d, int m,
+                                                          const LatentDev* __restrict__ lat) {
+  const int r = blockIdx.x * 256 + threadIdx.x;      // row (l, s)
+  const int j = blockIdx.y;                          // column
+  if (r >= nrows) return;
+  double val = 0.0;
+  const int l = r / ns, s = r - l * ns;
+  if (l < m && j < m * n) {
+    const int lj = j / n, jj = j - lj * n;
+    if (lj == l) {
+      const LatentDev g = lat[l];
+      double rr, r2;
+      if (d == 1) { rr = fabs(xs[s] - x[jj]) * g.inv_ls; r2 = rr * rr; }
+      else { r2 = scaled_dist2(xs + (size_t)s * d, x + (size_t)jj * d, d, g.inv_ls); rr = sqrt(r2); }
+      val = kappa(g.kind, g.var, rr, r2);
+    }
+  }
+  R[(size_t)j * ldr + r] = val;
+}
+
+// Dense-ILMM posterior variance (reference src/ilmm.jl:122-129 on a PosteriorGP latent):
+//   V[o, s] = sum_l H[o,l]^2 (k_l(0) + jitter) + sigma2 - sum_k ( sum_l H[o,l] R[(l,s), k] )^2,   R = Kxs' L^-T.
+__global__ __launch_bounds__(256) void dense_var_kernel(const double* __restrict__ R, int ldr, int ns, int m, int Ncols,
+                                                        const double* __restrict__ Hm, int p,
+                                                        const LatentDev* __restrict__ lat, double jitter, double sigma2,
+                                                        double* __restrict__ out) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  const int o = blockIdx.y;
+  if (s >= ns) return;
+  double base = sigma2, q = 0.0;
+  for (int l = 0; l < m; ++l) { const double h = Hm[o + (size_t)l * p]; base = __builtin_fma(h * h, lat[l].var + jitter, base); }
+  for (int k = 0; k < Ncols; ++k) {
+    double t = 0.0;
+    for (int l = 0; l < m; ++l) t = __builtin_fma(Hm[o + (size_t)l * p], R[(size_t)k * ldr + l * ns + s], t);
+    q = __builtin_fma(t, t, q);
+  }
+  out[(size_t)o * ns + s] = base - q;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // K2a: 64x64 diagonal block: Cholesky factor L and its inverse W = L^-1 in one symmetric Gaussian
 // elimination of [A | I] held in LDS (one barrier per pivot).  One workgroup, latency bound.
@@ -795,17 +838,23 @@ __global__ void add_diag_kernel(double* A, int ld, int n, double v) {
 // f64 MFMA issue-rate microbenchmark (the guide gives no FP64 matrix peak).
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mfma_f64_peak_kernel(double* out, int iters) {
-  d4 acc[8];
+  // v_mfma_f64_4x4x4_4b_f64 with the update kernel's operand pattern: 4 A-fragments x 16 B-fragments, 64 accumulators
+  double acc[64], a[4], b[16];
 #pragma unroll
-  for (int q = 0; q < 8; ++q) acc[q] = (d4){0.0, 0.0, 0.0, 0.0};
-  double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+  for (int q = 0; q < 64; ++q) acc[q] = 0.0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) a[q] = 1.0 + (threadIdx.x + 7 * q) * 1e-3;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) b[q] = 1.0 - (threadIdx.x + 3 * q) * 1e-3;
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[q], 0, 0, 0);
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[u * 16 + v] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[u], b[v], acc[u * 16 + v], 0, 0, 0);
   }
   double s = 0.0;
 #pragma unroll
-  for (int q = 0; q < 8; ++q) s += acc[q][0] + acc[q][1] + acc[q][2] + acc[q][3];
+  for (int q = 0; q < 64; ++q) s += acc[q];
   out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
@@ -815,6 +864,18 @@ __global__ __launch_bounds__(256) void mfma_f64_peak_kernel(double* out, int ite
 void launch_gram(const GramArgs& a, hipStream_t st) {
   dim3 grid(a.nrows / 64 - a.row_tile0, a.ncols / 64);
   hipLaunchKernelGGL(gram_kernel, grid, dim3(256), 0, st, a);
+}
+
+void launch_dense_cross(double* R, int ldr, int nrows, int ncols, const double* xs, int ns, const double* x, int n, int d,
+                        int m, const LatentDev* lat, hipStream_t st) {
+  dim3 grid((nrows + 255) / 256, ncols);
+  hipLaunchKernelGGL(dense_cross_kernel, grid, dim3(256), 0, st, R, ldr, nrows, ncols, xs, ns, x, n, d, m, lat);
+}
+
+void launch_dense_var(const double* R, int ldr, int ns, int m, int Ncols, const double* Hm, int p, const LatentDev* lat,
+                      double jitter, double sigma2, double* out, hipStream_t st) {
+  dim3 grid((ns + 255) / 256, p);
+  hipLaunchKernelGGL(dense_var_kernel, grid, dim3(256), 0, st, R, ldr, ns, m, Ncols, Hm, p, lat, jitter, sigma2, out);
 }
 
 void launch_dense_assemble(const DenseArgs& a, hipStream_t st) {

@@ -326,17 +326,21 @@ def mean_and_var(fx: FiniteGP, add_noise: bool = True):
         L.check(lib.lmm_latent_marginals(post, gps, m, xa.ptr, x.dim, x.n, ma.ptr, va.ptr))
         return mean, var + s2                      # var(f, x) + Sigma_y diagonal
     unpack(fx)
-    if not f.is_oilmm:
-        raise NotImplementedError("mean_and_var for dense-H ILMM (SURVEY.md 8a row A13) is not built yet; "
-                                  "use an Orthogonal mixing matrix")
     Ua, Sa, p, m = _H_args(f.H)
+    if not f.is_oilmm and f.f._post is not None:
+        # dense-H posterior: coupled latents (reference src/ilmm.jl:108-129 on the PosteriorGP of :196-197)
+        mean, var = _alloc_like(x.x, x.n * p), _alloc_like(x.x, x.n * p)
+        ma, va = L.Arr(mean, True), L.Arr(var, True)
+        L.check(lib.lmm_ilmm_post_mean_and_var(f.f._post.ptr, C.c_double(s2), xa.ptr, x.dim, x.n, None, ma.ptr, va.ptr))
+        return mean, var
     l0, l1 = f.shard
     mean, var = _alloc_like(x.x, x.n * p), _alloc_like(x.x, x.n * p)
     ma, va = L.Arr(mean, True), L.Arr(var, True)
     post = f.f._post.ptr if f.f._post is not None else None
     gps = L.gps_array([g.desc() for g in f.f.fs])
-    L.check(lib.lmm_oilmm_mean_and_var(post, gps, Ua.ptr, Sa.ptr, p, m, l0, l1, C.c_double(s2), int(add_noise), xa.ptr,
-                                       x.dim, x.n, None, ma.ptr, va.ptr))
+    # dense-H prior: latents are independent, so V = abs2.(H) * V_latent + s2 exactly as in the OILMM form (S == NULL)
+    L.check(lib.lmm_oilmm_mean_and_var(post, gps, Ua.ptr, Sa.ptr if Sa is not None else None, p, m, l0, l1,
+                                       C.c_double(s2), int(add_noise), xa.ptr, x.dim, x.n, None, ma.ptr, va.ptr))
     return mean, var
 
 

@@ -190,6 +190,17 @@ def test_ilmm_dense_toy_shapes(lmm, m):
     got = lmm.logpdf(fx, ytr)
     assert got == pytest.approx(O.ilmm_logpdf(gps, H, xtr, 1e-6, ytr), rel=RTOL)
     assert got == pytest.approx(O.naive_logpdf(gps, H, xtr, 1e-6, ytr), rel=RTOL)
+    # prior marginals (test/ilmm.jl:10-14) and posterior marginals at the test points (test/ilmm.jl:23-26)
+    mu, v = lmm.mean_and_var(fx)
+    mo, vo = O.ilmm_mean_var(gps, H, xtr, 1e-6)
+    np.testing.assert_allclose(mu, mo, atol=1e-12); np.testing.assert_allclose(v, vo, rtol=1e-12)
+    xte = x[perm[3:]]
+    post = lmm.posterior(fx, ytr)
+    mu, v = lmm.mean_and_var(post(lmm.MOInputIsotopicByOutputs(xte, 3), 1e-6))
+    mn, Cn = O.naive_posterior_mean_cov(gps, H, xtr, 1e-6, ytr, xte)
+    mo, vo = O.ilmm_mean_var(O.ilmm_posterior(gps, H, xtr, 1e-6, ytr), H, xte, 1e-6)
+    np.testing.assert_allclose(mu, mo, rtol=1e-5, atol=1e-6); np.testing.assert_allclose(v, vo, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(mu, mn, rtol=1e-5, atol=1e-6); np.testing.assert_allclose(v, np.diag(Cn) + 1e-6, rtol=1e-5, atol=1e-7)
 
 
 def test_mogp_toy(lmm):
@@ -270,6 +281,10 @@ def test_ilmm_dense_mid(lmm):
     P["gps"][1]["kind"] = "matern32"; P["gps"][2]["lengthscale"] = 0.7
     fx = lmm.ILMM(_to_model(lmm, P["gps"]), P["H"])(lmm.MOInputIsotopicByOutputs(P["x"], 5), 0.1)
     assert lmm.logpdf(fx, P["y"]) == pytest.approx(O.ilmm_logpdf(P["gps"], P["H"], P["x"], 0.1, P["y"]), rel=1e-8)
+    xs = P["x"][:40] + 0.013
+    mu, v = lmm.mean_and_var(lmm.posterior(fx, P["y"])(lmm.MOInputIsotopicByOutputs(xs, 5), 0.1))
+    mo, vo = O.ilmm_mean_var(O.ilmm_posterior(P["gps"], P["H"], P["x"], 0.1, P["y"]), P["H"], xs, 0.1)
+    np.testing.assert_allclose(mu, mo, rtol=1e-7, atol=1e-9); np.testing.assert_allclose(v, vo, rtol=1e-7)
 
 
 def test_rand_matches_oracle_given_normals(lmm):
