@@ -93,9 +93,18 @@ __device__ __forceinline__ double scaled_dist2(const double* __restrict__ a, con
   return s;
 }
 
-__global__ __launch_bounds__(256) void gram_kernel(GramArgs a) {
-  const int ti = blockIdx.x + a.row_tile0, tj = blockIdx.y;
-  if (!a.full && ti < tj) return;                          // lower tiles only
+template <int KIND>
+__device__ __forceinline__ double kappa_t(double var, double r, double r2) {
+  if (KIND == LMM_KERNEL_SE) return var * exp_nonpos(-0.5 * r2);
+  if (KIND == LMM_KERNEL_MATERN32) {
+    const double s = 1.7320508075688772 * r;
+    return var * (1.0 + s) * exp_nonpos(-s);
+  }
+  const double s = 2.23606797749979 * r;
+  return var * __builtin_fma(5.0 / 3.0, r2, 1.0 + s) * exp_nonpos(-s);
+}
+
+__device__ __forceinline__ void gram_tile_generic(const GramArgs& a, int ti, int tj) {
   const int t = threadIdx.x;
   const int i0 = ti * 64 + 2 * (t & 31);
   const int cg = t >> 5;
@@ -144,6 +153,36 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs a) {
       v.x = out[0]; v.y = out[1];
     }
     *reinterpret_cast<d2*>(a.A + (size_t)j * a.ld + (i0 - a.row_shift)) = v;
+  }
+}
+
+// Interior tiles (all 64 rows and 64 columns are data points, d == 1) take a branch-free path specialised on the
+// kernel kind; border / rider / pad tiles and d > 1 use the generic tile routine.
+template <int KIND>
+__global__ __launch_bounds__(256) void gram_kernel(GramArgs a) {
+  const int ti = blockIdx.x + a.row_tile0, tj = blockIdx.y;
+  if (!a.full && ti < tj) return;                          // lower tiles only
+  const bool interior = (a.d == 1) && (ti * 64 + 63 < a.n) && (tj * 64 + 63 < a.n);
+  if (!interior) { gram_tile_generic(a, ti, tj); return; }
+  const int t = threadIdx.x;
+  const int i0 = ti * 64 + 2 * (t & 31);
+  const int cg = t >> 5;
+  const double x0 = a.x[i0], x1 = a.x[i0 + 1];
+  double* out = a.A + (size_t)(tj * 64 + cg) * a.ld + (i0 - a.row_shift);
+  const double* xc = a.x + tj * 64 + cg;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const double xj = xc[8 * q];
+    const double r0 = fabs(x0 - xj) * a.inv_ls, r1 = fabs(x1 - xj) * a.inv_ls;
+    d2 v;
+    v.x = kappa_t<KIND>(a.var, r0, r0 * r0);
+    v.y = kappa_t<KIND>(a.var, r1, r1 * r1);
+    if (ti == tj) {
+      const int j = tj * 64 + cg + 8 * q;
+      if (i0 == j) v.x += a.diag_add;
+      if (i0 + 1 == j) v.y += a.diag_add;
+    }
+    *reinterpret_cast<d2*>(out + (size_t)(8 * q) * a.ld) = v;
   }
 }
 
@@ -464,17 +503,25 @@ __global__ __launch_bounds__(256, 2) void gemm44_kernel(double* C, int ldc, cons
     const int r = tile - full_items;
     tile = full_items + r / splitk; part = r - (r / splitk) * splitk; nparts = splitk;
   }
-  int tj = 0, ti;
-  if (lower) {
+  // Tile order: bands of 16 row tiles, column-major inside a band, so that the ~256 tiles in flight form a compact
+  // ~16 x 16 patch of C (32 operand panels instead of ~68 for plain column-major order): fewer HBM re-reads of A/B.
+  int tj = 0, ti = 0;
+  {
+    const int NTc = (N + BN - 1) / BN;
     int rem = tile;
-    for (;;) {
-      const int first = (tj * BN) / BM;
-      const int cnt = MT - first;
-      if (rem < cnt) { ti = first + rem; break; }
-      rem -= cnt; ++tj;
+    for (int r0 = 0; r0 < MT; r0 += 16) {
+      const int r1 = (r0 + 16 < MT) ? r0 + 16 : MT;           // band rows [r0, r1)
+      bool found = false;
+      for (int c = 0; c < NTc; ++c) {
+        int first = lower ? (c * BN) / BM : 0;                 // first active row tile of column c
+        if (first < r0) first = r0;
+        const int cnt = r1 - first;
+        if (cnt <= 0) break;                                   // columns further right are above the diagonal for this band
+        if (rem < cnt) { tj = c; ti = first + rem; found = true; break; }
+        rem -= cnt;
+      }
+      if (found) break;
     }
-  } else {
-    tj = tile / MT; ti = tile - tj * MT;
   }
   const int bm = ti * BM, bn = tj * BN;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -863,7 +910,9 @@ __global__ __launch_bounds__(256) void mfma_f64_peak_kernel(double* out, int ite
 // ---------------------------------------------------------------------------------------------------
 void launch_gram(const GramArgs& a, hipStream_t st) {
   dim3 grid(a.nrows / 64 - a.row_tile0, a.ncols / 64);
-  hipLaunchKernelGGL(gram_kernel, grid, dim3(256), 0, st, a);
+  if (a.kind == LMM_KERNEL_SE) hipLaunchKernelGGL((gram_kernel<LMM_KERNEL_SE>), grid, dim3(256), 0, st, a);
+  else if (a.kind == LMM_KERNEL_MATERN32) hipLaunchKernelGGL((gram_kernel<LMM_KERNEL_MATERN32>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((gram_kernel<LMM_KERNEL_MATERN52>), grid, dim3(256), 0, st, a);
 }
 
 void launch_dense_cross(double* R, int ldr, int nrows, int ncols, const double* xs, int ns, const double* x, int n, int d,
