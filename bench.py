@@ -31,7 +31,9 @@ WORKLOADS = {
     "c0": (3, 5, 200, "se", True, "configs[0]: OILMM, 3 SEKernel latents, p=5, n=200, f64"),
     "small": (8, 16, 2048, "matern52", True, "reduced smoke workload (NOT a BASELINE config)"),
 }
-FP64_MFMA_PEAK_TFLOPS = 78.6      # AMD MI355X datasheet FP64 matrix (= vector) peak; not in the local guide
+FP64_MFMA_PEAK_TFLOPS = 78.6      # AMD MI355X datasheet FP64 matrix (= vector) peak; the local guide lists no FP64 MFMA
+                                  # rate.  Measured here: v_mfma_f64_4x4x4_4b_f64 issues at 76.8 TFLOP/s (tools/mfma_probe3,
+                                  # profiles/r01_probes/probe3.log) = 97.7 % of it, so 78.6 is the denominator.
 HBM_PEAK_GBS = 8000.0             # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
@@ -162,9 +164,15 @@ def main():
         up = prof["update"]
         if up["launches"] and up["ms"] > 0:
             ach = up["work"] / (up["ms"] * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "gemm_nt_kernel<128,SUB> (f64 MFMA SYRK/GEMM trailing update)",
+            traffic = None       # HBM-side bytes per launch from the committed rocprofv3 --pmc passes (separate runs)
+            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(tpath):
+                tj = json.load(open(tpath))
+                if tj.get("workload") == args.workload:
+                    traffic = tj.get("gemm44_kernel<128, false>", {}).get("bytes_per_launch")
+            roof = {"bound": "mfma", "kernel": "gemm44_kernel<128,false> (v_mfma_f64_4x4x4_4b_f64 SYRK/GEMM trailing update)",
                     "achieved": round(ach, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "frac": round(ach / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                     "launches": up["launches"], "avg_launch_ms": round(up["ms"] / up["launches"], 4),
                     "flops_per_launch": up["work"] / up["launches"],
                     "mode": f"serial-stream instrumented pass over {nprof} latent(s)"}

@@ -387,6 +387,11 @@ int latent_lmls(const double* xd, int d, int n, const lmm_gp_t* gps, const doubl
   Buf<int> info(ms);
   HIPCHK(hipMemsetAsync(info.p, 0, ms * sizeof(int), g.streams[0]));
   fork_slots(nslots);
+  {
+    static double stagger_us = -1.0;          // experiment: de-correlate the slots' recursion phases
+    if (stagger_us < 0) { const char* e = getenv("LMM_STAGGER_US"); stagger_us = e ? atof(e) : 0.0; }
+    if (stagger_us > 0 && !g.prof) for (int s = 1; s < nslots; ++s) launch_delay(stagger_us * s, slots[s].st);
+  }
   for (int k = 0; k < ms; ++k) {
     Slot& s = slots[k % nslots];
     const lmm_gp_t& gp = gps[l0 + k];
@@ -1153,11 +1158,11 @@ int lmm_dev_mfma_f64_peak(double* tflops) {
   std::lock_guard<std::mutex> lk(g_mu);
   REQUIRE_INIT();
   LMM_TRY
-  const int blocks = 256 * 2, iters = 4000;
+  const int blocks = 256 * 2, iters = 20000;
   Buf<double> out((size_t)blocks * 256);
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-  launch_mfma_peak(out.p, blocks, 100, g.streams[0]);
+  launch_mfma_peak(out.p, blocks, iters, g.streams[0]);   // warm-up of the same length (clock ramp)
   HIPCHK(hipEventRecord(e0, g.streams[0]));
   launch_mfma_peak(out.p, blocks, iters, g.streams[0]);
   HIPCHK(hipEventRecord(e1, g.streams[0]));

@@ -55,4 +55,5 @@ void launch_trmv_lower(const double* L, int ld, int n, const double* z, double m
                        hipStream_t st);
 void launch_add_diag(double* A, int ld, int n, double v, hipStream_t st);
 void launch_vec_lin(const double* a, const double* b, double sb, int n, double* out, hipStream_t st);  // out = a + sb*b
+void launch_delay(double us, hipStream_t st);
 void launch_mfma_peak(double* out, int blocks, int iters, hipStream_t st);

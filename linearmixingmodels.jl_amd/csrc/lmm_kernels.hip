@@ -618,6 +618,14 @@ __global__ __launch_bounds__(256, 2) void gemm44_kernel(double* C, int ldc, cons
   const int li = lane >> 4, lb = (lane >> 2) & 3, lj = lane & 3;
 #pragma unroll
   for (int h = 0; h < TN / 2; ++h) {
+    double* cp = C + (size_t)(bn + wc + 32 * h) * ldc + bm + wr + lane;
+    // all 32 C loads of this half are issued before the LDS transpose (the accumulators they replace are dead by
+    // then), so the read-modify-write pays ONE memory round trip per half instead of one per few columns
+    double cv[32];
+    if (!SET && nparts == 1) {
+#pragma unroll
+      for (int c = 0; c < 32; ++c) cv[c] = cp[(size_t)c * ldc];
+    }
 #pragma unroll
     for (int u = 0; u < TM; ++u)
 #pragma unroll
@@ -626,14 +634,15 @@ __global__ __launch_bounds__(256, 2) void gemm44_kernel(double* C, int ldc, cons
         for (int s = 0; s < 4; ++s)
           ep[(16 * vv + 4 * ((lb + s) & 3) + lj) * ES + 16 * u + 4 * lb + li] = acc[u][2 * h + vv][s];
     __builtin_amdgcn_wave_barrier();
-    double* cp = C + (size_t)(bn + wc + 32 * h) * ldc + bm + wr + lane;
-#pragma unroll 8
-    for (int c = 0; c < 32; ++c) {
-      const double val = ep[c * ES + lane];
-      double* p = cp + (size_t)c * ldc;
-      if (SET) *p = val;
-      else if (nparts == 1) *p -= val;
-      else unsafeAtomicAdd(p, -val);
+    if (SET) {
+#pragma unroll
+      for (int c = 0; c < 32; ++c) cp[(size_t)c * ldc] = ep[c * ES + lane];
+    } else if (nparts == 1) {
+#pragma unroll
+      for (int c = 0; c < 32; ++c) cp[(size_t)c * ldc] = cv[c] - ep[c * ES + lane];
+    } else {
+#pragma unroll
+      for (int c = 0; c < 32; ++c) unsafeAtomicAdd(cp + (size_t)c * ldc, -ep[c * ES + lane]);
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -1047,6 +1056,12 @@ void launch_add_diag(double* A, int ld, int n, double v, hipStream_t st) {
 void launch_vec_lin(const double* a, const double* b, double sb, int n, double* out, hipStream_t st) {
   hipLaunchKernelGGL(vec_lin_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a, b, sb, n, out);
 }
+
+__global__ void delay_kernel(long long ticks) {       // s_memrealtime ticks are 10 ns
+  const long long t0 = __builtin_amdgcn_s_memrealtime();
+  while ((long long)__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+void launch_delay(double us, hipStream_t st) { hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, st, (long long)(us * 100.0)); }
 
 void launch_mfma_peak(double* out, int blocks, int iters, hipStream_t st) {
   hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, st, out, iters);

@@ -15,6 +15,7 @@ int main(int argc, char** argv) {
   double *C, *A;
   hipMalloc(&C, (size_t)ld * N * 8); hipMalloc(&A, (size_t)ld * K * 8);
   const int rnd = argc > 5 ? atoi(argv[5]) : 1;
+  const int reps = argc > 6 ? atoi(argv[6]) : 3;
   hipMemset(C, 0, (size_t)ld * N * 8); hipMemset(A, 0, (size_t)ld * K * 8);
   if (rnd) { fill_rand<<<2048, 256>>>(A, (size_t)ld * K, 1u); fill_rand<<<2048, 256>>>(C, (size_t)ld * N, 2u); }
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -23,9 +24,9 @@ int main(int argc, char** argv) {
     launch_gemm_nt(C, ld, A, ld, A, ld, M, N, K, lower, false, 0);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    for (int r = 0; r < 3; ++r) launch_gemm_nt(C, ld, A, ld, A, ld, M, N, K, lower, false, 0);
+    for (int r = 0; r < reps; ++r) launch_gemm_nt(C, ld, A, ld, A, ld, M, N, K, lower, false, 0);
     hipEventRecord(e1); hipEventSynchronize(e1);
-    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 3;
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
     double fl = lower ? 2.0 * K * ((double)N * (N + 1) / 2 + (double)(M - N) * N) : 2.0 * M * N * (double)K;
     printf("%s rnd=%d M=%d N=%d K=%d lower=%d: %.3f ms  %.2f TFLOP/s (algorithmic)\n", which ? "mfma16x16x4" : "mfma4x4x4_4b", rnd, M, N, K, lower, ms, fl / ms / 1e9);
   }
