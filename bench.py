@@ -149,11 +149,11 @@ def main():
     roof = None
     extra = {}
     if rank == 0 and not args.no_roofline:
-        # Roofline leg: one more evaluation of (a few latents of) the same workload with every launch of the hot
-        # kernels bracketed by HIP events on its own stream, latents forced onto ONE stream so that an event pair
-        # times its kernel alone (DESIGN.md "Measurement").
+        # Roofline leg: one more evaluation of one batch of latents of the same workload with every launch of the hot
+        # kernels bracketed by HIP events on its stream; the batch runs on ONE stream so that an event pair times its
+        # kernel alone (the timed region above runs several batches on concurrent streams).  DESIGN.md "Measurement".
         lib = lmm_amd.load()
-        nprof = min(2, shard[1] - shard[0]) if orth else m
+        nprof = min(8, shard[1] - shard[0]) if orth else m      # one production-sized batch of latents
         fprof = lmm_amd.ILMM(fs, H, shard=(shard[0], shard[0] + nprof))(xin, 0.1) if orth else fx
         L.check(lib.lmm_profile_begin(1))
         lmm_amd.logpdf(fprof, yd, False)

@@ -198,30 +198,49 @@ inline int split(int w) {            // left width of the recursive split (multi
   return (w == 192) ? 128 : 64;
 }
 
-// Factor columns [j0, j0+w) of A (rows j0..NR-1 participate).  W: NC/64 inverse diagonal blocks.
-void potrf_rec(double* A, int ld, int NR, int j0, int w, double* W, int n_real, int* info, hipStream_t st) {
+// A batch of up to LMM_MAX_BATCH same-shaped factor matrices factored in lock-step by the same launches
+// (blockIdx.y / blockIdx.x selects the matrix): the small recursion levels then fill the chip and the launch
+// count per latent drops by the batch size.
+struct Batch {
+  int nb = 0;
+  BatchPtr A{}, W{};
+  BatchInfo info{};
+  void add(double* a, double* w, int* i) { A.p[nb] = a; W.p[nb] = w; info.p[nb] = i; ++nb; }
+};
+
+// Factor columns [j0, j0+w) of every matrix of the batch (rows j0..NR-1 participate).  W: NC/64 inverse diagonal blocks.
+void potrf_rec(const Batch& B, int ld, int NR, int j0, int w, int n_real, hipStream_t st) {
+  const double nb = B.nb;
   if (w <= 64) {
-    double* blk = A + (size_t)j0 * ld + j0;
-    double* Wb = W + (size_t)(j0 / 64) * 4096;
-    { ProfScope ps(LMM_PROF_DIAG, 2.0 * 64.0 * 64.0 * 64.0 / 3.0, st); launch_diag64(blk, ld, Wb, j0, n_real, info, st); }
+    const size_t offW = (size_t)(j0 / 64) * 4096;
+    {
+      ProfScope ps(LMM_PROF_DIAG, nb * 2.0 * 64.0 * 64.0 * 64.0 / 3.0, st);
+      launch_diag64(B.A, (size_t)j0 * ld + j0, ld, B.W, offW, j0, n_real, B.info, B.nb, st);
+    }
     const int M = NR - (j0 + 64);
     if (M > 0) {
-      double* pan = A + (size_t)j0 * ld + (j0 + 64);
-      ProfScope ps(LMM_PROF_TRSM, (double)M * 64.0 * 64.0, st);   // triangular solve: M * 64^2 flops
-      launch_gemm_nt(pan, ld, pan, ld, Wb, 64, M, 64, 64, 0, true, st);
+      const size_t offP = (size_t)j0 * ld + (j0 + 64);
+      ProfScope ps(LMM_PROF_TRSM, nb * (double)M * 64.0 * 64.0, st);   // triangular solve: M * 64^2 flops
+      launch_gemm_nt(B.A, offP, ld, B.A, offP, ld, B.W, offW, 64, M, 64, 64, 0, true, B.nb, st);
     }
     return;
   }
   const int h = split(w);
-  potrf_rec(A, ld, NR, j0, h, W, n_real, info, st);
+  potrf_rec(B, ld, NR, j0, h, n_real, st);
   const int r0 = j0 + h;
   {
     const double Mr = NR - r0, Nc = w - h;     // lower trapezoid: Nc(Nc+1)/2 + (Mr-Nc)Nc outputs, 2h flops each
-    ProfScope ps(Nc <= 64 ? LMM_PROF_UPDATE_NARROW : LMM_PROF_UPDATE, 2.0 * h * (Nc * (Nc + 1.0) / 2.0 + (Mr - Nc) * Nc), st, NR - r0, w - h, h);
-    launch_gemm_nt(A + (size_t)r0 * ld + r0, ld, A + (size_t)j0 * ld + r0, ld, A + (size_t)j0 * ld + r0, ld,
-                   NR - r0, w - h, h, 1, false, st);
+    ProfScope ps(Nc <= 64 ? LMM_PROF_UPDATE_NARROW : LMM_PROF_UPDATE, nb * 2.0 * h * (Nc * (Nc + 1.0) / 2.0 + (Mr - Nc) * Nc), st,
+                 NR - r0, w - h, h);
+    const size_t offA = (size_t)j0 * ld + r0;
+    launch_gemm_nt(B.A, (size_t)r0 * ld + r0, ld, B.A, offA, ld, B.A, offA, ld, NR - r0, w - h, h, 1, false, B.nb, st);
   }
-  potrf_rec(A, ld, NR, r0, w - h, W, n_real, info, st);
+  potrf_rec(B, ld, NR, r0, w - h, n_real, st);
+}
+
+void potrf_rec(double* A, int ld, int NR, int j0, int w, double* W, int n_real, int* info, hipStream_t st) {
+  Batch B; B.add(A, W, info);
+  potrf_rec(B, ld, NR, j0, w, n_real, st);
 }
 
 // R (nr x NC, ldr) <- R * L^-T for an already factored L (ld) with inverse diagonal blocks W.
@@ -238,16 +257,30 @@ void trsm_rec(double* R, int ldr, int nr, const double* L, int ld, const double*
   trsm_rec(R, ldr, nr, L, ld, W, j0 + h, w - h, st);
 }
 
-struct Slot {
-  Buf<double> A, W;
+// How many latents share one batch and how many streams carry batches, for a shard of ms latents.
+void batch_plan(int ms, int* nb_per, int* nstreams_used) {
+  static int bmax = -1;
+  if (bmax < 0) { const char* e = getenv("LMM_BATCH"); bmax = e ? atoi(e) : 8; if (bmax < 1) bmax = 1; if (bmax > LMM_MAX_BATCH) bmax = LMM_MAX_BATCH; }
+  int b = std::min(bmax, std::max(1, ms / 2));          // keep at least two batches in flight when ms >= 2
+  if (getenv("LMM_BATCH_FORCE")) b = std::min(bmax, ms);  // tuning sweeps only
+  if (g.prof && g.prof_serial) b = std::min(bmax, ms);  // instrumented pass: production-sized batches on ONE stream
+  const int nbatches = (ms + b - 1) / b;
+  *nb_per = b;
+  *nstreams_used = std::max(1, std::min(nbatches, eff_streams()));
+}
+
+struct Slot {                 // one stream + the factor matrices of the batch it carries
+  std::vector<Buf<double>> A, W;
   hipStream_t st;
 };
 
-void make_slots(std::vector<Slot>& slots, int count, size_t a_elems, int NC) {
+void make_slots(std::vector<Slot>& slots, int count, int nb_per, size_t a_elems, int NC) {
   slots.resize(count);
   for (int s = 0; s < count; ++s) {
-    slots[s].A = Buf<double>(a_elems);
-    slots[s].W = Buf<double>((size_t)(NC / 64) * 4096);
+    for (int j = 0; j < nb_per; ++j) {
+      slots[s].A.emplace_back(a_elems);
+      slots[s].W.emplace_back((size_t)(NC / 64) * 4096);
+    }
     slots[s].st = g.streams[s];
   }
 }
@@ -380,29 +413,32 @@ int latent_lmls(const double* xd, int d, int n, const lmm_gp_t* gps, const doubl
   lml.assign(ms, 0.0);
   if (ms == 0) return LMM_OK;
   Dims D(n, 1);
-  const int nslots = std::min(ms, eff_streams());
+  int nb_per = 1, nslots = 1;
+  batch_plan(ms, &nb_per, &nslots);
   std::vector<Slot> slots;
-  make_slots(slots, nslots, D.elems(), D.NC);
+  make_slots(slots, nslots, nb_per, D.elems(), D.NC);
   Buf<double> out(ms);
   Buf<int> info(ms);
   HIPCHK(hipMemsetAsync(info.p, 0, ms * sizeof(int), g.streams[0]));
   fork_slots(nslots);
-  {
-    static double stagger_us = -1.0;          // experiment: de-correlate the slots' recursion phases
-    if (stagger_us < 0) { const char* e = getenv("LMM_STAGGER_US"); stagger_us = e ? atof(e) : 0.0; }
-    if (stagger_us > 0 && !g.prof) for (int s = 1; s < nslots; ++s) launch_delay(stagger_us * s, slots[s].st);
-  }
-  for (int k = 0; k < ms; ++k) {
-    Slot& s = slots[k % nslots];
-    const lmm_gp_t& gp = gps[l0 + k];
-    GramArgs a{};
-    a.A = s.A.p; a.ld = D.ld; a.nrows = D.NR; a.ncols = D.NC; a.row_tile0 = 0; a.row_shift = 0; a.full = 0;
-    a.x = xd; a.d = d; a.n = n; a.kind = gp.kind; a.var = gp.variance; a.inv_ls = 1.0 / gp.lengthscale;
-    a.diag_add = noise[l0 + k]; a.pad_diag = 1.0;
-    a.rider = delta + (size_t)k * n; a.rider_ld = n; a.nrider = 1; a.xs = nullptr; a.ns = 0;
-    { ProfScope ps(LMM_PROF_GRAM, (double)n * ((double)n + 1.0) / 2.0 * 8.0, s.st); launch_gram(a, s.st); }
-    potrf_rec(s.A.p, D.ld, D.NR, 0, D.NC, s.W.p, n, info.p + k, s.st);
-    launch_lml_reduce(s.A.p, D.ld, n, D.NC, 1, out.p + k, s.st);
+  int bi = 0;
+  for (int k0 = 0; k0 < ms; k0 += nb_per, ++bi) {
+    Slot& s = slots[bi % nslots];
+    const int nb = std::min(nb_per, ms - k0);
+    Batch B;
+    for (int j = 0; j < nb; ++j) {
+      const int k = k0 + j;
+      const lmm_gp_t& gp = gps[l0 + k];
+      GramArgs a{};
+      a.A = s.A[j].p; a.ld = D.ld; a.nrows = D.NR; a.ncols = D.NC; a.row_tile0 = 0; a.row_shift = 0; a.full = 0;
+      a.x = xd; a.d = d; a.n = n; a.kind = gp.kind; a.var = gp.variance; a.inv_ls = 1.0 / gp.lengthscale;
+      a.diag_add = noise[l0 + k]; a.pad_diag = 1.0;
+      a.rider = delta + (size_t)k * n; a.rider_ld = n; a.nrider = 1; a.xs = nullptr; a.ns = 0;
+      { ProfScope ps(LMM_PROF_GRAM, (double)n * ((double)n + 1.0) / 2.0 * 8.0, s.st); launch_gram(a, s.st); }
+      B.add(s.A[j].p, s.W[j].p, info.p + k);
+    }
+    potrf_rec(B, D.ld, D.NR, 0, D.NC, n, s.st);
+    for (int j = 0; j < nb; ++j) launch_lml_reduce(s.A[j].p, D.ld, n, D.NC, 1, out.p + k0 + j, s.st);
   }
   join_slots(nslots);
   std::vector<int> hinfo(ms);
@@ -662,24 +698,37 @@ static int posterior_create_common(const double* xd, int d, int n, const lmm_gp_
     HIPCHK(hipMemcpyAsync(P->x.p, xd, (size_t)d * n * sizeof(double), hipMemcpyDeviceToDevice, g.streams[0]));
     Buf<int> info(std::max(ms, 1));
     HIPCHK(hipMemsetAsync(info.p, 0, std::max(ms, 1) * sizeof(int), g.streams[0]));
-    const int nslots = std::max(1, std::min(ms, g.nstreams));
-    fork_slots(nslots);
+    int nb_per = 1, nslots = 1;
+    batch_plan(std::max(ms, 1), &nb_per, &nslots);
     for (int k = 0; k < ms; ++k) {
-      hipStream_t st = g.streams[k % nslots];
       P->L.emplace_back((size_t)D.elems());
       P->W.emplace_back((size_t)(D.NC / 64) * 4096);
       P->alpha.emplace_back((size_t)D.NC);
-      const lmm_gp_t& gp = gps[l0 + k];
-      GramArgs a{};
-      a.A = P->L[k].p; a.ld = D.ld; a.nrows = D.NR; a.ncols = D.NC; a.x = P->x.p; a.d = d; a.n = n;
-      a.kind = gp.kind; a.var = gp.variance; a.inv_ls = 1.0 / gp.lengthscale; a.diag_add = noise[l0 + k]; a.pad_diag = 1.0;
-      a.rider = delta + (size_t)k * n; a.rider_ld = n; a.nrider = 1;
-      launch_gram(a, st);
-      potrf_rec(P->L[k].p, D.ld, D.NR, 0, D.NC, P->W[k].p, n, info.p + k, st);
-      // alpha = L^-T (L^-1 delta): the rider row is z = L^-1 delta
-      HIPCHK(hipMemsetAsync(P->alpha[k].p, 0, (size_t)D.NC * sizeof(double), st));
-      launch_extract_row(P->L[k].p, D.ld, D.NC, n, P->alpha[k].p, st);
-      launch_backsolve(P->L[k].p, D.ld, P->W[k].p, D.NC / 64, P->alpha[k].p, st);
+    }
+    fork_slots(nslots);
+    int bi = 0;
+    for (int k0 = 0; k0 < ms; k0 += nb_per, ++bi) {
+      hipStream_t st = g.streams[bi % nslots];
+      const int nb = std::min(nb_per, ms - k0);
+      Batch B;
+      for (int j = 0; j < nb; ++j) {
+        const int k = k0 + j;
+        const lmm_gp_t& gp = gps[l0 + k];
+        GramArgs a{};
+        a.A = P->L[k].p; a.ld = D.ld; a.nrows = D.NR; a.ncols = D.NC; a.x = P->x.p; a.d = d; a.n = n;
+        a.kind = gp.kind; a.var = gp.variance; a.inv_ls = 1.0 / gp.lengthscale; a.diag_add = noise[l0 + k]; a.pad_diag = 1.0;
+        a.rider = delta + (size_t)k * n; a.rider_ld = n; a.nrider = 1;
+        launch_gram(a, st);
+        B.add(P->L[k].p, P->W[k].p, info.p + k);
+      }
+      potrf_rec(B, D.ld, D.NR, 0, D.NC, n, st);
+      for (int j = 0; j < nb; ++j) {
+        const int k = k0 + j;
+        // alpha = L^-T (L^-1 delta): the rider row is z = L^-1 delta
+        HIPCHK(hipMemsetAsync(P->alpha[k].p, 0, (size_t)D.NC * sizeof(double), st));
+        launch_extract_row(P->L[k].p, D.ld, D.NC, n, P->alpha[k].p, st);
+        launch_backsolve(P->L[k].p, D.ld, P->W[k].p, D.NC / 64, P->alpha[k].p, st);
+      }
     }
     join_slots(nslots);
     std::vector<int> hinfo(std::max(ms, 1), 0);

@@ -3,6 +3,10 @@
 #include <hip/hip_runtime.h>
 #include "../../include/lmm_hip.h"
 
+#define LMM_MAX_BATCH 8
+struct BatchPtr { double* p[LMM_MAX_BATCH]; };   // base pointers of the matrices of one batch (kernel argument, by value)
+struct BatchInfo { int* p[LMM_MAX_BATCH]; };
+
 struct LatentDev {
   int kind;
   double var, inv_ls, mean;
@@ -35,7 +39,10 @@ void launch_dense_cross(double* R, int ldr, int nrows, int ncols, const double* 
                         int m, const LatentDev* lat, hipStream_t st);
 void launch_dense_var(const double* R, int ldr, int ns, int m, int Ncols, const double* Hm, int p, const LatentDev* lat,
                       double jitter, double sigma2, double* out, hipStream_t st);
-void launch_diag64(double* Ablk, int ld, double* Wblk, int gcol0, int n_real, int* info, hipStream_t st);
+void launch_diag64(const BatchPtr& A, size_t offA, int ld, const BatchPtr& W, size_t offW, int gcol0, int n_real,
+                   const BatchInfo& info, int nb, hipStream_t st);
+void launch_gemm_nt(const BatchPtr& C, size_t offC, int ldc, const BatchPtr& A, size_t offA, int lda, const BatchPtr& B,
+                    size_t offB, int ldb, int M, int N, int K, int lower, bool set, int nb, hipStream_t st);
 void launch_gemm_nt(double* C, int ldc, const double* A, int lda, const double* B, int ldb, int M, int N, int K,
                     int lower, bool set, hipStream_t st);
 void launch_lml_reduce(const double* A, int ld, int n, int rider_row0, int nrhs, double* out, hipStream_t st);

@@ -8,8 +8,8 @@
 //
 // Kernels:
 //   K1 gram_kernel / ilmm_dense_assemble_kernel   HBM-write bound   (A17, A6, A7)
-//   K2 diag64_kernel + gemm_nt_kernel<.., SET> (TRSM by inverse) + gemm_nt_kernel<.., SUB>
-//      (v_mfma_f64_16x16x4_f64 SYRK/GEMM trailing update)        MFMA-f64 bound (A6, A7, A10, A11, A14)
+//   K2 diag64_kernel + gemm44_kernel<64, SET> (TRSM by inverse) + gemm44_kernel<.., SUB>
+//      (v_mfma_f64_4x4x4_4b_f64 SYRK/GEMM trailing update), batched over latents   MFMA-f64 bound (A6, A7, A10, A11, A14)
 //   K3/K6 lml_reduce_kernel (logdet + quadratic form, wavefront shuffles), backsolve_step_kernel
 //   K4/K5 tall_skinny_kernel (T*Y projection, H*T*Y residual norm), mix_kernel (H unprojection)
 //   K7 trmv_lower_kernel (sample transform), axpy noise
@@ -282,8 +282,11 @@ __global__ __launch_bounds__(256) void dense_var_kernel(const double* __restrict
 //   after eliminating column j with multipliers A_ij/d_j:  [A | I] -> [D L1' | L1^-1];
 //   L = L1 D^1/2,  W = D^-1/2 L1^-1.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void diag64_kernel(double* __restrict__ A, int ld, double* __restrict__ W,
-                                                     int gcol0, int n_real, int* __restrict__ info) {
+__global__ __launch_bounds__(256) void diag64_kernel(BatchPtr Ab, size_t offA, int ld, BatchPtr Wb, size_t offW,
+                                                     int gcol0, int n_real, BatchInfo infob) {
+  double* __restrict__ A = Ab.p[blockIdx.x] + offA;
+  double* __restrict__ W = Wb.p[blockIdx.x] + offW;
+  int* __restrict__ info = infob.p[blockIdx.x];
   // Register-resident elimination: thread (i = t & 63, q = t >> 6) owns row i, columns 16q..16q+15 of both the
   // S part (the block being factored) and the W part (identity -> L1^-1).  Per pivot j the owners publish, through
   // double-buffered LDS, column j (colb: every row's multiplier numerator; cmsk: the same masked to rows > j, which by
@@ -346,131 +349,14 @@ __global__ __launch_bounds__(256) void diag64_kernel(double* __restrict__ A, int
 }
 
 // ---------------------------------------------------------------------------------------------------
-// K2b: C (M x N) {-=, =} A (M x K) * B (N x K)^T  on v_mfma_f64_16x16x4_f64.
-//   128 x BN block tile, 4 waves (2 x 2), wave tile 64 x BN/2 = (4 x BN/32) MFMA 16x16 tiles,
-//   BK = 16 k-columns per LDS stage, two LDS stages, one barrier per stage.
-//   LDS image is k-major ([k][row], row stride BM+16 doubles): a k-column of the tile is one contiguous
-//   1-KiB global segment (coalesced 16-B loads) and the MFMA operand read (lane l: row l&15, k l>>4) is
-//   one conflict-free ds_read_b64.
-//   MFMA A-operand <- B tile (C's column index), MFMA B-operand <- A tile (C's row index), so lane&15 of
-//   the f64 C/D map (col = lane&15, row = (lane>>4) + 4*reg) runs along C's contiguous rows.
-//   M, N multiples of 64; K multiple of 16.  lower != 0: tiles strictly above the diagonal of the
-//   (common-origin) region are skipped (SYRK on the lower triangle).
-// ---------------------------------------------------------------------------------------------------
-template <int BN, bool SET>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(double* C, int ldc,
-                                                          const double* A, int lda,
-                                                          const double* __restrict__ B, int ldb,
-                                                          int M, int N, int K, int lower) {
-  constexpr int BM = 128, BK = 16;
-  constexpr int WN = BN / 2;
-  constexpr int TM = 4, TN = WN / 16;
-  constexpr int SA = BM + 16, SB = BN + 16;
-  constexpr int NLA = (BM * BK / 2) / 256;     // 16-byte loads per thread for the A tile (4)
-  constexpr int NLB = (BN * BK / 2) / 256;     // (4 or 2)
-  __shared__ double As[2][BK * SA];
-  __shared__ double Bs[2][BK * SB];
-
-  const int bm = blockIdx.x * BM, bn = blockIdx.y * BN;
-  if (lower && bm + BM - 1 < bn) return;
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const int wr = (w & 1) * 64, wc = (w >> 1) * WN;
-  const bool active = (bm + wr < M) && (bn + wc < N) && !(lower && bm + wr + 63 < bn + wc);
-
-  // global -> register staging addresses (clamped: out-of-range rows re-read valid memory, unused)
-  const double* ga[NLA];
-  const double* gb[NLB];
-  int sa[NLA], sb[NLB];
-#pragma unroll
-  for (int q = 0; q < NLA; ++q) {
-    const int u = t + 256 * q, rp = u % (BM / 2), k = u / (BM / 2);
-    int row = bm + 2 * rp; if (row > M - 2) row = M - 2;
-    ga[q] = A + (size_t)k * lda + row;
-    sa[q] = k * SA + 2 * rp;
-  }
-#pragma unroll
-  for (int q = 0; q < NLB; ++q) {
-    const int u = t + 256 * q, rp = u % (BN / 2), k = u / (BN / 2);
-    int row = bn + 2 * rp; if (row > N - 2) row = N - 2;
-    gb[q] = B + (size_t)k * ldb + row;
-    sb[q] = k * SB + 2 * rp;
-  }
-  d2 ra[NLA], rb[NLB];
-#pragma unroll
-  for (int q = 0; q < NLA; ++q) ra[q] = *reinterpret_cast<const d2*>(ga[q]);
-#pragma unroll
-  for (int q = 0; q < NLB; ++q) rb[q] = *reinterpret_cast<const d2*>(gb[q]);
-#pragma unroll
-  for (int q = 0; q < NLA; ++q) *reinterpret_cast<d2*>(&As[0][sa[q]]) = ra[q];
-#pragma unroll
-  for (int q = 0; q < NLB; ++q) *reinterpret_cast<d2*>(&Bs[0][sb[q]]) = rb[q];
-  __syncthreads();
-
-  d4 acc[TN][TM];
-#pragma unroll
-  for (int jj = 0; jj < TN; ++jj)
-#pragma unroll
-    for (int ii = 0; ii < TM; ++ii) acc[jj][ii] = (d4){0.0, 0.0, 0.0, 0.0};
-
-  const int nk = K / BK;
-  const int fr = lane & 15, fk = lane >> 4;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) {
-      const size_t offa = (size_t)(kt + 1) * BK * lda, offb = (size_t)(kt + 1) * BK * ldb;
-#pragma unroll
-      for (int q = 0; q < NLA; ++q) ra[q] = *reinterpret_cast<const d2*>(ga[q] + offa);
-#pragma unroll
-      for (int q = 0; q < NLB; ++q) rb[q] = *reinterpret_cast<const d2*>(gb[q] + offb);
-    }
-    if (active) {
-      const double* as = &As[buf][0];
-      const double* bs = &Bs[buf][0];
-#pragma unroll
-      for (int s = 0; s < BK / 4; ++s) {
-        double fa[TN], fb[TM];
-#pragma unroll
-        for (int jj = 0; jj < TN; ++jj) fa[jj] = bs[(4 * s + fk) * SB + wc + jj * 16 + fr];
-#pragma unroll
-        for (int ii = 0; ii < TM; ++ii) fb[ii] = as[(4 * s + fk) * SA + wr + ii * 16 + fr];
-#pragma unroll
-        for (int jj = 0; jj < TN; ++jj)
-#pragma unroll
-          for (int ii = 0; ii < TM; ++ii)
-            acc[jj][ii] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[jj], fb[ii], acc[jj][ii], 0, 0, 0);
-      }
-    }
-    if (kt + 1 < nk) {
-#pragma unroll
-      for (int q = 0; q < NLA; ++q) *reinterpret_cast<d2*>(&As[buf ^ 1][sa[q]]) = ra[q];
-#pragma unroll
-      for (int q = 0; q < NLB; ++q) *reinterpret_cast<d2*>(&Bs[buf ^ 1][sb[q]]) = rb[q];
-    }
-    __syncthreads();
-  }
-
-  if (!active) return;
-  // epilogue: lane holds C[row = ii*16 + (lane&15), col = jj*16 + (lane>>4) + 4*reg]
-#pragma unroll
-  for (int jj = 0; jj < TN; ++jj) {
-#pragma unroll
-    for (int ii = 0; ii < TM; ++ii) {
-      const int row = bm + wr + ii * 16 + fr;
-      const int col0 = bn + wc + jj * 16 + fk;
-      if (lower && (bm + wr + ii * 16 + 15 < bn + wc + jj * 16)) continue;   // 16x16 tile above diagonal
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        double* p = C + (size_t)(col0 + 4 * r) * ldc + row;
-        if (SET) *p = acc[jj][ii][r];
-        else *p -= acc[jj][ii][r];
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// K2c: the same product on v_mfma_f64_4x4x4_4b_f64 -- the FP64 MFMA form that issues at the full FP64 rate on
-// gfx950 (measured tools/mfma_probe3: 76.8 TFLOP/s vs 36-47 for the 16x16x4 form).  The instruction computes 4
+// K2b: C (M x N) {-=, =} A (M x K) * B (N x K)^T  (column-major; M, N multiples of 64, K of 16), batched over up to
+// LMM_MAX_BATCH independent matrices (blockIdx.y), on v_mfma_f64_4x4x4_4b_f64 -- the FP64 MFMA form that issues at the
+// full FP64 rate on gfx950 (tools/mfma_probe3: 76.8 TFLOP/s; the 16x16x4 form issues at 36-59 depending on the
+// operand pattern; an earlier 16x16x4 version of this kernel is in the git history).
+//   128 x BN block tile, 4 waves (2 x 2), wave tile 64 x BN/2, BK = 16 k-columns per LDS stage, two stages, one
+//   barrier per stage.  LDS image is k-major ([k][row], row stride BM+16 doubles): a k-column of the tile is one
+//   contiguous 1-KiB global segment (coalesced 16-B loads) and an operand read is one conflict-free ds_read_b64.
+//   lower != 0: only tiles on/below the diagonal of the (common-origin) region (SYRK on the lower triangle).  The instruction computes 4
 // independent 4x4x4 products; measured lane map (tools/mfma_map):
 //     A[blk][i][k] : lane 16k + 4 blk + i      B[blk][k][j] : lane 16k + 4 blk + j      D[blk][i][j] : lane 16i + 4 blk + j
 // A wave's 64 x WN tile is covered by fragments  fa[u] (rows 16u + (lane&15), k = lane>>4 -- the same LDS read as the
@@ -479,10 +365,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(double* C, int ldc,
 // 16 x 16 tile.  Per k-step of 4: 4 + 4 TN ds_read_b64 feed 16 TN MFMAs (16 cycles each).
 // ---------------------------------------------------------------------------------------------------
 template <int BN, bool SET>
-__global__ __launch_bounds__(256, 2) void gemm44_kernel(double* C, int ldc, const double* A, int lda,
-                                                         const double* __restrict__ B, int ldb,
+__global__ __launch_bounds__(256, 2) void gemm44_kernel(BatchPtr Cb, size_t goffC, int ldc, BatchPtr Ab, size_t goffA, int lda,
+                                                         BatchPtr Bb, size_t goffB, int ldb,
                                                          int M, int N, int K, int lower, int MT, int full_items,
                                                          int splitk) {
+  double* C = Cb.p[blockIdx.y] + goffC;
+  const double* A = Ab.p[blockIdx.y] + goffA;
+  const double* B = Bb.p[blockIdx.y] + goffB;
   constexpr int BM = 128, BK = 16;
   constexpr int WN = BN / 2;
   constexpr int TM = 4, TN = WN / 16;
@@ -941,58 +830,55 @@ void launch_dense_assemble(const DenseArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(ilmm_dense_assemble_kernel, grid, dim3(256), 0, st, a);
 }
 
-void launch_diag64(double* Ablk, int ld, double* Wblk, int gcol0, int n_real, int* info, hipStream_t st) {
-  hipLaunchKernelGGL(diag64_kernel, dim3(1), dim3(256), 0, st, Ablk, ld, Wblk, gcol0, n_real, info);
+void launch_diag64(const BatchPtr& A, size_t offA, int ld, const BatchPtr& W, size_t offW, int gcol0, int n_real,
+                   const BatchInfo& info, int nb, hipStream_t st) {
+  hipLaunchKernelGGL(diag64_kernel, dim3(nb), dim3(256), 0, st, A, offA, ld, W, offW, gcol0, n_real, info);
 }
 
-static int g_use_mfma16 = -1;   // LMM_MFMA16=1 selects the 16x16x4 MFMA kernels (A/B comparisons)
+void launch_gemm_nt(const BatchPtr& C, size_t offC, int ldc, const BatchPtr& A, size_t offA, int lda, const BatchPtr& B,
+                    size_t offB, int ldb, int M, int N, int K, int lower, bool set, int nb, hipStream_t st) {
+  if (M <= 0 || N <= 0 || K <= 0 || nb <= 0) return;
+  const bool narrow = (N <= 64);
+  const int MT = (M + 127) / 128;
+  if (set) {   // in-place TRSM by inverse: one block column, no K split
+    hipLaunchKernelGGL((gemm44_kernel<64, true>), dim3(MT, nb), dim3(256), 0, st, C, offC, ldc, A, offA, lda, B, offB, ldb, M, N,
+                       K, 0, MT, MT, 1);
+    return;
+  }
+  const int BNsel = narrow ? 64 : 128;
+  const int NT = narrow ? 1 : (N + 127) / 128;
+  long long T = 0;
+  for (int tj = 0; tj < NT; ++tj) T += lower ? (MT - (tj * BNsel) / 128) : MT;
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0; cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  }
+  // Scheduling round = one tile per CU: the MFMA pipe, not residency, is the resource (one workgroup per CU already runs
+  // at ~80 % of the CU's f64 rate, tools/stream_overlap).  With nb matrices in the batch a round holds cus / nb tiles of
+  // each.  Tiles of the last, partial round are split along K (f64 atomics) so the launch ends without a long tail.
+  const int slots = (cus / nb) > 0 ? (cus / nb) : 1;
+  const int nk = K / 16;
+  int full_items = (int)(T / slots) * slots, splitk = 1;
+  const int R = (int)(T - full_items);
+  static int deterministic = -1;          // LMM_DETERMINISTIC=1: no split-K atomics (bitwise reproducible, slower tail)
+  if (deterministic < 0) { const char* e = getenv("LMM_DETERMINISTIC"); deterministic = (e && atoi(e) != 0) ? 1 : 0; }
+  if (!deterministic && R > 0 && R <= slots / 2 && nk >= 8) {
+    splitk = slots / R; if (splitk > nk / 4) splitk = nk / 4; if (splitk < 1) splitk = 1;
+  }
+  if (splitk == 1) full_items = (int)T;
+  const int items = full_items + (int)(T - full_items) * splitk;
+  if (narrow) hipLaunchKernelGGL((gemm44_kernel<64, false>), dim3(items, nb), dim3(256), 0, st, C, offC, ldc, A, offA, lda, B, offB,
+                                 ldb, M, N, K, lower, MT, full_items, splitk);
+  else hipLaunchKernelGGL((gemm44_kernel<128, false>), dim3(items, nb), dim3(256), 0, st, C, offC, ldc, A, offA, lda, B, offB,
+                          ldb, M, N, K, lower, MT, full_items, splitk);
+}
 
 void launch_gemm_nt(double* C, int ldc, const double* A, int lda, const double* B, int ldb, int M, int N, int K,
                     int lower, bool set, hipStream_t st) {
-  if (M <= 0 || N <= 0 || K <= 0) return;
-  if (g_use_mfma16 < 0) { const char* e = getenv("LMM_MFMA16"); g_use_mfma16 = (e && atoi(e) != 0) ? 1 : 0; }
-  const bool narrow = (N <= 64);
-  if (!g_use_mfma16) {
-    const int MT = (M + 127) / 128;
-    if (set) {   // in-place TRSM by inverse: one block column, no K split
-      hipLaunchKernelGGL((gemm44_kernel<64, true>), dim3(MT), dim3(256), 0, st, C, ldc, A, lda, B, ldb, M, N, K, 0, MT, MT, 1);
-      return;
-    }
-    const int BNsel = narrow ? 64 : 128;
-    const int NT = narrow ? 1 : (N + 127) / 128;
-    long long T = 0;
-    for (int tj = 0; tj < NT; ++tj) T += lower ? (MT - (tj * BNsel) / 128) : MT;
-    static int slots = 0;
-    if (slots == 0) {
-      int dev = 0, cus = 256;
-      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-      slots = cus;    // the MFMA pipe, not residency, is the resource: one workgroup per CU already runs at ~80 % of the
-                      // CU's f64 rate (tools/stream_overlap), so a round is one tile per CU
-    }
-    const int nk = K / 16;
-    int full_items = (int)(T / slots) * slots, splitk = 1;
-    const int R = (int)(T - full_items);
-    static int deterministic = -1;          // LMM_DETERMINISTIC=1: no split-K atomics (bitwise reproducible, slower tail)
-    if (deterministic < 0) { const char* e = getenv("LMM_DETERMINISTIC"); deterministic = (e && atoi(e) != 0) ? 1 : 0; }
-    if (!deterministic && R > 0 && R <= slots / 2 && nk >= 8) {   // a thin last round: split its tiles along K to fill the chip
-      splitk = slots / R; if (splitk > nk / 4) splitk = nk / 4; if (splitk < 1) splitk = 1;
-    }
-    if (splitk == 1) full_items = (int)T;
-    const int items = full_items + (int)(T - full_items) * splitk;
-    if (narrow) hipLaunchKernelGGL((gemm44_kernel<64, false>), dim3(items), dim3(256), 0, st, C, ldc, A, lda, B, ldb, M, N, K, lower, MT, full_items, splitk);
-    else hipLaunchKernelGGL((gemm44_kernel<128, false>), dim3(items), dim3(256), 0, st, C, ldc, A, lda, B, ldb, M, N, K, lower, MT, full_items, splitk);
-    return;
-  }
-  dim3 grid((M + 127) / 128, narrow ? 1 : (N + 127) / 128);
-  if (set) {
-    // in-place TRSM-by-inverse needs the full column extent in one block column
-    hipLaunchKernelGGL((gemm_nt_kernel<64, true>), dim3((M + 127) / 128, (N + 63) / 64), dim3(256), 0, st, C, ldc, A, lda, B,
-                       ldb, M, N, K, 0);
-  } else if (narrow) {
-    hipLaunchKernelGGL((gemm_nt_kernel<64, false>), grid, dim3(256), 0, st, C, ldc, A, lda, B, ldb, M, N, K, lower);
-  } else {
-    hipLaunchKernelGGL((gemm_nt_kernel<128, false>), grid, dim3(256), 0, st, C, ldc, A, lda, B, ldb, M, N, K, lower);
-  }
+  BatchPtr c{}, a{}, b{};
+  c.p[0] = C; a.p[0] = const_cast<double*>(A); b.p[0] = const_cast<double*>(B);
+  launch_gemm_nt(c, 0, ldc, a, 0, lda, b, 0, ldb, M, N, K, lower, set, 1, st);
 }
 
 void launch_lml_reduce(const double* A, int ld, int n, int rider_row0, int nrhs, double* out, hipStream_t st) {

@@ -20,7 +20,7 @@ int main(int argc, char** argv) {
   if (rnd) { fill_rand<<<2048, 256>>>(A, (size_t)ld * K, 1u); fill_rand<<<2048, 256>>>(C, (size_t)ld * N, 2u); }
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int which = 0; which < 2; ++which) {
-    setenv("LMM_MFMA16", which ? "1" : "0", 1); g_use_mfma16 = -1;
+    if (which) break;
     launch_gemm_nt(C, ld, A, ld, A, ld, M, N, K, lower, false, 0);
     hipDeviceSynchronize();
     hipEventRecord(e0);
