@@ -144,7 +144,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt[0])
     steps = max(args.steps, 1)
-    evals_per_s = (steps * (world if not orth else 1)) / dt     # replicas: every rank evaluates the whole job
+    # --steps 0: roofline leg only (used for the rocprofv3 summary of the serial-stream pass); value is then null
+    evals_per_s = (steps * (world if not orth else 1)) / dt if args.steps > 0 else None   # replicas: every rank runs the job
 
     roof = None
     extra = {}
@@ -188,7 +189,8 @@ def main():
         if lib.lmm_dev_mfma_f64_peak(C.byref(tf)) == 0:
             extra["mfma_f64_issue_rate_measured_tflops"] = round(tf.value, 2)
         fl = m * n ** 3 / 3.0 if orth else (m * n) ** 3 / 3.0
-        extra["end_to_end_cholesky_tflops"] = round(fl * evals_per_s / 1e12 / (1 if orth else world), 3)
+        if evals_per_s:
+            extra["end_to_end_cholesky_tflops"] = round(fl * evals_per_s / 1e12 / (1 if orth else world), 3)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -197,7 +199,7 @@ def main():
     if rank == 0:
         line = {
             "metric": "logpdf evals/sec", "value": evals_per_s, "unit": "evals/s",
-            "obs_per_s": evals_per_s * n * p,
+            "obs_per_s": evals_per_s * n * p if evals_per_s else None,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if orth else "replicas", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
