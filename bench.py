@@ -27,7 +27,10 @@ import numpy as np  # noqa: E402
 WORKLOADS = {
     # name: (m, p, n, kernel, orthogonal, BASELINE.json config it is)
     "c2": (32, 64, 16384, "matern52", True, "configs[2]: OILMM, Orthogonal(U,S) 64x32, 32 Matern52 latents, n=16384, f64"),
-    "c1": (8, 16, 4096, "se", False, "configs[1]: ILMM, dense H 16x8, 8 SEKernel latents, n=4096, f64 (dense (mn)x(mn) path)"),
+    "c1": (8, 16, 4096, "se", False, "configs[1]: ILMM, dense H 16x8, 8 SEKernel latents, n=4096, f64 (identical kernels: "
+                                     "decoupled shortcut, m independent n x n factorisations)"),
+    "c1dense": (8, 16, 4096, "se", False, "configs[1]: ILMM, dense H 16x8, 8 SEKernel latents, n=4096, f64 (the reference's "
+                                          "single (mn)x(mn) factorisation, shortcut disabled)"),
     "c0": (3, 5, 200, "se", True, "configs[0]: OILMM, 3 SEKernel latents, p=5, n=200, f64"),
     "small": (8, 16, 2048, "matern52", True, "reduced smoke workload (NOT a BASELINE config)"),
 }
@@ -100,6 +103,8 @@ def main():
     from oracle import lmm_oracle as O      # synthetic problem generator + cpu_baseline leg only
     lmm_amd.init(local_rank)
     dev = torch.device("cuda", local_rank)
+    from lmm_amd import model as lmm_model
+    lmm_model.ILMM_ALLOW_DECOUPLED = (args.workload != "c1dense")
 
     m, p, n, kind, orth, desc = WORKLOADS[args.workload]
     P = O.synthetic_problem(m, p, n, kind, orth, s2=0.1, seed=0)

@@ -84,6 +84,15 @@ int lmm_ilmm_logpdf(const double* x, int d, int n, const double* y, int p,
                     const double* H, int m, double sigma2, const lmm_gp_t* gps,
                     const lmm_jitters_t* jit, double* out);
 
+/* Same, with control over the decoupled shortcut: when every latent has the SAME kernel (kind, variance, lengthscale)
+ * the latent covariance I (x) K + SigmaT (x) I block-diagonalises under the m x m eigen-rotation of SigmaT (SURVEY.md
+ * section 3.2), and the value is obtained from m independent n x n factorisations instead of one (mn) x (mn).
+ * allow_decoupled = 0 forces the reference's dense operation; *path_used (may be NULL) = 1 if the shortcut ran.
+ * lmm_ilmm_logpdf == allow_decoupled 1. */
+int lmm_ilmm_logpdf_ex(const double* x, int d, int n, const double* y, int p,
+                       const double* H, int m, double sigma2, const lmm_gp_t* gps,
+                       const lmm_jitters_t* jit, int allow_decoupled, int* path_used, double* out);
+
 /* logpdf(ft::FiniteGP{<:IndependentMOGP,<:MOInputIsotopicByOutputs,<:Diagonal{<:Real,<:Fill}}, y):
  * reference src/independent_mogp.jl:74-80.  y is n x m. */
 int lmm_mogp_logpdf(const double* x, int d, int n, const double* y, int m, double sigma2,

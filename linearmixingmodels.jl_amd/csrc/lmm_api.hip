@@ -342,6 +342,39 @@ bool host_cholesky(std::vector<double>& A, int m) {   // lower, in place, column
   return true;
 }
 
+// Symmetric eigendecomposition A = Q diag(lam) Q' by cyclic Jacobi (m <= a few hundred; host).  A, Q column-major.
+void host_jacobi_eig(std::vector<double> A, int m, std::vector<double>& lam, std::vector<double>& Q) {
+  Q.assign((size_t)m * m, 0.0);
+  for (int i = 0; i < m; ++i) Q[i + (size_t)i * m] = 1.0;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0.0, diag = 0.0;
+    for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j) (i == j ? diag : off) += A[i + (size_t)j * m] * A[i + (size_t)j * m];
+    if (off <= 1e-30 * diag) break;
+    for (int pi = 0; pi < m - 1; ++pi)
+      for (int qi = pi + 1; qi < m; ++qi) {
+        const double apq = A[pi + (size_t)qi * m];
+        if (apq == 0.0) continue;
+        const double theta = (A[qi + (size_t)qi * m] - A[pi + (size_t)pi * m]) / (2.0 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < m; ++k) {       // A <- A J
+          const double akp = A[k + (size_t)pi * m], akq = A[k + (size_t)qi * m];
+          A[k + (size_t)pi * m] = c * akp - s * akq; A[k + (size_t)qi * m] = s * akp + c * akq;
+        }
+        for (int k = 0; k < m; ++k) {       // A <- J' A
+          const double apk = A[pi + (size_t)k * m], aqk = A[qi + (size_t)k * m];
+          A[pi + (size_t)k * m] = c * apk - s * aqk; A[qi + (size_t)k * m] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < m; ++k) {       // Q <- Q J
+          const double qkp = Q[k + (size_t)pi * m], qkq = Q[k + (size_t)qi * m];
+          Q[k + (size_t)pi * m] = c * qkp - s * qkq; Q[k + (size_t)qi * m] = s * qkp + c * qkq;
+        }
+      }
+  }
+  lam.resize(m);
+  for (int i = 0; i < m; ++i) lam[i] = A[i + (size_t)i * m];
+}
+
 // reference src/ilmm.jl:61-68.  T m x p, ST m x m (column-major); also logdet(ST) for src/ilmm.jl:179.
 int project_dense(const double* H, int p, int m, double s2, double jitter, std::vector<double>& T,
                   std::vector<double>& ST, double* logdetST) {
@@ -630,8 +663,8 @@ int lmm_mogp_logpdf(const double* x, int d, int n, const double* y, int m, doubl
   LMM_CATCH
 }
 
-int lmm_ilmm_logpdf(const double* x, int d, int n, const double* y, int p, const double* H, int m, double sigma2,
-                    const lmm_gp_t* gps, const lmm_jitters_t* jit, double* out) {
+int lmm_ilmm_logpdf_ex(const double* x, int d, int n, const double* y, int p, const double* H, int m, double sigma2,
+                       const lmm_gp_t* gps, const lmm_jitters_t* jit, int allow_decoupled, int* path_used, double* out) {
   std::lock_guard<std::mutex> lk(g_mu);
   REQUIRE_INIT();
   LMM_TRY
@@ -655,6 +688,42 @@ int lmm_ilmm_logpdf(const double* x, int d, int n, const double* y, int p, const
   Buf<double> Ty((size_t)n * m), delta((size_t)n * m), partial(tall_skinny_partials(n, p)), resid_dev(1);
   project_on_device(yd.p, n, p, Td.buf, m, 0, m, nullptr, Ty.p, st0);
   residual_on_device(yd.p, n, p, Ty.p, m, Hd.buf, partial.p, resid_dev.p, st0);
+  // reference src/ilmm.jl:171-181 (scalar part; the residual comes from the device below)
+  auto regulariser = [&](double resid) {
+    return -((double)n * ((double)(p - m) * kLog2Pi + ((double)p * std::log(sigma2) - logdetST)) + resid / sigma2) / 2.0;
+  };
+  bool identical = allow_decoupled != 0;
+  for (int l = 1; l < m && identical; ++l)
+    identical = gps[l].kind == gps[0].kind && gps[l].variance == gps[0].variance && gps[l].lengthscale == gps[0].lengthscale;
+  if (path_used) *path_used = identical ? 1 : 0;
+  if (identical) {
+    // Decoupled shortcut: with one shared latent kernel the covariance is I (x) K + SigmaT (x) I;
+    // SigmaT = Q Lam Q' rotates it to blockdiag(K + lam_a I), so the (mn)^3/3 factorisation becomes m independent n^3/3
+    // ones on the rotated projections (Q'T) Y - Q' mu.  Same value up to rounding; not the reference's operation count.
+    std::vector<double> lam, Q;
+    host_jacobi_eig(ST, m, lam, Q);
+    std::vector<double> T2((size_t)m * p, 0.0), mu2(m, 0.0);
+    for (int aI = 0; aI < m; ++aI) {
+      for (int o = 0; o < p; ++o) {
+        double s = 0.0;
+        for (int b = 0; b < m; ++b) s += Q[b + (size_t)aI * m] * T[b + (size_t)o * m];
+        T2[aI + (size_t)o * m] = s;
+      }
+      for (int b = 0; b < m; ++b) mu2[aI] += Q[b + (size_t)aI * m] * gps[b].mean;
+      if (!(lam[aI] > 0.0)) return fail(LMM_ERR_NOT_PD, "PosDefException: SigmaT has a non-positive eigenvalue");
+    }
+    Uploaded T2d(T2, st0), mu2d(mu2, st0);
+    project_on_device(yd.p, n, p, T2d.buf, m, 0, m, mu2d.buf.p, delta.p, st0);
+    std::vector<lmm_gp_t> g2(m, gps[0]);
+    std::vector<double> lml;
+    double resid = 0.0;
+    HIPCHK(hipMemcpyAsync(&resid, resid_dev.p, sizeof(double), hipMemcpyDeviceToHost, st0));
+    if (int rc = latent_lmls(xd.p, d, n, g2.data(), lam.data(), 0, m, delta.p, lml)) return rc;   // synchronises st0
+    double total = 0.0;
+    for (int l = 0; l < m; ++l) total += lml[l];
+    *out = total + regulariser(resid);
+    return LMM_OK;
+  }
   project_on_device(yd.p, n, p, Td.buf, m, 0, m, meansd.buf.p, delta.p, st0);
   // one dense (mn) x (mn) factorisation: reference src/ilmm.jl:160-162
   const int N = m * n;
@@ -675,11 +744,14 @@ int lmm_ilmm_logpdf(const double* x, int d, int n, const double* y, int p, const
   HIPCHK(hipMemcpyAsync(&hinfo, info.p, sizeof(int), hipMemcpyDeviceToHost, st0));
   HIPCHK(hipStreamSynchronize(st0));
   if (int rc = check_info(std::vector<int>{hinfo}, 0)) return rc;
-  // reference src/ilmm.jl:171-181
-  const double reg = -((double)n * ((double)(p - m) * kLog2Pi + ((double)p * std::log(sigma2) - logdetST)) + resid / sigma2) / 2.0;
-  *out = lml + reg;
+  *out = lml + regulariser(resid);
   return LMM_OK;
   LMM_CATCH
+}
+
+int lmm_ilmm_logpdf(const double* x, int d, int n, const double* y, int p, const double* H, int m, double sigma2,
+                    const lmm_gp_t* gps, const lmm_jitters_t* jit, double* out) {
+  return lmm_ilmm_logpdf_ex(x, d, n, y, p, H, m, sigma2, gps, jit, 1, nullptr, out);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -227,6 +227,12 @@ def _alloc_like(ref, count: int):
     return np.empty(count, dtype=np.float64)
 
 
+# Dense-H ILMM logpdf: allow the identical-kernel decoupled shortcut (exact).  Set False to force
+# the reference's single (mn) x (mn) factorisation.  ILMM_LAST_PATH records which ran.
+ILMM_ALLOW_DECOUPLED = True
+ILMM_LAST_PATH = None
+
+
 # ---- the AbstractGPs verbs ----------------------------------------------------------------------------
 def logpdf(fx: FiniteGP, y, with_regulariser: bool = True) -> float:
     """logpdf(fx, y).  ILMM/OILMM: reference src/oilmm.jl:79-93, src/ilmm.jl:150-163; IndependentMOGP:
@@ -264,7 +270,11 @@ def logpdf(fx: FiniteGP, y, with_regulariser: bool = True) -> float:
     else:
         if (l0, l1) != (0, m):
             raise NotImplementedError("dense-H ILMM does not shard (SURVEY.md 8e: replicas only)")
-        L.check(lib.lmm_ilmm_logpdf(xa.ptr, x.dim, x.n, ya.ptr, p, Ua.ptr, m, C.c_double(s2), gps, None, C.byref(out)))
+        path = C.c_int(0)
+        L.check(lib.lmm_ilmm_logpdf_ex(xa.ptr, x.dim, x.n, ya.ptr, p, Ua.ptr, m, C.c_double(s2), gps, None,
+                                       int(ILMM_ALLOW_DECOUPLED), C.byref(path), C.byref(out)))
+        global ILMM_LAST_PATH
+        ILMM_LAST_PATH = "decoupled" if path.value else "dense"
     return out.value
 
 

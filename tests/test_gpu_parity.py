@@ -287,6 +287,31 @@ def test_ilmm_dense_mid(lmm):
     np.testing.assert_allclose(mu, mo, rtol=1e-7, atol=1e-9); np.testing.assert_allclose(v, vo, rtol=1e-7)
 
 
+def test_ilmm_identical_kernels_decoupled_equals_dense(lmm):
+    """Dense-H ILMM whose latents share one kernel (BASELINE configs[1] shape): the decoupled shortcut (m independent
+    n x n factorisations under the eigen-rotation of SigmaT) equals the reference's single (mn) x (mn) factorisation."""
+    from lmm_amd import model as M
+    P = O.synthetic_problem(4, 6, 200, "se", False, seed=7)
+    for g, mu in zip(P["gps"], [0.3, -1.0, 0.0, 2.0]):
+        g["mean"] = mu                      # means may differ; kernels are identical
+    fx = lmm.ILMM(_to_model(lmm, P["gps"]), P["H"])(lmm.MOInputIsotopicByOutputs(P["x"], 6), 0.1)
+    ref = O.ilmm_logpdf(P["gps"], P["H"], P["x"], 0.1, P["y"])
+    try:
+        M.ILMM_ALLOW_DECOUPLED = True
+        dec = lmm.logpdf(fx, P["y"]); assert M.ILMM_LAST_PATH == "decoupled"
+        M.ILMM_ALLOW_DECOUPLED = False
+        den = lmm.logpdf(fx, P["y"]); assert M.ILMM_LAST_PATH == "dense"
+    finally:
+        M.ILMM_ALLOW_DECOUPLED = True
+    assert dec == pytest.approx(ref, rel=1e-9) and den == pytest.approx(ref, rel=1e-9)
+    assert dec == pytest.approx(den, rel=1e-10)
+    # distinct kernels never take the shortcut
+    P["gps"][1]["lengthscale"] = 0.5
+    fx2 = lmm.ILMM(_to_model(lmm, P["gps"]), P["H"])(lmm.MOInputIsotopicByOutputs(P["x"], 6), 0.1)
+    assert lmm.logpdf(fx2, P["y"]) == pytest.approx(O.ilmm_logpdf(P["gps"], P["H"], P["x"], 0.1, P["y"]), rel=1e-9)
+    assert M.ILMM_LAST_PATH == "dense"
+
+
 def test_rand_matches_oracle_given_normals(lmm):
     """Same standard normals in the reference's draw order => same sample (reference src/oilmm.jl:40-54)."""
     rng = np.random.default_rng(11)
