@@ -136,6 +136,16 @@ int lmm_oilmm_mean_and_var(const lmm_post_t* post, const lmm_gp_t* gps,
                            const double* xs, int d, int ns, const lmm_jitters_t* jit,
                            double* mean_out, double* var_out);
 
+/* mean_and_cov(fx) / cov(fx): reference src/ilmm.jl:132-139,147 (+ src/independent_mogp.jl:60-63 through H = I) for
+ * independent latents (OILMM prior or posterior, dense-H prior with S == NULL):
+ *   C[(o,i),(o',j)] = sum_l H[o,l] H[o',l] (Cov_l[i,j] + jitter [i==j]) + sigma2 [o==o', i==j],
+ * (p ns) x (p ns) column-major, by-outputs ordering.  Same numbers as the reference's Xt_A_X(cholesky(latent_cov), H_full')
+ * + sigma2 I without its Cholesky of a 1e-18-jittered covariance.  Partial sums over the shard as in lmm_oilmm_mean_and_var. */
+int lmm_lmm_mean_and_cov(const lmm_post_t* post, const lmm_gp_t* gps, const double* U, const double* S, int p, int m,
+                         int latent_begin, int latent_end, double sigma2, int add_noise,
+                         const double* xs, int d, int ns, const lmm_jitters_t* jit,
+                         double* mean_out, double* cov_out);
+
 /* logpdf(po(xs, sigma2), ys) where po is the posterior OILMM (reference test/oilmm.jl:25; the posterior
  * is again an OILMM with the same H, reference src/oilmm.jl:133): per-latent posterior covariance at
  * xs (Schur complement) + the reference src/oilmm.jl:79-93 algorithm. */

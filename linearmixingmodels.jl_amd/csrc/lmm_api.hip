@@ -1050,10 +1050,10 @@ int lmm_oilmm_mean_and_var(const lmm_post_t* post, const lmm_gp_t* gps, const do
 }
 
 // Per-latent posterior (or prior) covariance at xs as a factor matrix B (NRs x NCs): gram(xs) + diag_add
-// - R R' (posterior), rider row = rider_vec.  Factorises it.  Caller holds g_mu.  st: stream.
+// - R R' (posterior), rider row = rider_vec.  Factorises it unless factor == false.  Caller holds g_mu.  st: stream.
 static void build_and_factor_at_xs(const lmm_post* P, int k, const lmm_gp_t& gp, const double* xsd, int d, int ns,
                                    double diag_add, const double* rider_vec, const Dims& Ds, double* B, double* WB,
-                                   double* Rk, int ldr, int nsr, int* info, hipStream_t st) {
+                                   double* Rk, int ldr, int nsr, int* info, hipStream_t st, bool factor = true) {
   GramArgs a{};
   a.A = B; a.ld = Ds.ld; a.nrows = Ds.NR; a.ncols = Ds.NC; a.x = xsd; a.d = d; a.n = ns;
   a.kind = gp.kind; a.var = gp.variance; a.inv_ls = 1.0 / gp.lengthscale; a.diag_add = diag_add; a.pad_diag = 1.0;
@@ -1069,7 +1069,67 @@ static void build_and_factor_at_xs(const lmm_post* P, int k, const lmm_gp_t& gp,
     // Schur complement on the leading NCs x NCs block (rows of R beyond ns are zero)
     launch_gemm_nt(B, Ds.ld, Rk, ldr, Rk, ldr, Ds.NC, Ds.NC, P->NC, 1, false, st);
   }
-  potrf_rec(B, Ds.ld, Ds.NR, 0, Ds.NC, WB, ns, info, st);
+  if (factor) potrf_rec(B, Ds.ld, Ds.NR, 0, Ds.NC, WB, ns, info, st);
+}
+
+extern "C" int lmm_lmm_mean_and_cov(const lmm_post_t* post, const lmm_gp_t* gps, const double* U, const double* S, int p, int m,
+                                    int latent_begin, int latent_end, double sigma2, int add_noise, const double* xs, int d,
+                                    int ns, const lmm_jitters_t* jit, double* mean_out, double* cov_out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  REQUIRE_INIT();
+  LMM_TRY
+  if (!U || !xs || !mean_out || !cov_out || d <= 0 || ns <= 0 || p <= 0 || m <= 0) return fail(LMM_ERR_ARG, "bad arguments");
+  if ((double)p * ns * (double)p * ns > 4e8) return fail(LMM_ERR_UNSUPPORTED, "full covariance (p*ns)^2 too large");
+  if (!jit) jit = &kDefaultJit;
+  const lmm_post* P = post;
+  int l0 = latent_begin, l1 = latent_end;
+  if (P) {
+    if (P->kind != 0) return fail(LMM_ERR_UNSUPPORTED, "full covariance of the dense-H posterior is not built");
+    l0 = P->l0; l1 = P->l1;
+    if (P->m != m) return fail(LMM_ERR_DIM, "posterior has %d latents, H has %d", P->m, m);
+    if (P->d != d) return fail(LMM_ERR_DIM, "input dimension mismatch");
+  } else if (int rc = check_gps(gps, m)) return rc;
+  if (l0 < 0 || l1 > m || l0 > l1) return fail(LMM_ERR_ARG, "bad latent shard");
+  const int ms = l1 - l0;
+  hipStream_t st0 = g.streams[0];
+  std::vector<double> Hs((size_t)p * std::max(ms, 1), 0.0);
+  for (int k = 0; k < ms; ++k)
+    for (int o = 0; o < p; ++o) Hs[o + (size_t)k * p] = U[o + (size_t)(l0 + k) * p] * (S ? std::sqrt(S[l0 + k]) : 1.0);
+  Uploaded Hd(Hs, st0);
+  DevIn xsd(xs, (size_t)d * ns, st0);
+  DevOut mo(mean_out, (size_t)ns * p), co(cov_out, (size_t)ns * p * ns * p);
+  Buf<double> ml((size_t)ns * std::max(ms, 1));
+  Dims Ds(ns, 0);
+  const int nsr = rup(ns, 64);
+  int ldr = nsr; if ((ldr % 512) == 0) ldr += 16;
+  const int CH = LMM_MAX_BATCH;
+  std::vector<Buf<double>> Cm;
+  for (int c = 0; c < std::min(CH, std::max(ms, 1)); ++c) Cm.emplace_back(Ds.elems());
+  Buf<double> R(P ? (size_t)ldr * P->NC : 1);
+  if (ms == 0) {
+    HIPCHK(hipMemsetAsync(mo.p, 0, (size_t)ns * p * sizeof(double), st0));
+    BatchPtr none{};
+    launch_cov_mix(none, Ds.ld, 0, Hd.buf.p, p, ns, 0.0, add_noise ? sigma2 : 0.0, 1, co.p, st0);
+  }
+  for (int k0 = 0; k0 < ms; k0 += CH) {
+    const int nl = std::min(CH, ms - k0);
+    BatchPtr cl{};
+    for (int j = 0; j < nl; ++j) {
+      const int k = k0 + j;
+      const lmm_gp_t& gp = P ? P->gps[l0 + k] : gps[l0 + k];
+      launch_post_mean(xsd.p, ns, P ? P->x.p : nullptr, P ? P->n : 0, d, P ? P->alpha[k].p : nullptr, to_dev(gp),
+                       ml.p + (size_t)k * ns, st0);
+      build_and_factor_at_xs(P, k, gp, xsd.p, d, ns, 0.0, nullptr, Ds, Cm[j].p, nullptr, R.p, ldr, nsr, nullptr, st0, false);
+      cl.p[j] = Cm[j].p;
+    }
+    launch_cov_mix(cl, Ds.ld, nl, Hd.buf.p + (size_t)k0 * p, p, ns, jit->default_jitter, add_noise ? sigma2 : 0.0,
+                   k0 == 0 ? 1 : 0, co.p, st0);
+  }
+  if (ms > 0) launch_mix(ml.p, ns, ms, Hd.buf.p, p, 1, 0.0, 0.0, nullptr, 0.0, mo.p, st0);
+  mo.finish(st0); co.finish(st0);
+  HIPCHK(hipStreamSynchronize(st0));
+  return LMM_OK;
+  LMM_CATCH
 }
 
 int lmm_oilmm_post_logpdf(const lmm_post_t* post, const double* U, const double* S, int p, int m, double sigma2,

@@ -743,6 +743,27 @@ __global__ __launch_bounds__(256) void mix_kernel(const double* __restrict__ lat
   out[(size_t)o * ns + s] = acc;
 }
 
+// Full mixed covariance (reference src/ilmm.jl:132-139 / AbstractGPs cov):
+//   out[(o,i),(o',j)] (+)= sum_{l in chunk} H[o,l] H[o',l] (C_l[i,j] + jitter [i==j])  (+ sigma2 [o==o', i==j] on init)
+// C_l is the lower triangle of a factor-matrix-layout buffer (mirrored here).  out is (p ns) x (p ns) column-major.
+__global__ __launch_bounds__(256) void cov_mix_kernel(BatchPtr Cl, int ldcl, int nl, const double* __restrict__ Hs, int p,
+                                                      int ns, double jitter, double sigma2, int init,
+                                                      double* __restrict__ out) {
+  const int i = blockIdx.x * 16 + (threadIdx.x & 15), j = blockIdx.y * 16 + (threadIdx.x >> 4);
+  if (i >= ns || j >= ns) return;
+  const int o = blockIdx.z / p, o2 = blockIdx.z - o * p;
+  double acc = 0.0;
+  const int hi = i > j ? i : j, lo = i > j ? j : i;
+  for (int l = 0; l < nl; ++l) {
+    double c = Cl.p[l][(size_t)lo * ldcl + hi];
+    if (i == j) c += jitter;
+    acc = __builtin_fma(Hs[o + (size_t)l * p] * Hs[o2 + (size_t)l * p], c, acc);
+  }
+  double* q = out + ((size_t)o2 * ns + j) * ((size_t)p * ns) + (size_t)o * ns + i;
+  if (init) *q = acc + ((o == o2 && i == j) ? sigma2 : 0.0);
+  else *q += acc;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // K7: sample transform  out = mu + L z  (lower-triangular, column-major).  Thread per row, k-split over
 // blockIdx.y with deterministic two-pass partials.
@@ -934,6 +955,12 @@ void launch_mix(const double* lat, int ns, int ml, const double* Hm, int p, int 
                 const double* eps, double eps_scale, double* out, hipStream_t st) {
   dim3 grid((ns + 255) / 256, p);
   hipLaunchKernelGGL(mix_kernel, grid, dim3(256), 0, st, lat, ns, ml, Hm, p, pw, lat_add, out_add, eps, eps_scale, out);
+}
+
+void launch_cov_mix(const BatchPtr& Cl, int ldcl, int nl, const double* Hs, int p, int ns, double jitter, double sigma2,
+                    int init, double* out, hipStream_t st) {
+  dim3 grid((ns + 15) / 16, (ns + 15) / 16, p * p);
+  hipLaunchKernelGGL(cov_mix_kernel, grid, dim3(256), 0, st, Cl, ldcl, nl, Hs, p, ns, jitter, sigma2, init, out);
 }
 
 int trmv_chunks(int n) { int c = (n + 2047) / 2048; return c < 1 ? 1 : c; }

@@ -354,6 +354,38 @@ def mean_and_var(fx: FiniteGP, add_noise: bool = True):
     return mean, var
 
 
+def mean_and_cov(fx: FiniteGP):
+    """mean_and_cov(fx): reference src/ilmm.jl:132-139 (ILMM/OILMM) and AbstractGPs' generic form over
+    src/independent_mogp.jl:60-63 (IndependentMOGP).  Returns (mean, C) with C (p n) x (p n), by-outputs order."""
+    L.ensure_init()
+    lib = L.load()
+    f, x, s2 = fx.f, fx.x, fx.sigma2
+    xa = x.carr()
+    if isinstance(f, IndependentMOGP):
+        m = len(f.fs)
+        if x.out_dim != m:
+            raise RuntimeError("out dim of x != out dim of f.")
+        Ua, Sa, p, post, descs, shard = L.Arr(L.colmajor(np.eye(m))), None, m, f._post, [g.desc() for g in f.fs], (0, m)
+        jit = L.jitters((1e-9, 0.0, 0.0))          # cov(f, x) + Sigma_y: no latent jitter for a bare MOGP
+    else:
+        unpack(fx)
+        if not f.is_oilmm and f.f._post is not None:
+            raise NotImplementedError("full covariance of the dense-H posterior ILMM is not built")
+        Ua, Sa, p, m = _H_args(f.H)
+        post, descs, shard, jit = f.f._post, [g.desc() for g in f.f.fs], f.shard, None
+    n = x.n
+    mean, cov = np.empty(n * p), np.empty((n * p) * (n * p))
+    L.check(lib.lmm_lmm_mean_and_cov(post.ptr if post is not None else None, L.gps_array(descs), Ua.ptr,
+                                     Sa.ptr if Sa is not None else None, p, m, shard[0], shard[1], C.c_double(s2), 1, xa.ptr,
+                                     x.dim, n, jit, L.Arr(mean, True).ptr, L.Arr(cov, True).ptr))
+    return mean, cov.reshape(n * p, n * p).T       # column-major -> (row, col); symmetric
+
+
+def cov(fx: FiniteGP):
+    """reference src/ilmm.jl:147."""
+    return mean_and_cov(fx)[1]
+
+
 def mean(fx: FiniteGP):
     """reference src/ilmm.jl:142."""
     return mean_and_var(fx)[0]

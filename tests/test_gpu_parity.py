@@ -203,6 +203,37 @@ def test_ilmm_dense_toy_shapes(lmm, m):
     np.testing.assert_allclose(mu, mn, rtol=1e-5, atol=1e-6); np.testing.assert_allclose(v, np.diag(Cn) + 1e-6, rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("m", [3, 2])
+def test_cov_and_mean_and_cov(lmm, m):
+    """cov / mean_and_cov (test/ilmm.jl:12, test/oilmm.jl:12; reference src/ilmm.jl:132-147): prior OILMM, prior dense-H
+    ILMM, posterior OILMM at test points, and the block-diagonal IndependentMOGP covariance."""
+    rng = np.random.default_rng(300 + m)
+    x = np.linspace(0, 10, 7); xtr, xte = x[:4], x[4:]
+    gps = _gps(["se", "matern32", "matern52"][:m], rng)
+    U, S = _orth(rng, 3, m)
+    H = O.orthogonal_dense(U, S)
+    ytr = rng.standard_normal(12)
+    xin = lmm.MOInputIsotopicByOutputs(xtr, 3)
+    fo = lmm.ILMM(_to_model(lmm, gps), lmm.Orthogonal(U, S))
+    fd = lmm.ILMM(_to_model(lmm, gps), H)
+    Mref, Cref = O.ilmm_mean_cov(gps, H, xtr, 0.1)
+    for f in (fo, fd):
+        M, Cm = lmm.mean_and_cov(f(xin, 0.1))
+        np.testing.assert_allclose(M, Mref, rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(Cm, Cref, rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(lmm.cov(f(xin, 0.1)), O.naive_cov(gps, H, xtr) + 0.1 * np.eye(12), rtol=1e-12, atol=1e-13)
+    post = lmm.posterior(fo(xin, 0.1), ytr)
+    M, Cm = lmm.mean_and_cov(post(lmm.MOInputIsotopicByOutputs(xte, 3), 0.1))
+    Mn, Cn = O.naive_posterior_mean_cov(gps, H, xtr, 0.1, ytr, xte)
+    np.testing.assert_allclose(M, Mn, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(Cm, Cn + 0.1 * np.eye(9), rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(np.diag(Cm), lmm.var(post(lmm.MOInputIsotopicByOutputs(xte, 3), 0.1)), rtol=1e-10)
+    # IndependentMOGP: dense block-diagonal covariance (reference src/independent_mogp.jl:60-63) + Sigma_y
+    fm = _to_model(lmm, gps)
+    Cb = lmm.cov(fm(lmm.MOInputIsotopicByOutputs(xtr, m), 0.1))
+    np.testing.assert_allclose(Cb, O.mogp_cov(gps, xtr) + 0.1 * np.eye(4 * m), rtol=1e-12, atol=1e-13)
+
+
 def test_mogp_toy(lmm):
     """test/independent_mogp.jl:33-60."""
     rng = np.random.default_rng(5)
