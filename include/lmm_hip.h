@@ -77,6 +77,18 @@ int lmm_oilmm_logpdf(const double* x, int d, int n, const double* y, int p,
                      const lmm_gp_t* gps, int latent_begin, int latent_end, int with_regulariser,
                      double* out);
 
+/* logpdf(fx, Y::AbstractMatrix): one value per column of Y ((n p) x ncol, column-major) from ONE factorisation per latent
+ * (the extra columns ride the factorisation as rider rows).  The reference does not overload this (it falls to AbstractGPs'
+ * dense generic path); AbstractGPs.TestUtils calls it.  out: ncol values. */
+int lmm_oilmm_logpdf_multi(const double* x, int d, int n, const double* Y, int p, int ncol,
+                           const double* U, const double* S, int m, double sigma2,
+                           const lmm_gp_t* gps, int latent_begin, int latent_end, int with_regulariser,
+                           double* out);
+
+/* MOInputIsotopicByFeatures <-> MOInputIsotopicByOutputs reordering of an n*p vector (reference
+ * src/independent_mogp.jl:135-159 reorder_by_outputs / its inverse).  to_outputs != 0: out[o n + i] = in[i p + o]. */
+int lmm_reorder(const double* in, int n, int p, int to_outputs, double* out);
+
 /* logpdf(fx::FiniteGP{<:ILMM}, y), dense H (p x m): reference src/ilmm.jl:150-163 (+ project :61-68,
  * regulariser :171-181; cov(::IndependentMOGP) src/independent_mogp.jl:60-63): ONE (mn) x (mn)
  * factorisation.  Does not shard (replicas only). */
@@ -166,6 +178,15 @@ int lmm_lmm_rand(const lmm_post_t* post, const lmm_gp_t* gps,
                  int latent_begin, int latent_end, double sigma2, int add_noise,
                  const double* xs, int d, int ns, const double* z_lat, const double* eps,
                  const lmm_jitters_t* jit, double* out);
+
+/* rand(rng, fx, N): N samples from ONE factorisation per latent (the reference repeats the whole call N times,
+ * src/ilmm.jl:90-92, src/independent_mogp.jl:92-96).  z_lat: [sample][m][ns], eps / out: [sample][p][ns]; per sample the
+ * draw order is the reference's (m blocks of ns latent normals, then ns*p noise normals). */
+int lmm_lmm_rand_multi(const lmm_post_t* post, const lmm_gp_t* gps,
+                       const double* U, const double* S, int p, int m,
+                       int latent_begin, int latent_end, double sigma2, int add_noise,
+                       const double* xs, int d, int ns, int nsamples, const double* z_lat, const double* eps,
+                       const lmm_jitters_t* jit, double* out);
 
 /* ---- building blocks exported for tests / profiling (device pointers only) ------------------ */
 /* In-place lower Cholesky of the leading ncols columns of an nrows x ncols column-major matrix (ld),

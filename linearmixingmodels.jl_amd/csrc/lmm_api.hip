@@ -439,18 +439,19 @@ void residual_on_device(const double* Y, int n, int p, const double* Ty_all, int
 }
 
 // Core: per-latent log marginal likelihoods for latents [l0, l1) given the device rider vectors
-// delta (n x (l1-l0), ld n) and per-latent noise.  Returns lml per latent (host).
+// delta ([latent][rhs][n]) and per-latent noise.  Returns lml[latent * nrhs + rhs] (host).  nrhs > 1: several
+// right-hand sides (matrix-Y logpdf) ride one factorisation.
 int latent_lmls(const double* xd, int d, int n, const lmm_gp_t* gps, const double* noise, int l0, int l1,
-                const double* delta, std::vector<double>& lml) {
+                const double* delta, std::vector<double>& lml, int nrhs = 1) {
   const int ms = l1 - l0;
-  lml.assign(ms, 0.0);
+  lml.assign((size_t)ms * nrhs, 0.0);
   if (ms == 0) return LMM_OK;
-  Dims D(n, 1);
+  Dims D(n, nrhs);
   int nb_per = 1, nslots = 1;
   batch_plan(ms, &nb_per, &nslots);
   std::vector<Slot> slots;
   make_slots(slots, nslots, nb_per, D.elems(), D.NC);
-  Buf<double> out(ms);
+  Buf<double> out((size_t)ms * nrhs);
   Buf<int> info(ms);
   HIPCHK(hipMemsetAsync(info.p, 0, ms * sizeof(int), g.streams[0]));
   fork_slots(nslots);
@@ -466,16 +467,16 @@ int latent_lmls(const double* xd, int d, int n, const lmm_gp_t* gps, const doubl
       a.A = s.A[j].p; a.ld = D.ld; a.nrows = D.NR; a.ncols = D.NC; a.row_tile0 = 0; a.row_shift = 0; a.full = 0;
       a.x = xd; a.d = d; a.n = n; a.kind = gp.kind; a.var = gp.variance; a.inv_ls = 1.0 / gp.lengthscale;
       a.diag_add = noise[l0 + k]; a.pad_diag = 1.0;
-      a.rider = delta + (size_t)k * n; a.rider_ld = n; a.nrider = 1; a.xs = nullptr; a.ns = 0;
+      a.rider = delta + (size_t)k * nrhs * n; a.rider_ld = n; a.nrider = nrhs; a.xs = nullptr; a.ns = 0;
       { ProfScope ps(LMM_PROF_GRAM, (double)n * ((double)n + 1.0) / 2.0 * 8.0, s.st); launch_gram(a, s.st); }
       B.add(s.A[j].p, s.W[j].p, info.p + k);
     }
     potrf_rec(B, D.ld, D.NR, 0, D.NC, n, s.st);
-    for (int j = 0; j < nb; ++j) launch_lml_reduce(s.A[j].p, D.ld, n, D.NC, 1, out.p + k0 + j, s.st);
+    for (int j = 0; j < nb; ++j) launch_lml_reduce(s.A[j].p, D.ld, n, D.NC, nrhs, out.p + (size_t)(k0 + j) * nrhs, s.st);
   }
   join_slots(nslots);
   std::vector<int> hinfo(ms);
-  HIPCHK(hipMemcpyAsync(lml.data(), out.p, ms * sizeof(double), hipMemcpyDeviceToHost, g.streams[0]));
+  HIPCHK(hipMemcpyAsync(lml.data(), out.p, (size_t)ms * nrhs * sizeof(double), hipMemcpyDeviceToHost, g.streams[0]));
   HIPCHK(hipMemcpyAsync(hinfo.data(), info.p, ms * sizeof(int), hipMemcpyDeviceToHost, g.streams[0]));
   HIPCHK(hipStreamSynchronize(g.streams[0]));
   return check_info(hinfo, l0);
@@ -633,6 +634,71 @@ int lmm_oilmm_logpdf(const double* x, int d, int n, const double* y, int p, cons
     total += -((double)n * (logdetS + (double)(p - m) * std::log(2.0 * M_PI * sigma2)) + resid / sigma2) / 2.0;
   }
   *out = total;
+  return LMM_OK;
+  LMM_CATCH
+}
+
+// logpdf(fx, Y::AbstractMatrix) -- one logpdf per column of Y with ONE factorisation per latent (SURVEY.md 8f next #3;
+// the reference answers it through AbstractGPs' dense generic fallback).  Y is (n p) x ncol column-major.
+int lmm_oilmm_logpdf_multi(const double* x, int d, int n, const double* Y, int p, int ncol, const double* U, const double* S,
+                           int m, double sigma2, const lmm_gp_t* gps, int latent_begin, int latent_end,
+                           int with_regulariser, double* out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  REQUIRE_INIT();
+  LMM_TRY
+  if (!x || !Y || !U || !S || !out || d <= 0 || n <= 0 || p <= 0 || m <= 0 || ncol <= 0) return fail(LMM_ERR_ARG, "bad arguments");
+  if (m > p) return fail(LMM_ERR_DIM, "out dim of x != out dim of f.");
+  if (latent_begin < 0 || latent_end > m || latent_begin > latent_end) return fail(LMM_ERR_ARG, "bad latent shard");
+  if (int rc = check_gps(gps, m)) return rc;
+  hipStream_t st0 = g.streams[0];
+  std::vector<double> T, ST, H;
+  project_orthogonal(U, S, p, m, sigma2, T, ST, H);
+  DevIn xd(x, (size_t)d * n, st0), yd(Y, (size_t)n * p * ncol, st0);
+  Uploaded Td(T, st0), Hd(H, st0);
+  std::vector<double> means(m);
+  for (int l = 0; l < m; ++l) means[l] = gps[l].mean;
+  Uploaded meansd(means, st0);
+  const int l0 = latent_begin, l1 = latent_end, ms = l1 - l0;
+  Buf<double> delta((size_t)n * std::max(ms, 1) * ncol), Ty((size_t)n * m), partial(tall_skinny_partials(n, p)), resid_dev(ncol);
+  std::vector<double> resid(ncol, 0.0);
+  for (int c = 0; c < ncol; ++c) {
+    const double* yc = yd.p + (size_t)c * n * p;
+    // rider [latent k][column c]: delta + (k ncol + c) n  ==  output column stride ncol*n
+    if (ms > 0) launch_tall_skinny(yc, n, n, p, Td.buf.p + l0, m, ms, delta.p + (size_t)c * n, ncol * n, meansd.buf.p + l0, nullptr, 0,
+                                   nullptr, 0, st0);
+    if (with_regulariser) {
+      project_on_device(yc, n, p, Td.buf, m, 0, m, nullptr, Ty.p, st0);
+      residual_on_device(yc, n, p, Ty.p, m, Hd.buf, partial.p, resid_dev.p + c, st0);
+    }
+  }
+  if (with_regulariser) HIPCHK(hipMemcpyAsync(resid.data(), resid_dev.p, ncol * sizeof(double), hipMemcpyDeviceToHost, st0));
+  std::vector<double> lml;
+  if (int rc = latent_lmls(xd.p, d, n, gps, ST.data(), l0, l1, delta.p, lml, ncol)) return rc;
+  double logdetS = 0.0;
+  for (int l = 0; l < m; ++l) logdetS += std::log(S[l]);
+  for (int c = 0; c < ncol; ++c) {
+    double total = 0.0;
+    for (int k = 0; k < ms; ++k) total += lml[(size_t)k * ncol + c];
+    if (with_regulariser) total += -((double)n * (logdetS + (double)(p - m) * std::log(2.0 * M_PI * sigma2)) + resid[c] / sigma2) / 2.0;
+    out[c] = total;
+  }
+  return LMM_OK;
+  LMM_CATCH
+}
+
+// MOInputIsotopicByFeatures <-> MOInputIsotopicByOutputs reordering of a length n*p vector (reference
+// src/independent_mogp.jl:135-159): to_outputs != 0: out[o n + i] = in[i p + o]; else the inverse.
+int lmm_reorder(const double* in, int n, int p, int to_outputs, double* out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  REQUIRE_INIT();
+  LMM_TRY
+  if (!in || !out || n <= 0 || p <= 0) return fail(LMM_ERR_ARG, "bad arguments");
+  hipStream_t st0 = g.streams[0];
+  DevIn ind(in, (size_t)n * p, st0);
+  DevOut od(out, (size_t)n * p);
+  launch_reorder(ind.p, n, p, to_outputs, od.p, st0);
+  od.finish(st0);
+  HIPCHK(hipStreamSynchronize(st0));
   return LMM_OK;
   LMM_CATCH
 }
@@ -1201,13 +1267,13 @@ int lmm_oilmm_post_logpdf(const lmm_post_t* post, const double* U, const double*
   LMM_CATCH
 }
 
-int lmm_lmm_rand(const lmm_post_t* post, const lmm_gp_t* gps, const double* U, const double* S, int p, int m,
-                 int latent_begin, int latent_end, double sigma2, int add_noise, const double* xs, int d, int ns,
-                 const double* z_lat, const double* eps, const lmm_jitters_t* jit, double* out) {
+int lmm_lmm_rand_multi(const lmm_post_t* post, const lmm_gp_t* gps, const double* U, const double* S, int p, int m,
+                       int latent_begin, int latent_end, double sigma2, int add_noise, const double* xs, int d, int ns,
+                       int nsamples, const double* z_lat, const double* eps, const lmm_jitters_t* jit, double* out) {
   std::lock_guard<std::mutex> lk(g_mu);
   REQUIRE_INIT();
   LMM_TRY
-  if (!U || !xs || !z_lat || !out || d <= 0 || ns <= 0 || p <= 0 || m <= 0) return fail(LMM_ERR_ARG, "bad arguments");
+  if (!U || !xs || !z_lat || !out || d <= 0 || ns <= 0 || p <= 0 || m <= 0 || nsamples <= 0) return fail(LMM_ERR_ARG, "bad arguments");
   if (add_noise && !eps) return fail(LMM_ERR_ARG, "eps is NULL");
   if (!jit) jit = &kDefaultJit;
   const lmm_post* P = post;
@@ -1223,8 +1289,9 @@ int lmm_lmm_rand(const lmm_post_t* post, const lmm_gp_t* gps, const double* U, c
   for (int k = 0; k < ms; ++k)
     for (int o = 0; o < p; ++o) Hs[o + (size_t)k * p] = U[o + (size_t)(l0 + k) * p] * (S ? std::sqrt(S[l0 + k]) : 1.0);
   Uploaded Hd(Hs, st0);
-  DevIn xsd(xs, (size_t)d * ns, st0), zd(z_lat + (size_t)l0 * ns, (size_t)ns * std::max(ms, 1), st0);
-  DevIn epsd(add_noise ? eps : nullptr, (size_t)ns * p, st0);
+  // z_lat: [sample][m][ns], eps: [sample][p][ns], out: [sample][p][ns]
+  DevIn xsd(xs, (size_t)d * ns, st0), zd(z_lat, (size_t)ns * m * nsamples, st0);
+  DevIn epsd(add_noise ? eps : nullptr, (size_t)ns * p * nsamples, st0);
   Dims Ds(ns, 0);
   const int nsr = rup(ns, 64);
   int ldr = nsr; if ((ldr % 512) == 0) ldr += 16;
@@ -1235,7 +1302,7 @@ int lmm_lmm_rand(const lmm_post_t* post, const lmm_gp_t* gps, const double* U, c
     R.emplace_back(P ? (size_t)ldr * P->NC : 1); mu.emplace_back((size_t)ns);
     part.emplace_back((size_t)ns * trmv_chunks(ns));
   }
-  Buf<double> X((size_t)ns * std::max(ms, 1));
+  Buf<double> X((size_t)ns * std::max(ms, 1) * nsamples);     // [sample][latent of the shard][ns]
   Buf<int> info(std::max(ms, 1));
   HIPCHK(hipMemsetAsync(info.p, 0, std::max(ms, 1) * sizeof(int), st0));
   fork_slots(nslots);
@@ -1249,19 +1316,30 @@ int lmm_lmm_rand(const lmm_post_t* post, const lmm_gp_t* gps, const double* U, c
       launch_post_mean(xsd.p, ns, P->x.p, P->n, d, P->alpha[k].p, to_dev(gp), mu[s].p, st);
       mu_const = 0.0;
     }
-    launch_trmv_lower(Bm[s].p, Ds.ld, ns, zd.p + (size_t)k * ns, mu_const, part[s].p, X.p + (size_t)k * ns, st);
-    if (P) launch_vec_lin(X.p + (size_t)k * ns, mu[s].p, 1.0, ns, X.p + (size_t)k * ns, st);
+    for (int q = 0; q < nsamples; ++q) {     // ONE factorisation, nsamples triangular products
+      double* Xq = X.p + ((size_t)q * ms + k) * ns;
+      launch_trmv_lower(Bm[s].p, Ds.ld, ns, zd.p + ((size_t)q * m + l0 + k) * ns, mu_const, part[s].p, Xq, st);
+      if (P) launch_vec_lin(Xq, mu[s].p, 1.0, ns, Xq, st);
+    }
   }
   join_slots(nslots);
-  DevOut od(out, (size_t)ns * p);
+  DevOut od(out, (size_t)ns * p * nsamples);
   // reference src/oilmm.jl:50-53 / src/ilmm.jl:86: F = vec((H X')') + sqrt(sigma2) eps
-  launch_mix(X.p, ns, ms, Hd.buf.p, p, 1, 0.0, 0.0, add_noise ? epsd.p : nullptr, std::sqrt(sigma2), od.p, st0);
+  for (int q = 0; q < nsamples; ++q)
+    launch_mix(X.p + (size_t)q * ms * ns, ns, ms, Hd.buf.p, p, 1, 0.0, 0.0, add_noise ? epsd.p + (size_t)q * ns * p : nullptr,
+               std::sqrt(sigma2), od.p + (size_t)q * ns * p, st0);
   od.finish(st0);
   std::vector<int> hinfo(std::max(ms, 1), 0);
   HIPCHK(hipMemcpyAsync(hinfo.data(), info.p, std::max(ms, 1) * sizeof(int), hipMemcpyDeviceToHost, st0));
   HIPCHK(hipStreamSynchronize(st0));
   return check_info(hinfo, l0);
   LMM_CATCH
+}
+
+int lmm_lmm_rand(const lmm_post_t* post, const lmm_gp_t* gps, const double* U, const double* S, int p, int m,
+                 int latent_begin, int latent_end, double sigma2, int add_noise, const double* xs, int d, int ns,
+                 const double* z_lat, const double* eps, const lmm_jitters_t* jit, double* out) {
+  return lmm_lmm_rand_multi(post, gps, U, S, p, m, latent_begin, latent_end, sigma2, add_noise, xs, d, ns, 1, z_lat, eps, jit, out);
 }
 
 // ------------------------------------------------------------------------------------------------

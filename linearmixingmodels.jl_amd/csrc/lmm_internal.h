@@ -62,6 +62,7 @@ void launch_cov_mix(const BatchPtr& Cl, int ldcl, int nl, const double* Hs, int 
 int trmv_chunks(int n);
 void launch_trmv_lower(const double* L, int ld, int n, const double* z, double mu, double* partial, double* out,
                        hipStream_t st);
+void launch_reorder(const double* in, int n, int p, int to_outputs, double* out, hipStream_t st);
 void launch_add_diag(double* A, int ld, int n, double v, hipStream_t st);
 void launch_vec_lin(const double* a, const double* b, double sb, int n, double* out, hipStream_t st);  // out = a + sb*b
 void launch_delay(double us, hipStream_t st);

@@ -806,6 +806,14 @@ __global__ void vec_lin_kernel(const double* a, const double* b, double sb, int 
   if (k < n) out[k] = a[k] + sb * b[k];
 }
 
+// by-features <-> by-outputs reordering (an n x p transpose): reference src/independent_mogp.jl:135-159
+__global__ void reorder_kernel(const double* __restrict__ in, int n, int p, int to_outputs, double* __restrict__ out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n * p) return;
+  if (to_outputs) { const int o = k / n, i = k - o * n; out[k] = in[(size_t)i * p + o]; }
+  else { const int i = k / p, o = k - i * p; out[k] = in[(size_t)o * n + i]; }
+}
+
 // Add a constant to the first n diagonal entries (noise / jitter on a Schur complement).
 __global__ void add_diag_kernel(double* A, int ld, int n, double v) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -972,6 +980,10 @@ void launch_trmv_lower(const double* L, int ld, int n, const double* z, double m
   dim3 grid((n + 255) / 256, nch);
   hipLaunchKernelGGL(trmv_lower_kernel, grid, dim3(256), 0, st, L, ld, n, z, kchunk, partial);
   hipLaunchKernelGGL(trmv_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, st, partial, n, nch, mu, out);
+}
+
+void launch_reorder(const double* in, int n, int p, int to_outputs, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(reorder_kernel, dim3((n * p + 255) / 256), dim3(256), 0, st, in, n, p, to_outputs, out);
 }
 
 void launch_add_diag(double* A, int ld, int n, double v, hipStream_t st) {

@@ -131,6 +131,45 @@ class MOInputIsotopicByOutputs:
         return self.n * self.out_dim
 
 
+class MOInputIsotopicByFeatures:
+    """KernelFunctions.MOInputIsotopicByFeatures(x, out_dim): index k -> (x[k // p], k % p) (all outputs of x_1, then x_2, ...).
+    The reference supports it for IndependentMOGP only (src/independent_mogp.jl:128-229; ILMM `unpack` rejects it,
+    src/ilmm.jl:45)."""
+
+    def __init__(self, x, out_dim: int):
+        self.x, self.out_dim = x, int(out_dim)
+
+    @property
+    def n(self) -> int:
+        return int(self.x.shape[-1])
+
+    def by_outputs(self) -> MOInputIsotopicByOutputs:
+        return MOInputIsotopicByOutputs(self.x, self.out_dim)
+
+    def __len__(self):
+        return self.n * self.out_dim
+
+
+def indices_which_reorder_features_to_outputs(x) -> np.ndarray:
+    """reference src/independent_mogp.jl:141-145 (1-based, as in test/independent_mogp.jl:86-98): applied to a vector
+    ordered by features it orders it by outputs."""
+    return np.arange(1, len(x) + 1).reshape(x.n, x.out_dim).T.reshape(-1)
+
+
+def indices_which_reorder_outputs_to_features(x) -> np.ndarray:
+    """reference src/independent_mogp.jl:135-139."""
+    return np.arange(1, len(x) + 1).reshape(x.out_dim, x.n).T.reshape(-1)
+
+
+def _reorder(v, n: int, p: int, to_outputs: bool):
+    """lmm_reorder: by-features <-> by-outputs (index permutation done by the library)."""
+    L.ensure_init()
+    a = L.Arr(v)
+    out = _alloc_like(v, n * p)
+    L.check(L.load().lmm_reorder(a.ptr, n, p, int(to_outputs), L.Arr(out, True).ptr))
+    return out
+
+
 class _PostHandle:
     """Owns an lmm_post_t* (device-resident posterior state); freed with the Python object, as the Julia
     shim does with a finalizer."""
@@ -241,6 +280,12 @@ def logpdf(fx: FiniteGP, y, with_regulariser: bool = True) -> float:
     L.ensure_init()
     lib = L.load()
     f, x, s2 = fx.f, fx.x, fx.sigma2
+    if isinstance(x, MOInputIsotopicByFeatures):          # reference src/independent_mogp.jl:222-229
+        if not isinstance(f, IndependentMOGP):
+            raise TypeError("ILMM needs MOInputIsotopicByOutputs (reference src/ilmm.jl:45)")
+        return logpdf(FiniteGP(f, x.by_outputs(), s2), _reorder(y, x.n, x.out_dim, True))
+    if hasattr(y, "shape") and len(y.shape) == 2:         # logpdf(fx, Y::AbstractMatrix): one value per column
+        return _logpdf_matrix(fx, y, with_regulariser)
     out = C.c_double()
     xa, ya = x.carr(), L.Arr(y)
     if isinstance(f, IndependentMOGP):
@@ -278,6 +323,32 @@ def logpdf(fx: FiniteGP, y, with_regulariser: bool = True) -> float:
     return out.value
 
 
+def _logpdf_matrix(fx: FiniteGP, Y, with_regulariser: bool = True) -> np.ndarray:
+    """logpdf(fx, Y) for Y of shape (n*p, ncol): ONE factorisation per latent, the columns ride as extra right-hand sides."""
+    lib = L.load()
+    f, x, s2 = fx.f, fx.x, fx.sigma2
+    ncol = int(Y.shape[1])
+    Yc = Y.T.contiguous() if L._is_torch(Y) else np.ascontiguousarray(np.asarray(Y, dtype=np.float64).T)   # column-major image
+    if isinstance(f, IndependentMOGP):
+        m = len(f.fs)
+        descs, Ua, Sa, p, shard, post = [g.desc() for g in f.fs], L.Arr(L.colmajor(np.eye(m))), L.Arr(np.ones(m)), m, (0, m), f._post
+        with_regulariser = False                   # U = I, S = 1, p == m: the regulariser is identically 0 only up to its
+        s2_eff = s2                                # log S = 0 and (p-m) = 0 terms; skip it exactly
+    else:
+        unpack(fx)
+        if not f.is_oilmm:
+            raise NotImplementedError("matrix-Y logpdf is built for Orthogonal H and IndependentMOGP")
+        descs, (Ua, Sa, p, m), shard, post, s2_eff = [g.desc() for g in f.f.fs], _H_args(f.H), f.shard, f.f._post, s2
+    if post is not None:
+        raise NotImplementedError("matrix-Y logpdf on a posterior")
+    if x.out_dim != p:
+        raise RuntimeError("out dim of x != out dim of f.")
+    out = np.empty(ncol)
+    L.check(lib.lmm_oilmm_logpdf_multi(x.carr().ptr, x.dim, x.n, L.Arr(Yc).ptr, p, ncol, Ua.ptr, Sa.ptr, m, C.c_double(s2_eff),
+                                       L.gps_array(descs), shard[0], shard[1], int(with_regulariser), L.Arr(out, True).ptr))
+    return out
+
+
 def _post_logpdf(post: _PostHandle, descs, U, S, x, s2, ya, with_reg) -> float:
     lib = L.load()
     out = C.c_double()
@@ -294,6 +365,8 @@ def posterior(fx: FiniteGP, y):
     L.ensure_init()
     lib = L.load()
     f, x, s2 = fx.f, fx.x, fx.sigma2
+    if isinstance(x, MOInputIsotopicByFeatures):
+        return posterior(FiniteGP(f, x.by_outputs(), s2), _reorder(y, x.n, x.out_dim, True))
     xa, ya = x.carr(), L.Arr(y)
     handle = C.c_void_p()
     if isinstance(f, IndependentMOGP):
@@ -324,6 +397,9 @@ def mean_and_var(fx: FiniteGP, add_noise: bool = True):
     L.ensure_init()
     lib = L.load()
     f, x, s2 = fx.f, fx.x, fx.sigma2
+    if isinstance(x, MOInputIsotopicByFeatures):          # reference src/independent_mogp.jl:169-215
+        mo, vo = mean_and_var(FiniteGP(f, x.by_outputs(), s2), add_noise)
+        return _reorder(mo, x.n, x.out_dim, False), _reorder(vo, x.n, x.out_dim, False)
     xa = x.carr()
     if isinstance(f, IndependentMOGP):
         m = len(f.fs)
@@ -406,13 +482,37 @@ def rand(rng, fx: FiniteGP, N: Optional[int] = None, jitters=None, add_noise: bo
     """rand(rng, fx[, N]): reference src/oilmm.jl:40-54, src/ilmm.jl:78-92, src/independent_mogp.jl:83-96.
     `rng` is a numpy Generator; standard normals are drawn on the host in the reference's order (m blocks of n
     latent normals, then n*p noise normals) and handed to the device, as the Julia shim does with randn(rng, ...)."""
-    if N is not None:
-        return np.stack([rand(rng, fx, None, jitters, add_noise) for _ in range(N)], axis=1)   # src/ilmm.jl:90-92
+    f, x, s2 = fx.f, fx.x, fx.sigma2
+    if isinstance(x, MOInputIsotopicByFeatures):          # reference src/independent_mogp.jl:217-220
+        s = rand(rng, FiniteGP(f, x.by_outputs(), s2), N, jitters, add_noise)
+        if N is None:
+            return _reorder(s, x.n, x.out_dim, False)
+        return np.stack([_reorder(np.ascontiguousarray(s[:, q]), x.n, x.out_dim, False) for q in range(N)], axis=1)
     L.ensure_init()
     lib = L.load()
-    f, x, s2 = fx.f, fx.x, fx.sigma2
     xa = x.carr()
     n = x.n
+    if N is not None:
+        # reference src/ilmm.jl:90-92 / src/independent_mogp.jl:92-96 repeat the whole call N times; here ONE factorisation
+        # serves all N samples (lmm_lmm_rand_multi).  Normals are still drawn sample by sample in the reference's order.
+        if isinstance(f, IndependentMOGP):
+            m = p = len(f.fs)
+            Ua, Sa, descs, post, shard, jit, noise = L.Arr(L.colmajor(np.eye(m))), None, [g.desc() for g in f.fs], f._post, (0, m), \
+                L.jitters((1e-9, s2, s2)), 0
+        else:
+            unpack(fx)
+            Ua, Sa, p, m = _H_args(f.H)
+            descs, post, shard, jit, noise = [g.desc() for g in f.f.fs], f.f._post, f.shard, L.jitters(jitters), int(add_noise)
+        z = np.empty((N, m * n)); eps = np.empty((N, n * p))
+        for q in range(N):
+            z[q] = rng.standard_normal(m * n)
+            if not isinstance(f, IndependentMOGP):
+                eps[q] = rng.standard_normal(n * p)
+        out = np.empty((N, n * p))
+        L.check(lib.lmm_lmm_rand_multi(post.ptr if post is not None else None, L.gps_array(descs), Ua.ptr,
+                                       Sa.ptr if Sa is not None else None, p, m, shard[0], shard[1], C.c_double(s2), noise, xa.ptr,
+                                       x.dim, n, N, L.Arr(z).ptr, L.Arr(eps).ptr if noise else None, jit, L.Arr(out, True).ptr))
+        return out.T
     if isinstance(f, IndependentMOGP):
         # vcat(rand(rng, f_l(x, s2))): latent jitter = s2, H = I, no extra noise term
         m = len(f.fs)

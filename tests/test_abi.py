@@ -89,3 +89,15 @@ def test_latent_shard_partition():
             assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
             sizes = [b - a for a, b in blocks]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_reorder_indices_known_answers():
+    """reference test/independent_mogp.jl:86-98."""
+    x = lmm_amd.MOInputIsotopicByFeatures(np.linspace(0.0, 2.0, 3), 2)
+    v_by_output, v_by_features = np.array([1, 1, 1, 2, 2, 2]), np.array([1, 2, 1, 2, 1, 2])
+    o2f = lmm_amd.indices_which_reorder_outputs_to_features(x) - 1
+    f2o = lmm_amd.indices_which_reorder_features_to_outputs(x) - 1
+    np.testing.assert_array_equal(v_by_output[o2f], v_by_features)
+    np.testing.assert_array_equal(v_by_features[f2o], v_by_output)
+    np.testing.assert_array_equal(v_by_output[o2f][f2o], v_by_output)
+    np.testing.assert_array_equal(v_by_features[f2o][o2f], v_by_features)

@@ -343,6 +343,63 @@ def test_ilmm_identical_kernels_decoupled_equals_dense(lmm):
     assert M.ILMM_LAST_PATH == "dense"
 
 
+def test_mogp_by_features(lmm):
+    """MOInputIsotopicByFeatures on an IndependentMOGP (reference src/independent_mogp.jl:128-229; test/independent_mogp.jl:
+    106-128 shape: x = range(0,2;length=3), kernels SE and 0.5*SE, scalar noise): equals the by-outputs answer after
+    reordering, and the naive GP with H = I."""
+    rng = np.random.default_rng(123456)
+    xv = np.linspace(0.0, 2.0, 3)
+    gps = [{"kind": "se", "variance": 1.0, "lengthscale": 1.0, "mean": 0.0}, {"kind": "se", "variance": 0.5, "lengthscale": 1.0, "mean": 0.0}]
+    f = _to_model(lmm, gps)
+    xf = lmm.MOInputIsotopicByFeatures(xv, 2)
+    y_bf = rng.standard_normal(6)
+    f2o = lmm.indices_which_reorder_features_to_outputs(xf) - 1
+    y_bo = y_bf[f2o]
+    assert lmm.logpdf(f(xf, 0.1), y_bf) == pytest.approx(O.mogp_logpdf(gps, xv, 0.1, y_bo), rel=1e-12)
+    assert lmm.logpdf(f(xf, 0.1), y_bf) == pytest.approx(O.naive_logpdf(gps, np.eye(2), xv, 0.1, y_bo), rel=1e-12)
+    mu, v = lmm.mean_and_var(f(xf, 0.1))
+    mo, vo = O.mogp_mean_var(gps, xv)
+    o2f = lmm.indices_which_reorder_outputs_to_features(xf) - 1
+    np.testing.assert_allclose(mu, mo[o2f], atol=1e-14); np.testing.assert_allclose(v, (vo + 0.1)[o2f], rtol=1e-13)
+    post = lmm.posterior(f(xf, 0.1), y_bf)
+    mu, v = lmm.mean_and_var(post(xf, 0.1))
+    mo, vo = O.mogp_mean_var(O.mogp_posterior(gps, xv, 0.1, y_bo), xv)
+    np.testing.assert_allclose(mu, mo[o2f], rtol=1e-10); np.testing.assert_allclose(v, (vo + 0.1)[o2f], rtol=1e-10)
+    assert len(lmm.rand(np.random.default_rng(0), f(xf, 0.1))) == 6
+
+
+def test_matrix_y_logpdf_and_rand_n(lmm):
+    """logpdf(fx, Y::Matrix) and rand(rng, fx, N) (AbstractGPs.TestUtils primary interface; SURVEY.md 8f next #3): one
+    factorisation per latent serves every column / sample; values equal the per-column reference answers."""
+    rng = np.random.default_rng(17)
+    n, p, m, N = 150, 4, 3, 5
+    x = np.sort(rng.uniform(0, 10, n))
+    gps = _gps(["matern32", "matern52", "se"], rng)
+    U, S = _orth(rng, p, m)
+    f = lmm.ILMM(_to_model(lmm, gps), lmm.Orthogonal(U, S))
+    fx = f(lmm.MOInputIsotopicByOutputs(x, p), 0.1)
+    Y = rng.standard_normal((n * p, N))
+    got = lmm.logpdf(fx, Y)
+    ref = np.array([O.oilmm_logpdf(gps, U, S, x, 0.1, Y[:, c]) for c in range(N)])
+    np.testing.assert_allclose(got, ref, rtol=1e-10)
+    np.testing.assert_allclose(got, [lmm.logpdf(fx, np.ascontiguousarray(Y[:, c])) for c in range(N)], rtol=1e-12)
+    # IndependentMOGP matrix-Y
+    fm = _to_model(lmm, gps)
+    Ym = rng.standard_normal((n * m, 3))
+    np.testing.assert_allclose(lmm.logpdf(fm(lmm.MOInputIsotopicByOutputs(x, m), 0.1), Ym),
+                               [O.mogp_logpdf(gps, x, 0.1, Ym[:, c]) for c in range(3)], rtol=1e-10)
+    # rand(rng, fx, N): same normals => column q equals the single-sample call made with the same stream position
+    jit = (1e-9, 1e-6, 1e-6)
+    Smp = lmm.rand(np.random.default_rng(4), fx, N, jitters=jit)
+    assert Smp.shape == (n * p, N)
+    g2 = np.random.default_rng(4)
+    for q in range(N):
+        z = g2.standard_normal(m * n); eps = g2.standard_normal(n * p)
+        X = np.stack([O.gp_rand(g, x, 1e-6, z[l * n:(l + 1) * n]) for l, g in enumerate(gps)])
+        ref_q = (O.orthogonal_dense(U, S) @ X).reshape(-1) + math.sqrt(0.1) * eps
+        np.testing.assert_allclose(Smp[:, q], ref_q, rtol=1e-7, atol=1e-8)
+
+
 def test_rand_matches_oracle_given_normals(lmm):
     """Same standard normals in the reference's draw order => same sample (reference src/oilmm.jl:40-54)."""
     rng = np.random.default_rng(11)
