@@ -77,6 +77,18 @@ int lmm_oilmm_logpdf(const double* x, int d, int n, const double* y, int p,
                      const lmm_gp_t* gps, int latent_begin, int latent_end, int with_regulariser,
                      double* out);
 
+/* Value and gradient of logpdf(fx::FiniteGP{<:OILMM}, y) -- what `Zygote.gradient(logpdf, fx, y)` differentiates in the
+ * reference's tests (test/oilmm.jl:31-32), to be wrapped in a ChainRulesCore.rrule by the
+ * Julia shim.  Gradients w.r.t. y (n*p, by-outputs), sigma2, S (m), U (p x m, treated as an unconstrained matrix as Zygote
+ * treats the field) and each latent's (variance, lengthscale, mean).  Any grad pointer may be NULL.  Outputs are partial
+ * sums over the latent shard; entries of grad_gps outside the shard are 0. */
+typedef struct { double variance; double lengthscale; double mean; } lmm_gp_grad_t;
+int lmm_oilmm_logpdf_grad(const double* x, int d, int n, const double* y, int p,
+                          const double* U, const double* S, int m, double sigma2,
+                          const lmm_gp_t* gps, int latent_begin, int latent_end, int with_regulariser,
+                          double* out_logpdf, double* grad_y, double* grad_sigma2, double* grad_S, double* grad_U,
+                          lmm_gp_grad_t* grad_gps);
+
 /* logpdf(fx, Y::AbstractMatrix): one value per column of Y ((n p) x ncol, column-major) from ONE factorisation per latent
  * (the extra columns ride the factorisation as rider rows).  The reference does not overload this (it falls to AbstractGPs'
  * dense generic path); AbstractGPs.TestUtils calls it.  out: ncol values. */

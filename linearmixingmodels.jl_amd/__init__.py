@@ -5,7 +5,7 @@ The directory name contains a dot, so import it through the root-level loader:  
 from ._lib import LMMError, PosDefException, init, load, LIB_PATH, SYMBOLS
 from .model import (GP, ILMM, OILMM, FiniteGP, IndependentMOGP, Matern32Kernel, Matern52Kernel,
                     MOInputIsotopicByFeatures, MOInputIsotopicByOutputs, Normal, indices_which_reorder_features_to_outputs,
-                    indices_which_reorder_outputs_to_features, Orthogonal, SEKernel, get_latent_gp, independent_mogp, logpdf,
+                    indices_which_reorder_outputs_to_features, Orthogonal, SEKernel, get_latent_gp, independent_mogp, logpdf, logpdf_and_gradient,
                     marginals, mean, mean_and_cov, cov, mean_and_var, noise_var, posterior, rand, reshape_y, unpack, var)
 from .parallel import latent_shard, sharded_logpdf, sharded_mean_and_var
 
@@ -13,6 +13,6 @@ __all__ = [
     "ILMM", "IndependentMOGP", "independent_mogp", "Orthogonal", "OILMM", "get_latent_gp",   # the reference's 6 exports
     "GP", "SEKernel", "Matern32Kernel", "Matern52Kernel", "MOInputIsotopicByOutputs", "MOInputIsotopicByFeatures", "FiniteGP", "Normal",
     "indices_which_reorder_features_to_outputs", "indices_which_reorder_outputs_to_features",
-    "logpdf", "posterior", "rand", "marginals", "mean_and_var", "mean_and_cov", "mean", "var", "cov", "noise_var", "reshape_y", "unpack",
+    "logpdf", "logpdf_and_gradient", "posterior", "rand", "marginals", "mean_and_var", "mean_and_cov", "mean", "var", "cov", "noise_var", "reshape_y", "unpack",
     "latent_shard", "sharded_logpdf", "sharded_mean_and_var", "init", "load", "PosDefException", "LMMError",
 ]

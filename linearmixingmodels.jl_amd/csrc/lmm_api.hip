@@ -244,17 +244,21 @@ void potrf_rec(double* A, int ld, int NR, int j0, int w, double* W, int n_real, 
 }
 
 // R (nr x NC, ldr) <- R * L^-T for an already factored L (ld) with inverse diagonal blocks W.
-void trsm_rec(double* R, int ldr, int nr, const double* L, int ld, const double* W, int j0, int w, hipStream_t st) {
+// tri: R starts as the identity, so rows >= j0 + w are still zero in these columns and are skipped (R becomes the upper
+// triangular L^-T at ~half the flops of a rectangular solve).
+void trsm_rec(double* R, int ldr, int nr, const double* L, int ld, const double* W, int j0, int w, hipStream_t st,
+              bool tri = false) {
+  const int rows = tri ? std::min(nr, j0 + w) : nr;
   if (w <= 64) {
     double* pan = R + (size_t)j0 * ldr;
-    launch_gemm_nt(pan, ldr, pan, ldr, W + (size_t)(j0 / 64) * 4096, 64, nr, 64, 64, 0, true, st);
+    launch_gemm_nt(pan, ldr, pan, ldr, W + (size_t)(j0 / 64) * 4096, 64, rows, 64, 64, 0, true, st);
     return;
   }
   const int h = split(w);
-  trsm_rec(R, ldr, nr, L, ld, W, j0, h, st);
+  trsm_rec(R, ldr, nr, L, ld, W, j0, h, st, tri);
   launch_gemm_nt(R + (size_t)(j0 + h) * ldr, ldr, R + (size_t)j0 * ldr, ldr, L + (size_t)j0 * ld + (j0 + h), ld,
-                 nr, w - h, h, 0, false, st);
-  trsm_rec(R, ldr, nr, L, ld, W, j0 + h, w - h, st);
+                 rows, w - h, h, 0, false, st);
+  trsm_rec(R, ldr, nr, L, ld, W, j0 + h, w - h, st, tri);
 }
 
 // How many latents share one batch and how many streams carry batches, for a shard of ms latents.
@@ -634,6 +638,163 @@ int lmm_oilmm_logpdf(const double* x, int d, int n, const double* y, int p, cons
     total += -((double)n * (logdetS + (double)(p - m) * std::log(2.0 * M_PI * sigma2)) + resid / sigma2) / 2.0;
   }
   *out = total;
+  return LMM_OK;
+  LMM_CATCH
+}
+
+// Value and gradient of logpdf(fx::FiniteGP{<:OILMM}, y) (reference src/oilmm.jl:79-93; what the reference's
+// Zygote.gradient(logpdf, fx, y) differentiates, test/oilmm.jl:31-32) w.r.t. y, sigma2, S, U and every latent's
+// (variance, lengthscale, mean).  Per latent: factor, alpha = Kt^-1 delta, Kt^-1 = L^-T L^-1 (triangular solve of identity
+// riders + an upper-triangular SYRK on the MFMA kernels), then one fused contraction kernel; the chain rule through
+// T = S^-1/2 U', SigmaT = sigma2 / S and the regulariser is small host algebra.  Partial sums over the shard.
+int lmm_oilmm_logpdf_grad(const double* x, int d, int n, const double* y, int p, const double* U, const double* S, int m,
+                          double sigma2, const lmm_gp_t* gps, int latent_begin, int latent_end, int with_regulariser,
+                          double* out_logpdf, double* grad_y, double* grad_sigma2, double* grad_S, double* grad_U,
+                          lmm_gp_grad_t* grad_gps) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  REQUIRE_INIT();
+  LMM_TRY
+  if (!x || !y || !U || !S || !out_logpdf || d <= 0 || n <= 0 || p <= 0 || m <= 0) return fail(LMM_ERR_ARG, "bad arguments");
+  if (m > p) return fail(LMM_ERR_DIM, "out dim of x != out dim of f.");
+  if (latent_begin < 0 || latent_end > m || latent_begin > latent_end) return fail(LMM_ERR_ARG, "bad latent shard");
+  if (int rc = check_gps(gps, m)) return rc;
+  hipStream_t st0 = g.streams[0];
+  const int l0 = latent_begin, l1 = latent_end, ms = l1 - l0;
+  std::vector<double> T, ST, H;
+  project_orthogonal(U, S, p, m, sigma2, T, ST, H);
+  DevIn xd(x, (size_t)d * n, st0), yd(y, (size_t)n * p, st0);
+  Uploaded Td(T, st0);
+  std::vector<double> means(m);
+  for (int l = 0; l < m; ++l) means[l] = gps[l].mean;
+  Uploaded meansd(means, st0);
+  // projections: Ty (all m, for the regulariser and dS), delta for the shard
+  Buf<double> Ty((size_t)n * m), delta((size_t)n * std::max(ms, 1));
+  project_on_device(yd.p, n, p, Td.buf, m, 0, m, nullptr, Ty.p, st0);
+  if (ms > 0) project_on_device(yd.p, n, p, Td.buf, m, l0, ms, meansd.buf.p + l0, delta.p, st0);
+  // per-latent factorisation, alpha, inverse, contractions
+  Dims D(n, 1);
+  const int nslots = std::max(1, std::min(ms, eff_streams()));
+  std::vector<Buf<double>> Am, Wm, Rm, part;
+  for (int s = 0; s < nslots; ++s) {
+    Am.emplace_back(D.elems()); Wm.emplace_back((size_t)(D.NC / 64) * 4096);
+    Rm.emplace_back((size_t)D.ld * D.NC); part.emplace_back((size_t)grad_partials(n));
+  }
+  Buf<double> alpha((size_t)D.NC * std::max(ms, 1)), lmld(std::max(ms, 1)), red((size_t)5 * std::max(ms, 1));
+  Buf<int> info(std::max(ms, 1));
+  HIPCHK(hipMemsetAsync(info.p, 0, std::max(ms, 1) * sizeof(int), st0));
+  HIPCHK(hipMemsetAsync(alpha.p, 0, (size_t)D.NC * std::max(ms, 1) * sizeof(double), st0));
+  fork_slots(nslots);
+  for (int k = 0; k < ms; ++k) {
+    const int s = k % nslots;
+    hipStream_t st = g.streams[s];
+    const lmm_gp_t& gp = gps[l0 + k];
+    double* al = alpha.p + (size_t)k * D.NC;
+    GramArgs a{};
+    a.A = Am[s].p; a.ld = D.ld; a.nrows = D.NR; a.ncols = D.NC; a.x = xd.p; a.d = d; a.n = n;
+    a.kind = gp.kind; a.var = gp.variance; a.inv_ls = 1.0 / gp.lengthscale; a.diag_add = ST[l0 + k]; a.pad_diag = 1.0;
+    a.rider = delta.p + (size_t)k * n; a.rider_ld = n; a.nrider = 1;
+    launch_gram(a, st);
+    potrf_rec(Am[s].p, D.ld, D.NR, 0, D.NC, Wm[s].p, n, info.p + k, st);
+    launch_lml_reduce(Am[s].p, D.ld, n, D.NC, 1, lmld.p + k, st);
+    launch_extract_row(Am[s].p, D.ld, D.NC, n, al, st);
+    launch_backsolve(Am[s].p, D.ld, Wm[s].p, D.NC / 64, al, st);
+    launch_set_identity(Rm[s].p, D.ld, D.NC, st);
+    trsm_rec(Rm[s].p, D.ld, D.NC, Am[s].p, D.ld, Wm[s].p, 0, D.NC, st, true);     // R = L^-T (upper triangular)
+    launch_syrk_upper_set(Am[s].p, D.ld, Rm[s].p, D.ld, D.NC, st);                  // lower(A) = L^-T L^-1 = Kt^-1
+    launch_grad_reduce(Am[s].p, D.ld, n, al, delta.p + (size_t)k * n, xd.p, d, to_dev(gp), part[s].p, red.p + (size_t)5 * k, st);
+  }
+  join_slots(nslots);
+  std::vector<double> lml(std::max(ms, 1), 0.0), hred((size_t)5 * std::max(ms, 1), 0.0);
+  std::vector<int> hinfo(std::max(ms, 1), 0);
+  HIPCHK(hipMemcpyAsync(lml.data(), lmld.p, std::max(ms, 1) * sizeof(double), hipMemcpyDeviceToHost, st0));
+  HIPCHK(hipMemcpyAsync(hred.data(), red.p, (size_t)5 * std::max(ms, 1) * sizeof(double), hipMemcpyDeviceToHost, st0));
+  HIPCHK(hipMemcpyAsync(hinfo.data(), info.p, std::max(ms, 1) * sizeof(int), hipMemcpyDeviceToHost, st0));
+  // small dense products needed by the chain rule: YA = Y' alpha (p x ms), aTy = alpha_l . (T y)_l, M2 = Y Y' (p x p)
+  Buf<double> YAd((size_t)p * std::max(ms, 1)), aTyd((size_t)std::max(ms, 1) * m), M2d((size_t)p * p);
+  if (ms > 0) {
+    launch_atb(yd.p, n, alpha.p, D.NC, n, p, ms, YAd.p, st0);
+    launch_atb(alpha.p, D.NC, Ty.p, n, n, ms, m, aTyd.p, st0);       // [k, l]; only l = l0 + k is used
+  }
+  if (with_regulariser) launch_atb(yd.p, n, yd.p, n, n, p, p, M2d.p, st0);
+  std::vector<double> YA((size_t)p * std::max(ms, 1), 0.0), aTy((size_t)std::max(ms, 1) * m, 0.0), M2((size_t)p * p, 0.0);
+  HIPCHK(hipMemcpyAsync(YA.data(), YAd.p, YA.size() * sizeof(double), hipMemcpyDeviceToHost, st0));
+  HIPCHK(hipMemcpyAsync(aTy.data(), aTyd.p, aTy.size() * sizeof(double), hipMemcpyDeviceToHost, st0));
+  if (with_regulariser) HIPCHK(hipMemcpyAsync(M2.data(), M2d.p, M2.size() * sizeof(double), hipMemcpyDeviceToHost, st0));
+  HIPCHK(hipStreamSynchronize(st0));
+  if (int rc = check_info(hinfo, l0)) return rc;
+
+  // ---- host chain rule ----
+  double total = 0.0, gs2 = 0.0;
+  std::vector<double> gS(m, 0.0), gU((size_t)p * m, 0.0);
+  if (grad_gps) for (int l = 0; l < m; ++l) { grad_gps[l].variance = 0.0; grad_gps[l].lengthscale = 0.0; grad_gps[l].mean = 0.0; }
+  for (int k = 0; k < ms; ++k) {
+    const int l = l0 + k;
+    total += lml[k];
+    const double cl = hred[5 * k + 0], trinv = hred[5 * k + 1], aa = hred[5 * k + 2], ad = hred[5 * k + 3], sa = hred[5 * k + 4];
+    const double s = ST[l], v = gps[l].variance;
+    const double g_s = 0.5 * (aa - trinv);                       // d lml / d noise_l
+    if (grad_gps) {
+      grad_gps[l].variance = 0.5 * ((ad - s * aa) - ((double)n - s * trinv)) / v;     // 1/2 tr((aa' - Kinv) K) / v
+      grad_gps[l].lengthscale = cl;                              // sum_{i>j} (a_i a_j - Kinv_ij) dK_ij/dl (x2 / 2)
+      grad_gps[l].mean = sa;
+    }
+    gs2 += g_s / S[l];
+    gS[l] += -g_s * sigma2 / (S[l] * S[l]) + 0.5 * aTy[k + (size_t)l * ms] / S[l];
+    for (int o = 0; o < p; ++o) gU[o + (size_t)l * p] += -YA[o + (size_t)k * p] / std::sqrt(S[l]);
+  }
+  std::vector<double> PtP;       // P'P for the regulariser's dY
+  if (with_regulariser) {
+    std::vector<double> Pm((size_t)p * p, 0.0);
+    for (int a1 = 0; a1 < p; ++a1)
+      for (int b1 = 0; b1 < p; ++b1) {
+        double s = (a1 == b1) ? 1.0 : 0.0;
+        for (int l = 0; l < m; ++l) s -= U[a1 + (size_t)l * p] * U[b1 + (size_t)l * p];
+        Pm[a1 + (size_t)b1 * p] = s;
+      }
+    auto matmul = [&](const std::vector<double>& A1, int r, int c, const std::vector<double>& B1, int c2) {
+      std::vector<double> Cc((size_t)r * c2, 0.0);
+      for (int j = 0; j < c2; ++j) for (int kk = 0; kk < c; ++kk) { const double b = B1[kk + (size_t)j * c]; for (int i = 0; i < r; ++i) Cc[i + (size_t)j * r] += A1[i + (size_t)kk * r] * b; }
+      return Cc;
+    };
+    PtP = matmul(Pm, p, p, Pm, p);                               // P symmetric: P'P = P P
+    double Rn = 0.0;                                             // |P Y|_F^2 = tr(P'P Y Y')
+    for (int a1 = 0; a1 < p; ++a1) for (int b1 = 0; b1 < p; ++b1) Rn += PtP[a1 + (size_t)b1 * p] * M2[b1 + (size_t)a1 * p];
+    double logdetS = 0.0;
+    for (int l = 0; l < m; ++l) logdetS += std::log(S[l]);
+    total += -((double)n * (logdetS + (double)(p - m) * std::log(2.0 * M_PI * sigma2)) + Rn / sigma2) / 2.0;   // src/oilmm.jl:101-113
+    for (int l = 0; l < m; ++l) gS[l] += -(double)n / (2.0 * S[l]);
+    gs2 += -0.5 * ((double)n * (double)(p - m) / sigma2 - Rn / (sigma2 * sigma2));
+    std::vector<double> Uv(U, U + (size_t)p * m);
+    std::vector<double> M2U = matmul(M2, p, p, Uv, m), PU = matmul(Pm, p, p, Uv, m);
+    std::vector<double> t1 = matmul(Pm, p, p, M2U, m), t2 = matmul(M2, p, p, PU, m);
+    for (size_t q = 0; q < gU.size(); ++q) gU[q] += (t1[q] + t2[q]) / sigma2;
+  }
+  *out_logpdf = total;
+  if (grad_sigma2) *grad_sigma2 = gs2;
+  if (grad_S) std::copy(gS.begin(), gS.end(), grad_S);
+  if (grad_U) std::copy(gU.begin(), gU.end(), grad_U);
+  if (grad_y) {
+    // dL/dY[o, i] = - sum_l T[l, o] alpha_l[i]  - (P'P Y)[o, i] / sigma2
+    DevOut gy(grad_y, (size_t)n * p);
+    std::vector<double> negTt((size_t)p * std::max(ms, 1), 0.0);
+    for (int k = 0; k < ms; ++k) for (int o = 0; o < p; ++o) negTt[o + (size_t)k * p] = -T[(l0 + k) + (size_t)o * m];
+    Uploaded nT(negTt, st0);
+    Buf<double> ga((size_t)n * p);
+    // mix reads lat[l*ns + s] with ns = n: alpha is stored with stride NC -> compact copy first
+    Buf<double> ac((size_t)n * std::max(ms, 1));
+    for (int k = 0; k < ms; ++k) HIPCHK(hipMemcpyAsync(ac.p + (size_t)k * n, alpha.p + (size_t)k * D.NC, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st0));
+    launch_mix(ac.p, n, ms, nT.buf.p, p, 1, 0.0, 0.0, nullptr, 0.0, ga.p, st0);
+    if (with_regulariser) {
+      Uploaded Qd(PtP, st0);
+      Buf<double> gr((size_t)n * p);
+      launch_tall_skinny(yd.p, n, n, p, Qd.buf.p, p, p, gr.p, n, nullptr, nullptr, 0, nullptr, 0, st0);   // (Y' (P'P)')' rows
+      launch_vec_lin(ga.p, gr.p, -1.0 / sigma2, n * p, gy.p, st0);
+    } else {
+      HIPCHK(hipMemcpyAsync(gy.p, ga.p, (size_t)n * p * sizeof(double), hipMemcpyDeviceToDevice, st0));
+    }
+    gy.finish(st0);
+    HIPCHK(hipStreamSynchronize(st0));
+  }
   return LMM_OK;
   LMM_CATCH
 }

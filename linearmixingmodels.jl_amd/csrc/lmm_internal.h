@@ -62,6 +62,12 @@ void launch_cov_mix(const BatchPtr& Cl, int ldcl, int nl, const double* Hs, int 
 int trmv_chunks(int n);
 void launch_trmv_lower(const double* L, int ld, int n, const double* z, double mu, double* partial, double* out,
                        hipStream_t st);
+void launch_syrk_upper_set(double* C, int ldc, const double* X, int ldx, int N, hipStream_t st);
+void launch_set_identity(double* R, int ld, int nc, hipStream_t st);
+int grad_partials(int n);
+void launch_grad_reduce(const double* Kinv, int ld, int n, const double* alpha, const double* delta, const double* x, int d,
+                        LatentDev g, double* partial, double* out5, hipStream_t st);
+void launch_atb(const double* X, int ldx, const double* Z, int ldz, int n, int na, int nb, double* out, hipStream_t st);
 void launch_reorder(const double* in, int n, int p, int to_outputs, double* out, hipStream_t st);
 void launch_add_diag(double* A, int ld, int n, double v, hipStream_t st);
 void launch_vec_lin(const double* a, const double* b, double sb, int n, double* out, hipStream_t st);  // out = a + sb*b

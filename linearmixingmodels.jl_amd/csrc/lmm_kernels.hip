@@ -368,7 +368,7 @@ template <int BN, bool SET>
 __global__ __launch_bounds__(256, 2) void gemm44_kernel(BatchPtr Cb, size_t goffC, int ldc, BatchPtr Ab, size_t goffA, int lda,
                                                          BatchPtr Bb, size_t goffB, int ldb,
                                                          int M, int N, int K, int lower, int MT, int full_items,
-                                                         int splitk) {
+                                                         int splitk, int kfrom_row) {
   double* C = Cb.p[blockIdx.y] + goffC;
   const double* A = Ab.p[blockIdx.y] + goffA;
   const double* B = Bb.p[blockIdx.y] + goffB;
@@ -429,7 +429,11 @@ __global__ __launch_bounds__(256, 2) void gemm44_kernel(BatchPtr Cb, size_t goff
   const int wr = (w & 1) * 64, wc = (w >> 1) * WN;
   const bool active = (bm + wr < M) && (bn + wc < N) && !(lower && bm + wr + 63 < bn + wc);
   const int nk_all = K / BK;
-  const int kc0 = (int)((long long)nk_all * part / nparts), kc1 = (int)((long long)nk_all * (part + 1) / nparts);
+  int kc0 = (int)((long long)nk_all * part / nparts);
+  const int kc1 = (int)((long long)nk_all * (part + 1) / nparts);
+  // kfrom_row: the operands are upper triangular (X[i,k] = 0 for k < i), so the product over k starts at the tile's
+  // first row (LAUUM-like X X' for the inverse from its Cholesky factor)
+  if (kfrom_row && kc0 < bm / BK) kc0 = bm / BK;
   A += (size_t)kc0 * BK * lda;
   B += (size_t)kc0 * BK * ldb;
 
@@ -806,6 +810,88 @@ __global__ void vec_lin_kernel(const double* a, const double* b, double sb, int 
   if (k < n) out[k] = a[k] + sb * b[k];
 }
 
+// R = I on an nc x nc block (ld), zero elsewhere: the riders whose triangular solve gives L^-T.
+__global__ void set_identity_kernel(double* __restrict__ R, int ld, int nc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y;
+  if (i < nc) R[(size_t)j * ld + i] = (i == j) ? 1.0 : 0.0;
+}
+
+// d kappa / d lengthscale at scaled distance r (r2 = r^2):  SE v e^{-r2/2} r2 / ell;  Matern32 v s^2 e^{-s} / ell;
+// Matern52 v e^{-s} (s^2/3)(1+s) / ell   (s = sqrt(3) r, sqrt(5) r).
+__device__ __forceinline__ double dkappa_dell(int kind, double var, double inv_ls, double r, double r2) {
+  if (kind == LMM_KERNEL_SE) return var * exp_nonpos(-0.5 * r2) * r2 * inv_ls;
+  if (kind == LMM_KERNEL_MATERN32) { const double s = 1.7320508075688772 * r; return var * s * s * exp_nonpos(-s) * inv_ls; }
+  const double s = 2.23606797749979 * r;
+  return var * exp_nonpos(-s) * (s * s / 3.0) * (1.0 + s) * inv_ls;
+}
+
+// Gradient contractions of one latent: per 64x64 lower tile (ti >= tj) of Kinv
+//   partial[5*tile + 0] = sum_{i>j in tile} (alpha_i alpha_j - Kinv_ij) dK_ij/d ell        (lengthscale)
+//   partial[5*tile + 1] = sum_{i in tile, diagonal tiles} Kinv_ii                           (trace of the inverse)
+//   partial[5*tile + 2..4] = alpha.alpha, alpha.delta, sum alpha over the tile's rows (diagonal tiles only)
+__global__ __launch_bounds__(256) void grad_reduce_kernel(const double* __restrict__ Kinv, int ld, int n,
+                                                          const double* __restrict__ alpha, const double* __restrict__ delta,
+                                                          const double* __restrict__ x, int d, LatentDev g, int nt,
+                                                          double* __restrict__ partial) {
+  __shared__ double sh[4];
+  const int ti = blockIdx.x, tj = blockIdx.y;
+  if (ti < tj) return;
+  const int t = threadIdx.x;
+  const int i0 = ti * 64 + (t & 63);
+  const int cg = t >> 6;
+  double acc = 0.0;
+  if (i0 < n) {
+    const double ai = alpha[i0];
+    for (int q = 0; q < 16; ++q) {
+      const int j = tj * 64 + cg + 4 * q;
+      if (j < i0 && j < n) {
+        double r, r2;
+        if (d == 1) { r = fabs(x[i0] - x[j]) * g.inv_ls; r2 = r * r; }
+        else { r2 = scaled_dist2(x + (size_t)i0 * d, x + (size_t)j * d, d, g.inv_ls); r = sqrt(r2); }
+        acc = __builtin_fma(ai * alpha[j] - Kinv[(size_t)j * ld + i0], dkappa_dell(g.kind, g.var, g.inv_ls, r, r2), acc);
+      }
+    }
+  }
+  const int tile = ti * nt + tj;
+  const double tl = block_sum_256(acc, sh);
+  double tr = 0.0, aa = 0.0, ad = 0.0, sa = 0.0;
+  if (ti == tj && t < 64 && i0 < n) {
+    const double ai = alpha[i0];
+    tr = Kinv[(size_t)i0 * ld + i0]; aa = ai * ai; ad = ai * delta[i0]; sa = ai;
+  }
+  const double s1 = block_sum_256(tr, sh), s2 = block_sum_256(aa, sh), s3 = block_sum_256(ad, sh), s4 = block_sum_256(sa, sh);
+  if (t == 0) {
+    partial[5 * tile + 0] = tl; partial[5 * tile + 1] = s1; partial[5 * tile + 2] = s2; partial[5 * tile + 3] = s3;
+    partial[5 * tile + 4] = s4;
+  }
+}
+
+// out[c] = sum over the nt*nt tile partials of component c (c < 5); upper tiles were never written -> skip them.
+__global__ __launch_bounds__(256) void grad_finish_kernel(const double* __restrict__ partial, int nt, double* __restrict__ out) {
+  __shared__ double sh[4];
+  for (int c = 0; c < 5; ++c) {
+    double s = 0.0;
+    for (int k = threadIdx.x; k < nt * nt; k += 256) {
+      const int ti = k / nt, tj = k - ti * nt;
+      if (ti >= tj) s += partial[5 * k + c];
+    }
+    const double tot = block_sum_256(s, sh);
+    if (threadIdx.x == 0) out[c] = tot;
+  }
+}
+
+// out[a + b*na] = sum_i X[i + a*ldx] Z[i + b*ldz]   (X' Z for tall-skinny X (n x na), Z (n x nb)); one block per (a, b).
+__global__ __launch_bounds__(256) void atb_kernel(const double* __restrict__ X, int ldx, const double* __restrict__ Z, int ldz,
+                                                  int n, int na, double* __restrict__ out) {
+  __shared__ double sh[4];
+  const int a = blockIdx.x, b = blockIdx.y;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s = __builtin_fma(X[(size_t)a * ldx + i], Z[(size_t)b * ldz + i], s);
+  const double tot = block_sum_256(s, sh);
+  if (threadIdx.x == 0) out[a + (size_t)b * na] = tot;
+}
+
 // by-features <-> by-outputs reordering (an n x p transpose): reference src/independent_mogp.jl:135-159
 __global__ void reorder_kernel(const double* __restrict__ in, int n, int p, int to_outputs, double* __restrict__ out) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -883,7 +969,7 @@ void launch_gemm_nt(const BatchPtr& C, size_t offC, int ldc, const BatchPtr& A, 
   const int MT = (M + 127) / 128;
   if (set) {   // in-place TRSM by inverse: one block column, no K split
     hipLaunchKernelGGL((gemm44_kernel<64, true>), dim3(MT, nb), dim3(256), 0, st, C, offC, ldc, A, offA, lda, B, offB, ldb, M, N,
-                       K, 0, MT, MT, 1);
+                       K, 0, MT, MT, 1, 0);
     return;
   }
   const int BNsel = narrow ? 64 : 128;
@@ -910,9 +996,21 @@ void launch_gemm_nt(const BatchPtr& C, size_t offC, int ldc, const BatchPtr& A, 
   if (splitk == 1) full_items = (int)T;
   const int items = full_items + (int)(T - full_items) * splitk;
   if (narrow) hipLaunchKernelGGL((gemm44_kernel<64, false>), dim3(items, nb), dim3(256), 0, st, C, offC, ldc, A, offA, lda, B, offB,
-                                 ldb, M, N, K, lower, MT, full_items, splitk);
+                                 ldb, M, N, K, lower, MT, full_items, splitk, 0);
   else hipLaunchKernelGGL((gemm44_kernel<128, false>), dim3(items, nb), dim3(256), 0, st, C, offC, ldc, A, offA, lda, B, offB,
-                          ldb, M, N, K, lower, MT, full_items, splitk);
+                          ldb, M, N, K, lower, MT, full_items, splitk, 0);
+}
+
+// C (lower triangle, N x N) = X X' for an upper-triangular X (N x N): the inverse K^-1 = L^-T L^-1 from X = L^-T.
+void launch_syrk_upper_set(double* C, int ldc, const double* X, int ldx, int N, hipStream_t st) {
+  if (N <= 0) return;
+  const int MT = (N + 127) / 128, NT = (N + 127) / 128;
+  long long T = 0;
+  for (int tj = 0; tj < NT; ++tj) T += MT - tj;
+  BatchPtr c{}, a{};
+  c.p[0] = C; a.p[0] = const_cast<double*>(X);
+  hipLaunchKernelGGL((gemm44_kernel<128, true>), dim3((int)T, 1), dim3(256), 0, st, c, (size_t)0, ldc, a, (size_t)0, ldx, a, (size_t)0, ldx,
+                     N, N, N, 1, MT, (int)T, 1, 1);
 }
 
 void launch_gemm_nt(double* C, int ldc, const double* A, int lda, const double* B, int ldb, int M, int N, int K,
@@ -980,6 +1078,23 @@ void launch_trmv_lower(const double* L, int ld, int n, const double* z, double m
   dim3 grid((n + 255) / 256, nch);
   hipLaunchKernelGGL(trmv_lower_kernel, grid, dim3(256), 0, st, L, ld, n, z, kchunk, partial);
   hipLaunchKernelGGL(trmv_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, st, partial, n, nch, mu, out);
+}
+
+void launch_set_identity(double* R, int ld, int nc, hipStream_t st) {
+  hipLaunchKernelGGL(set_identity_kernel, dim3((nc + 255) / 256, nc), dim3(256), 0, st, R, ld, nc);
+}
+
+int grad_partials(int n) { const int nt = (n + 63) / 64; return 5 * nt * nt; }
+
+void launch_grad_reduce(const double* Kinv, int ld, int n, const double* alpha, const double* delta, const double* x, int d,
+                        LatentDev g, double* partial, double* out5, hipStream_t st) {
+  const int nt = (n + 63) / 64;
+  hipLaunchKernelGGL(grad_reduce_kernel, dim3(nt, nt), dim3(256), 0, st, Kinv, ld, n, alpha, delta, x, d, g, nt, partial);
+  hipLaunchKernelGGL(grad_finish_kernel, dim3(1), dim3(256), 0, st, partial, nt, out5);
+}
+
+void launch_atb(const double* X, int ldx, const double* Z, int ldz, int n, int na, int nb, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(atb_kernel, dim3(na, nb), dim3(256), 0, st, X, ldx, Z, ldz, n, na, out);
 }
 
 void launch_reorder(const double* in, int n, int p, int to_outputs, double* out, hipStream_t st) {

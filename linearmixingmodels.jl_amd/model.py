@@ -323,6 +323,29 @@ def logpdf(fx: FiniteGP, y, with_regulariser: bool = True) -> float:
     return out.value
 
 
+def logpdf_and_gradient(fx: FiniteGP, y, with_regulariser: bool = True) -> dict:
+    """Value and gradient of logpdf(fx, y) for an OILMM (what `Zygote.gradient(logpdf, fx, y)` returns in the reference's
+    tests, test/oilmm.jl:31-32): {"value", "y", "sigma2", "S", "U", "gps": [{"variance","lengthscale","mean"}, ...]}.
+    Partial sums over the latent shard."""
+    L.ensure_init()
+    lib = L.load()
+    f, x, s2 = fx.f, fx.x, fx.sigma2
+    if not isinstance(f, ILMM) or not f.is_oilmm or f.f._post is not None:
+        raise NotImplementedError("gradients are built for the prior OILMM logpdf")
+    unpack(fx)
+    Ua, Sa, p, m = _H_args(f.H)
+    descs = [g.desc() for g in f.f.fs]
+    n = x.n
+    val, gs2 = C.c_double(), C.c_double()
+    gy, gS, gU = _alloc_like(y if L._is_torch(y) else x.x, n * p), np.empty(m), np.empty(p * m)
+    gg = (L.GpGradT * m)()
+    L.check(lib.lmm_oilmm_logpdf_grad(x.carr().ptr, x.dim, n, L.Arr(y).ptr, p, Ua.ptr, Sa.ptr, m, C.c_double(s2),
+                                      L.gps_array(descs), f.shard[0], f.shard[1], int(with_regulariser), C.byref(val),
+                                      L.Arr(gy, True).ptr, C.byref(gs2), L.Arr(gS, True).ptr, L.Arr(gU, True).ptr, gg))
+    return {"value": val.value, "y": gy, "sigma2": gs2.value, "S": gS, "U": gU.reshape(m, p).T.copy(),
+            "gps": [{"variance": gg[l].variance, "lengthscale": gg[l].lengthscale, "mean": gg[l].mean} for l in range(m)]}
+
+
 def _logpdf_matrix(fx: FiniteGP, Y, with_regulariser: bool = True) -> np.ndarray:
     """logpdf(fx, Y) for Y of shape (n*p, ncol): ONE factorisation per latent, the columns ride as extra right-hand sides."""
     lib = L.load()

@@ -435,3 +435,64 @@ def synthetic_problem(m: int, p: int, n: int, kind: str, orthogonal: bool, s2: f
         out["H"] = A
     out["y"] = np.random.default_rng(seed + 3).standard_normal(n * p)
     return out
+
+
+# ----------------------------------------------------------------------------------------
+# Gradients of the OILMM logpdf (SURVEY.md section 8f "next" #1: what Zygote.gradient(logpdf, fx, y) differentiates,
+# reference test/oilmm.jl:31-32).  Analytic, dense; checked against central finite differences in tests/test_oracle.py.
+# ----------------------------------------------------------------------------------------
+def kernel_dlengthscale(kind: str, variance: float, lengthscale: float, r: np.ndarray) -> np.ndarray:
+    """d kappa(r/ell) / d ell."""
+    d = r / lengthscale
+    if kind == "se":
+        return variance * np.exp(-0.5 * d * d) * d * d / lengthscale
+    if kind == "matern32":
+        s = math.sqrt(3.0) * d
+        return variance * s * s * np.exp(-s) / lengthscale
+    s = math.sqrt(5.0) * d
+    return variance * np.exp(-s) * (s * s / 3.0) * (1.0 + s) / lengthscale
+
+
+def oilmm_logpdf_grad(gps: Sequence[Dict], U: np.ndarray, S: np.ndarray, x: np.ndarray, s2: float, y: np.ndarray) -> Dict:
+    """Value and gradients of src/oilmm.jl:79-93 w.r.t. y, sigma2, S, U (treated as an unconstrained p x m matrix, as
+    Zygote treats the field) and each latent's (variance, lengthscale, mean)."""
+    n = npoints(x)
+    p, m = U.shape
+    Y = reshape_y(y, n)
+    T, ST = project_orthogonal(U, S, s2)
+    Ty = T @ Y
+    gY = np.zeros_like(Y)
+    gU = np.zeros_like(U)
+    gS = np.zeros(m)
+    gs2 = 0.0
+    ggps = []
+    val = 0.0
+    R = pairwise_dist(x)
+    for l, g in enumerate(gps):
+        v, ell, mu = g.get("variance", 1.0), g.get("lengthscale", 1.0), g.get("mean", 0.0)
+        K = kernel_eval(g["kind"], v, ell, R)
+        Kt = K + ST[l] * np.eye(n)
+        L = np.linalg.cholesky(Kt)
+        delta = Ty[l] - mu
+        alpha = sla.cho_solve((L, True), delta)
+        Kinv = sla.cho_solve((L, True), np.eye(n))
+        val += -0.5 * (n * LOG2PI + 2.0 * np.sum(np.log(np.diag(L))) + delta @ alpha)
+        A = np.outer(alpha, alpha) - Kinv
+        g_s = 0.5 * np.trace(A)                                 # d lml / d noise_l
+        ggps.append({"variance": 0.5 * np.sum(A * K) / v,
+                     "lengthscale": 0.5 * np.sum(A * kernel_dlengthscale(g["kind"], v, ell, R)),
+                     "mean": float(np.sum(alpha))})
+        gs2 += g_s / S[l]
+        gS[l] += -g_s * s2 / S[l] ** 2 + 0.5 * (alpha @ Ty[l]) / S[l]
+        gU[:, l] += -(Y @ alpha) / math.sqrt(S[l])
+        gY += -np.outer(T[l], alpha)
+    Pm = np.eye(p) - U @ U.T
+    PY = Pm @ Y
+    Rn = np.sum(PY * PY)
+    val += -(n * (np.sum(np.log(S)) + (p - m) * math.log(2.0 * math.pi * s2)) + Rn / s2) / 2.0
+    gS += -n / (2.0 * S)
+    gs2 += -0.5 * (n * (p - m) / s2 - Rn / s2 ** 2)
+    M2 = Y @ Y.T
+    gU += (Pm @ M2 @ U + M2 @ Pm @ U) / s2                     # -(1/(2 s2)) dR/dU, dR/dU = -2 (P M2 U + M2 P U)
+    gY += -(Pm.T @ PY) / s2
+    return {"value": float(val), "y": gY.reshape(-1), "sigma2": float(gs2), "S": gS, "U": gU, "gps": ggps}

@@ -400,6 +400,36 @@ def test_matrix_y_logpdf_and_rand_n(lmm):
         np.testing.assert_allclose(Smp[:, q], ref_q, rtol=1e-7, atol=1e-8)
 
 
+@pytest.mark.parametrize("n,d", [(9, 1), (150, 1), (130, 2)])
+def test_logpdf_gradient_vs_oracle(lmm, n, d):
+    """Gradient of the OILMM logpdf (reference test/oilmm.jl:31-32 `gradient(logpdf, oilmmx, y_train)`)
+    against the oracle's analytic gradient (itself checked against finite differences in tests/test_oracle.py)."""
+    rng = np.random.default_rng(1000 + n)
+    p, m = 4, 3
+    x = np.sort(rng.uniform(0, 6, n)) if d == 1 else rng.uniform(0, 4, size=(d, n))
+    gps = _gps(["matern52", "se", "matern32"], rng)
+    U, S = _orth(rng, p, m)
+    y = rng.standard_normal(n * p)
+    fx = lmm.ILMM(_to_model(lmm, gps), lmm.Orthogonal(U, S))(lmm.MOInputIsotopicByOutputs(x, p), 0.3)
+    G = lmm.logpdf_and_gradient(fx, y)
+    R = O.oilmm_logpdf_grad(gps, U, S, x, 0.3, y)
+    assert G["value"] == pytest.approx(R["value"], rel=1e-10)
+    assert G["value"] == pytest.approx(lmm.logpdf(fx, y), rel=1e-12)
+    np.testing.assert_allclose(G["y"], R["y"], rtol=1e-7, atol=1e-9)
+    assert G["sigma2"] == pytest.approx(R["sigma2"], rel=1e-7)
+    np.testing.assert_allclose(G["S"], R["S"], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(G["U"], R["U"], rtol=1e-7, atol=1e-8)
+    for l in range(m):
+        for key in ("variance", "lengthscale", "mean"):
+            assert G["gps"][l][key] == pytest.approx(R["gps"][l][key], rel=1e-6, abs=1e-8), (l, key)
+    # shards add up (as the all-reduce would)
+    parts = [lmm.logpdf_and_gradient(lmm.ILMM(_to_model(lmm, gps), lmm.Orthogonal(U, S), shard=sh)(
+        lmm.MOInputIsotopicByOutputs(x, p), 0.3), y, r == 0) for r, sh in enumerate([(0, 2), (2, 3)])]
+    np.testing.assert_allclose(parts[0]["y"] + parts[1]["y"], G["y"], rtol=1e-9, atol=1e-11)
+    assert parts[0]["sigma2"] + parts[1]["sigma2"] == pytest.approx(G["sigma2"], rel=1e-10)
+    np.testing.assert_allclose(parts[0]["U"] + parts[1]["U"], G["U"], rtol=1e-9, atol=1e-11)
+
+
 def test_rand_matches_oracle_given_normals(lmm):
     """Same standard normals in the reference's draw order => same sample (reference src/oilmm.jl:40-54)."""
     rng = np.random.default_rng(11)

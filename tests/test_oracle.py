@@ -140,3 +140,37 @@ def test_helpers():
     np.testing.assert_allclose(O.orthogonal_dense(U, S), U @ np.diag(np.sqrt(S)))
     with pytest.raises(RuntimeError, match="out dim"):
         O.oilmm_logpdf([{"kind": "se"}], U[:, :1], S[:1], np.arange(3.0), 0.1, np.zeros(3 * 4))
+
+
+def test_oilmm_logpdf_grad_matches_finite_differences():
+    """Analytic gradient of the oracle's OILMM logpdf (what Zygote.gradient(logpdf, fx, y) would return;
+    reference test/oilmm.jl:31-32) against central finite differences."""
+    rng = np.random.default_rng(42)
+    n, p, m = 9, 4, 2
+    x = np.sort(rng.uniform(0, 5, n))
+    gps = [{"kind": "matern52", "variance": 1.3, "lengthscale": 0.8, "mean": 0.2},
+           {"kind": "se", "variance": 0.7, "lengthscale": 1.4, "mean": -0.5}]
+    U, S, _ = np.linalg.svd(rng.uniform(size=(p, m)), full_matrices=False)
+    y = rng.standard_normal(n * p)
+    G = O.oilmm_logpdf_grad(gps, U, S, x, 0.3, y)
+    assert G["value"] == pytest.approx(O.oilmm_logpdf(gps, U, S, x, 0.3, y), rel=1e-13)
+    h = 1e-6
+
+    def fd(fun):
+        return (fun(h) - fun(-h)) / (2 * h)
+
+    for k in (0, 7, 20):
+        e = np.zeros(n * p); e[k] = 1.0
+        assert G["y"][k] == pytest.approx(fd(lambda t: O.oilmm_logpdf(gps, U, S, x, 0.3, y + t * e)), rel=1e-6, abs=1e-7)
+    assert G["sigma2"] == pytest.approx(fd(lambda t: O.oilmm_logpdf(gps, U, S, x, 0.3 + t, y)), rel=1e-6)
+    for l in range(m):
+        e = np.zeros(m); e[l] = 1.0
+        assert G["S"][l] == pytest.approx(fd(lambda t: O.oilmm_logpdf(gps, U, S + t * e, x, 0.3, y)), rel=1e-6)
+        for key in ("variance", "lengthscale", "mean"):
+            def f(t, l=l, key=key):
+                g2 = [dict(g) for g in gps]; g2[l][key] += t
+                return O.oilmm_logpdf(g2, U, S, x, 0.3, y)
+            assert G["gps"][l][key] == pytest.approx(fd(f), rel=1e-5, abs=1e-7)
+    for (o, l) in ((0, 0), (3, 1), (2, 0)):
+        E = np.zeros((p, m)); E[o, l] = 1.0
+        assert G["U"][o, l] == pytest.approx(fd(lambda t: O.oilmm_logpdf(gps, U + t * E, S, x, 0.3, y)), rel=1e-5, abs=1e-6)
