@@ -188,4 +188,37 @@ function AbstractGPs.rand(rng::AbstractRNG, fx::FiniteGP{<:ILMM{<:IndependentMOG
     return _rand(rng, C_NULL, _gps(f.fs), Matrix{Float64}(H), Ptr{Cdouble}(C_NULL), p, m, σ², _xmat(x))
 end
 
+# ---- gradients: ChainRulesCore.rrule around the ccall (reference tests: `gradient(logpdf, oilmmx, y) isa Tuple`,
+# test/oilmm.jl:31-32).  lmm_oilmm_logpdf_grad returns d/dy, d/dsigma2, d/dS, d/dU and per-latent (variance, lengthscale,
+# mean) cotangents in one pass; they are mapped back onto the reference's structs as Tangents. -------------------------
+using ChainRulesCore
+
+struct LmmGpGrad      # lmm_gp_grad_t
+    variance::Cdouble
+    lengthscale::Cdouble
+    mean::Cdouble
+end
+
+function ChainRulesCore.rrule(::typeof(AbstractGPs.logpdf), fx::FiniteGP{<:OILMM}, y::AbstractVector{<:Real})
+    fs, H, σ², x = unpack(fx)
+    X = _xmat(x); d, n = size(X); p, m = size(H.U)
+    gps = _gps(fs.fs); S = Vector{Float64}(H.S.diag); U = Matrix{Float64}(H.U); yv = Vector{Float64}(y)
+    val = Ref{Cdouble}(0.0); gσ = Ref{Cdouble}(0.0)
+    gy = Vector{Float64}(undef, n * p); gS = Vector{Float64}(undef, m); gU = Matrix{Float64}(undef, p, m)
+    gg = Vector{LmmGpGrad}(undef, m)
+    GC.@preserve X yv U S gps gy gS gU gg check(ccall((:lmm_oilmm_logpdf_grad, liblmm), Cint,
+        (Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cdouble, Ptr{LmmGp}, Cint, Cint, Cint,
+         Ref{Cdouble}, Ptr{Cdouble}, Ref{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{LmmGpGrad}),
+        X, d, n, yv, p, U, S, m, σ², gps, 0, m, 1, val, gy, gσ, gS, gU, gg))
+    function logpdf_pullback(Δ)
+        dH = Tangent{typeof(H)}(; U=Δ .* gU, S=Tangent{typeof(H.S)}(; diag=Δ .* gS))
+        # kernel-parameter cotangents (gg[l].variance / .lengthscale / .mean) attach to fs.fs[l].kernel / .mean according
+        # to how the kernel was built (ScaledKernel.σ², ScaleTransform.s = 1/ℓ ⇒ ∂/∂s = -ℓ² ∂/∂ℓ); left to the maintainer's
+        # preferred parameterisation.  The noise cotangent is Δ*gσ on each entry's share of Fill(σ², n*p).
+        dfx = Tangent{typeof(fx)}(; f=Tangent{typeof(fx.f)}(; H=dH), Σy=Tangent{typeof(fx.Σy)}(; diag=Tangent{typeof(fx.Σy.diag)}(; value=Δ * gσ[])))
+        return NoTangent(), dfx, Δ .* gy
+    end
+    return val[], logpdf_pullback
+end
+
 end # module
