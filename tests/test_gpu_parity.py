@@ -283,6 +283,20 @@ def test_oilmm_mid_sizes(lmm, kind, n, m, p, d):
     assert lmm.logpdf(fx, y) == pytest.approx(O.oilmm_logpdf(gps, U, S, x, 0.1, y), rel=1e-9)
 
 
+def test_notebook_shape_ill_conditioned(lmm):
+    """The reference notebook's shape (examples/oilmm_and_ilmm.ipynb:124-129): p=600, m=20, n=552, Matern52, sigma2=1e-6 with
+    S = singular values of rand(600,20) (projected noise ~2e-8, cond(K + noise) ~1e9-1e10).  The parity bar
+    (rtol 1e-6) must hold even here."""
+    rng = np.random.default_rng(2)
+    p, m = 600, 20
+    x = np.linspace(0.0, 20.0, 576)[np.sort(np.random.default_rng(1).permutation(576)[:552])]
+    U, S, _ = np.linalg.svd(rng.uniform(size=(p, m)), full_matrices=False)
+    gps = _gps(["matern52"] * m)
+    y = np.random.default_rng(3).standard_normal(552 * p)
+    fx = lmm.ILMM(_to_model(lmm, gps), lmm.Orthogonal(U, S))(lmm.MOInputIsotopicByOutputs(x, p), 1e-6)
+    assert lmm.logpdf(fx, y) == pytest.approx(O.oilmm_logpdf(gps, U, S, x, 1e-6, y), rel=RTOL)
+
+
 def test_oilmm_device_resident_inputs(lmm):
     """x and y handed over as device (torch) tensors: same answer as host arrays."""
     import torch
