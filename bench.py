@@ -175,8 +175,8 @@ def main():
         lmm_amd.logpdf(fprof, yd, False)
         ent = (L.ProfEntryT * len(L.PROF_CLASSES))()
         L.check(lib.lmm_profile_end(ent))
-        prof = {c: {"launches": int(ent[i].launches), "ms": float(ent[i].ms), "work": float(ent[i].work)}
-                for i, c in enumerate(L.PROF_CLASSES)}
+        prof = {c: {"launches": int(ent[i].launches), "ms": float(ent[i].ms), "work": float(ent[i].work),
+                    "bytes": float(ent[i].bytes)} for i, c in enumerate(L.PROF_CLASSES)}
         up = prof["update"]
         if up["launches"] and up["ms"] > 0:
             ach = up["work"] / (up["ms"] * 1e-3) / 1e12
@@ -191,6 +191,7 @@ def main():
                     "frac": round(ach / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                     "launches": up["launches"], "avg_launch_ms": round(up["ms"] / up["launches"], 4),
                     "flops_per_launch": up["work"] / up["launches"],
+                    "algorithmic_bytes_per_launch": up["bytes"] / up["launches"],
                     "mode": f"serial-stream instrumented pass over {nprof} latent(s)"}
         gr = prof["gram"]
         if gr["launches"] and gr["ms"] > 0:

@@ -65,6 +65,7 @@ int lmm_shutdown(void);
 const char* lmm_last_error_string(void);
 int lmm_last_error_detail(int* latent, int* info);
 int lmm_device_synchronize(void);
+int lmm_release_cached_memory(void);      /* return the caching device-memory pool (factor-matrix slots) to HIP */
 
 /* ---- Orthogonal(U, S) validation: reference src/orthogonal_matrix.jl:21-23 -------------- */
 int lmm_orthogonal_validate(const double* U, int p, int m);
@@ -224,7 +225,7 @@ typedef enum {
   LMM_PROF_DIAG = 4,          /* diag64_kernel: 64x64 factor + inverse, flops                           */
   LMM_PROF_COUNT = 5
 } lmm_prof_class;
-typedef struct { long long launches; double ms; double work; } lmm_prof_entry_t;
+typedef struct { long long launches; double ms; double work; double bytes; /* algorithmic HBM bytes */ } lmm_prof_entry_t;
 int lmm_profile_begin(int serial);
 int lmm_profile_end(lmm_prof_entry_t* out /* LMM_PROF_COUNT entries */);
 

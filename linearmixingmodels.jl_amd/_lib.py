@@ -16,7 +16,7 @@ KERNEL_KINDS = {"se": 0, "matern32": 1, "matern52": 2}
 
 # Every symbol include/lmm_hip.h declares (tests/test_abi.py checks the library exports each one).
 SYMBOLS = [
-    "lmm_init", "lmm_shutdown", "lmm_last_error_string", "lmm_last_error_detail", "lmm_device_synchronize",
+    "lmm_init", "lmm_shutdown", "lmm_last_error_string", "lmm_last_error_detail", "lmm_device_synchronize", "lmm_release_cached_memory",
     "lmm_orthogonal_validate", "lmm_oilmm_logpdf", "lmm_oilmm_logpdf_grad", "lmm_oilmm_logpdf_multi", "lmm_reorder", "lmm_ilmm_logpdf", "lmm_ilmm_logpdf_ex", "lmm_mogp_logpdf",
     "lmm_oilmm_posterior_create", "lmm_mogp_posterior_create", "lmm_ilmm_posterior_create", "lmm_post_destroy", "lmm_ilmm_post_mean_and_var",
     "lmm_latent_marginals", "lmm_oilmm_mean_and_var", "lmm_lmm_mean_and_cov", "lmm_oilmm_post_logpdf", "lmm_lmm_rand", "lmm_lmm_rand_multi",
@@ -38,7 +38,7 @@ class GpGradT(C.Structure):
 
 
 class ProfEntryT(C.Structure):
-    _fields_ = [("launches", C.c_longlong), ("ms", C.c_double), ("work", C.c_double)]
+    _fields_ = [("launches", C.c_longlong), ("ms", C.c_double), ("work", C.c_double), ("bytes", C.c_double)]
 
 
 PROF_CLASSES = ["gram", "update", "update_narrow", "trsm", "diag"]

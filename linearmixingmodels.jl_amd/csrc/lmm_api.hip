@@ -43,7 +43,7 @@ struct Ctx {
   int err_latent = -1, err_info = 0;
   // measurement hooks
   bool prof = false, prof_serial = false;
-  struct ProfRec { int cls; double work; hipEvent_t e0, e1; int M, N, K; };
+  struct ProfRec { int cls; double work, bytes; hipEvent_t e0, e1; int M, N, K; };
   std::vector<ProfRec> prof_recs;
   std::vector<hipEvent_t> ev_pool;
 };
@@ -148,9 +148,10 @@ inline int rup(int v, int m) { return (v + m - 1) / m * m; }
 // Brackets one launch with events when profiling is on (lmm_profile_begin); otherwise just launches.
 struct ProfScope {
   bool on; hipStream_t st; size_t idx;
-  ProfScope(int cls, double work, hipStream_t st_, int M = 0, int N = 0, int K = 0) : on(g.prof), st(st_), idx(0) {
+  ProfScope(int cls, double work, hipStream_t st_, int M = 0, int N = 0, int K = 0, double bytes = 0.0)
+      : on(g.prof), st(st_), idx(0) {
     if (!on) return;
-    Ctx::ProfRec r; r.cls = cls; r.work = work; r.M = M; r.N = N; r.K = K;
+    Ctx::ProfRec r; r.cls = cls; r.work = work; r.bytes = bytes; r.M = M; r.N = N; r.K = K;
     for (hipEvent_t* e : {&r.e0, &r.e1}) {
       if (!g.ev_pool.empty()) { *e = g.ev_pool.back(); g.ev_pool.pop_back(); }
       else HIPCHK(hipEventCreate(e));
@@ -230,8 +231,10 @@ void potrf_rec(const Batch& B, int ld, int NR, int j0, int w, int n_real, hipStr
   const int r0 = j0 + h;
   {
     const double Mr = NR - r0, Nc = w - h;     // lower trapezoid: Nc(Nc+1)/2 + (Mr-Nc)Nc outputs, 2h flops each
-    ProfScope ps(Nc <= 64 ? LMM_PROF_UPDATE_NARROW : LMM_PROF_UPDATE, nb * 2.0 * h * (Nc * (Nc + 1.0) / 2.0 + (Mr - Nc) * Nc), st,
-                 NR - r0, w - h, h);
+    const double outs = Nc * (Nc + 1.0) / 2.0 + (Mr - Nc) * Nc;
+    // algorithmic bytes: C read + written once (16 B per output), the A panel (Mr x h, which contains B) read once
+    ProfScope ps(Nc <= 64 ? LMM_PROF_UPDATE_NARROW : LMM_PROF_UPDATE, nb * 2.0 * h * outs, st, NR - r0, w - h, h,
+                 nb * (16.0 * outs + 8.0 * Mr * h));
     const size_t offA = (size_t)j0 * ld + r0;
     launch_gemm_nt(B.A, (size_t)r0 * ld + r0, ld, B.A, offA, ld, B.A, offA, ld, NR - r0, w - h, h, 1, false, B.nb, st);
   }
@@ -472,7 +475,7 @@ int latent_lmls(const double* xd, int d, int n, const lmm_gp_t* gps, const doubl
       a.x = xd; a.d = d; a.n = n; a.kind = gp.kind; a.var = gp.variance; a.inv_ls = 1.0 / gp.lengthscale;
       a.diag_add = noise[l0 + k]; a.pad_diag = 1.0;
       a.rider = delta + (size_t)k * nrhs * n; a.rider_ld = n; a.nrider = nrhs; a.xs = nullptr; a.ns = 0;
-      { ProfScope ps(LMM_PROF_GRAM, (double)n * ((double)n + 1.0) / 2.0 * 8.0, s.st); launch_gram(a, s.st); }
+      { const double gb = (double)n * ((double)n + 1.0) / 2.0 * 8.0; ProfScope ps(LMM_PROF_GRAM, gb, s.st, 0, 0, 0, gb); launch_gram(a, s.st); }
       B.add(s.A[j].p, s.W[j].p, info.p + k);
     }
     potrf_rec(B, D.ld, D.NR, 0, D.NC, n, s.st);
@@ -561,6 +564,15 @@ const char* lmm_last_error_string(void) { return g.err.c_str(); }
 int lmm_last_error_detail(int* latent, int* info) {
   if (latent) *latent = g.err_latent;
   if (info) *info = g.err_info;
+  return LMM_OK;
+}
+
+int lmm_release_cached_memory(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  REQUIRE_INIT();
+  (void)hipDeviceSynchronize();
+  for (auto& kv : g.pool) (void)hipFree(kv.second);
+  g.pool.clear();
   return LMM_OK;
 }
 
@@ -1559,11 +1571,11 @@ int lmm_profile_end(lmm_prof_entry_t* out) {
   LMM_TRY
   if (!out) return fail(LMM_ERR_ARG, "out is NULL");
   HIPCHK(hipDeviceSynchronize());
-  for (int c = 0; c < LMM_PROF_COUNT; ++c) { out[c].launches = 0; out[c].ms = 0.0; out[c].work = 0.0; }
+  for (int c = 0; c < LMM_PROF_COUNT; ++c) { out[c].launches = 0; out[c].ms = 0.0; out[c].work = 0.0; out[c].bytes = 0.0; }
   for (auto& r : g.prof_recs) {
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, r.e0, r.e1));
-    out[r.cls].launches += 1; out[r.cls].ms += ms; out[r.cls].work += r.work;
+    out[r.cls].launches += 1; out[r.cls].ms += ms; out[r.cls].work += r.work; out[r.cls].bytes += r.bytes;
     if (getenv("LMM_PROF_DUMP") && r.M > 0)
       fprintf(stderr, "[prof] cls=%d M=%d N=%d K=%d ms=%.4f tflops=%.2f\n", r.cls, r.M, r.N, r.K, ms, r.work / (ms * 1e-3) / 1e12);
     g.ev_pool.push_back(r.e0); g.ev_pool.push_back(r.e1);

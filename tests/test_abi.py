@@ -31,7 +31,7 @@ def test_header_symbols_all_exported():
 def test_struct_layouts_match_header():
     assert C.sizeof(L.GpT) == 32 and L.GpT.variance.offset == 8 and L.GpT.mean.offset == 24
     assert C.sizeof(L.JittersT) == 24
-    assert C.sizeof(L.ProfEntryT) == 24
+    assert C.sizeof(L.ProfEntryT) == 32 and C.sizeof(L.GpGradT) == 24
 
 
 def test_orthogonal_validate_host_only():
