@@ -484,6 +484,7 @@ __global__ __launch_bounds__(256, 2) void gemm44_kernel(BatchPtr Cb, size_t goff
 #endif
 #ifndef LMM_ABLATE_NOMFMA
     if (active) {
+      __builtin_amdgcn_s_setprio(1);     // two workgroups share each SIMD: let the one in its MFMA phase issue first (+2 %)
       const double* as = &As[buf][0];
       const double* bs = &Bs[buf][0];
 #pragma unroll
@@ -503,6 +504,7 @@ __global__ __launch_bounds__(256, 2) void gemm44_kernel(BatchPtr Cb, size_t goff
               acc[u][v][s] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[u], fb[s], acc[u][v][s], 0, 0, 0);
         }
       }
+      __builtin_amdgcn_s_setprio(0);
     }
 #endif
     if (kt + 1 < nk) {
