@@ -444,6 +444,43 @@ def test_logpdf_gradient_vs_oracle(lmm, n, d):
     np.testing.assert_allclose(parts[0]["U"] + parts[1]["U"], G["U"], rtol=1e-9, atol=1e-11)
 
 
+def test_wide_mixing_and_many_columns(lmm):
+    """Shapes that exercise the chunked projection kernels and multi-block riders: p = 40 > 32 outputs, m = 18 > 16 latents,
+    70 > 64 right-hand-side columns (rider rows spill into a second 64-row block), d = 5 inputs."""
+    rng = np.random.default_rng(77)
+    n, p, m, d = 90, 40, 18, 5
+    x = rng.uniform(0, 3, size=(d, n))
+    gps = _gps((["matern52", "se", "matern32"] * 6)[:m], rng)
+    U, S = _orth(rng, p, m)
+    S = np.linspace(2.0, 0.5, m)
+    f = lmm.ILMM(_to_model(lmm, gps), lmm.Orthogonal(U, S))
+    fx = f(lmm.MOInputIsotopicByOutputs(x, p), 0.2)
+    Y = rng.standard_normal((n * p, 70))
+    got = lmm.logpdf(fx, Y)
+    ref = np.array([O.oilmm_logpdf(gps, U, S, x, 0.2, Y[:, c]) for c in range(70)])
+    np.testing.assert_allclose(got, ref, rtol=1e-10)
+    y = np.ascontiguousarray(Y[:, 0])
+    post = lmm.posterior(fx, y)
+    xs = rng.uniform(0, 3, size=(d, 33))
+    mu, v = lmm.mean_and_var(post(lmm.MOInputIsotopicByOutputs(xs, p), 0.2))
+    mo, vo = O.oilmm_mean_var(O.oilmm_posterior(gps, U, S, x, 0.2, y), U, S, xs, 0.2)
+    np.testing.assert_allclose(mu, mo, rtol=1e-8, atol=1e-10); np.testing.assert_allclose(v, vo, rtol=1e-9)
+
+
+def test_deterministic_mode_is_bitwise_reproducible():
+    """LMM_DETERMINISTIC=1 disables the split-K f64 atomics: two runs give identical bits (fresh processes)."""
+    import subprocess, sys, os
+    code = ("import sys; sys.path.insert(0, %r); import numpy as np, lmm_amd; from oracle import lmm_oracle as O; lmm_amd.init(0);"
+            "P = O.synthetic_problem(3, 5, 2500, 'matern52', True, seed=9);"
+            "f = lmm_amd.ILMM(lmm_amd.independent_mogp([lmm_amd.GP(lmm_amd.Matern52Kernel()) for _ in range(3)]), lmm_amd.Orthogonal(P['U'], P['S']));"
+            "print(repr(lmm_amd.logpdf(f(lmm_amd.MOInputIsotopicByOutputs(P['x'], 5), 0.1), P['y'])))") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = [subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LMM_DETERMINISTIC="1"), capture_output=True, text=True).stdout.strip().splitlines()[-1]
+            for _ in range(2)]
+    assert outs[0] == outs[1] and "-" in outs[0]
+    P = O.synthetic_problem(3, 5, 2500, "matern52", True, seed=9)
+    assert float(outs[0]) == pytest.approx(O.oilmm_logpdf(P["gps"], P["U"], P["S"], P["x"], 0.1, P["y"]), rel=1e-9)
+
+
 def test_rand_matches_oracle_given_normals(lmm):
     """Same standard normals in the reference's draw order => same sample (reference src/oilmm.jl:40-54)."""
     rng = np.random.default_rng(11)
