@@ -94,10 +94,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal switches (not used by the driver): LMM_BENCH_BACKEND=gloo reduces over CPU tensors and
+    # LMM_BENCH_SHARE_GPU=1 puts every rank on GPU 0, so the N > 1 path can be exercised on a one-GPU box.
+    backend = os.environ.get("LMM_BENCH_BACKEND", "nccl")
+    if os.environ.get("LMM_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
@@ -129,7 +137,8 @@ def main():
         shard = (0, m)                       # dense ILMM does not shard: replicas only
         f = lmm_amd.ILMM(fs, H)
     fx = f(xin, s2)
-    red = torch.zeros(1, dtype=torch.float64, device=dev)
+    rdev = dev if backend == "nccl" else torch.device("cpu")      # where the collectives' tensors live
+    red = torch.zeros(1, dtype=torch.float64, device=rdev)
 
     def step():
         part = lmm_amd.logpdf(fx, yd, rank == 0)
@@ -154,7 +163,7 @@ def main():
         val = step()
     fence()
     dt = time.perf_counter() - t0
-    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tt = torch.tensor([dt], dtype=torch.float64, device=rdev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt[0])
