@@ -269,7 +269,6 @@ void batch_plan(int ms, int* nb_per, int* nstreams_used) {
   static int bmax = -1;
   if (bmax < 0) { const char* e = getenv("LMM_BATCH"); bmax = e ? atoi(e) : 8; if (bmax < 1) bmax = 1; if (bmax > LMM_MAX_BATCH) bmax = LMM_MAX_BATCH; }
   int b = std::min(bmax, std::max(1, ms / 2));          // keep at least two batches in flight when ms >= 2
-  if (getenv("LMM_BATCH_FORCE")) b = std::min(bmax, ms);  // tuning sweeps only
   if (g.prof && g.prof_serial) b = std::min(bmax, ms);  // instrumented pass: production-sized batches on ONE stream
   const int nbatches = (ms + b - 1) / b;
   *nb_per = b;

@@ -1200,12 +1200,6 @@ void launch_vec_lin(const double* a, const double* b, double sb, int n, double* 
   hipLaunchKernelGGL(vec_lin_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a, b, sb, n, out);
 }
 
-__global__ void delay_kernel(long long ticks) {       // s_memrealtime ticks are 10 ns
-  const long long t0 = __builtin_amdgcn_s_memrealtime();
-  while ((long long)__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
-}
-void launch_delay(double us, hipStream_t st) { hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, st, (long long)(us * 100.0)); }
-
 void launch_mfma_peak(double* out, int blocks, int iters, hipStream_t st) {
   hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, st, out, iters);
 }
