@@ -138,6 +138,14 @@ int lmm_ilmm_posterior_create(const double* x, int d, int n, const double* y, in
                               const double* H, int m, double sigma2, const lmm_gp_t* gps,
                               const lmm_jitters_t* jit, lmm_post_t** out);
 int lmm_post_destroy(lmm_post_t* post);
+/* logpdf(pi(xs, sigma2), ys) on the dense-H posterior ILMM: reference test/ilmm.jl:25 (src/ilmm.jl:150-163 applied to the
+ * PosteriorGP latent of :196-197).  One (m ns) x (m ns) factorisation. */
+int lmm_ilmm_post_logpdf(const lmm_post_t* post, double sigma2, const double* xs, int d, int ns, const double* ys,
+                         const lmm_jitters_t* jit, double* out);
+/* rand(rng, pi(xs, sigma2)) on the dense-H posterior ILMM: reference src/ilmm.jl:78-87.  z_lat: m*ns normals (by latents),
+ * eps: ns*p normals (by outputs), in the reference's draw order. */
+int lmm_ilmm_post_rand(const lmm_post_t* post, double sigma2, int add_noise, const double* xs, int d, int ns,
+                       const double* z_lat, const double* eps, const lmm_jitters_t* jit, double* out);
 /* mean_and_var / marginals of the dense-H posterior ILMM at xs: reference src/ilmm.jl:108-129,142-145 applied to the
  * PosteriorGP latent of src/ilmm.jl:196-197.  Outputs length ns*p, by-outputs; sigma2 included. */
 int lmm_ilmm_post_mean_and_var(const lmm_post_t* post, double sigma2, const double* xs, int d, int ns,

@@ -1187,6 +1187,105 @@ int lmm_ilmm_post_mean_and_var(const lmm_post_t* post, double sigma2, const doub
   LMM_CATCH
 }
 
+// Dense-H posterior: latent joint covariance at xs as a factor matrix,  blockdiag(K_l(xs,xs)) + SigAdd (x) I_ns - R R'
+// with R = Kxs' L^-T, optional rider row, then its Cholesky.  Caller holds g_mu.
+static void dense_post_cov_factor(const lmm_post* P, const double* xsd, int d, int ns, const double* sigadd_dev,
+                                  const double* rider, const Dims& Ds, double* A, double* WA, double* R, int ldr, int* info,
+                                  hipStream_t st) {
+  const int m = P->m;
+  DenseArgs a{};
+  a.A = A; a.ld = Ds.ld; a.nrows = Ds.NR; a.ncols = Ds.NC; a.x = xsd; a.d = d; a.n = ns; a.m = m;
+  a.lat = P->latd.p; a.sigmaT = sigadd_dev; a.rider = rider; a.rider_ld = m * ns; a.nrider = rider ? 1 : 0;
+  launch_dense_assemble(a, st);
+  launch_dense_cross(R, ldr, Ds.NC, P->NC, xsd, ns, P->x.p, P->n, d, m, P->latd.p, st);
+  trsm_rec(R, ldr, Ds.NC, P->L[0].p, P->ld, P->W[0].p, 0, P->NC, st);
+  launch_gemm_nt(A, Ds.ld, R, ldr, R, ldr, Ds.NC, Ds.NC, P->NC, 1, false, st);
+  potrf_rec(A, Ds.ld, Ds.NR, 0, Ds.NC, WA, m * ns, info, st);
+}
+
+// logpdf(pi(xs, sigma2), ys) on the dense-H posterior ILMM (reference test/ilmm.jl:25; src/ilmm.jl:150-163 with the
+// PosteriorGP latent of :196-197): project ys, one (m ns) x (m ns) factorisation of latent posterior cov + SigmaT (x) I.
+int lmm_ilmm_post_logpdf(const lmm_post_t* post, double sigma2, const double* xs, int d, int ns, const double* ys,
+                         const lmm_jitters_t* jit, double* out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  REQUIRE_INIT();
+  LMM_TRY
+  if (!post || !xs || !ys || !out || d <= 0 || ns <= 0) return fail(LMM_ERR_ARG, "bad arguments");
+  const lmm_post* P = post;
+  if (P->kind != 1) return fail(LMM_ERR_ARG, "not a dense-H ILMM posterior");
+  if (P->d != d) return fail(LMM_ERR_DIM, "input dimension mismatch");
+  if (!jit) jit = &kDefaultJit;
+  hipStream_t st0 = g.streams[0];
+  const int m = P->m, p = P->p, n = P->n, Ns = m * ns;
+  std::vector<double> T, ST;
+  double logdetST = 0.0;
+  if (int rc = project_dense(P->H.data(), p, m, sigma2, jit->project_jitter, T, ST, &logdetST)) return rc;
+  DevIn xsd(xs, (size_t)d * ns, st0), ysd(ys, (size_t)ns * p, st0);
+  Uploaded Td(T, st0), STd(ST, st0), Hd(P->H, st0);
+  Buf<double> Ty((size_t)ns * m), ml((size_t)ns * m), delta((size_t)ns * m), partial(tall_skinny_partials(ns, p)), resid_dev(1);
+  project_on_device(ysd.p, ns, p, Td.buf, m, 0, m, nullptr, Ty.p, st0);
+  residual_on_device(ysd.p, ns, p, Ty.p, m, Hd.buf, partial.p, resid_dev.p, st0);
+  for (int l = 0; l < m; ++l)
+    launch_post_mean(xsd.p, ns, P->x.p, n, d, P->alpha[0].p + (size_t)l * n, to_dev(P->gps[l]), ml.p + (size_t)l * ns, st0);
+  launch_vec_lin(Ty.p, ml.p, -1.0, Ns, delta.p, st0);
+  Dims Ds(Ns, 1);
+  int ldr = Ds.NC; if ((ldr % 512) == 0) ldr += 16;
+  Buf<double> A(Ds.elems()), WA((size_t)(Ds.NC / 64) * 4096), R((size_t)ldr * P->NC), lml_dev(1);
+  Buf<int> info(1);
+  HIPCHK(hipMemsetAsync(info.p, 0, sizeof(int), st0));
+  dense_post_cov_factor(P, xsd.p, d, ns, STd.buf.p, delta.p, Ds, A.p, WA.p, R.p, ldr, info.p, st0);
+  launch_lml_reduce(A.p, Ds.ld, Ns, Ds.NC, 1, lml_dev.p, st0);
+  double lml = 0.0, resid = 0.0;
+  int hinfo = 0;
+  HIPCHK(hipMemcpyAsync(&lml, lml_dev.p, sizeof(double), hipMemcpyDeviceToHost, st0));
+  HIPCHK(hipMemcpyAsync(&resid, resid_dev.p, sizeof(double), hipMemcpyDeviceToHost, st0));
+  HIPCHK(hipMemcpyAsync(&hinfo, info.p, sizeof(int), hipMemcpyDeviceToHost, st0));
+  HIPCHK(hipStreamSynchronize(st0));
+  if (int rc = check_info(std::vector<int>{hinfo}, 0)) return rc;
+  *out = lml - ((double)ns * ((double)(p - m) * kLog2Pi + ((double)p * std::log(sigma2) - logdetST)) + resid / sigma2) / 2.0;
+  return LMM_OK;
+  LMM_CATCH
+}
+
+// rand(rng, pi(xs, sigma2)) on the dense-H posterior ILMM (reference src/ilmm.jl:78-87 with the PosteriorGP latent): the
+// latent joint sample mean + chol(Cov + 1e-12 I).U' z  (z: m*ns normals), mixed by H, plus sqrt(sigma2) eps.
+int lmm_ilmm_post_rand(const lmm_post_t* post, double sigma2, int add_noise, const double* xs, int d, int ns,
+                       const double* z_lat, const double* eps, const lmm_jitters_t* jit, double* out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  REQUIRE_INIT();
+  LMM_TRY
+  if (!post || !xs || !z_lat || !out || d <= 0 || ns <= 0 || (add_noise && !eps)) return fail(LMM_ERR_ARG, "bad arguments");
+  const lmm_post* P = post;
+  if (P->kind != 1) return fail(LMM_ERR_ARG, "not a dense-H ILMM posterior");
+  if (P->d != d) return fail(LMM_ERR_DIM, "input dimension mismatch");
+  if (!jit) jit = &kDefaultJit;
+  hipStream_t st0 = g.streams[0];
+  const int m = P->m, p = P->p, n = P->n, Ns = m * ns;
+  std::vector<double> J((size_t)m * m, 0.0);
+  for (int l = 0; l < m; ++l) J[l + (size_t)l * m] = jit->ilmm_rand_jitter;
+  DevIn xsd(xs, (size_t)d * ns, st0), zd(z_lat, (size_t)Ns, st0), epsd(add_noise ? eps : nullptr, (size_t)ns * p, st0);
+  Uploaded Jd(J, st0), Hd(P->H, st0);
+  Buf<double> ml((size_t)Ns), X((size_t)Ns);
+  for (int l = 0; l < m; ++l)
+    launch_post_mean(xsd.p, ns, P->x.p, n, d, P->alpha[0].p + (size_t)l * n, to_dev(P->gps[l]), ml.p + (size_t)l * ns, st0);
+  Dims Ds(Ns, 0);
+  int ldr = Ds.NC; if ((ldr % 512) == 0) ldr += 16;
+  Buf<double> A(Ds.elems()), WA((size_t)(Ds.NC / 64) * 4096), R((size_t)ldr * P->NC), part((size_t)Ns * trmv_chunks(Ns));
+  Buf<int> info(1);
+  HIPCHK(hipMemsetAsync(info.p, 0, sizeof(int), st0));
+  dense_post_cov_factor(P, xsd.p, d, ns, Jd.buf.p, nullptr, Ds, A.p, WA.p, R.p, ldr, info.p, st0);
+  launch_trmv_lower(A.p, Ds.ld, Ns, zd.p, 0.0, part.p, X.p, st0);
+  launch_vec_lin(X.p, ml.p, 1.0, Ns, X.p, st0);
+  DevOut od(out, (size_t)ns * p);
+  launch_mix(X.p, ns, m, Hd.buf.p, p, 1, 0.0, 0.0, add_noise ? epsd.p : nullptr, std::sqrt(sigma2), od.p, st0);
+  od.finish(st0);
+  int hinfo = 0;
+  HIPCHK(hipMemcpyAsync(&hinfo, info.p, sizeof(int), hipMemcpyDeviceToHost, st0));
+  HIPCHK(hipStreamSynchronize(st0));
+  return check_info(std::vector<int>{hinfo}, 0);
+  LMM_CATCH
+}
+
 int lmm_post_destroy(lmm_post_t* post) {
   std::lock_guard<std::mutex> lk(g_mu);
   if (post) {

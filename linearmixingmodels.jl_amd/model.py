@@ -306,8 +306,9 @@ def logpdf(fx: FiniteGP, y, with_regulariser: bool = True) -> float:
     Ua, Sa, p, m = _H_args(f.H)
     l0, l1 = f.shard
     if f.f._post is not None:
-        if not f.is_oilmm:
-            raise NotImplementedError("logpdf on a dense-H posterior ILMM (SURVEY 8a row A11/A13)")
+        if not f.is_oilmm:         # dense-H posterior: reference test/ilmm.jl:25
+            L.check(lib.lmm_ilmm_post_logpdf(f.f._post.ptr, C.c_double(s2), xa.ptr, x.dim, x.n, ya.ptr, None, C.byref(out)))
+            return out.value
         return _post_logpdf(f.f._post, descs, f.H.U, f.H.S, x, s2, ya, with_regulariser)
     if f.is_oilmm:
         L.check(lib.lmm_oilmm_logpdf(xa.ptr, x.dim, x.n, ya.ptr, p, Ua.ptr, Sa.ptr, m, C.c_double(s2), gps, l0, l1,
@@ -553,6 +554,10 @@ def rand(rng, fx: FiniteGP, N: Optional[int] = None, jitters=None, add_noise: bo
     z = rng.standard_normal(m * n)
     eps = rng.standard_normal(n * p)
     out = np.empty(n * p)
+    if not f.is_oilmm and f.f._post is not None:      # dense-H posterior: coupled latents, reference src/ilmm.jl:78-87
+        L.check(lib.lmm_ilmm_post_rand(f.f._post.ptr, C.c_double(s2), int(add_noise), xa.ptr, x.dim, n, L.Arr(z).ptr,
+                                       L.Arr(eps).ptr, L.jitters(jitters), L.Arr(out, True).ptr))
+        return out
     gps = L.gps_array([g.desc() for g in f.f.fs])
     post = f.f._post.ptr if f.f._post is not None else None
     l0, l1 = f.shard

@@ -201,6 +201,11 @@ def test_ilmm_dense_toy_shapes(lmm, m):
     mo, vo = O.ilmm_mean_var(O.ilmm_posterior(gps, H, xtr, 1e-6, ytr), H, xte, 1e-6)
     np.testing.assert_allclose(mu, mo, rtol=1e-5, atol=1e-6); np.testing.assert_allclose(v, vo, rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(mu, mn, rtol=1e-5, atol=1e-6); np.testing.assert_allclose(v, np.diag(Cn) + 1e-6, rtol=1e-5, atol=1e-7)
+    # logpdf(pi, y_test) (test/ilmm.jl:25) and rand(rng, pi) (test/ilmm.jl:27) on the dense-H posterior
+    yte = rng.standard_normal(6)
+    pix = post(lmm.MOInputIsotopicByOutputs(xte, 3), 1e-6)
+    assert lmm.logpdf(pix, yte) == pytest.approx(O.ilmm_logpdf(O.ilmm_posterior(gps, H, xtr, 1e-6, ytr), H, xte, 1e-6, yte), rel=1e-5)
+    assert len(lmm.rand(np.random.default_rng(0), pix, jitters=(1e-9, 1e-9, 1e-9))) == 3 * 2
 
 
 @pytest.mark.parametrize("m", [3, 2])
@@ -330,6 +335,17 @@ def test_ilmm_dense_mid(lmm):
     mu, v = lmm.mean_and_var(lmm.posterior(fx, P["y"])(lmm.MOInputIsotopicByOutputs(xs, 5), 0.1))
     mo, vo = O.ilmm_mean_var(O.ilmm_posterior(P["gps"], P["H"], P["x"], 0.1, P["y"]), P["H"], xs, 0.1)
     np.testing.assert_allclose(mu, mo, rtol=1e-7, atol=1e-9); np.testing.assert_allclose(v, vo, rtol=1e-7)
+    # logpdf and a sample of the dense-H posterior at the new points (coupled (m ns) x (m ns) latent covariance)
+    ys = np.random.default_rng(8).standard_normal(40 * 5)
+    po = O.ilmm_posterior(P["gps"], P["H"], P["x"], 0.1, P["y"])
+    pix = lmm.posterior(fx, P["y"])(lmm.MOInputIsotopicByOutputs(xs, 5), 0.1)
+    assert lmm.logpdf(pix, ys) == pytest.approx(O.ilmm_logpdf(po, P["H"], xs, 0.1, ys), rel=1e-8)
+    s = lmm.rand(np.random.default_rng(21), pix, jitters=(1e-9, 1e-8, 1e-8))
+    g2 = np.random.default_rng(21); z = g2.standard_normal(3 * 40); eps = g2.standard_normal(40 * 5)
+    mlat, Clat = O._ilmm_latent_joint(po, xs)
+    lat = mlat + np.linalg.cholesky(Clat + 1e-8 * np.eye(120)) @ z
+    ref = (P["H"] @ lat.reshape(3, 40)).reshape(-1) + math.sqrt(0.1) * eps
+    np.testing.assert_allclose(s, ref, rtol=1e-6, atol=1e-7)
 
 
 def test_ilmm_identical_kernels_decoupled_equals_dense(lmm):
