@@ -627,13 +627,14 @@ int lmm_oilmm_logpdf(const double* x, int d, int n, const double* y, int p, cons
   double resid = 0.0;
   Buf<double> resid_dev(1);
   if (C > 0) project_on_device(yd.p, n, p, Td.buf, m, c0, C, nullptr, Ty.p, st0);
+  Uploaded Hd;                 // function scope: the residual kernels run asynchronously until latent_lmls' final sync
+  Buf<double> partial;
   if (with_regulariser) {
-    Uploaded Hd(H, st0);
-    Buf<double> partial(tall_skinny_partials(n, p));
+    Hd = Uploaded(H, st0);
+    partial = Buf<double>(tall_skinny_partials(n, p));
     // reference src/oilmm.jl:112: sum(abs2, (I - U U') Y)  ==  |Y - H T Y|_F^2 since H T = U U'
     residual_on_device(yd.p, n, p, Ty.p, m, Hd.buf, partial.p, resid_dev.p, st0);
-    HIPCHK(hipMemcpyAsync(&resid, resid_dev.p, sizeof(double), hipMemcpyDeviceToHost, st0));
-    HIPCHK(hipStreamSynchronize(st0));
+    HIPCHK(hipMemcpyAsync(&resid, resid_dev.p, sizeof(double), hipMemcpyDeviceToHost, st0));   // read after latent_lmls' sync
   }
   // delta_l = (T y)_l - mean_l
   Buf<double> delta((size_t)n * std::max(ms, 1));

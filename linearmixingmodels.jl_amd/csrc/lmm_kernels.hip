@@ -733,14 +733,19 @@ __global__ __launch_bounds__(256) void tall_skinny_kernel(const double* __restri
                                                           const double* __restrict__ sub,
                                                           const double* __restrict__ Ref, int ldr,
                                                           double* __restrict__ partial, int mode) {
+  // 64 rows per workgroup; the 4 waves split the K loop (k = wave, wave + 4, ...) and combine through LDS, so that
+  // short-and-wide problems (n of a few hundred, K = p of several hundred) still expose enough parallelism.
+  __shared__ double red[3][CH][64];
   __shared__ double sh[4];
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, ks = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
   const int c0 = blockIdx.y * CH;
   double acc[CH];
 #pragma unroll
   for (int c = 0; c < CH; ++c) acc[c] = 0.0;
   if (i < n) {
-    for (int k = 0; k < K; ++k) {
+#pragma unroll 4
+    for (int k = ks; k < K; k += 4) {
       const double v = In[(size_t)k * ldi + i];
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
@@ -749,22 +754,23 @@ __global__ __launch_bounds__(256) void tall_skinny_kernel(const double* __restri
       }
     }
   }
-  if (mode == 0) {
-    if (i < n) {
+  if (ks > 0) {
 #pragma unroll
-      for (int c = 0; c < CH; ++c)
-        if (c0 + c < C) Out[(size_t)(c0 + c) * ldo + i] = acc[c] - (sub ? sub[c0 + c] : 0.0);
-    }
-  } else {
-    double s = 0.0;
-    if (i < n) {
+    for (int c = 0; c < CH; ++c) red[ks - 1][c][lane] = acc[c];
+  }
+  __syncthreads();
+  double s = 0.0;
+  if (ks == 0 && i < n) {
 #pragma unroll
-      for (int c = 0; c < CH; ++c)
-        if (c0 + c < C) {
-          const double r = Ref[(size_t)(c0 + c) * ldr + i] - acc[c];
-          s = __builtin_fma(r, r, s);
-        }
+    for (int c = 0; c < CH; ++c) {
+      const double val = acc[c] + red[0][c][lane] + red[1][c][lane] + red[2][c][lane];
+      if (c0 + c < C) {
+        if (mode == 0) Out[(size_t)(c0 + c) * ldo + i] = val - (sub ? sub[c0 + c] : 0.0);
+        else { const double r = Ref[(size_t)(c0 + c) * ldr + i] - val; s = __builtin_fma(r, r, s); }
+      }
     }
+  }
+  if (mode != 0) {
     const double tot = block_sum_256(s, sh);
     if (threadIdx.x == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = tot;
   }
@@ -1132,12 +1138,12 @@ void launch_backsolve(const double* L, int ld, const double* W, int nblk, double
 
 void launch_tall_skinny(const double* In, int ldi, int n, int K, const double* Mx, int ldm, int C, double* Out, int ldo,
                         const double* sub, const double* Ref, int ldr, double* partial, int mode, hipStream_t st) {
-  dim3 grid((n + 255) / 256, (C + 15) / 16);
-  hipLaunchKernelGGL((tall_skinny_kernel<16>), grid, dim3(256), 0, st, In, ldi, n, K, Mx, ldm, C, Out, ldo, sub, Ref, ldr,
+  dim3 grid((n + 63) / 64, (C + 7) / 8);
+  hipLaunchKernelGGL((tall_skinny_kernel<8>), grid, dim3(256), 0, st, In, ldi, n, K, Mx, ldm, C, Out, ldo, sub, Ref, ldr,
                      partial, mode);
 }
 
-int tall_skinny_partials(int n, int C) { return ((n + 255) / 256) * ((C + 15) / 16); }
+int tall_skinny_partials(int n, int C) { return ((n + 63) / 64) * ((C + 7) / 8); }
 
 void launch_sum_partials(const double* partial, int count, double* out, hipStream_t st) {
   hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, partial, count, out);
