@@ -407,22 +407,33 @@ __global__ __launch_bounds__(256) void diag64_kernel(BatchPtr Ab, size_t offA, i
       }
       __syncthreads();
       const double dj = colb[b][j];
-      if (t == 0) {
-        dd[j] = dj;
-        if (!(dj > 0.0) && gcol0 + j < n_real) atomicCAS(info, 0, gcol0 + j + 1);
-      }
-      const double mult = (i > j) ? colb[b][i] / dj : 0.0;
+      const double ci = colb[b][i];
       const d2* rs = reinterpret_cast<const d2*>(&cmsk[b][16 * q]);
       const d2* rw = reinterpret_cast<const d2*>(&roww[b][16 * q]);
+      d2 ps[8], pw[8];
+#pragma unroll
+      for (int c2 = 0; c2 < 8; ++c2) { ps[c2] = rs[c2]; pw[c2] = rw[c2]; }     // issued before the reciprocal: overlaps it
+      if (t == 0) dd[j] = dj;
+      // 1/d_j by v_rcp_f64 + two Newton steps (<= 1-2 ulp; an IEEE division is ~3x the dependent latency on the
+      // pivot-to-pivot critical path); non-positive pivots are detected after the loop from dd[].
+      double rinv = __builtin_amdgcn_rcp(dj);
+      rinv = __builtin_fma(__builtin_fma(-dj, rinv, 1.0), rinv, rinv);
+      rinv = __builtin_fma(__builtin_fma(-dj, rinv, 1.0), rinv, rinv);
+      const double mult = (i > j) ? ci * rinv : 0.0;
 #pragma unroll
       for (int c2 = 0; c2 < 8; ++c2) {
-        const d2 ps = rs[c2], pw = rw[c2];
-        s[2 * c2] = __builtin_fma(-mult, ps.x, s[2 * c2]);
-        s[2 * c2 + 1] = __builtin_fma(-mult, ps.y, s[2 * c2 + 1]);
-        w[2 * c2] = __builtin_fma(-mult, pw.x, w[2 * c2]);
-        w[2 * c2 + 1] = __builtin_fma(-mult, pw.y, w[2 * c2 + 1]);
+        s[2 * c2] = __builtin_fma(-mult, ps[c2].x, s[2 * c2]);
+        s[2 * c2 + 1] = __builtin_fma(-mult, ps[c2].y, s[2 * c2 + 1]);
+        w[2 * c2] = __builtin_fma(-mult, pw[c2].x, w[2 * c2]);
+        w[2 * c2 + 1] = __builtin_fma(-mult, pw[c2].y, w[2 * c2 + 1]);
       }
     }
+  }
+  __syncthreads();
+  if (t < 64) {                                    // LAPACK-style info: first non-positive (or NaN) pivot, 1-based
+    const bool bad = !(dd[t] > 0.0) && (gcol0 + t < n_real);
+    const unsigned long long mask = __ballot(bad);
+    if (t == 0 && mask != 0ull) atomicCAS(info, 0, gcol0 + __builtin_ctzll(mask) + 1);
   }
   __syncthreads();
   const double rsi = 1.0 / sqrt(dd[i]);           // row scale of W = D^-1/2 L1^-1
