@@ -71,3 +71,23 @@ def sharded_mean_and_var(fx_shard: M.FiniteGP, local_fn: Optional[Callable] = No
     t = torch.stack([torch.as_tensor(mean, dtype=torch.float64), torch.as_tensor(var, dtype=torch.float64)]).to(dev)
     _all_reduce_sum(t)
     return t[0], t[1]
+
+
+def sharded_posterior(f: M.ILMM, x: M.MOInputIsotopicByOutputs, sigma2: float, y) -> M.ILMM:
+    """posterior(fx, y) with the latents sharded: each rank conditions ITS block of latents (no collective; the posterior
+    state stays sharded by latent and is never gathered -- SURVEY.md section 8e).  Returns this rank's shard model."""
+    rank, world = _world()
+    shard = latent_shard(len(f.f.fs), rank, world)
+    return M.posterior(M.ILMM(f.f, f.H, shard=shard)(x, sigma2), y)
+
+
+def sharded_rand(rng, fx_shard: M.FiniteGP, local_fn: Optional[Callable] = None, jitters=None):
+    """rand(rng, fx) with sharded latents: every rank draws the SAME normals (same seed; the reference's draw order: m blocks of
+    n latent normals, then n*p noise normals), mixes its own latents' samples through its columns of H, and ONE all-reduce of the
+    n*p partial sums finishes the sample; rank 0 alone adds the noise term (rand row)."""
+    import torch
+    rank, _ = _world()
+    fn = local_fn or (lambda fx, add_noise: M.rand(rng, fx, None, jitters, add_noise))
+    part = fn(fx_shard, rank == 0)
+    t = torch.as_tensor(part, dtype=torch.float64).to(_reduce_device())
+    return _all_reduce_sum(t)

@@ -53,8 +53,18 @@ def _worker(rank, world, port, q):
 
     fxs = lmm_amd.ILMM(fs, f.H, shard=shard)(lmm_amd.MOInputIsotopicByOutputs(xs, 7), 0.1)
     mean, var = lmm_amd.sharded_mean_and_var(fxs, local_fn=local_mv)
+    # rand: every rank draws the same normals; rank r mixes its latents; all-reduce; rank 0 adds the noise
+    n = len(P["x"])
+    def local_rand(fx, add_noise):
+        l0, l1 = fx.f.shard
+        g = np.random.default_rng(99); z = g.standard_normal(5 * n); eps = g.standard_normal(n * 7)
+        X = np.stack([O.gp_rand(P["gps"][l], P["x"], 1e-6, z[l * n:(l + 1) * n]) for l in range(l0, l1)])
+        part = (O.orthogonal_dense(P["U"], P["S"])[:, l0:l1] @ X).reshape(-1)
+        return part + (np.sqrt(fx.sigma2) * eps if add_noise else 0.0)
+    fxr = lmm_amd.ILMM(fs, f.H, shard=shard)(x, 0.1)
+    smp = lmm_amd.sharded_rand(None, fxr, local_fn=local_rand)
     if rank == 0:
-        q.put((total, mean.numpy(), var.numpy()))
+        q.put((total, mean.numpy(), var.numpy(), smp.numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -68,7 +78,7 @@ def test_sharded_logpdf_and_marginals_world2():
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     [p.start() for p in procs]
-    total, mean, var = q.get(timeout=150)
+    total, mean, var, smp = q.get(timeout=150)
     [p.join(30) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     P = O.synthetic_problem(5, 7, 40, "matern52", True, seed=1)
@@ -77,3 +87,6 @@ def test_sharded_logpdf_and_marginals_world2():
     mo, vo = O.oilmm_mean_var(post, P["U"], P["S"], P["x"][:9] + 0.02, 0.1)
     np.testing.assert_allclose(mean, mo, rtol=1e-12, atol=1e-13)
     np.testing.assert_allclose(var, vo, rtol=1e-12)
+    g = np.random.default_rng(99); z = g.standard_normal(5 * 40); eps = g.standard_normal(40 * 7)
+    X = np.stack([O.gp_rand(P["gps"][l], P["x"], 1e-6, z[l * 40:(l + 1) * 40]) for l in range(5)])
+    np.testing.assert_allclose(smp, (O.orthogonal_dense(P["U"], P["S"]) @ X).reshape(-1) + np.sqrt(0.1) * eps, rtol=1e-12, atol=1e-13)
