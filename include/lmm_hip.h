@@ -133,6 +133,11 @@ int lmm_oilmm_posterior_create(const double* x, int d, int n, const double* y, i
 /* posterior(ft::IsotropicByOutputsFiniteIndependentMOGP, y): reference src/independent_mogp.jl:119-126. */
 int lmm_mogp_posterior_create(const double* x, int d, int n, const double* y, int m, double sigma2,
                               const lmm_gp_t* gps, int latent_begin, int latent_end, lmm_post_t** out);
+/* posterior(po(x2, sigma2), y2): condition a posterior OILMM / IndependentMOGP (U = I, S = 1) on further observations
+ * (AbstractGPs.TestUtils exercises `posterior` on `po`: reference test/oilmm.jl:34-37, test/independent_mogp.jl:68-76).
+ * Returns a NEW handle (the old one stays valid). */
+int lmm_post_condition(const lmm_post_t* post, const double* U, const double* S, int p, int m, double sigma2,
+                       const double* x2, int d, int n2, const double* y2, lmm_post_t** out);
 /* posterior(fx::FiniteGP{<:ILMM}, y), dense H: reference src/ilmm.jl:184-198. */
 int lmm_ilmm_posterior_create(const double* x, int d, int n, const double* y, int p,
                               const double* H, int m, double sigma2, const lmm_gp_t* gps,

@@ -506,6 +506,8 @@ struct lmm_post {
   std::vector<Buf<double>> L; // per latent of the shard: factor matrix (NR x NC, ld)
   std::vector<Buf<double>> W; // inverse diagonal blocks
   std::vector<Buf<double>> alpha;
+  std::vector<Buf<double>> delta;     // per latent: projected residuals (T y)_l - mean_l   (kept for sequential conditioning)
+  std::vector<Buf<double>> noisev;    // per latent: per-point projected noise
   // dense ILMM (kind 1): L[0] is the (mn) x (mn) factor, alpha[0] the (mn) weights
   int p = 0;
   std::vector<double> H;        // p x m column-major (host)
@@ -998,8 +1000,10 @@ int lmm_ilmm_logpdf(const double* x, int d, int n, const double* y, int p, const
 // ------------------------------------------------------------------------------------------------
 // posterior
 // ------------------------------------------------------------------------------------------------
+// noise: per-latent scalar (host, indexed by latent) used when noisevec == NULL; noisevec: device [k][n] per-point noise.
 static int posterior_create_common(const double* xd, int d, int n, const lmm_gp_t* gps, int m, const double* noise,
-                                   int l0, int l1, const double* delta, lmm_post_t** out) {
+                                   int l0, int l1, const double* delta, lmm_post_t** out,
+                                   const double* noisevec = nullptr) {
   const int ms = l1 - l0;
   lmm_post* P = new lmm_post();
   try {
@@ -1017,6 +1021,11 @@ static int posterior_create_common(const double* xd, int d, int n, const lmm_gp_
       P->L.emplace_back((size_t)D.elems());
       P->W.emplace_back((size_t)(D.NC / 64) * 4096);
       P->alpha.emplace_back((size_t)D.NC);
+      P->delta.emplace_back((size_t)n);
+      P->noisev.emplace_back((size_t)n);
+      HIPCHK(hipMemcpyAsync(P->delta[k].p, delta + (size_t)k * n, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, g.streams[0]));
+      if (noisevec) HIPCHK(hipMemcpyAsync(P->noisev[k].p, noisevec + (size_t)k * n, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, g.streams[0]));
+      else launch_fill(P->noisev[k].p, n, noise[l0 + k], g.streams[0]);
     }
     fork_slots(nslots);
     int bi = 0;
@@ -1029,7 +1038,8 @@ static int posterior_create_common(const double* xd, int d, int n, const lmm_gp_
         const lmm_gp_t& gp = gps[l0 + k];
         GramArgs a{};
         a.A = P->L[k].p; a.ld = D.ld; a.nrows = D.NR; a.ncols = D.NC; a.x = P->x.p; a.d = d; a.n = n;
-        a.kind = gp.kind; a.var = gp.variance; a.inv_ls = 1.0 / gp.lengthscale; a.diag_add = noise[l0 + k]; a.pad_diag = 1.0;
+        a.kind = gp.kind; a.var = gp.variance; a.inv_ls = 1.0 / gp.lengthscale; a.pad_diag = 1.0;
+        a.diag_add = 0.0; a.diag_vec = P->noisev[k].p;
         a.rider = delta + (size_t)k * n; a.rider_ld = n; a.nrider = 1;
         launch_gram(a, st);
         B.add(P->L[k].p, P->W[k].p, info.p + k);
@@ -1075,6 +1085,45 @@ int lmm_oilmm_posterior_create(const double* x, int d, int n, const double* y, i
   Buf<double> delta((size_t)n * std::max(ms, 1));
   if (ms > 0) project_on_device(yd.p, n, p, Td.buf, m, latent_begin, ms, meansd.buf.p + latent_begin, delta.p, st0);
   return posterior_create_common(xd.p, d, n, gps, m, ST.data(), latent_begin, latent_end, delta.p, out);
+  LMM_CATCH
+}
+
+// posterior(po(x2, sigma2), y2) -- conditioning a posterior OILMM / IndependentMOGP on further observations (exercised by
+// AbstractGPs.TestUtils on `po` in reference test/oilmm.jl:34-37; AbstractGPs updates the Cholesky factor).  Latent by
+// latent the result is the posterior of the PRIOR given both data sets, each with its own projected noise, so the new state is
+// built from the concatenated inputs, the kept residuals and per-point noise.  U, S: the mixing matrix (U = I, S = 1 for a
+// bare IndependentMOGP, with p == m).
+int lmm_post_condition(const lmm_post_t* post, const double* U, const double* S, int p, int m, double sigma2,
+                       const double* x2, int d, int n2, const double* y2, lmm_post_t** out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  REQUIRE_INIT();
+  LMM_TRY
+  if (!post || !U || !S || !x2 || !y2 || !out || d <= 0 || n2 <= 0) return fail(LMM_ERR_ARG, "bad arguments");
+  const lmm_post* P = post;
+  if (P->kind != 0) return fail(LMM_ERR_UNSUPPORTED, "sequential conditioning of the dense-H posterior is not built");
+  if (P->m != m) return fail(LMM_ERR_DIM, "posterior has %d latents, H has %d", P->m, m);
+  if (P->d != d) return fail(LMM_ERR_DIM, "input dimension mismatch");
+  if (m > p) return fail(LMM_ERR_DIM, "out dim of x != out dim of f.");
+  hipStream_t st0 = g.streams[0];
+  const int l0 = P->l0, l1 = P->l1, ms = l1 - l0, n1 = P->n, n = n1 + n2;
+  std::vector<double> T, ST, H;
+  project_orthogonal(U, S, p, m, sigma2, T, ST, H);
+  DevIn x2d(x2, (size_t)d * n2, st0), y2d(y2, (size_t)n2 * p, st0);
+  Uploaded Td(T, st0);
+  std::vector<double> means(m);
+  for (int l = 0; l < m; ++l) means[l] = P->gps[l].mean;
+  Uploaded meansd(means, st0);
+  Buf<double> xall((size_t)d * n), delta((size_t)n * std::max(ms, 1)), nv((size_t)n * std::max(ms, 1)), d2buf((size_t)n2 * std::max(ms, 1));
+  HIPCHK(hipMemcpyAsync(xall.p, P->x.p, (size_t)d * n1 * sizeof(double), hipMemcpyDeviceToDevice, st0));
+  HIPCHK(hipMemcpyAsync(xall.p + (size_t)d * n1, x2d.p, (size_t)d * n2 * sizeof(double), hipMemcpyDeviceToDevice, st0));
+  if (ms > 0) project_on_device(y2d.p, n2, p, Td.buf, m, l0, ms, meansd.buf.p + l0, d2buf.p, st0);
+  for (int k = 0; k < ms; ++k) {
+    HIPCHK(hipMemcpyAsync(delta.p + (size_t)k * n, P->delta[k].p, (size_t)n1 * sizeof(double), hipMemcpyDeviceToDevice, st0));
+    HIPCHK(hipMemcpyAsync(delta.p + (size_t)k * n + n1, d2buf.p + (size_t)k * n2, (size_t)n2 * sizeof(double), hipMemcpyDeviceToDevice, st0));
+    HIPCHK(hipMemcpyAsync(nv.p + (size_t)k * n, P->noisev[k].p, (size_t)n1 * sizeof(double), hipMemcpyDeviceToDevice, st0));
+    launch_fill(nv.p + (size_t)k * n + n1, n2, ST[l0 + k], st0);
+  }
+  return posterior_create_common(xall.p, d, n, P->gps.data(), m, ST.data(), l0, l1, delta.p, out, nv.p);
   LMM_CATCH
 }
 

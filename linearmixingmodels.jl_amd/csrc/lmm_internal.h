@@ -21,6 +21,7 @@ struct GramArgs {
   int full;             // 1: no lower-triangle skip (rectangular rider matrix)
   const double* x; int d, n;
   int kind; double var, inv_ls, diag_add, pad_diag;
+  const double* diag_vec;                      // optional per-point diagonal term (length n), added to diag_add
   const double* rider; int rider_ld, nrider;   // rows ncols + r  <- rider[r*rider_ld + j]
   const double* xs; int ns;                    // rows ncols + r  <- kappa(xs_r, x_j)
 };
@@ -68,6 +69,7 @@ int grad_partials(int n);
 void launch_grad_reduce(const double* Kinv, int ld, int n, const double* alpha, const double* delta, const double* x, int d,
                         LatentDev g, double* partial, double* out5, hipStream_t st);
 void launch_atb(const double* X, int ldx, const double* Z, int ldz, int n, int na, int nb, double* out, hipStream_t st);
+void launch_fill(double* p, int n, double v, hipStream_t st);
 void launch_reorder(const double* in, int n, int p, int to_outputs, double* out, hipStream_t st);
 void launch_add_diag(double* A, int ld, int n, double v, hipStream_t st);
 void launch_vec_lin(const double* a, const double* b, double sb, int n, double* out, hipStream_t st);  // out = a + sb*b

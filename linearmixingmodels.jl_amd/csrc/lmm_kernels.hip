@@ -148,7 +148,7 @@ __device__ __forceinline__ void gram_tile_generic(const GramArgs& a, int ti, int
           if (a.d == 1) { r = fabs(rx[e] - xj) * a.inv_ls; r2 = r * r; }
           else { r2 = scaled_dist2(rpt[e], a.x + (size_t)j * a.d, a.d, a.inv_ls); r = sqrt(r2); }
           val = kappa(a.kind, a.var, r, r2);
-          if (rtype[e] == 0 && i0 + e == j) val += a.diag_add;
+          if (rtype[e] == 0 && i0 + e == j) val += a.diag_add + (a.diag_vec ? a.diag_vec[j] : 0.0);
         } else if (rtype[e] == 2) {
           val = rpt[e][j];
         }
@@ -250,8 +250,9 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs a) {
         }
         if (ti == tj) {
           const int j = tj * 64 + jl;
-          if (i0 == j) v.x += a.diag_add;
-          if (i0 + 1 == j) v.y += a.diag_add;
+          const double da = a.diag_add + (a.diag_vec ? a.diag_vec[j] : 0.0);     // per-point noise (sequential conditioning)
+          if (i0 == j) v.x += da;
+          if (i0 + 1 == j) v.y += da;
         }
         *reinterpret_cast<d2*>(out + (size_t)(8 * q) * a.ld) = v;
       }
@@ -266,8 +267,9 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs a) {
         v.y = kappa_t<KIND>(a.var, r1, r1 * r1);
         if (ti == tj) {
           const int j = tj * 64 + cg + 8 * q;
-          if (i0 == j) v.x += a.diag_add;
-          if (i0 + 1 == j) v.y += a.diag_add;
+          const double da = a.diag_add + (a.diag_vec ? a.diag_vec[j] : 0.0);
+          if (i0 == j) v.x += da;
+          if (i0 + 1 == j) v.y += da;
         }
         *reinterpret_cast<d2*>(out + (size_t)(8 * q) * a.ld) = v;
       }
@@ -1000,6 +1002,11 @@ __global__ __launch_bounds__(256) void atb_kernel(const double* __restrict__ X, 
   if (threadIdx.x == 0) out[a + (size_t)b * na] = tot;
 }
 
+__global__ void fill_kernel(double* __restrict__ p, int n, double v) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) p[k] = v;
+}
+
 // by-features <-> by-outputs reordering (an n x p transpose): reference src/independent_mogp.jl:135-159
 __global__ void reorder_kernel(const double* __restrict__ in, int n, int p, int to_outputs, double* __restrict__ out) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1203,6 +1210,10 @@ void launch_grad_reduce(const double* Kinv, int ld, int n, const double* alpha, 
 
 void launch_atb(const double* X, int ldx, const double* Z, int ldz, int n, int na, int nb, double* out, hipStream_t st) {
   hipLaunchKernelGGL(atb_kernel, dim3(na, nb), dim3(256), 0, st, X, ldx, Z, ldz, n, na, out);
+}
+
+void launch_fill(double* p, int n, double v, hipStream_t st) {
+  hipLaunchKernelGGL(fill_kernel, dim3((n + 255) / 256), dim3(256), 0, st, p, n, v);
 }
 
 void launch_reorder(const double* in, int n, int p, int to_outputs, double* out, hipStream_t st) {

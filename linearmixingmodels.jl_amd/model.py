@@ -394,18 +394,25 @@ def posterior(fx: FiniteGP, y):
     xa, ya = x.carr(), L.Arr(y)
     handle = C.c_void_p()
     if isinstance(f, IndependentMOGP):
-        if f._post is not None:
-            raise NotImplementedError("sequential conditioning (SURVEY.md 8f next #4)")
-        gps = L.gps_array([g.desc() for g in f.fs])
         m = len(f.fs)
+        if f._post is not None:        # sequential conditioning: posterior(po(x2, s2), y2)
+            Ui, Si = L.Arr(L.colmajor(np.eye(m))), L.Arr(np.ones(m))
+            L.check(lib.lmm_post_condition(f._post.ptr, Ui.ptr, Si.ptr, m, m, C.c_double(s2), xa.ptr, x.dim, x.n, ya.ptr,
+                                           C.byref(handle)))
+            return IndependentMOGP(f.fs, _PostHandle(handle, 0, m))
+        gps = L.gps_array([g.desc() for g in f.fs])
         L.check(lib.lmm_mogp_posterior_create(xa.ptr, x.dim, x.n, ya.ptr, m, C.c_double(s2), gps, 0, m, C.byref(handle)))
         return IndependentMOGP(f.fs, _PostHandle(handle, 0, m))
     unpack(fx)
-    if f.f._post is not None:
-        raise NotImplementedError("sequential conditioning (SURVEY.md 8f next #4)")
-    gps = L.gps_array([g.desc() for g in f.f.fs])
     Ua, Sa, p, m = _H_args(f.H)
     l0, l1 = f.shard
+    if f.f._post is not None:          # sequential conditioning of a posterior OILMM (same H: reference src/oilmm.jl:133)
+        if not f.is_oilmm:
+            raise NotImplementedError("sequential conditioning of the dense-H posterior")
+        L.check(lib.lmm_post_condition(f.f._post.ptr, Ua.ptr, Sa.ptr, p, m, C.c_double(s2), xa.ptr, x.dim, x.n, ya.ptr,
+                                       C.byref(handle)))
+        return ILMM(IndependentMOGP(f.f.fs, _PostHandle(handle, l0, l1)), f.H, shard=f.shard)
+    gps = L.gps_array([g.desc() for g in f.f.fs])
     if f.is_oilmm:
         L.check(lib.lmm_oilmm_posterior_create(xa.ptr, x.dim, x.n, ya.ptr, p, Ua.ptr, Sa.ptr, m, C.c_double(s2), gps, l0,
                                                l1, C.byref(handle)))

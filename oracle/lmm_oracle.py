@@ -143,14 +143,24 @@ def gp_logpdf(gp: Dict, x: np.ndarray, noise: float, y: np.ndarray) -> float:
 
 
 def gp_posterior(gp: Dict, x: np.ndarray, noise: float, y: np.ndarray) -> Dict:
-    """AbstractGPs generic posterior(fx, y) on a *prior* GP: delta = y - m; alpha = C \\ delta."""
-    if gp.get("post") is not None:
-        raise NotImplementedError("sequential conditioning is SURVEY 8f 'next' #4")
-    m, K = gp_mean_cov(gp, x)
-    L = np.linalg.cholesky(K + noise * np.eye(len(m)))
-    alpha = sla.cho_solve((L, True), y - m)
-    out = dict(gp)
-    out["post"] = {"x": np.asarray(x, dtype=np.float64), "alpha": alpha, "L": L}
+    """AbstractGPs generic posterior(fx, y): delta = y - m; alpha = C \\ delta.  On a PosteriorGP (sequential
+    conditioning; AbstractGPs updates the Cholesky factor) the result is the posterior of the PRIOR given both data sets,
+    each with its own noise -- restated here by conditioning the prior on the concatenation."""
+    prior = {k: v for k, v in gp.items() if k != "post"}
+    xa = _as_cols(x)
+    delta = np.asarray(y, dtype=np.float64) - float(prior.get("mean", 0.0))
+    nz = np.full(xa.shape[1], float(noise))
+    old = gp.get("post")
+    if old is not None:
+        xa = np.concatenate([_as_cols(old["x"]), xa], axis=1)
+        delta = np.concatenate([old["delta"], delta])
+        nz = np.concatenate([old["noise"], nz])
+    xall = xa[0] if np.asarray(x).ndim == 1 else xa
+    K = kernelmatrix(prior, xall)
+    L = np.linalg.cholesky(K + np.diag(nz))
+    alpha = sla.cho_solve((L, True), delta)
+    out = dict(prior)
+    out["post"] = {"x": xall, "alpha": alpha, "L": L, "delta": delta, "noise": nz}
     return out
 
 

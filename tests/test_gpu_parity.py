@@ -497,6 +497,38 @@ def test_deterministic_mode_is_bitwise_reproducible():
     assert float(outs[0]) == pytest.approx(O.oilmm_logpdf(P["gps"], P["U"], P["S"], P["x"], 0.1, P["y"]), rel=1e-9)
 
 
+def test_sequential_conditioning(lmm):
+    """posterior(po(x2, s2), y2) (AbstractGPs.TestUtils exercises `posterior` on `po`: reference test/oilmm.jl:34-37): the
+    posterior of the posterior equals conditioning the prior on both data sets with their own noise levels."""
+    rng = np.random.default_rng(31)
+    n1, n2, p, m = 70, 45, 4, 3
+    x1, x2 = np.sort(rng.uniform(0, 8, n1)), np.sort(rng.uniform(0, 8, n2))
+    gps = _gps(["matern52", "se", "matern32"], rng)
+    U, S = _orth(rng, p, m)
+    y1, y2 = rng.standard_normal(n1 * p), rng.standard_normal(n2 * p)
+    f = lmm.ILMM(_to_model(lmm, gps), lmm.Orthogonal(U, S))
+    po = lmm.posterior(f(lmm.MOInputIsotopicByOutputs(x1, p), 0.1), y1)
+    po2 = lmm.posterior(po(lmm.MOInputIsotopicByOutputs(x2, p), 0.3), y2)        # different noise for the second batch
+    ro = O.oilmm_posterior(O.oilmm_posterior(gps, U, S, x1, 0.1, y1), U, S, x2, 0.3, y2)
+    xs = np.linspace(0, 8, 37)
+    mu, v = lmm.mean_and_var(po2(lmm.MOInputIsotopicByOutputs(xs, p), 0.2))
+    mo, vo = O.oilmm_mean_var(ro, U, S, xs, 0.2)
+    np.testing.assert_allclose(mu, mo, rtol=1e-8, atol=1e-10); np.testing.assert_allclose(v, vo, rtol=1e-8)
+    ys = rng.standard_normal(37 * p)
+    assert lmm.logpdf(po2(lmm.MOInputIsotopicByOutputs(xs, p), 0.2), ys) == pytest.approx(O.oilmm_logpdf(ro, U, S, xs, 0.2, ys), rel=1e-8)
+    # the first posterior is untouched
+    mu1, _ = lmm.mean_and_var(po(lmm.MOInputIsotopicByOutputs(xs, p), 0.2))
+    np.testing.assert_allclose(mu1, O.oilmm_mean_var(O.oilmm_posterior(gps, U, S, x1, 0.1, y1), U, S, xs, 0.2)[0], rtol=1e-8, atol=1e-10)
+    # IndependentMOGP
+    fm = _to_model(lmm, gps)
+    ym1, ym2 = rng.standard_normal(n1 * m), rng.standard_normal(n2 * m)
+    pm2 = lmm.posterior(lmm.posterior(fm(lmm.MOInputIsotopicByOutputs(x1, m), 0.1), ym1)(lmm.MOInputIsotopicByOutputs(x2, m), 0.1), ym2)
+    mu, v = lmm.mean_and_var(pm2(lmm.MOInputIsotopicByOutputs(xs, m), 0.1))
+    rm = O.mogp_posterior(O.mogp_posterior(gps, x1, 0.1, ym1), x2, 0.1, ym2)
+    mo, vo = O.mogp_mean_var(rm, xs)
+    np.testing.assert_allclose(mu, mo, rtol=1e-8, atol=1e-10); np.testing.assert_allclose(v, vo + 0.1, rtol=1e-8)
+
+
 def test_rand_matches_oracle_given_normals(lmm):
     """Same standard normals in the reference's draw order => same sample (reference src/oilmm.jl:40-54)."""
     rng = np.random.default_rng(11)
