@@ -331,20 +331,32 @@ def logpdf_and_gradient(fx: FiniteGP, y, with_regulariser: bool = True) -> dict:
     L.ensure_init()
     lib = L.load()
     f, x, s2 = fx.f, fx.x, fx.sigma2
-    if not isinstance(f, ILMM) or not f.is_oilmm or f.f._post is not None:
-        raise NotImplementedError("gradients are built for the prior OILMM logpdf")
-    unpack(fx)
-    Ua, Sa, p, m = _H_args(f.H)
-    descs = [g.desc() for g in f.f.fs]
+    mogp = isinstance(f, IndependentMOGP)
+    if mogp:                      # gradient(logpdf, fx, y) on an IndependentMOGP (reference test/independent_mogp.jl:65-66):
+        if f._post is not None:   # the OILMM with U = I, S = 1 (regulariser identically 0, so it is skipped)
+            raise NotImplementedError("gradients are built for prior models")
+        m = p = len(f.fs)
+        if x.out_dim != m:
+            raise RuntimeError("out dim of x != out dim of f.")
+        Ua, Sa, descs, shard, with_regulariser = L.Arr(L.colmajor(np.eye(m))), L.Arr(np.ones(m)), [g.desc() for g in f.fs], (0, m), False
+    else:
+        if not isinstance(f, ILMM) or not f.is_oilmm or f.f._post is not None:
+            raise NotImplementedError("gradients are built for the prior OILMM / IndependentMOGP logpdf")
+        unpack(fx)
+        Ua, Sa, p, m = _H_args(f.H)
+        descs, shard = [g.desc() for g in f.f.fs], f.shard
     n = x.n
     val, gs2 = C.c_double(), C.c_double()
     gy, gS, gU = _alloc_like(y if L._is_torch(y) else x.x, n * p), np.empty(m), np.empty(p * m)
     gg = (L.GpGradT * m)()
     L.check(lib.lmm_oilmm_logpdf_grad(x.carr().ptr, x.dim, n, L.Arr(y).ptr, p, Ua.ptr, Sa.ptr, m, C.c_double(s2),
-                                      L.gps_array(descs), f.shard[0], f.shard[1], int(with_regulariser), C.byref(val),
+                                      L.gps_array(descs), shard[0], shard[1], int(with_regulariser), C.byref(val),
                                       L.Arr(gy, True).ptr, C.byref(gs2), L.Arr(gS, True).ptr, L.Arr(gU, True).ptr, gg))
-    return {"value": val.value, "y": gy, "sigma2": gs2.value, "S": gS, "U": gU.reshape(m, p).T.copy(),
-            "gps": [{"variance": gg[l].variance, "lengthscale": gg[l].lengthscale, "mean": gg[l].mean} for l in range(m)]}
+    out = {"value": val.value, "y": gy, "sigma2": gs2.value,
+           "gps": [{"variance": gg[l].variance, "lengthscale": gg[l].lengthscale, "mean": gg[l].mean} for l in range(m)]}
+    if not mogp:
+        out["S"], out["U"] = gS, gU.reshape(m, p).T.copy()
+    return out
 
 
 def _logpdf_matrix(fx: FiniteGP, Y, with_regulariser: bool = True) -> np.ndarray:

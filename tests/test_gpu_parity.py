@@ -529,6 +529,30 @@ def test_sequential_conditioning(lmm):
     np.testing.assert_allclose(mu, mo, rtol=1e-8, atol=1e-10); np.testing.assert_allclose(v, vo + 0.1, rtol=1e-8)
 
 
+def test_mogp_gradient(lmm):
+    """gradient(logpdf, fx, y_train) on an IndependentMOGP (reference test/independent_mogp.jl:65-66) vs central finite
+    differences of the oracle."""
+    rng = np.random.default_rng(55)
+    n, m = 60, 2
+    x = np.sort(rng.uniform(0, 5, n))
+    gps = [{"kind": "matern32", "variance": 1.1, "lengthscale": 0.9, "mean": 2.0}, {"kind": "se", "variance": 0.8, "lengthscale": 1.3, "mean": -1.0}]
+    y = rng.standard_normal(n * m) + np.repeat([2.0, -1.0], n)
+    G = lmm.logpdf_and_gradient(_to_model(lmm, gps)(lmm.MOInputIsotopicByOutputs(x, m), 0.2), y)
+    assert G["value"] == pytest.approx(O.mogp_logpdf(gps, x, 0.2, y), rel=1e-11)
+    h = 1e-6
+    fd = lambda fun: (fun(h) - fun(-h)) / (2 * h)
+    assert G["sigma2"] == pytest.approx(fd(lambda t: O.mogp_logpdf(gps, x, 0.2 + t, y)), rel=1e-6)
+    for k in (0, 59, 100):
+        e = np.zeros(n * m); e[k] = 1.0
+        assert G["y"][k] == pytest.approx(fd(lambda t: O.mogp_logpdf(gps, x, 0.2, y + t * e)), rel=1e-6, abs=1e-7)
+    for l in range(m):
+        for key in ("variance", "lengthscale", "mean"):
+            def f(t, l=l, key=key):
+                g2 = [dict(g) for g in gps]; g2[l][key] += t
+                return O.mogp_logpdf(g2, x, 0.2, y)
+            assert G["gps"][l][key] == pytest.approx(fd(f), rel=1e-5, abs=1e-7)
+
+
 def test_rand_matches_oracle_given_normals(lmm):
     """Same standard normals in the reference's draw order => same sample (reference src/oilmm.jl:40-54)."""
     rng = np.random.default_rng(11)
