@@ -71,6 +71,5 @@ void launch_grad_reduce(const double* Kinv, int ld, int n, const double* alpha, 
 void launch_atb(const double* X, int ldx, const double* Z, int ldz, int n, int na, int nb, double* out, hipStream_t st);
 void launch_fill(double* p, int n, double v, hipStream_t st);
 void launch_reorder(const double* in, int n, int p, int to_outputs, double* out, hipStream_t st);
-void launch_add_diag(double* A, int ld, int n, double v, hipStream_t st);
 void launch_vec_lin(const double* a, const double* b, double sb, int n, double* out, hipStream_t st);  // out = a + sb*b
 void launch_mfma_peak(double* out, int blocks, int iters, hipStream_t st);

@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void ilmm_dense_assemble_kernel(DenseArgs a) {
 
 // Dense-ILMM cross-covariance riders: row (l, s) of R (m*ns rows) is K_l(xs_s, x) placed in the column block of
 // latent l (reference src/independent_mogp.jl:66-71: block-diagonal cov(f, x, y)); zero elsewhere and in the pad.
-__global__ __launch_bounds__(256) void dense_cross_kernel(double* __restrict__ R, int ldr, int nrows, int ncols,
+__global__ __launch_bounds__(256) void dense_cross_kernel(double* __restrict__ R, int ldr, int nrows, int /*ncols*/,
                                                           const double* __restrict__ xs, int ns,
                                                           const double* __restrict__ x, int n, int d, int m,
                                                           const LatentDev* __restrict__ lat) {
@@ -893,7 +893,7 @@ __global__ __launch_bounds__(256) void trmv_lower_kernel(const double* __restric
   double acc = 0.0;
   for (int kb = k0; kb < k1 && kb <= rowmax; kb += 256) {
     __syncthreads();
-    zs[threadIdx.x] = (kb + threadIdx.x < k1) ? zv[kb + threadIdx.x] : 0.0;
+    zs[threadIdx.x] = (kb + (int)threadIdx.x < k1) ? zv[kb + threadIdx.x] : 0.0;
     __syncthreads();
     const int lim = (k1 - kb < 256) ? (k1 - kb) : 256;
     if (i < n) {
@@ -1013,12 +1013,6 @@ __global__ void reorder_kernel(const double* __restrict__ in, int n, int p, int 
   if (k >= n * p) return;
   if (to_outputs) { const int o = k / n, i = k - o * n; out[k] = in[(size_t)i * p + o]; }
   else { const int i = k / p, o = k - i * p; out[k] = in[(size_t)o * n + i]; }
-}
-
-// Add a constant to the first n diagonal entries (noise / jitter on a Schur complement).
-__global__ void add_diag_kernel(double* A, int ld, int n, double v) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < n) A[(size_t)k * ld + k] += v;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1218,10 +1212,6 @@ void launch_fill(double* p, int n, double v, hipStream_t st) {
 
 void launch_reorder(const double* in, int n, int p, int to_outputs, double* out, hipStream_t st) {
   hipLaunchKernelGGL(reorder_kernel, dim3((n * p + 255) / 256), dim3(256), 0, st, in, n, p, to_outputs, out);
-}
-
-void launch_add_diag(double* A, int ld, int n, double v, hipStream_t st) {
-  hipLaunchKernelGGL(add_diag_kernel, dim3((n + 255) / 256), dim3(256), 0, st, A, ld, n, v);
 }
 
 void launch_vec_lin(const double* a, const double* b, double sb, int n, double* out, hipStream_t st) {
