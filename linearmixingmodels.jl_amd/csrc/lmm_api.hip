@@ -266,15 +266,40 @@ void trsm_rec(double* R, int ldr, int nr, const double* L, int ld, const double*
   trsm_rec(R, ldr, nr, L, ld, W, j0 + h, w - h, st, tri);
 }
 
+// alpha (in place over z = L^-1 delta) <- L^-T z for one factor matrix
+void backsolve1(const double* L, int ld, const double* W, int nblk, double* z, hipStream_t st) {
+  BatchPtr Lb{}, Wb{}, zb{};
+  Lb.p[0] = const_cast<double*>(L); Wb.p[0] = const_cast<double*>(W); zb.p[0] = z;
+  launch_backsolve(Lb, ld, Wb, nblk, zb, 1, st);
+}
+
 // How many latents share one batch and how many streams carry batches, for a shard of ms latents.
-void batch_plan(int ms, int* nb_per, int* nstreams_used) {
+// bytes_per_latent > 0: the working set one latent needs while its batch is in flight; the plan is then shrunk (batch first,
+// streams second) until nb_per * nstreams * bytes_per_latent fits in 80 % of the free device memory (+ this library's cache).
+void batch_plan(int ms, int* nb_per, int* nstreams_used, double bytes_per_latent = 0.0) {
   static int bmax = -1;
   if (bmax < 0) { const char* e = getenv("LMM_BATCH"); bmax = e ? atoi(e) : 8; if (bmax < 1) bmax = 1; if (bmax > LMM_MAX_BATCH) bmax = LMM_MAX_BATCH; }
-  int b = std::min(bmax, std::max(1, ms / 2));          // keep at least two batches in flight when ms >= 2
+  static int minb = -1;
+  if (minb < 0) { const char* e = getenv("LMM_MIN_BATCHES"); minb = e ? atoi(e) : 2; if (minb < 1) minb = 1; }
+  int b = std::min(bmax, std::max(1, ms / minb));       // keep at least minb (2) batches in flight when ms >= 2
   if (g.prof && g.prof_serial) b = std::min(bmax, ms);  // instrumented pass: production-sized batches on ONE stream
-  const int nbatches = (ms + b - 1) / b;
+  int nbatches = (ms + b - 1) / b;
+  int ns = std::max(1, std::min(nbatches, eff_streams()));
+  if (bytes_per_latent > 0.0) {
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
+      double avail = (double)fr;
+      for (const auto& kv : g.pool) avail += (double)kv.first;
+      const double budget = 0.8 * avail;
+      while ((double)b * ns * bytes_per_latent > budget && (b > 1 || ns > 1)) {
+        if (b > 1) b = (b + 1) / 2; else --ns;
+        nbatches = (ms + b - 1) / b;
+        ns = std::max(1, std::min(ns, nbatches));
+      }
+    } else (void)hipGetLastError();
+  }
   *nb_per = b;
-  *nstreams_used = std::max(1, std::min(nbatches, eff_streams()));
+  *nstreams_used = ns;
 }
 
 struct Slot {                 // one stream + the factor matrices of the batch it carries
@@ -456,7 +481,7 @@ int latent_lmls(const double* xd, int d, int n, const lmm_gp_t* gps, const doubl
   if (ms == 0) return LMM_OK;
   Dims D(n, nrhs);
   int nb_per = 1, nslots = 1;
-  batch_plan(ms, &nb_per, &nslots);
+  batch_plan(ms, &nb_per, &nslots, (double)D.elems() * sizeof(double));
   std::vector<Slot> slots;
   make_slots(slots, nslots, nb_per, D.elems(), D.NC);
   Buf<double> out((size_t)ms * nrhs);
@@ -505,7 +530,8 @@ struct lmm_post {
   Buf<double> x;              // d x n
   std::vector<Buf<double>> L; // per latent of the shard: factor matrix (NR x NC, ld)
   std::vector<Buf<double>> W; // inverse diagonal blocks
-  std::vector<Buf<double>> alpha;
+  std::vector<Buf<double>> alpha;     // C \\ delta
+  std::vector<Buf<double>> z;         // per latent: L^-1 delta (contiguous copy of the rider row)
   std::vector<Buf<double>> delta;     // per latent: projected residuals (T y)_l - mean_l   (kept for sequential conditioning)
   std::vector<Buf<double>> noisev;    // per latent: per-point projected noise
   // dense ILMM (kind 1): L[0] is the (mn) x (mn) factor, alpha[0] the (mn) weights
@@ -713,7 +739,7 @@ int lmm_oilmm_logpdf_grad(const double* x, int d, int n, const double* y, int p,
     potrf_rec(Am[s].p, D.ld, D.NR, 0, D.NC, Wm[s].p, n, info.p + k, st);
     launch_lml_reduce(Am[s].p, D.ld, n, D.NC, 1, lmld.p + k, st);
     launch_extract_row(Am[s].p, D.ld, D.NC, n, al, st);
-    launch_backsolve(Am[s].p, D.ld, Wm[s].p, D.NC / 64, al, st);
+    backsolve1(Am[s].p, D.ld, Wm[s].p, D.NC / 64, al, st);
     launch_set_identity(Rm[s].p, D.ld, D.NC, st);
     trsm_rec(Rm[s].p, D.ld, D.NC, Am[s].p, D.ld, Wm[s].p, 0, D.NC, st, true);     // R = L^-T (upper triangular)
     launch_syrk_upper_set(Am[s].p, D.ld, Rm[s].p, D.ld, D.NC, st);                  // lower(A) = L^-T L^-1 = Kt^-1
@@ -1021,6 +1047,7 @@ static int posterior_create_common(const double* xd, int d, int n, const lmm_gp_
       P->L.emplace_back((size_t)D.elems());
       P->W.emplace_back((size_t)(D.NC / 64) * 4096);
       P->alpha.emplace_back((size_t)D.NC);
+      P->z.emplace_back((size_t)D.NC);
       P->delta.emplace_back((size_t)n);
       P->noisev.emplace_back((size_t)n);
       HIPCHK(hipMemcpyAsync(P->delta[k].p, delta + (size_t)k * n, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, g.streams[0]));
@@ -1045,13 +1072,16 @@ static int posterior_create_common(const double* xd, int d, int n, const lmm_gp_
         B.add(P->L[k].p, P->W[k].p, info.p + k);
       }
       potrf_rec(B, D.ld, D.NR, 0, D.NC, n, st);
+      BatchPtr ab{};
       for (int j = 0; j < nb; ++j) {
         const int k = k0 + j;
         // alpha = L^-T (L^-1 delta): the rider row is z = L^-1 delta
         HIPCHK(hipMemsetAsync(P->alpha[k].p, 0, (size_t)D.NC * sizeof(double), st));
         launch_extract_row(P->L[k].p, D.ld, D.NC, n, P->alpha[k].p, st);
-        launch_backsolve(P->L[k].p, D.ld, P->W[k].p, D.NC / 64, P->alpha[k].p, st);
+        HIPCHK(hipMemcpyAsync(P->z[k].p, P->alpha[k].p, (size_t)D.NC * sizeof(double), hipMemcpyDeviceToDevice, st));
+        ab.p[j] = P->alpha[k].p;
       }
+      launch_backsolve(B.A, D.ld, B.W, D.NC / 64, ab, nb, st);
     }
     join_slots(nslots);
     std::vector<int> hinfo(std::max(ms, 1), 0);
@@ -1193,7 +1223,7 @@ int lmm_ilmm_posterior_create(const double* x, int d, int n, const double* y, in
     potrf_rec(P->L[0].p, D.ld, D.NR, 0, D.NC, P->W[0].p, N, info.p, st0);
     HIPCHK(hipMemsetAsync(P->alpha[0].p, 0, (size_t)D.NC * sizeof(double), st0));
     launch_extract_row(P->L[0].p, D.ld, D.NC, N, P->alpha[0].p, st0);
-    launch_backsolve(P->L[0].p, D.ld, P->W[0].p, D.NC / 64, P->alpha[0].p, st0);
+    backsolve1(P->L[0].p, D.ld, P->W[0].p, D.NC / 64, P->alpha[0].p, st0);
     int hinfo = 0;
     HIPCHK(hipMemcpyAsync(&hinfo, info.p, sizeof(int), hipMemcpyDeviceToHost, st0));
     HIPCHK(hipStreamSynchronize(st0));
@@ -1223,8 +1253,9 @@ int lmm_ilmm_post_mean_and_var(const lmm_post_t* post, double sigma2, const doub
   DevIn xsd(xs, (size_t)d * ns, st0);
   Uploaded Hd(P->H, st0);
   Buf<double> ml((size_t)ns * m);
+  Buf<double> pm_part(post_mean_partial_elems(ns, n));
   for (int l = 0; l < m; ++l)
-    launch_post_mean(xsd.p, ns, P->x.p, n, d, P->alpha[0].p + (size_t)l * n, to_dev(P->gps[l]), ml.p + (size_t)l * ns, st0);
+    launch_post_mean(xsd.p, ns, P->x.p, n, d, P->alpha[0].p + (size_t)l * n, to_dev(P->gps[l]), pm_part.p, ml.p + (size_t)l * ns, st0);
   const int nr = rup(m * ns, 64);
   int ldr = nr; if ((ldr % 512) == 0) ldr += 16;
   Buf<double> R((size_t)ldr * P->NC);
@@ -1277,8 +1308,9 @@ int lmm_ilmm_post_logpdf(const lmm_post_t* post, double sigma2, const double* xs
   Buf<double> Ty((size_t)ns * m), ml((size_t)ns * m), delta((size_t)ns * m), partial(tall_skinny_partials(ns, p)), resid_dev(1);
   project_on_device(ysd.p, ns, p, Td.buf, m, 0, m, nullptr, Ty.p, st0);
   residual_on_device(ysd.p, ns, p, Ty.p, m, Hd.buf, partial.p, resid_dev.p, st0);
+  Buf<double> pm_part(post_mean_partial_elems(ns, n));
   for (int l = 0; l < m; ++l)
-    launch_post_mean(xsd.p, ns, P->x.p, n, d, P->alpha[0].p + (size_t)l * n, to_dev(P->gps[l]), ml.p + (size_t)l * ns, st0);
+    launch_post_mean(xsd.p, ns, P->x.p, n, d, P->alpha[0].p + (size_t)l * n, to_dev(P->gps[l]), pm_part.p, ml.p + (size_t)l * ns, st0);
   launch_vec_lin(Ty.p, ml.p, -1.0, Ns, delta.p, st0);
   Dims Ds(Ns, 1);
   int ldr = Ds.NC; if ((ldr % 512) == 0) ldr += 16;
@@ -1318,11 +1350,12 @@ int lmm_ilmm_post_rand(const lmm_post_t* post, double sigma2, int add_noise, con
   DevIn xsd(xs, (size_t)d * ns, st0), zd(z_lat, (size_t)Ns, st0), epsd(add_noise ? eps : nullptr, (size_t)ns * p, st0);
   Uploaded Jd(J, st0), Hd(P->H, st0);
   Buf<double> ml((size_t)Ns), X((size_t)Ns);
+  Buf<double> pm_part(post_mean_partial_elems(ns, n));
   for (int l = 0; l < m; ++l)
-    launch_post_mean(xsd.p, ns, P->x.p, n, d, P->alpha[0].p + (size_t)l * n, to_dev(P->gps[l]), ml.p + (size_t)l * ns, st0);
+    launch_post_mean(xsd.p, ns, P->x.p, n, d, P->alpha[0].p + (size_t)l * n, to_dev(P->gps[l]), pm_part.p, ml.p + (size_t)l * ns, st0);
   Dims Ds(Ns, 0);
   int ldr = Ds.NC; if ((ldr % 512) == 0) ldr += 16;
-  Buf<double> A(Ds.elems()), WA((size_t)(Ds.NC / 64) * 4096), R((size_t)ldr * P->NC), part((size_t)Ns * trmv_chunks(Ns));
+  Buf<double> A(Ds.elems()), WA((size_t)(Ds.NC / 64) * 4096), R((size_t)ldr * P->NC), part(strip_partial_elems(Ns, Ns, 1));
   Buf<int> info(1);
   HIPCHK(hipMemsetAsync(info.p, 0, sizeof(int), st0));
   dense_post_cov_factor(P, xsd.p, d, ns, Jd.buf.p, nullptr, Ds, A.p, WA.p, R.p, ldr, info.p, st0);
@@ -1356,9 +1389,9 @@ static int latent_marginals_dev(const lmm_post* P, const lmm_gp_t* gps_shard, in
     fork_slots(1);
     for (int k = 0; k < ms; ++k) {
       LatentDev gd = to_dev(gps_shard[k]);
-      launch_post_mean(xsd, ns, nullptr, 0, d, nullptr, gd, mean_lat + (size_t)k * ns, g.streams[0]);
-      // prior variance kappa(0) = variance: base - 0
-      launch_rider_var(nullptr, 0, ns, 0, gps_shard[k].variance, var_lat + (size_t)k * ns, g.streams[0]);
+      // prior: constant mean, variance kappa(0)
+      launch_rider_stats(nullptr, 0, ns, 0, nullptr, gd.mean, gps_shard[k].variance, nullptr, mean_lat + (size_t)k * ns,
+                         var_lat + (size_t)k * ns, g.streams[0]);
     }
     return LMM_OK;
   }
@@ -1366,22 +1399,22 @@ static int latent_marginals_dev(const lmm_post* P, const lmm_gp_t* gps_shard, in
   const int nsr = rup(ns, 64);
   const int nslots = std::min(ms, g.nstreams);
   int ldr = nsr; if ((ldr % 512) == 0) ldr += 16;
-  std::vector<Buf<double>> R;
-  for (int s = 0; s < nslots; ++s) R.emplace_back((size_t)ldr * P->NC);
+  std::vector<Buf<double>> R, part;
+  for (int s = 0; s < nslots; ++s) { R.emplace_back((size_t)ldr * P->NC); part.emplace_back(strip_partial_elems(nsr, P->NC, 2)); }
   fork_slots(nslots);
   for (int k = 0; k < ms; ++k) {
     hipStream_t st = g.streams[k % nslots];
     double* Rk = R[k % nslots].p;
     const lmm_gp_t& gp = P->gps[P->l0 + k];
-    LatentDev gd = to_dev(gp);
-    launch_post_mean(xsd, ns, P->x.p, P->n, d, P->alpha[k].p, gd, mean_lat + (size_t)k * ns, st);
     GramArgs a{};
     a.A = Rk; a.ld = ldr; a.nrows = P->NC + nsr; a.ncols = P->NC; a.row_tile0 = P->NC / 64; a.row_shift = P->NC; a.full = 1;
     a.x = P->x.p; a.d = d; a.n = P->n; a.kind = gp.kind; a.var = gp.variance; a.inv_ls = 1.0 / gp.lengthscale;
     a.diag_add = 0.0; a.pad_diag = 0.0; a.xs = xsd; a.ns = ns;
     launch_gram(a, st);
     trsm_rec(Rk, ldr, nsr, P->L[k].p, P->ld, P->W[k].p, 0, P->NC, st);
-    launch_rider_var(Rk, ldr, ns, P->n, gp.variance, var_lat + (size_t)k * ns, st);
+    // mean = mu + K(x*,x) alpha = mu + R' (L^-1 delta);  var = kappa(0) - colsumsq(R)   (one pass over R)
+    launch_rider_stats(Rk, ldr, ns, P->n, P->z[k].p, gp.mean, gp.variance, part[k % nslots].p, mean_lat + (size_t)k * ns,
+                       var_lat + (size_t)k * ns, st);
   }
   join_slots(nslots);
   HIPCHK(hipStreamSynchronize(g.streams[0]));   // R buffers are released on return
@@ -1438,28 +1471,52 @@ int lmm_oilmm_mean_and_var(const lmm_post_t* post, const lmm_gp_t* gps, const do
   LMM_CATCH
 }
 
-// Per-latent posterior (or prior) covariance at xs as a factor matrix B (NRs x NCs): gram(xs) + diag_add
-// - R R' (posterior), rider row = rider_vec.  Factorises it unless factor == false.  Caller holds g_mu.  st: stream.
-static void build_and_factor_at_xs(const lmm_post* P, int k, const lmm_gp_t& gp, const double* xsd, int d, int ns,
-                                   double diag_add, const double* rider_vec, const Dims& Ds, double* B, double* WB,
-                                   double* Rk, int ldr, int nsr, int* info, hipStream_t st, bool factor = true) {
+// R (nsr x NC, ldr) = K(xs, x) L^-T for latent k of the posterior: the riders of the cross-Gram solved against the factor.
+static void cross_solve(const lmm_post* P, int k, const lmm_gp_t& gp, const double* xsd, int d, int ns, double* Rk, int ldr,
+                        int nsr, hipStream_t st) {
+  GramArgs r{};
+  r.A = Rk; r.ld = ldr; r.nrows = P->NC + nsr; r.ncols = P->NC; r.row_tile0 = P->NC / 64; r.row_shift = P->NC; r.full = 1;
+  r.x = P->x.p; r.d = d; r.n = P->n; r.kind = gp.kind; r.var = gp.variance; r.inv_ls = 1.0 / gp.lengthscale;
+  r.xs = xsd; r.ns = ns;
+  launch_gram(r, st);
+  trsm_rec(Rk, ldr, nsr, P->L[k].p, P->ld, P->W[k].p, 0, P->NC, st);
+}
+
+// Per-latent posterior (or prior) covariance at xs as a factor matrix B (NRs x NCs): gram(xs) + diag_add - R R' (posterior,
+// R from cross_solve), rider row = rider_vec.  Not factorised here (the caller batches potrf_rec).  Caller holds g_mu.
+static void cov_at_xs(const lmm_post* P, const lmm_gp_t& gp, const double* xsd, int d, int ns, double diag_add,
+                      const double* rider_vec, const Dims& Ds, double* B, const double* Rk, int ldr, hipStream_t st) {
   GramArgs a{};
   a.A = B; a.ld = Ds.ld; a.nrows = Ds.NR; a.ncols = Ds.NC; a.x = xsd; a.d = d; a.n = ns;
   a.kind = gp.kind; a.var = gp.variance; a.inv_ls = 1.0 / gp.lengthscale; a.diag_add = diag_add; a.pad_diag = 1.0;
   a.rider = rider_vec; a.rider_ld = ns; a.nrider = rider_vec ? 1 : 0;
   launch_gram(a, st);
-  if (P != nullptr) {
-    GramArgs r{};
-    r.A = Rk; r.ld = ldr; r.nrows = P->NC + nsr; r.ncols = P->NC; r.row_tile0 = P->NC / 64; r.row_shift = P->NC; r.full = 1;
-    r.x = P->x.p; r.d = d; r.n = P->n; r.kind = gp.kind; r.var = gp.variance; r.inv_ls = 1.0 / gp.lengthscale;
-    r.xs = xsd; r.ns = ns;
-    launch_gram(r, st);
-    trsm_rec(Rk, ldr, nsr, P->L[k].p, P->ld, P->W[k].p, 0, P->NC, st);
-    // Schur complement on the leading NCs x NCs block (rows of R beyond ns are zero)
-    launch_gemm_nt(B, Ds.ld, Rk, ldr, Rk, ldr, Ds.NC, Ds.NC, P->NC, 1, false, st);
-  }
-  if (factor) potrf_rec(B, Ds.ld, Ds.NR, 0, Ds.NC, WB, ns, info, st);
+  // Schur complement on the leading NCs x NCs block (rows of R beyond ns are zero)
+  if (P != nullptr) launch_gemm_nt(B, Ds.ld, Rk, ldr, Rk, ldr, Ds.NC, Ds.NC, P->NC, 1, false, st);
 }
+
+// Working buffers of the batched "covariance at xs" loops (rand, posterior logpdf): per stream slot nb_per factor matrices
+// with their inverse blocks, means and riders, ONE cross-solve block R and one reduction scratch (reused latent after latent
+// in stream order).
+struct XsSlots {
+  int nb_per = 1, nslots = 1, ldr = 0, nsr = 0;
+  std::vector<std::vector<Buf<double>>> B, WB, mu, rid;
+  std::vector<Buf<double>> R, part;
+  XsSlots(const lmm_post* P, int ms, int ns, const Dims& Ds) {
+    nsr = rup(ns, 64);
+    ldr = nsr; if ((ldr % 512) == 0) ldr += 16;
+    batch_plan(std::max(ms, 1), &nb_per, &nslots, (double)Ds.elems() * sizeof(double));
+    B.resize(nslots); WB.resize(nslots); mu.resize(nslots); rid.resize(nslots);
+    for (int s = 0; s < nslots; ++s) {
+      for (int j = 0; j < nb_per; ++j) {
+        B[s].emplace_back(Ds.elems()); WB[s].emplace_back((size_t)(Ds.NC / 64) * 4096);
+        mu[s].emplace_back((size_t)ns); rid[s].emplace_back((size_t)ns);
+      }
+      R.emplace_back(P ? (size_t)ldr * P->NC : 1);
+      part.emplace_back(std::max(strip_partial_elems(nsr, P ? P->NC : 1, 1), strip_partial_elems(ns, ns, 1)));
+    }
+  }
+};
 
 extern "C" int lmm_lmm_mean_and_cov(const lmm_post_t* post, const lmm_gp_t* gps, const double* U, const double* S, int p, int m,
                                     int latent_begin, int latent_end, double sigma2, int add_noise, const double* xs, int d,
@@ -1494,7 +1551,7 @@ extern "C" int lmm_lmm_mean_and_cov(const lmm_post_t* post, const lmm_gp_t* gps,
   const int CH = LMM_MAX_BATCH;
   std::vector<Buf<double>> Cm;
   for (int c = 0; c < std::min(CH, std::max(ms, 1)); ++c) Cm.emplace_back(Ds.elems());
-  Buf<double> R(P ? (size_t)ldr * P->NC : 1);
+  Buf<double> R(P ? (size_t)ldr * P->NC : 1), part(strip_partial_elems(nsr, P ? P->NC : 1, 1));
   if (ms == 0) {
     HIPCHK(hipMemsetAsync(mo.p, 0, (size_t)ns * p * sizeof(double), st0));
     BatchPtr none{};
@@ -1506,9 +1563,10 @@ extern "C" int lmm_lmm_mean_and_cov(const lmm_post_t* post, const lmm_gp_t* gps,
     for (int j = 0; j < nl; ++j) {
       const int k = k0 + j;
       const lmm_gp_t& gp = P ? P->gps[l0 + k] : gps[l0 + k];
-      launch_post_mean(xsd.p, ns, P ? P->x.p : nullptr, P ? P->n : 0, d, P ? P->alpha[k].p : nullptr, to_dev(gp),
-                       ml.p + (size_t)k * ns, st0);
-      build_and_factor_at_xs(P, k, gp, xsd.p, d, ns, 0.0, nullptr, Ds, Cm[j].p, nullptr, R.p, ldr, nsr, nullptr, st0, false);
+      if (P) cross_solve(P, k, gp, xsd.p, d, ns, R.p, ldr, nsr, st0);
+      launch_rider_stats(P ? R.p : nullptr, ldr, ns, P ? P->n : 0, P ? P->z[k].p : nullptr, gp.mean, 0.0, part.p,
+                         ml.p + (size_t)k * ns, nullptr, st0);
+      cov_at_xs(P, gp, xsd.p, d, ns, 0.0, nullptr, Ds, Cm[j].p, R.p, ldr, st0);
       cl.p[j] = Cm[j].p;
     }
     launch_cov_mix(cl, Ds.ld, nl, Hd.buf.p + (size_t)k0 * p, p, ns, jit->default_jitter, add_noise ? sigma2 : 0.0,
@@ -1549,27 +1607,28 @@ int lmm_oilmm_post_logpdf(const lmm_post_t* post, const double* U, const double*
   }
   const double* Ty_shard = Ty.p + (size_t)(l0 - c0) * ns;
   Dims Ds(ns, 1);
-  const int nsr = rup(ns, 64);
-  int ldr = nsr; if ((ldr % 512) == 0) ldr += 16;
-  const int nslots = std::max(1, std::min(ms, g.nstreams));
-  std::vector<Buf<double>> Bm, WB, R, dl, mu;
-  for (int s = 0; s < nslots; ++s) {
-    Bm.emplace_back(Ds.elems()); WB.emplace_back((size_t)(Ds.NC / 64) * 4096); R.emplace_back((size_t)ldr * P->NC);
-    dl.emplace_back((size_t)ns); mu.emplace_back((size_t)ns);
-  }
+  XsSlots X(P, ms, ns, Ds);
+  const int nslots = X.nslots;
   Buf<double> outd(std::max(ms, 1));
   Buf<int> info(std::max(ms, 1));
   HIPCHK(hipMemsetAsync(info.p, 0, std::max(ms, 1) * sizeof(int), st0));
   fork_slots(nslots);
-  for (int k = 0; k < ms; ++k) {
-    const int s = k % nslots;
+  int bi = 0;
+  for (int k0 = 0; k0 < ms; k0 += X.nb_per, ++bi) {
+    const int s = bi % nslots, nb = std::min(X.nb_per, ms - k0);
     hipStream_t st = g.streams[s];
-    const lmm_gp_t& gp = P->gps[l0 + k];
-    launch_post_mean(xsd.p, ns, P->x.p, P->n, d, P->alpha[k].p, to_dev(gp), mu[s].p, st);
-    launch_vec_lin(Ty_shard + (size_t)k * ns, mu[s].p, -1.0, ns, dl[s].p, st);
-    build_and_factor_at_xs(P, k, gp, xsd.p, d, ns, ST[l0 + k], dl[s].p, Ds, Bm[s].p, WB[s].p, R[s].p, ldr, nsr,
-                           info.p + k, st);
-    launch_lml_reduce(Bm[s].p, Ds.ld, ns, Ds.NC, 1, outd.p + k, st);
+    Batch Bt;
+    for (int j = 0; j < nb; ++j) {
+      const int k = k0 + j;
+      const lmm_gp_t& gp = P->gps[l0 + k];
+      cross_solve(P, k, gp, xsd.p, d, ns, X.R[s].p, X.ldr, X.nsr, st);
+      launch_rider_stats(X.R[s].p, X.ldr, ns, P->n, P->z[k].p, gp.mean, 0.0, X.part[s].p, X.mu[s][j].p, nullptr, st);
+      launch_vec_lin(Ty_shard + (size_t)k * ns, X.mu[s][j].p, -1.0, ns, X.rid[s][j].p, st);
+      cov_at_xs(P, gp, xsd.p, d, ns, ST[l0 + k], X.rid[s][j].p, Ds, X.B[s][j].p, X.R[s].p, X.ldr, st);
+      Bt.add(X.B[s][j].p, X.WB[s][j].p, info.p + k);
+    }
+    potrf_rec(Bt, Ds.ld, Ds.NR, 0, Ds.NC, ns, st);
+    for (int j = 0; j < nb; ++j) launch_lml_reduce(X.B[s][j].p, Ds.ld, ns, Ds.NC, 1, outd.p + k0 + j, st);
   }
   join_slots(nslots);
   std::vector<double> lml(std::max(ms, 1), 0.0);
@@ -1616,33 +1675,36 @@ int lmm_lmm_rand_multi(const lmm_post_t* post, const lmm_gp_t* gps, const double
   DevIn xsd(xs, (size_t)d * ns, st0), zd(z_lat, (size_t)ns * m * nsamples, st0);
   DevIn epsd(add_noise ? eps : nullptr, (size_t)ns * p * nsamples, st0);
   Dims Ds(ns, 0);
-  const int nsr = rup(ns, 64);
-  int ldr = nsr; if ((ldr % 512) == 0) ldr += 16;
-  const int nslots = std::max(1, std::min(ms, g.nstreams));
-  std::vector<Buf<double>> Bm, WB, R, mu, part;
-  for (int s = 0; s < nslots; ++s) {
-    Bm.emplace_back(Ds.elems()); WB.emplace_back((size_t)(Ds.NC / 64) * 4096);
-    R.emplace_back(P ? (size_t)ldr * P->NC : 1); mu.emplace_back((size_t)ns);
-    part.emplace_back((size_t)ns * trmv_chunks(ns));
-  }
+  XsSlots Xs(P, ms, ns, Ds);
+  const int nslots = Xs.nslots;
   Buf<double> X((size_t)ns * std::max(ms, 1) * nsamples);     // [sample][latent of the shard][ns]
   Buf<int> info(std::max(ms, 1));
   HIPCHK(hipMemsetAsync(info.p, 0, std::max(ms, 1) * sizeof(int), st0));
   fork_slots(nslots);
-  for (int k = 0; k < ms; ++k) {
-    const int s = k % nslots;
+  int bi = 0;
+  for (int k0 = 0; k0 < ms; k0 += Xs.nb_per, ++bi) {
+    const int s = bi % nslots, nb = std::min(Xs.nb_per, ms - k0);
     hipStream_t st = g.streams[s];
-    const lmm_gp_t& gp = P ? P->gps[l0 + k] : gps[l0 + k];
-    build_and_factor_at_xs(P, k, gp, xsd.p, d, ns, jitter, nullptr, Ds, Bm[s].p, WB[s].p, R[s].p, ldr, nsr, info.p + k, st);
-    double mu_const = gp.mean;
-    if (P) {   // posterior mean vector: sample = mean(xs) + L z
-      launch_post_mean(xsd.p, ns, P->x.p, P->n, d, P->alpha[k].p, to_dev(gp), mu[s].p, st);
-      mu_const = 0.0;
+    Batch Bt;
+    for (int j = 0; j < nb; ++j) {
+      const int k = k0 + j;
+      const lmm_gp_t& gp = P ? P->gps[l0 + k] : gps[l0 + k];
+      if (P) {   // posterior mean vector: sample = mean(xs) + L z
+        cross_solve(P, k, gp, xsd.p, d, ns, Xs.R[s].p, Xs.ldr, Xs.nsr, st);
+        launch_rider_stats(Xs.R[s].p, Xs.ldr, ns, P->n, P->z[k].p, gp.mean, 0.0, Xs.part[s].p, Xs.mu[s][j].p, nullptr, st);
+      }
+      cov_at_xs(P, gp, xsd.p, d, ns, jitter, nullptr, Ds, Xs.B[s][j].p, Xs.R[s].p, Xs.ldr, st);
+      Bt.add(Xs.B[s][j].p, Xs.WB[s][j].p, info.p + k);
     }
-    for (int q = 0; q < nsamples; ++q) {     // ONE factorisation, nsamples triangular products
-      double* Xq = X.p + ((size_t)q * ms + k) * ns;
-      launch_trmv_lower(Bm[s].p, Ds.ld, ns, zd.p + ((size_t)q * m + l0 + k) * ns, mu_const, part[s].p, Xq, st);
-      if (P) launch_vec_lin(Xq, mu[s].p, 1.0, ns, Xq, st);
+    potrf_rec(Bt, Ds.ld, Ds.NR, 0, Ds.NC, ns, st);      // ONE factorisation per latent, nsamples triangular products
+    for (int j = 0; j < nb; ++j) {
+      const int k = k0 + j;
+      const double mu_const = P ? 0.0 : gps[l0 + k].mean;
+      for (int q = 0; q < nsamples; ++q) {
+        double* Xq = X.p + ((size_t)q * ms + k) * ns;
+        launch_trmv_lower(Xs.B[s][j].p, Ds.ld, ns, zd.p + ((size_t)q * m + l0 + k) * ns, mu_const, Xs.part[s].p, Xq, st);
+        if (P) launch_vec_lin(Xq, Xs.mu[s][j].p, 1.0, ns, Xq, st);
+      }
     }
   }
   join_slots(nslots);

@@ -48,19 +48,22 @@ void launch_gemm_nt(double* C, int ldc, const double* A, int lda, const double* 
                     int lower, bool set, hipStream_t st);
 void launch_lml_reduce(const double* A, int ld, int n, int rider_row0, int nrhs, double* out, hipStream_t st);
 void launch_extract_row(const double* A, int ld, int row, int n, double* out, hipStream_t st);
-void launch_rider_var(const double* R, int ld, int nr, int n, double base, double* out, hipStream_t st);
-void launch_backsolve(const double* L, int ld, const double* W, int nblk, double* z, hipStream_t st);
+int strip_kc(int nk);
+size_t strip_partial_elems(int nr, int nk, int nv);
+void launch_rider_stats(const double* R, int ld, int nr, int nk, const double* z, double mu, double base, double* partial,
+                        double* mean_out, double* var_out, hipStream_t st);
+void launch_backsolve(const BatchPtr& L, int ld, const BatchPtr& W, int nblk, const BatchPtr& z, int nb, hipStream_t st);
 void launch_tall_skinny(const double* In, int ldi, int n, int K, const double* Mx, int ldm, int C, double* Out, int ldo,
                         const double* sub, const double* Ref, int ldr, double* partial, int mode, hipStream_t st);
 int tall_skinny_partials(int n, int C);
 void launch_sum_partials(const double* partial, int count, double* out, hipStream_t st);
+size_t post_mean_partial_elems(int ns, int n);
 void launch_post_mean(const double* xs, int ns, const double* x, int n, int d, const double* alpha, LatentDev g,
-                      double* out, hipStream_t st);
+                      double* partial, double* out, hipStream_t st);
 void launch_mix(const double* lat, int ns, int ml, const double* Hm, int p, int pw, double lat_add, double out_add,
                 const double* eps, double eps_scale, double* out, hipStream_t st);
 void launch_cov_mix(const BatchPtr& Cl, int ldcl, int nl, const double* Hs, int p, int ns, double jitter, double sigma2,
                     int init, double* out, hipStream_t st);
-int trmv_chunks(int n);
 void launch_trmv_lower(const double* L, int ld, int n, const double* z, double mu, double* partial, double* out,
                        hipStream_t st);
 void launch_syrk_upper_set(double* C, int ldc, const double* X, int ldx, int N, hipStream_t st);

@@ -688,48 +688,125 @@ __global__ void extract_row_kernel(const double* __restrict__ A, int ld, int row
   if (k < n) out[k] = A[(size_t)k * ld + row];
 }
 
-// Column sum of squares over a rider block: out[r] = base[r] - sum_k R[r + k*ld]^2  (posterior variance:
-// k(x*,x*) - colsumsq(C.U' \ K(x,x*)); AbstractGPs PosteriorGP var).
-__global__ __launch_bounds__(256) void rider_var_kernel(const double* __restrict__ R, int ld, int nr, int n,
-                                                        double base, double* __restrict__ out) {
-  const int r = blockIdx.x * 256 + threadIdx.x;
-  if (r >= nr) return;
-  double q = 0.0;
-  for (int k = 0; k < n; ++k) {
-    const double v = R[(size_t)k * ld + r];
-    q = __builtin_fma(v, v, q);
+// Strip reductions over a column-major block M (rows r contiguous in memory, columns k, stride ld): for the 64-row strip
+// blockIdx.x and the k-chunk blockIdx.y (kc columns) of this workgroup
+//   dot[r] = sum_k M[r,k] v[k]        and, SQ:  sq[r] = sum_k M[r,k]^2       (TRI: only k <= r, i.e. the product L z)
+// into partial[(chunk * NV + val) * nrp + r] (NV = SQ ? 2 : 1, nrp = 64 gridDim.x); strip_finish_kernel adds the chunks
+// in a fixed order.  Serves the posterior marginals (mean = mu + R' z, var = k(x*,x*) - colsumsq(R) with R = L^-1 K(x,x*)
+// -- AbstractGPs PosteriorGP mean/var) and the sample transform L z.  The four waves take
+// interleaved 16-column slabs so that 16 independent coalesced 512-byte loads per wave are in flight.
+template <bool SQ, bool TRI>
+__global__ __launch_bounds__(256) void strip_reduce_kernel(const double* __restrict__ M, int ld, int nk, int kc,
+                                                           const double* __restrict__ v, double* __restrict__ partial) {
+  __shared__ double red[2][3][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int r = blockIdx.x * 64 + lane;
+  const int kbeg = blockIdx.y * kc;
+  int kend = kbeg + kc; if (kend > nk) kend = nk;
+  if (TRI) { const int rowmax = blockIdx.x * 64 + 63; if (kend > rowmax + 1) kend = rowmax + 1; if (kbeg > rowmax) return; }
+  double dot = 0.0, sq = 0.0;
+  const double* Mr = M + r;
+  for (int k0 = kbeg + w * 16; k0 < kend; k0 += 64) {
+    if (k0 + 16 <= kend) {
+      double a[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) a[u] = Mr[(size_t)(k0 + u) * ld];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const double av = (TRI && (k0 + u > r)) ? 0.0 : a[u];
+        dot = __builtin_fma(av, v[k0 + u], dot);
+        if (SQ) sq = __builtin_fma(av, av, sq);
+      }
+    } else {
+      for (int k = k0; k < kend; ++k) {
+        double av = Mr[(size_t)k * ld];
+        if (TRI && k > r) av = 0.0;
+        dot = __builtin_fma(av, v[k], dot);
+        if (SQ) sq = __builtin_fma(av, av, sq);
+      }
+    }
   }
-  out[r] = base - q;
+  if (w > 0) { red[0][w - 1][lane] = dot; if (SQ) red[1][w - 1][lane] = sq; }
+  __syncthreads();
+  if (w == 0) {
+    const int NV = SQ ? 2 : 1;
+    const size_t nrp = (size_t)gridDim.x * 64;
+    dot += red[0][0][lane] + red[0][1][lane] + red[0][2][lane];
+    partial[((size_t)blockIdx.y * NV) * nrp + r] = dot;
+    if (SQ) {
+      sq += red[1][0][lane] + red[1][1][lane] + red[1][2][lane];
+      partial[((size_t)blockIdx.y * NV + 1) * nrp + r] = sq;
+    }
+  }
+}
+
+// out_dot[r] = add_dot + sum_chunks dot;  out_sq[r] = base_sq - sum_chunks sq.   tri_kc > 0: chunks above the diagonal were
+// skipped by strip_reduce_kernel<.,true> and are skipped here too.
+__global__ void strip_finish_kernel(const double* __restrict__ partial, int nrp, int nch, int nv, int nr, int tri_kc,
+                                    double add_dot, double base_sq, double* __restrict__ out_dot,
+                                    double* __restrict__ out_sq) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nr) return;
+  double d = 0.0, q = 0.0;
+  for (int c = 0; c < nch; ++c) {
+    if (tri_kc > 0 && c * tri_kc > (r | 63)) break;
+    d += partial[((size_t)c * nv) * nrp + r];
+    if (nv > 1) q += partial[((size_t)c * nv + 1) * nrp + r];
+  }
+  if (out_dot) out_dot[r] = add_dot + d;
+  if (out_sq) out_sq[r] = base_sq - q;
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Back substitution  L' alpha = z  (alpha = C \ delta second half), one launch per 64-block, from the
-// last block to the first.  Step b: alpha_b = W_bb' z_b (recomputed by every workgroup), then
-// z_i -= sum_{j in b} L[j, i] alpha_j for the columns i < 64 b owned by this workgroup.
+// Back substitution  L' alpha = z  (alpha = C \ delta second half), one launch per 64-block from the last block to the
+// first, for every matrix of the batch (blockIdx.y).  Step b: alpha_b = W_bb' z_b (every workgroup recomputes it from an
+// LDS copy of the 64x64 inverse block), then z_i -= sum_{j in b} L[j, i] alpha_j for the 256 columns i < 64 b of this
+// workgroup: 16 lanes share a column (4 consecutive rows each, so a wave load covers 4 whole 512-byte column segments).
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void backsolve_step_kernel(const double* __restrict__ L, int ld,
-                                                             const double* __restrict__ W, int b,
-                                                             double* __restrict__ z) {
+__global__ __launch_bounds__(256) void backsolve_step_kernel(BatchPtr Lb, int ld, BatchPtr Wb_, int b, BatchPtr zb_) {
+  __shared__ double Ws[64 * 65];
   __shared__ double zb[64];
+  __shared__ double ps[4][64];
   __shared__ double ab[64];
-  const int t = threadIdx.x;
+  const double* __restrict__ L = Lb.p[blockIdx.y];
+  const double* __restrict__ Wb = Wb_.p[blockIdx.y] + (size_t)b * 4096;
+  double* __restrict__ z = zb_.p[blockIdx.y];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  // issue this workgroup's 32 panel loads first: they do not depend on alpha_b
+  const int c0 = blockIdx.x * 256 + w * 64;
+  const int jq = lane & 15, cq = lane >> 4;
+  double2 pa[16], pb[16];
+#pragma unroll
+  for (int gI = 0; gI < 16; ++gI) {
+    const int col = c0 + gI * 4 + cq;
+    if (col < b * 64) {
+      const double2* src = reinterpret_cast<const double2*>(L + (size_t)col * ld + b * 64 + jq * 4);
+      pa[gI] = src[0]; pb[gI] = src[1];
+    } else { pa[gI] = make_double2(0.0, 0.0); pb[gI] = pa[gI]; }
+  }
+  for (int e = t; e < 4096; e += 256) Ws[(e >> 6) * 65 + (e & 63)] = Wb[e];     // Wb[c*64 + j] = W[j, c]
   if (t < 64) zb[t] = z[b * 64 + t];
   __syncthreads();
-  if (t < 64) {
-    const double* Wb = W + (size_t)b * 4096;
+  {
     double s = 0.0;
-    for (int j = t; j < 64; ++j) s = __builtin_fma(Wb[t * 64 + j], zb[j], s);   // (W')[t,j] = W[j,t]
-    ab[t] = s;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int j = w * 16 + u;
+      if (j >= lane) s = __builtin_fma(Ws[lane * 65 + j], zb[j], s);          // (W')[t, j] = W[j, t], j >= t
+    }
+    ps[w][lane] = s;
   }
   __syncthreads();
+  if (t < 64) ab[t] = (ps[0][t] + ps[1][t]) + (ps[2][t] + ps[3][t]);
+  __syncthreads();
   if (blockIdx.x == 0 && t < 64) z[b * 64 + t] = ab[t];
-  const int i = blockIdx.x * 256 + t;
-  if (i < b * 64) {
-    const double* col = L + (size_t)i * ld + b * 64;
-    double s = 0.0;
-#pragma unroll 8
-    for (int j = 0; j < 64; ++j) s = __builtin_fma(col[j], ab[j], s);
-    z[i] -= s;
+  const double a0 = ab[jq * 4], a1 = ab[jq * 4 + 1], a2 = ab[jq * 4 + 2], a3 = ab[jq * 4 + 3];
+#pragma unroll
+  for (int gI = 0; gI < 16; ++gI) {
+    double s = __builtin_fma(pa[gI].x, a0, __builtin_fma(pa[gI].y, a1, __builtin_fma(pb[gI].x, a2, pb[gI].y * a3)));
+    s += __shfl_xor(s, 8); s += __shfl_xor(s, 4); s += __shfl_xor(s, 2); s += __shfl_xor(s, 1);
+    const int col = c0 + gI * 4 + cq;
+    if (jq == 0 && col < b * 64) z[col] -= s;
   }
 }
 
@@ -800,39 +877,40 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Posterior / prior latent mean at xs:  mean[s] = mu + sum_i kappa(xs_s, x_i) alpha_i   (cross-Gram fused
-// with the GEMV; never materialised).  alpha == nullptr -> prior mean.
+// Latent mean at xs from the weights:  mean[s] = mu + sum_i kappa(xs_s, x_i) alpha_i   (cross-Gram fused with the GEMV;
+// never materialised).  The i range is cut into chunks of ichunk (blockIdx.y) whose partial sums strip_finish_kernel adds.
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void post_mean_kernel(const double* __restrict__ xs, int ns,
-                                                        const double* __restrict__ x, int n, int d,
+                                                        const double* __restrict__ x, int n, int d, int ichunk,
                                                         const double* __restrict__ alpha, LatentDev g,
-                                                        double* __restrict__ out) {
+                                                        double* __restrict__ partial) {
   __shared__ double xa[256 * 2];
   const int s = blockIdx.x * 256 + threadIdx.x;
+  const int ibeg = blockIdx.y * ichunk;
+  int iend = ibeg + ichunk; if (iend > n) iend = n;
   double acc = 0.0;
-  if (alpha != nullptr) {
-    if (d == 1) {
-      const double xv = (s < ns) ? xs[s] : 0.0;
-      for (int i0 = 0; i0 < n; i0 += 256) {
-        __syncthreads();
-        const int i = i0 + threadIdx.x;
-        xa[threadIdx.x] = (i < n) ? x[i] : 0.0;
-        xa[256 + threadIdx.x] = (i < n) ? alpha[i] : 0.0;
-        __syncthreads();
-        const int lim = (n - i0 < 256) ? (n - i0) : 256;
-        for (int k = 0; k < lim; ++k) {
-          const double r = fabs(xv - xa[k]) * g.inv_ls;
-          acc = __builtin_fma(kappa(g.kind, g.var, r, r * r), xa[256 + k], acc);
-        }
-      }
-    } else if (s < ns) {
-      for (int i = 0; i < n; ++i) {
-        const double r2 = scaled_dist2(xs + (size_t)s * d, x + (size_t)i * d, d, g.inv_ls);
-        acc = __builtin_fma(kappa(g.kind, g.var, sqrt(r2), r2), alpha[i], acc);
+  if (d == 1) {
+    const double xv = (s < ns) ? xs[s] : 0.0;
+    for (int i0 = ibeg; i0 < iend; i0 += 256) {
+      __syncthreads();
+      const int i = i0 + threadIdx.x;
+      xa[threadIdx.x] = (i < iend) ? x[i] : 0.0;
+      xa[256 + threadIdx.x] = (i < iend) ? alpha[i] : 0.0;
+      __syncthreads();
+      const int lim = (iend - i0 < 256) ? (iend - i0) : 256;
+#pragma unroll 4
+      for (int k = 0; k < lim; ++k) {
+        const double r = fabs(xv - xa[k]) * g.inv_ls;
+        acc = __builtin_fma(kappa(g.kind, g.var, r, r * r), xa[256 + k], acc);
       }
     }
+  } else if (s < ns) {
+    for (int i = ibeg; i < iend; ++i) {
+      const double r2 = scaled_dist2(xs + (size_t)s * d, x + (size_t)i * d, d, g.inv_ls);
+      acc = __builtin_fma(kappa(g.kind, g.var, sqrt(r2), r2), alpha[i], acc);
+    }
   }
-  if (s < ns) out[s] = g.mean + acc;
+  partial[(size_t)blockIdx.y * ((size_t)gridDim.x * 256) + s] = acc;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -878,42 +956,7 @@ __global__ __launch_bounds__(256) void cov_mix_kernel(BatchPtr Cl, int ldcl, int
   else *q += acc;
 }
 
-// ---------------------------------------------------------------------------------------------------
-// K7: sample transform  out = mu + L z  (lower-triangular, column-major).  Thread per row, k-split over
-// blockIdx.y with deterministic two-pass partials.
-// ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void trmv_lower_kernel(const double* __restrict__ L, int ld, int n,
-                                                         const double* __restrict__ zv, int kchunk,
-                                                         double* __restrict__ partial) {
-  __shared__ double zs[256];
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  const int k0 = blockIdx.y * kchunk;
-  int k1 = k0 + kchunk; if (k1 > n) k1 = n;
-  const int rowmax = blockIdx.x * 256 + 255;
-  double acc = 0.0;
-  for (int kb = k0; kb < k1 && kb <= rowmax; kb += 256) {
-    __syncthreads();
-    zs[threadIdx.x] = (kb + (int)threadIdx.x < k1) ? zv[kb + threadIdx.x] : 0.0;
-    __syncthreads();
-    const int lim = (k1 - kb < 256) ? (k1 - kb) : 256;
-    if (i < n) {
-      for (int k = 0; k < lim; ++k) {
-        const int kk = kb + k;
-        if (kk <= i) acc = __builtin_fma(L[(size_t)kk * ld + i], zs[k], acc);
-      }
-    }
-  }
-  if (i < n) partial[(size_t)blockIdx.y * n + i] = acc;
-}
-
-__global__ void trmv_finish_kernel(const double* __restrict__ partial, int n, int nchunks, double mu,
-                                   double* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  double s = mu;
-  for (int c = 0; c < nchunks; ++c) s += partial[(size_t)c * n + i];
-  out[i] = s;
-}
+// K7: the sample transform  out = mu + L z  is strip_reduce_kernel<false, true> + strip_finish_kernel (above).
 
 __global__ void vec_lin_kernel(const double* a, const double* b, double sb, int n, double* out) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1137,14 +1180,34 @@ void launch_extract_row(const double* A, int ld, int row, int n, double* out, hi
   hipLaunchKernelGGL(extract_row_kernel, dim3((n + 255) / 256), dim3(256), 0, st, A, ld, row, n, out);
 }
 
-void launch_rider_var(const double* R, int ld, int nr, int n, double base, double* out, hipStream_t st) {
-  hipLaunchKernelGGL(rider_var_kernel, dim3((nr + 255) / 256), dim3(256), 0, st, R, ld, nr, n, base, out);
+// k-chunk width of the strip reductions: at most 64 chunks, a multiple of 256 columns
+int strip_kc(int nk) { int kc = ((nk + 63) / 64 + 255) / 256 * 256; return kc < 256 ? 256 : kc; }
+size_t strip_partial_elems(int nr, int nk, int nv) {
+  const int kc = strip_kc(nk);
+  return (size_t)((nk + kc - 1) / kc) * nv * ((nr + 63) / 64 * 64);
 }
 
-void launch_backsolve(const double* L, int ld, const double* W, int nblk, double* z, hipStream_t st) {
+// mean_out[r] = mu + sum_k R[r,k] z[k],  var_out[r] = base - sum_k R[r,k]^2  for the nr riders of R (ld, nk columns).
+// R == nullptr (prior): mean = mu, var = base.
+void launch_rider_stats(const double* R, int ld, int nr, int nk, const double* z, double mu, double base, double* partial,
+                        double* mean_out, double* var_out, hipStream_t st) {
+  if (R == nullptr || nk == 0) {
+    if (mean_out) hipLaunchKernelGGL(fill_kernel, dim3((nr + 255) / 256), dim3(256), 0, st, mean_out, nr, mu);
+    if (var_out) hipLaunchKernelGGL(fill_kernel, dim3((nr + 255) / 256), dim3(256), 0, st, var_out, nr, base);
+    return;
+  }
+  const int kc = strip_kc(nk), nch = (nk + kc - 1) / kc, nrp = (nr + 63) / 64 * 64;
+  dim3 grid(nrp / 64, nch);
+  if (var_out) hipLaunchKernelGGL((strip_reduce_kernel<true, false>), grid, dim3(256), 0, st, R, ld, nk, kc, z, partial);
+  else hipLaunchKernelGGL((strip_reduce_kernel<false, false>), grid, dim3(256), 0, st, R, ld, nk, kc, z, partial);
+  hipLaunchKernelGGL(strip_finish_kernel, dim3((nr + 255) / 256), dim3(256), 0, st, partial, nrp, nch, var_out ? 2 : 1, nr, 0,
+                     mu, base, mean_out, var_out);
+}
+
+void launch_backsolve(const BatchPtr& L, int ld, const BatchPtr& W, int nblk, const BatchPtr& z, int nb, hipStream_t st) {
   for (int b = nblk - 1; b >= 0; --b) {
     int grid = (b * 64 + 255) / 256; if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(backsolve_step_kernel, dim3(grid), dim3(256), 0, st, L, ld, W, b, z);
+    hipLaunchKernelGGL(backsolve_step_kernel, dim3(grid, nb), dim3(256), 0, st, L, ld, W, b, z);
   }
 }
 
@@ -1161,9 +1224,23 @@ void launch_sum_partials(const double* partial, int count, double* out, hipStrea
   hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, partial, count, out);
 }
 
+int post_mean_ichunk(int n) { return n > 512 ? 512 : (n < 1 ? 1 : n); }
+size_t post_mean_partial_elems(int ns, int n) {
+  const int ic = post_mean_ichunk(n);
+  return (size_t)((n + ic - 1) / ic) * ((ns + 255) / 256 * 256);
+}
+
+// out[s] = g.mean + sum_i kappa(xs_s, x_i) alpha_i;  alpha == nullptr: the prior mean.
 void launch_post_mean(const double* xs, int ns, const double* x, int n, int d, const double* alpha, LatentDev g,
-                      double* out, hipStream_t st) {
-  hipLaunchKernelGGL(post_mean_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, xs, ns, x, n, d, alpha, g, out);
+                      double* partial, double* out, hipStream_t st) {
+  if (alpha == nullptr || n == 0) {
+    hipLaunchKernelGGL(fill_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, out, ns, g.mean);
+    return;
+  }
+  const int ic = post_mean_ichunk(n), nch = (n + ic - 1) / ic, nsp = (ns + 255) / 256 * 256;
+  hipLaunchKernelGGL(post_mean_kernel, dim3(nsp / 256, nch), dim3(256), 0, st, xs, ns, x, n, d, ic, alpha, g, partial);
+  hipLaunchKernelGGL(strip_finish_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, partial, nsp, nch, 1, ns, 0, g.mean, 0.0,
+                     out, (double*)nullptr);
 }
 
 void launch_mix(const double* lat, int ns, int ml, const double* Hm, int p, int pw, double lat_add, double out_add,
@@ -1178,15 +1255,13 @@ void launch_cov_mix(const BatchPtr& Cl, int ldcl, int nl, const double* Hs, int 
   hipLaunchKernelGGL(cov_mix_kernel, grid, dim3(256), 0, st, Cl, ldcl, nl, Hs, p, ns, jitter, sigma2, init, out);
 }
 
-int trmv_chunks(int n) { int c = (n + 2047) / 2048; return c < 1 ? 1 : c; }
-
+// out = mu + L z for the leading n x n lower triangle of L (ld); partial: strip_partial_elems(n, n, 1) doubles.
 void launch_trmv_lower(const double* L, int ld, int n, const double* z, double mu, double* partial, double* out,
                        hipStream_t st) {
-  const int nch = trmv_chunks(n);
-  const int kchunk = ((n + nch - 1) / nch + 255) / 256 * 256;
-  dim3 grid((n + 255) / 256, nch);
-  hipLaunchKernelGGL(trmv_lower_kernel, grid, dim3(256), 0, st, L, ld, n, z, kchunk, partial);
-  hipLaunchKernelGGL(trmv_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, st, partial, n, nch, mu, out);
+  const int kc = strip_kc(n), nch = (n + kc - 1) / kc, nrp = (n + 63) / 64 * 64;
+  hipLaunchKernelGGL((strip_reduce_kernel<false, true>), dim3(nrp / 64, nch), dim3(256), 0, st, L, ld, n, kc, z, partial);
+  hipLaunchKernelGGL(strip_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, st, partial, nrp, nch, 1, n, kc, mu, 0.0, out,
+                     (double*)nullptr);
 }
 
 void launch_set_identity(double* R, int ld, int nc, hipStream_t st) {
