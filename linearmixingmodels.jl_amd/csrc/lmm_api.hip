@@ -1263,7 +1263,8 @@ int lmm_ilmm_post_mean_and_var(const lmm_post_t* post, double sigma2, const doub
   trsm_rec(R.p, ldr, nr, P->L[0].p, P->ld, P->W[0].p, 0, P->NC, st0);
   DevOut mo(mean_out, (size_t)ns * p), vo(var_out, (size_t)ns * p);
   launch_mix(ml.p, ns, m, Hd.buf.p, p, 1, 0.0, 0.0, nullptr, 0.0, mo.p, st0);
-  launch_dense_var(R.p, ldr, ns, m, N, Hd.buf.p, p, P->latd.p, jit->default_jitter, sigma2, vo.p, st0);
+  Buf<double> dv_part(dense_var_partial_elems(ns, p, N));
+  launch_dense_var(R.p, ldr, ns, m, N, Hd.buf.p, p, P->latd.p, jit->default_jitter, sigma2, dv_part.p, vo.p, st0);
   mo.finish(st0); vo.finish(st0);
   HIPCHK(hipStreamSynchronize(st0));
   return LMM_OK;

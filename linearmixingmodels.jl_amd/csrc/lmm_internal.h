@@ -38,8 +38,9 @@ void launch_gram(const GramArgs& a, hipStream_t st);
 void launch_dense_assemble(const DenseArgs& a, hipStream_t st);
 void launch_dense_cross(double* R, int ldr, int nrows, int ncols, const double* xs, int ns, const double* x, int n, int d,
                         int m, const LatentDev* lat, hipStream_t st);
+size_t dense_var_partial_elems(int ns, int p, int Ncols);
 void launch_dense_var(const double* R, int ldr, int ns, int m, int Ncols, const double* Hm, int p, const LatentDev* lat,
-                      double jitter, double sigma2, double* out, hipStream_t st);
+                      double jitter, double sigma2, double* partial, double* out, hipStream_t st);
 void launch_diag64(const BatchPtr& A, size_t offA, int ld, const BatchPtr& W, size_t offW, int gcol0, int n_real,
                    const BatchInfo& info, int nb, hipStream_t st);
 void launch_gemm_nt(const BatchPtr& C, size_t offC, int ldc, const BatchPtr& A, size_t offA, int lda, const BatchPtr& B,

@@ -350,21 +350,36 @@ __global__ __launch_bounds__(256) void dense_cross_kernel(double* __restrict__ R
 
 // Dense-ILMM posterior variance (reference src/ilmm.jl:122-129 on a PosteriorGP latent):
 //   V[o, s] = sum_l H[o,l]^2 (k_l(0) + jitter) + sigma2 - sum_k ( sum_l H[o,l] R[(l,s), k] )^2,   R = Kxs' L^-T.
-__global__ __launch_bounds__(256) void dense_var_kernel(const double* __restrict__ R, int ldr, int ns, int m, int Ncols,
-                                                        const double* __restrict__ Hm, int p,
-                                                        const LatentDev* __restrict__ lat, double jitter, double sigma2,
-                                                        double* __restrict__ out) {
-  const int s = blockIdx.x * 256 + threadIdx.x;
-  const int o = blockIdx.y;
-  if (s >= ns) return;
-  double base = sigma2, q = 0.0;
-  for (int l = 0; l < m; ++l) { const double h = Hm[o + (size_t)l * p]; base = __builtin_fma(h * h, lat[l].var + jitter, base); }
-  for (int k = 0; k < Ncols; ++k) {
+// Thread per output element e = o * ns + s, the k range cut into chunks of kc columns (blockIdx.y) whose partial sums
+// dense_var_finish_kernel subtracts from the prior term in a fixed order.
+__global__ __launch_bounds__(256) void dense_var_kernel(const double* __restrict__ R, int ldr, int ns, int m, int Ncols, int kc,
+                                                        const double* __restrict__ Hm, int p, double* __restrict__ partial) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= p * ns) return;
+  const int o = e / ns, s = e - o * ns;
+  const int k0 = blockIdx.y * kc;
+  int k1 = k0 + kc; if (k1 > Ncols) k1 = Ncols;
+  double q = 0.0;
+  for (int k = k0; k < k1; ++k) {
+    const double* col = R + (size_t)k * ldr + s;
     double t = 0.0;
-    for (int l = 0; l < m; ++l) t = __builtin_fma(Hm[o + (size_t)l * p], R[(size_t)k * ldr + l * ns + s], t);
+#pragma unroll 4
+    for (int l = 0; l < m; ++l) t = __builtin_fma(Hm[o + (size_t)l * p], col[(size_t)l * ns], t);
     q = __builtin_fma(t, t, q);
   }
-  out[(size_t)o * ns + s] = base - q;
+  partial[(size_t)blockIdx.y * ((size_t)p * ns) + e] = q;
+}
+
+__global__ void dense_var_finish_kernel(const double* __restrict__ partial, int nch, int ns, int m, const double* __restrict__ Hm,
+                                        int p, const LatentDev* __restrict__ lat, double jitter, double sigma2,
+                                        double* __restrict__ out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= p * ns) return;
+  const int o = e / ns;
+  double base = sigma2, q = 0.0;
+  for (int l = 0; l < m; ++l) { const double h = Hm[o + (size_t)l * p]; base = __builtin_fma(h * h, lat[l].var + jitter, base); }
+  for (int c = 0; c < nch; ++c) q += partial[(size_t)c * ((size_t)p * ns) + e];
+  out[e] = base - q;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1098,10 +1113,18 @@ void launch_dense_cross(double* R, int ldr, int nrows, int ncols, const double* 
   hipLaunchKernelGGL(dense_cross_kernel, grid, dim3(256), 0, st, R, ldr, nrows, ncols, xs, ns, x, n, d, m, lat);
 }
 
+int dense_var_kc(int Ncols) { int kc = ((Ncols + 127) / 128 + 63) / 64 * 64; return kc < 64 ? 64 : kc; }   // <= 128 chunks
+size_t dense_var_partial_elems(int ns, int p, int Ncols) {
+  const int kc = dense_var_kc(Ncols);
+  return (size_t)((Ncols + kc - 1) / kc) * p * ns;
+}
+
 void launch_dense_var(const double* R, int ldr, int ns, int m, int Ncols, const double* Hm, int p, const LatentDev* lat,
-                      double jitter, double sigma2, double* out, hipStream_t st) {
-  dim3 grid((ns + 255) / 256, p);
-  hipLaunchKernelGGL(dense_var_kernel, grid, dim3(256), 0, st, R, ldr, ns, m, Ncols, Hm, p, lat, jitter, sigma2, out);
+                      double jitter, double sigma2, double* partial, double* out, hipStream_t st) {
+  const int kc = dense_var_kc(Ncols), nch = (Ncols + kc - 1) / kc, ne = p * ns;
+  hipLaunchKernelGGL(dense_var_kernel, dim3((ne + 255) / 256, nch), dim3(256), 0, st, R, ldr, ns, m, Ncols, kc, Hm, p, partial);
+  hipLaunchKernelGGL(dense_var_finish_kernel, dim3((ne + 255) / 256), dim3(256), 0, st, partial, nch, ns, m, Hm, p, lat, jitter,
+                     sigma2, out);
 }
 
 void launch_dense_assemble(const DenseArgs& a, hipStream_t st) {

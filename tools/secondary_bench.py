@@ -12,7 +12,7 @@ from oracle import lmm_oracle as O      # synthetic problem generator only
 lmm_amd.init(0)
 lib = lmm_amd.load()
 reps = int(sys.argv[sys.argv.index("--reps") + 1]) if "--reps" in sys.argv else 2
-which = [a for a in sys.argv[1:] if a in ("c3", "c4", "c3small")] or ["c3", "c4"]
+which = [a for a in sys.argv[1:] if a in ("c3", "c4", "c3small", "notebook")] or ["c3", "c4", "notebook"]
 
 
 def timed(name, fn, flops, extra=None):
@@ -68,3 +68,35 @@ if "c3" in which:
     run("c3", 64, 128, 8192, 8192, 8)
 if "c4" in which:
     run("c4", 128, 256, 32768, 4096, 16)
+
+
+def notebook():
+    """The reference notebook's posterior timings: p = 600, m = 20 Matern52 latents, 552 training
+    points of a 576-point grid on [0, 20], the 24 held-out points as x*, sigma2 = 1e-6; published (unstated CPU, dense-H ILMM
+    path): marginals 708.977 ms, rand 578.937 ms, logpdf 5.634 s (ILMM) / 172.541 ms (OILMM)."""
+    m, p, s2 = 20, 600, 1e-6
+    perm = np.random.default_rng(1).permutation(576)
+    grid = np.linspace(0.0, 20.0, 576)
+    x, xs = grid[np.sort(perm[:552])], grid[np.sort(perm[552:])]
+    U, S, _ = np.linalg.svd(np.random.default_rng(2).uniform(size=(p, m)), full_matrices=False)
+    fs = lmm_amd.independent_mogp([lmm_amd.GP(lmm_amd.Matern52Kernel()) for _ in range(m)])
+    y = torch.from_numpy(np.random.default_rng(3).standard_normal(552 * p)).cuda()
+    xin = lmm_amd.MOInputIsotopicByOutputs(torch.from_numpy(x).cuda(), p)
+    xsin = lmm_amd.MOInputIsotopicByOutputs(torch.from_numpy(xs).cuda(), p)
+    rng = np.random.default_rng(0)
+    from lmm_amd import model as M
+    for tag, H, pub in (("OILMM", lmm_amd.Orthogonal(np.ascontiguousarray(U), S), (172.541, None, None)),
+                        ("ILMM dense-H", np.ascontiguousarray(U * np.sqrt(S)), (5634.0, 708.977, 578.937))):
+        M.ILMM_ALLOW_DECOUPLED = False          # identical latent kernels: keep the reference's coupled (mn) x (mn) path
+        f = lmm_amd.ILMM(fs, H)
+        cfg = {"config": f"notebook {tag}: p=600, m=20, n=552, n*=24, sigma2=1e-6, f64"}
+        timed(f"notebook {tag} logpdf", lambda: lmm_amd.logpdf(f(xin, s2), y), 0.0, dict(cfg, published_ms=pub[0]))
+        post = timed(f"notebook {tag} posterior", lambda: lmm_amd.posterior(f(xin, s2), y), 0.0, cfg)
+        timed(f"notebook {tag} marginals(post(x*))", lambda: lmm_amd.mean_and_var(post(xsin, s2)), 0.0, dict(cfg, published_ms=pub[1]))
+        timed(f"notebook {tag} rand(post(x*))", lambda: lmm_amd.rand(rng, post(xsin, s2)), 0.0, dict(cfg, published_ms=pub[2]))
+        del post
+    M.ILMM_ALLOW_DECOUPLED = True
+
+
+if "notebook" in which:
+    notebook()
