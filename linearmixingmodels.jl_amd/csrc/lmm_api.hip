@@ -285,7 +285,7 @@ void batch_plan(int ms, int* nb_per, int* nstreams_used, double bytes_per_latent
   if (g.prof && g.prof_serial) b = std::min(bmax, ms);  // instrumented pass: production-sized batches on ONE stream
   int nbatches = (ms + b - 1) / b;
   int ns = std::max(1, std::min(nbatches, eff_streams()));
-  if (bytes_per_latent > 0.0) {
+  if ((double)b * ns * bytes_per_latent > 8e9) {      // small working sets never need the (slow) driver query
     size_t fr = 0, tot = 0;
     if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
       double avail = (double)fr;
