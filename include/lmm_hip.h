@@ -122,6 +122,11 @@ int lmm_ilmm_logpdf_ex(const double* x, int d, int n, const double* y, int p,
  * reference src/independent_mogp.jl:74-80.  y is n x m. */
 int lmm_mogp_logpdf(const double* x, int d, int n, const double* y, int m, double sigma2,
                     const lmm_gp_t* gps, int latent_begin, int latent_end, double* out);
+/* logpdf(ft::FiniteGP{<:IndependentMOGP,<:MOInputIsotopicByFeatures,<:Diagonal{<:Real}}, y) after the reference's
+ * reorder_by_outputs (src/independent_mogp.jl:149-159, 222-229): per-point (heteroscedastic) noise variances
+ * noise_diag[i + l*n] (by-outputs order, n x m), y n x m by-outputs. */
+int lmm_mogp_logpdf_diag(const double* x, int d, int n, const double* y, int m, const double* noise_diag,
+                         const lmm_gp_t* gps, int latent_begin, int latent_end, double* out);
 
 /* ---- posterior ---------------------------------------------------------------------------- */
 /* posterior(fx::FiniteGP{<:OILMM}, y): reference src/oilmm.jl:116-134.  Keeps, per latent of the

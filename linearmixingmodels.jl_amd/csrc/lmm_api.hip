@@ -473,9 +473,10 @@ void residual_on_device(const double* Y, int n, int p, const double* Ty_all, int
 
 // Core: per-latent log marginal likelihoods for latents [l0, l1) given the device rider vectors
 // delta ([latent][rhs][n]) and per-latent noise.  Returns lml[latent * nrhs + rhs] (host).  nrhs > 1: several
-// right-hand sides (matrix-Y logpdf) ride one factorisation.
+// right-hand sides (matrix-Y logpdf) ride one factorisation.  noisevec ([latent of the shard][n], device) replaces the
+// scalar per-latent noise by a per-point diagonal.
 int latent_lmls(const double* xd, int d, int n, const lmm_gp_t* gps, const double* noise, int l0, int l1,
-                const double* delta, std::vector<double>& lml, int nrhs = 1) {
+                const double* delta, std::vector<double>& lml, int nrhs = 1, const double* noisevec = nullptr) {
   const int ms = l1 - l0;
   lml.assign((size_t)ms * nrhs, 0.0);
   if (ms == 0) return LMM_OK;
@@ -499,7 +500,8 @@ int latent_lmls(const double* xd, int d, int n, const lmm_gp_t* gps, const doubl
       GramArgs a{};
       a.A = s.A[j].p; a.ld = D.ld; a.nrows = D.NR; a.ncols = D.NC; a.row_tile0 = 0; a.row_shift = 0; a.full = 0;
       a.x = xd; a.d = d; a.n = n; a.kind = gp.kind; a.var = gp.variance; a.inv_ls = 1.0 / gp.lengthscale;
-      a.diag_add = noise[l0 + k]; a.pad_diag = 1.0;
+      a.diag_add = noisevec ? 0.0 : noise[l0 + k]; a.pad_diag = 1.0;
+      a.diag_vec = noisevec ? noisevec + (size_t)k * n : nullptr;      // per-point noise of latent k (device, n values)
       a.rider = delta + (size_t)k * nrhs * n; a.rider_ld = n; a.nrider = nrhs; a.xs = nullptr; a.ns = 0;
       { const double gb = (double)n * ((double)n + 1.0) / 2.0 * 8.0; ProfScope ps(LMM_PROF_GRAM, gb, s.st, 0, 0, 0, gb); launch_gram(a, s.st); }
       B.add(s.A[j].p, s.W[j].p, info.p + k);
@@ -925,6 +927,31 @@ int lmm_mogp_logpdf(const double* x, int d, int n, const double* y, int m, doubl
   if (ms > 0) project_on_device(yd.p, n, m, Td.buf, m, l0, ms, meansd.buf.p + l0, delta.p, st0);
   std::vector<double> lml;
   if (int rc = latent_lmls(xd.p, d, n, gps, noise.data(), l0, l1, delta.p, lml)) return rc;
+  double total = 0.0;
+  for (int k = 0; k < ms; ++k) total += lml[k];
+  *out = total;
+  return LMM_OK;
+  LMM_CATCH
+}
+
+int lmm_mogp_logpdf_diag(const double* x, int d, int n, const double* y, int m, const double* noise_diag, const lmm_gp_t* gps,
+                         int latent_begin, int latent_end, double* out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  REQUIRE_INIT();
+  LMM_TRY
+  if (!x || !y || !noise_diag || !out || d <= 0 || n <= 0 || m <= 0) return fail(LMM_ERR_ARG, "bad arguments");
+  if (latent_begin < 0 || latent_end > m || latent_begin > latent_end) return fail(LMM_ERR_ARG, "bad latent shard");
+  if (int rc = check_gps(gps, m)) return rc;
+  hipStream_t st0 = g.streams[0];
+  const int l0 = latent_begin, l1 = latent_end, ms = l1 - l0;
+  DevIn xd(x, (size_t)d * n, st0), yd(y, (size_t)n * m, st0), nd(noise_diag, (size_t)n * m, st0);
+  std::vector<double> T((size_t)m * m, 0.0), means(m), noise(m, 0.0);
+  for (int l = 0; l < m; ++l) { T[l + (size_t)l * m] = 1.0; means[l] = gps[l].mean; }
+  Uploaded Td(T, st0), meansd(means, st0);
+  Buf<double> delta((size_t)n * std::max(ms, 1));
+  if (ms > 0) project_on_device(yd.p, n, m, Td.buf, m, l0, ms, meansd.buf.p + l0, delta.p, st0);
+  std::vector<double> lml;
+  if (int rc = latent_lmls(xd.p, d, n, gps, noise.data(), l0, l1, delta.p, lml, 1, nd.p + (size_t)l0 * n)) return rc;
   double total = 0.0;
   for (int k = 0; k < ms; ++k) total += lml[k];
   *out = total;

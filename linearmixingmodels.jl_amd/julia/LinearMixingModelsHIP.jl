@@ -101,6 +101,20 @@ function AbstractGPs.logpdf(ft::LinearMixingModels.IsotropicByOutputsFiniteIndep
     return out[]
 end
 
+# ---- general Diagonal noise on a by-outputs IndependentMOGP (what reference src/independent_mogp.jl:222-229 reaches after
+# reorder_by_outputs, :149-159): per-point noise variances ride the Gram diagonal ------------------------------------
+function AbstractGPs.logpdf(
+    ft::FiniteGP{<:IndependentMOGP,<:MOInputIsotopicByOutputs,<:Diagonal{<:Real,<:Vector}}, y::AbstractVector{<:Real}
+)
+    X = _xmat(ft.x.x); d, n = size(X); m = length(ft.f.fs)
+    gps = _gps(ft.f.fs); yv = Vector{Float64}(y); nv = Vector{Float64}(ft.Σy.diag)
+    out = Ref{Cdouble}(0.0)
+    GC.@preserve X yv nv gps check(ccall((:lmm_mogp_logpdf_diag, liblmm), Cint,
+        (Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Ptr{LmmGp}, Cint, Cint, Ref{Cdouble}),
+        X, d, n, yv, m, nv, gps, 0, m, out))
+    return out[]
+end
+
 # ---- posterior: device-resident state behind an opaque handle ---------------------------------------------------
 # The reference returns ILMM(independent_mogp(posteriors), H) (src/oilmm.jl:133).  The shim returns the same ILMM
 # whose latent container is a `HIPPosteriorMOGP` (an AbstractGP holding the handle), so `post(x*, σ²)` builds a

@@ -71,8 +71,11 @@ class IndependentMOGP:
         self.fs = list(fs)
         self._post = _post
 
-    def __call__(self, x: "MOInputIsotopicByOutputs", sigma2: float = 1e-18) -> "FiniteGP":
-        return FiniteGP(self, x, float(sigma2))
+    def __call__(self, x: "MOInputIsotopicByOutputs", sigma2=1e-18) -> "FiniteGP":
+        """f(x, sigma2) or f(x, diag) with the diagonal of a general Diagonal noise (length n*p, ordered like x)."""
+        if np.isscalar(sigma2) or getattr(sigma2, "ndim", 1) == 0:
+            return FiniteGP(self, x, float(sigma2))
+        return FiniteGP(self, x, sigma2)
 
     def __eq__(self, o):
         return isinstance(o, IndependentMOGP) and self.fs == o.fs and self._post is o._post
@@ -223,10 +226,16 @@ class Normal:
 
 
 class FiniteGP:
-    """AbstractGPs.FiniteGP(f, x, Diagonal(Fill(sigma2, n*p)))."""
+    """AbstractGPs.FiniteGP(f, x, Diagonal(Fill(sigma2, n*p))).  `sigma2` may also be a length n*p vector -- the diagonal of a
+    general `Diagonal` noise, ordered like x -- which the reference accepts for IndependentMOGP logpdf only
+    (src/independent_mogp.jl:149-159, 222-229; ILMM `noise_var` requires a Fill, src/ilmm.jl:41)."""
 
-    def __init__(self, f, x: MOInputIsotopicByOutputs, sigma2: float):
+    def __init__(self, f, x: MOInputIsotopicByOutputs, sigma2):
         self.f, self.x, self.sigma2 = f, x, sigma2
+
+    @property
+    def heteroscedastic(self) -> bool:
+        return not np.isscalar(self.sigma2) and getattr(self.sigma2, "ndim", 1) > 0
 
     def __len__(self):
         return len(self.x)
@@ -283,7 +292,22 @@ def logpdf(fx: FiniteGP, y, with_regulariser: bool = True) -> float:
     if isinstance(x, MOInputIsotopicByFeatures):          # reference src/independent_mogp.jl:222-229
         if not isinstance(f, IndependentMOGP):
             raise TypeError("ILMM needs MOInputIsotopicByOutputs (reference src/ilmm.jl:45)")
+        if fx.heteroscedastic:                            # reorder_by_outputs(Sigma_y, x): src/independent_mogp.jl:149-151
+            s2 = _reorder(s2, x.n, x.out_dim, True)
         return logpdf(FiniteGP(f, x.by_outputs(), s2), _reorder(y, x.n, x.out_dim, True))
+    if fx.heteroscedastic:
+        if not isinstance(f, IndependentMOGP) or f._post is not None:
+            raise TypeError("per-point Diagonal noise is supported for the prior IndependentMOGP logpdf only "
+                            "(reference src/ilmm.jl:41 requires Diagonal{<:Real,<:Fill})")
+        if x.out_dim != len(f.fs):
+            raise RuntimeError("out dim of x != out dim of f.")
+        ya, na = L.Arr(y), L.Arr(s2)
+        if ya.size != x.n * x.out_dim or na.size != x.n * x.out_dim:
+            raise ValueError("length(y), length(diag(Sigma_y)) != n * out_dim")
+        out = C.c_double()
+        L.check(lib.lmm_mogp_logpdf_diag(x.carr().ptr, x.dim, x.n, ya.ptr, len(f.fs), na.ptr, L.gps_array([g.desc() for g in f.fs]),
+                                         0, len(f.fs), C.byref(out)))
+        return out.value
     if hasattr(y, "shape") and len(y.shape) == 2:         # logpdf(fx, Y::AbstractMatrix): one value per column
         return _logpdf_matrix(fx, y, with_regulariser)
     out = C.c_double()

@@ -243,6 +243,17 @@ def mogp_logpdf(gps: Sequence[Dict], x: np.ndarray, s2: float, y: np.ndarray) ->
     return float(sum(gp_logpdf(g, x, s2, Y[l]) for l, g in enumerate(gps)))
 
 
+def mogp_logpdf_diag(gps: Sequence[Dict], x: np.ndarray, noise_diag: np.ndarray, y: np.ndarray) -> float:
+    """logpdf of a by-outputs IndependentMOGP FiniteGP with a general Diagonal noise (what src/independent_mogp.jl:222-229
+    reaches after reorder_by_outputs, :149-159): no specialised method exists for a non-Fill Diagonal, so AbstractGPs'
+    generic dense logpdf runs on cov(f, x) (block diagonal, src/independent_mogp.jl:60-63) + Diagonal(noise_diag)."""
+    n = npoints(x)
+    blocks = [gp_mean_cov(g, x) for g in gps]
+    mean = np.concatenate([b[0] for b in blocks])
+    C = sla.block_diag(*[b[1] for b in blocks]) + np.diag(np.asarray(noise_diag, dtype=float))
+    return gaussian_logpdf(mean, C, np.asarray(y, dtype=float).reshape(len(gps) * n))
+
+
 def mogp_posterior(gps: Sequence[Dict], x: np.ndarray, s2: float, y: np.ndarray) -> List[Dict]:
     """src/independent_mogp.jl:119-126."""
     n = npoints(x)

@@ -174,3 +174,13 @@ def test_oilmm_logpdf_grad_matches_finite_differences():
     for (o, l) in ((0, 0), (3, 1), (2, 0)):
         E = np.zeros((p, m)); E[o, l] = 1.0
         assert G["U"][o, l] == pytest.approx(fd(lambda t: O.oilmm_logpdf(gps, U + t * E, S, x, 0.3, y)), rel=1e-5, abs=1e-6)
+
+
+def test_mogp_diagonal_noise_oracle_reduces_to_scalar_noise():
+    """oracle.mogp_logpdf_diag (dense generic path with a general Diagonal) == the per-latent scalar-noise path for a
+    constant diagonal (reference src/independent_mogp.jl:74-80 vs the generic fallback behind :222-229)."""
+    rng = np.random.default_rng(5)
+    x = np.sort(rng.uniform(0, 4, 25))
+    gps = [{"kind": "se", "variance": 1.3, "lengthscale": 0.7, "mean": 0.2}, {"kind": "matern52", "variance": 0.6, "lengthscale": 1.1, "mean": -0.1}]
+    y = rng.standard_normal(50)
+    assert O.mogp_logpdf_diag(gps, x, np.full(50, 0.3), y) == pytest.approx(O.mogp_logpdf(gps, x, 0.3, y), rel=1e-12)
