@@ -160,6 +160,16 @@ int lmm_ilmm_post_rand(const lmm_post_t* post, double sigma2, int add_noise, con
  * PosteriorGP latent of src/ilmm.jl:196-197.  Outputs length ns*p, by-outputs; sigma2 included. */
 int lmm_ilmm_post_mean_and_var(const lmm_post_t* post, double sigma2, const double* xs, int d, int ns,
                                const lmm_jitters_t* jit, double* mean_out, double* var_out);
+/* mean_and_cov / cov of the dense-H posterior ILMM at xs: reference src/ilmm.jl:132-147 on the PosteriorGP latent
+ * (AbstractGPs.TestUtils secondary interface on `pi`, test/ilmm.jl:34-37).  cov_out is (p ns) x (p ns) column-major,
+ * by-outputs order, sigma2 on the diagonal; small ns only ((p ns)^2 <= 4e8). */
+int lmm_ilmm_post_mean_and_cov(const lmm_post_t* post, double sigma2, const double* xs, int d, int ns,
+                               const lmm_jitters_t* jit, double* mean_out, double* cov_out);
+/* posterior(pi(x2, sigma2), y2): condition the dense-H posterior ILMM on further observations (reference src/ilmm.jl:184-198
+ * applied to the PosteriorGP latent; TestUtils on `pi`, test/ilmm.jl:34-37).  Returns a NEW handle (the old one stays
+ * valid); the two batches may carry different sigma2. */
+int lmm_ilmm_post_condition(const lmm_post_t* post, double sigma2, const double* x2, int d, int n2, const double* y2,
+                            const lmm_jitters_t* jit, lmm_post_t** out);
 
 /* Latent marginals of the (prior if post == NULL, else posterior) latent processes of the shard at xs:
  * mean_lat, var_lat are (m_shard x ns) row-per-latent, i.e. ns x m_shard column-major.  No jitter, no

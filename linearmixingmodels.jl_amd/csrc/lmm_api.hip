@@ -538,6 +538,9 @@ struct lmm_post {
   std::vector<Buf<double>> noisev;    // per latent: per-point projected noise
   // dense ILMM (kind 1): L[0] is the (mn) x (mn) factor, alpha[0] the (mn) weights
   int p = 0;
+  Buf<double> ddelta;           // (mn): projected residuals [latent][point]  (kept for sequential conditioning)
+  std::vector<double> sigs;     // nbatch x (m x m): SigmaT of every conditioning batch (host)
+  std::vector<int> sigidx;      // n: batch index of every training point (host)
   std::vector<double> H;        // p x m column-major (host)
   Buf<LatentDev> latd;          // device latent descriptors
 };
@@ -1204,26 +1207,15 @@ int lmm_mogp_posterior_create(const double* x, int d, int n, const double* y, in
   LMM_CATCH
 }
 
-// posterior(fx::FiniteGP{<:ILMM}, y), dense H: reference src/ilmm.jl:184-198.  One (mn) x (mn) factorisation kept on the
-// device with alpha = C \ (Yproj - mean).
-int lmm_ilmm_posterior_create(const double* x, int d, int n, const double* y, int p, const double* H, int m, double sigma2,
-                              const lmm_gp_t* gps, const lmm_jitters_t* jit, lmm_post_t** out) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  REQUIRE_INIT();
-  LMM_TRY
-  if (!x || !y || !H || !out || d <= 0 || n <= 0 || p <= 0 || m <= 0) return fail(LMM_ERR_ARG, "bad arguments");
-  if (int rc = check_gps(gps, m)) return rc;
-  if (!jit) jit = &kDefaultJit;
+// Dense-H posterior state from the stacked inputs xd (d x n, device), the projected residuals delta ([latent][point], m n,
+// device) and the per-batch SigmaT list: assemble blockdiag(K_l) + SigmaT_{batch(i)} (x) e_i e_i', factor, alpha = C \ delta.
+static int dense_posterior_build(const double* xd, int d, int n, const double* H, int p, int m, const lmm_gp_t* gps,
+                                 const double* delta, const std::vector<double>& sigs, const std::vector<int>& sigidx,
+                                 lmm_post_t** out) {
   if ((long long)m * n > 2000000000LL / 64) return fail(LMM_ERR_UNSUPPORTED, "m*n too large for the dense path");
   hipStream_t st0 = g.streams[0];
-  std::vector<double> T, ST;
-  if (int rc = project_dense(H, p, m, sigma2, jit->project_jitter, T, ST, nullptr)) return rc;
-  DevIn xd(x, (size_t)d * n, st0), yd(y, (size_t)n * p, st0);
-  Uploaded Td(T, st0), STd(ST, st0);
-  std::vector<double> means(m);
   std::vector<LatentDev> lat(m);
-  for (int l = 0; l < m; ++l) { means[l] = gps[l].mean; lat[l] = to_dev(gps[l]); }
-  Uploaded meansd(means, st0);
+  for (int l = 0; l < m; ++l) lat[l] = to_dev(gps[l]);
   const int N = m * n;
   Dims D(N, 1);
   lmm_post* P = new lmm_post();
@@ -1232,12 +1224,16 @@ int lmm_ilmm_posterior_create(const double* x, int d, int n, const double* y, in
     P->NC = D.NC; P->NR = D.NR; P->ld = D.ld;
     P->gps.assign(gps, gps + m);
     P->H.assign(H, H + (size_t)p * m);
+    P->sigs = sigs; P->sigidx = sigidx;
     P->x = Buf<double>((size_t)d * n);
-    HIPCHK(hipMemcpyAsync(P->x.p, xd.p, (size_t)d * n * sizeof(double), hipMemcpyDeviceToDevice, st0));
+    HIPCHK(hipMemcpyAsync(P->x.p, xd, (size_t)d * n * sizeof(double), hipMemcpyDeviceToDevice, st0));
     P->latd = Buf<LatentDev>(m);
     HIPCHK(hipMemcpyAsync(P->latd.p, lat.data(), m * sizeof(LatentDev), hipMemcpyHostToDevice, st0));
-    Buf<double> delta((size_t)n * m);
-    project_on_device(yd.p, n, p, Td.buf, m, 0, m, meansd.buf.p, delta.p, st0);
+    P->ddelta = Buf<double>((size_t)N);
+    HIPCHK(hipMemcpyAsync(P->ddelta.p, delta, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, st0));
+    Uploaded STd(sigs, st0);
+    Buf<int> idxd(n);
+    HIPCHK(hipMemcpyAsync(idxd.p, sigidx.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, st0));
     P->L.emplace_back(D.elems());
     P->W.emplace_back((size_t)(D.NC / 64) * 4096);
     P->alpha.emplace_back((size_t)D.NC);
@@ -1245,7 +1241,7 @@ int lmm_ilmm_posterior_create(const double* x, int d, int n, const double* y, in
     HIPCHK(hipMemsetAsync(info.p, 0, sizeof(int), st0));
     DenseArgs a{};
     a.A = P->L[0].p; a.ld = D.ld; a.nrows = D.NR; a.ncols = D.NC; a.x = P->x.p; a.d = d; a.n = n; a.m = m;
-    a.lat = P->latd.p; a.sigmaT = STd.buf.p; a.rider = delta.p; a.rider_ld = N; a.nrider = 1;
+    a.lat = P->latd.p; a.sigmaT = STd.buf.p; a.sig_idx = idxd.p; a.rider = P->ddelta.p; a.rider_ld = N; a.nrider = 1;
     launch_dense_assemble(a, st0);
     potrf_rec(P->L[0].p, D.ld, D.NR, 0, D.NC, P->W[0].p, N, info.p, st0);
     HIPCHK(hipMemsetAsync(P->alpha[0].p, 0, (size_t)D.NC * sizeof(double), st0));
@@ -1258,13 +1254,70 @@ int lmm_ilmm_posterior_create(const double* x, int d, int n, const double* y, in
   } catch (int code) { delete P; return code; }
   *out = P;
   return LMM_OK;
+}
+
+// posterior(fx::FiniteGP{<:ILMM}, y), dense H: reference src/ilmm.jl:184-198.  One (mn) x (mn) factorisation kept on the
+// device with alpha = C \ (Yproj - mean).
+int lmm_ilmm_posterior_create(const double* x, int d, int n, const double* y, int p, const double* H, int m, double sigma2,
+                              const lmm_gp_t* gps, const lmm_jitters_t* jit, lmm_post_t** out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  REQUIRE_INIT();
+  LMM_TRY
+  if (!x || !y || !H || !out || d <= 0 || n <= 0 || p <= 0 || m <= 0) return fail(LMM_ERR_ARG, "bad arguments");
+  if (int rc = check_gps(gps, m)) return rc;
+  if (!jit) jit = &kDefaultJit;
+  hipStream_t st0 = g.streams[0];
+  std::vector<double> T, ST;
+  if (int rc = project_dense(H, p, m, sigma2, jit->project_jitter, T, ST, nullptr)) return rc;
+  DevIn xd(x, (size_t)d * n, st0), yd(y, (size_t)n * p, st0);
+  Uploaded Td(T, st0);
+  std::vector<double> means(m);
+  for (int l = 0; l < m; ++l) means[l] = gps[l].mean;
+  Uploaded meansd(means, st0);
+  Buf<double> delta((size_t)n * m);
+  project_on_device(yd.p, n, p, Td.buf, m, 0, m, meansd.buf.p, delta.p, st0);
+  return dense_posterior_build(xd.p, d, n, H, p, m, gps, delta.p, ST, std::vector<int>(n, 0), out);
   LMM_CATCH
 }
 
-// mean_and_var(fx::FiniteGP{<:ILMM}) on the dense-H posterior: reference src/ilmm.jl:108-129 with the latent
-// PosteriorGP{IndependentMOGP} of src/ilmm.jl:196-197.  The same numbers as H_full * mu and
-// diag_Xt_A_X(cholesky(latent_cov), H_full') + sigma2, computed without the Cholesky of the 1e-18-jittered latent
-// covariance:  V = sum_l H^2 (k_l(0) + jitter) + sigma2 - rowsumsq((H (x) I) Kxs' L^-T).
+// posterior(pi(x2, sigma2), y2) on the dense-H posterior ILMM (AbstractGPs.TestUtils on `pi`, reference test/ilmm.jl:34-37;
+// src/ilmm.jl:184-198 applied to the PosteriorGP latent): the posterior of the PRIOR given both projected data sets, each
+// with its own SigmaT (x) I noise.  Returns a NEW handle.
+int lmm_ilmm_post_condition(const lmm_post_t* post, double sigma2, const double* x2, int d, int n2, const double* y2,
+                            const lmm_jitters_t* jit, lmm_post_t** out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  REQUIRE_INIT();
+  LMM_TRY
+  if (!post || !x2 || !y2 || !out || d <= 0 || n2 <= 0) return fail(LMM_ERR_ARG, "bad arguments");
+  const lmm_post* P = post;
+  if (P->kind != 1) return fail(LMM_ERR_ARG, "not a dense-H ILMM posterior");
+  if (P->d != d) return fail(LMM_ERR_DIM, "input dimension mismatch");
+  if (!jit) jit = &kDefaultJit;
+  hipStream_t st0 = g.streams[0];
+  const int m = P->m, p = P->p, n1 = P->n, n = n1 + n2;
+  std::vector<double> T, ST;
+  if (int rc = project_dense(P->H.data(), p, m, sigma2, jit->project_jitter, T, ST, nullptr)) return rc;
+  DevIn x2d(x2, (size_t)d * n2, st0), y2d(y2, (size_t)n2 * p, st0);
+  Uploaded Td(T, st0);
+  std::vector<double> means(m);
+  for (int l = 0; l < m; ++l) means[l] = P->gps[l].mean;
+  Uploaded meansd(means, st0);
+  Buf<double> d2((size_t)n2 * m), delta((size_t)n * m), xall((size_t)d * n);
+  project_on_device(y2d.p, n2, p, Td.buf, m, 0, m, meansd.buf.p, d2.p, st0);
+  HIPCHK(hipMemcpyAsync(xall.p, P->x.p, (size_t)d * n1 * sizeof(double), hipMemcpyDeviceToDevice, st0));
+  HIPCHK(hipMemcpyAsync(xall.p + (size_t)d * n1, x2d.p, (size_t)d * n2 * sizeof(double), hipMemcpyDeviceToDevice, st0));
+  for (int l = 0; l < m; ++l) {
+    HIPCHK(hipMemcpyAsync(delta.p + (size_t)l * n, P->ddelta.p + (size_t)l * n1, (size_t)n1 * sizeof(double), hipMemcpyDeviceToDevice, st0));
+    HIPCHK(hipMemcpyAsync(delta.p + (size_t)l * n + n1, d2.p + (size_t)l * n2, (size_t)n2 * sizeof(double), hipMemcpyDeviceToDevice, st0));
+  }
+  std::vector<double> sigs = P->sigs;
+  sigs.insert(sigs.end(), ST.begin(), ST.end());
+  std::vector<int> idx = P->sigidx;
+  idx.resize(n, (int)(P->sigs.size() / ((size_t)m * m)));
+  return dense_posterior_build(xall.p, d, n, P->H.data(), p, m, P->gps.data(), delta.p, sigs, idx, out);
+  LMM_CATCH
+}
+
 int lmm_ilmm_post_mean_and_var(const lmm_post_t* post, double sigma2, const double* xs, int d, int ns,
                                const lmm_jitters_t* jit, double* mean_out, double* var_out) {
   std::lock_guard<std::mutex> lk(g_mu);
@@ -1302,7 +1355,7 @@ int lmm_ilmm_post_mean_and_var(const lmm_post_t* post, double sigma2, const doub
 // with R = Kxs' L^-T, optional rider row, then its Cholesky.  Caller holds g_mu.
 static void dense_post_cov_factor(const lmm_post* P, const double* xsd, int d, int ns, const double* sigadd_dev,
                                   const double* rider, const Dims& Ds, double* A, double* WA, double* R, int ldr, int* info,
-                                  hipStream_t st) {
+                                  hipStream_t st, bool factor = true) {
   const int m = P->m;
   DenseArgs a{};
   a.A = A; a.ld = Ds.ld; a.nrows = Ds.NR; a.ncols = Ds.NC; a.x = xsd; a.d = d; a.n = ns; a.m = m;
@@ -1311,7 +1364,41 @@ static void dense_post_cov_factor(const lmm_post* P, const double* xsd, int d, i
   launch_dense_cross(R, ldr, Ds.NC, P->NC, xsd, ns, P->x.p, P->n, d, m, P->latd.p, st);
   trsm_rec(R, ldr, Ds.NC, P->L[0].p, P->ld, P->W[0].p, 0, P->NC, st);
   launch_gemm_nt(A, Ds.ld, R, ldr, R, ldr, Ds.NC, Ds.NC, P->NC, 1, false, st);
-  potrf_rec(A, Ds.ld, Ds.NR, 0, Ds.NC, WA, m * ns, info, st);
+  if (factor) potrf_rec(A, Ds.ld, Ds.NR, 0, Ds.NC, WA, m * ns, info, st);
+}
+
+// mean_and_cov(pi(xs, sigma2)) / cov on the dense-H posterior ILMM (reference src/ilmm.jl:132-147 with the PosteriorGP latent
+// of :196-197; AbstractGPs.TestUtils secondary interface on `pi`, test/ilmm.jl:34-37): C = H_full (Cov_latent + 1e-18 I)
+// H_full' + sigma2 I, (p ns) x (p ns) column-major, by-outputs order.
+int lmm_ilmm_post_mean_and_cov(const lmm_post_t* post, double sigma2, const double* xs, int d, int ns,
+                               const lmm_jitters_t* jit, double* mean_out, double* cov_out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  REQUIRE_INIT();
+  LMM_TRY
+  if (!post || !xs || !mean_out || !cov_out || d <= 0 || ns <= 0) return fail(LMM_ERR_ARG, "bad arguments");
+  const lmm_post* P = post;
+  if (P->kind != 1) return fail(LMM_ERR_ARG, "not a dense-H ILMM posterior");
+  if (P->d != d) return fail(LMM_ERR_DIM, "input dimension mismatch");
+  if (!jit) jit = &kDefaultJit;
+  const int m = P->m, p = P->p, n = P->n, Ns = m * ns;
+  if ((double)p * ns * (double)p * ns > 4e8) return fail(LMM_ERR_UNSUPPORTED, "full covariance (p*ns)^2 too large");
+  hipStream_t st0 = g.streams[0];
+  DevIn xsd(xs, (size_t)d * ns, st0);
+  Uploaded Hd(P->H, st0), Zd(std::vector<double>((size_t)m * m, 0.0), st0);
+  Buf<double> ml((size_t)Ns), pm_part(post_mean_partial_elems(ns, n));
+  for (int l = 0; l < m; ++l)
+    launch_post_mean(xsd.p, ns, P->x.p, n, d, P->alpha[0].p + (size_t)l * n, to_dev(P->gps[l]), pm_part.p, ml.p + (size_t)l * ns, st0);
+  Dims Ds(Ns, 0);
+  int ldr = Ds.NC; if ((ldr % 512) == 0) ldr += 16;
+  Buf<double> A(Ds.elems()), R((size_t)ldr * P->NC), T((size_t)p * ns * Ns);
+  dense_post_cov_factor(P, xsd.p, d, ns, Zd.buf.p, nullptr, Ds, A.p, nullptr, R.p, ldr, nullptr, st0, false);
+  DevOut mo(mean_out, (size_t)ns * p), co(cov_out, (size_t)ns * p * ns * p);
+  launch_mix(ml.p, ns, m, Hd.buf.p, p, 1, 0.0, 0.0, nullptr, 0.0, mo.p, st0);
+  launch_dense_cov(A.p, Ds.ld, ns, m, Hd.buf.p, p, jit->default_jitter, sigma2, T.p, co.p, st0);
+  mo.finish(st0); co.finish(st0);
+  HIPCHK(hipStreamSynchronize(st0));
+  return LMM_OK;
+  LMM_CATCH
 }
 
 // logpdf(pi(xs, sigma2), ys) on the dense-H posterior ILMM (reference test/ilmm.jl:25; src/ilmm.jl:150-163 with the

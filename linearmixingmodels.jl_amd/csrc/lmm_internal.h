@@ -30,12 +30,15 @@ struct DenseArgs {
   double* A; int ld, nrows, ncols;
   const double* x; int d, n, m;
   const LatentDev* lat;      // device, m entries
-  const double* sigmaT;      // device, m x m column-major
+  const double* sigmaT;      // device, m x m column-major (nbatch of them when sig_idx != nullptr)
+  const int* sig_idx;        // optional, device, n entries: which sigmaT the point's noise block uses (sequential conditioning)
   const double* rider; int rider_ld, nrider;
 };
 
 void launch_gram(const GramArgs& a, hipStream_t st);
 void launch_dense_assemble(const DenseArgs& a, hipStream_t st);
+void launch_dense_cov(const double* S, int lds, int ns, int m, const double* Hm, int p, double jitter, double sigma2, double* T,
+                      double* out, hipStream_t st);
 void launch_dense_cross(double* R, int ldr, int nrows, int ncols, const double* xs, int ns, const double* x, int n, int d,
                         int m, const LatentDev* lat, hipStream_t st);
 size_t dense_var_partial_elems(int ns, int p, int Ncols);

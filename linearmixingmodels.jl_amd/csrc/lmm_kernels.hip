@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void ilmm_dense_assemble_kernel(DenseArgs a) {
             else { r2 = scaled_dist2(a.x + (size_t)ii[e] * a.d, a.x + (size_t)jj * a.d, a.d, g.inv_ls); r = sqrt(r2); }
             val = kappa(g.kind, g.var, r, r2);
           }
-          if (ii[e] == jj) val += a.sigmaT[li[e] + lj * a.m];
+          if (ii[e] == jj) val += a.sigmaT[(size_t)(a.sig_idx ? a.sig_idx[jj] : 0) * a.m * a.m + li[e] + lj * a.m];
         } else if (i >= a.ncols) {
           const int r = i - a.ncols;
           if (a.rider != nullptr && r < a.nrider) val = a.rider[(size_t)r * a.rider_ld + j];
@@ -950,6 +950,39 @@ __global__ __launch_bounds__(256) void mix_kernel(const double* __restrict__ lat
   out[(size_t)o * ns + s] = acc;
 }
 
+// Dense-H posterior full covariance (reference src/ilmm.jl:132-139 with coupled latents): C = H_full S H_full' + sigma2 I
+// for the latent joint covariance S ((m ns) x (m ns), lower triangle of a factor-layout buffer, index l*ns + i), in two
+// passes:  T[(o,i), (l',j)] = sum_l H[o,l] S[(l,i),(l',j)]   then   C[(o,i),(o',j)] = sum_l' T[(o,i),(l',j)] H[o',l'].
+__global__ __launch_bounds__(256) void dense_cov_half_kernel(const double* __restrict__ S, int lds, int ns, int m,
+                                                             const double* __restrict__ Hm, int p, double jitter,
+                                                             double* __restrict__ T) {
+  const int a = blockIdx.x * 256 + threadIdx.x;      // (o, i)
+  const int c = blockIdx.y;                          // (l', j)
+  if (a >= p * ns) return;
+  const int o = a / ns, i = a - o * ns;
+  double acc = 0.0;
+  for (int l = 0; l < m; ++l) {
+    const int r = l * ns + i;
+    const int hi = r > c ? r : c, lo = r > c ? c : r;
+    double v = S[(size_t)lo * lds + hi];
+    if (r == c) v += jitter;
+    acc = __builtin_fma(Hm[o + (size_t)l * p], v, acc);
+  }
+  T[(size_t)c * ((size_t)p * ns) + a] = acc;
+}
+
+__global__ __launch_bounds__(256) void dense_cov_full_kernel(const double* __restrict__ T, int ns, int m,
+                                                             const double* __restrict__ Hm, int p, double sigma2,
+                                                             double* __restrict__ out) {
+  const int a = blockIdx.x * 256 + threadIdx.x;      // (o, i): row
+  const int b = blockIdx.y;                          // (o', j): column
+  if (a >= p * ns) return;
+  const int o2 = b / ns, j = b - o2 * ns;
+  double acc = (a == b) ? sigma2 : 0.0;
+  for (int l = 0; l < m; ++l) acc = __builtin_fma(T[(size_t)(l * ns + j) * ((size_t)p * ns) + a], Hm[o2 + (size_t)l * p], acc);
+  out[(size_t)b * ((size_t)p * ns) + a] = acc;
+}
+
 // Full mixed covariance (reference src/ilmm.jl:132-139 / AbstractGPs cov):
 //   out[(o,i),(o',j)] (+)= sum_{l in chunk} H[o,l] H[o',l] (C_l[i,j] + jitter [i==j])  (+ sigma2 [o==o', i==j] on init)
 // C_l is the lower triangle of a factor-matrix-layout buffer (mirrored here).  out is (p ns) x (p ns) column-major.
@@ -1125,6 +1158,14 @@ void launch_dense_var(const double* R, int ldr, int ns, int m, int Ncols, const 
   hipLaunchKernelGGL(dense_var_kernel, dim3((ne + 255) / 256, nch), dim3(256), 0, st, R, ldr, ns, m, Ncols, kc, Hm, p, partial);
   hipLaunchKernelGGL(dense_var_finish_kernel, dim3((ne + 255) / 256), dim3(256), 0, st, partial, nch, ns, m, Hm, p, lat, jitter,
                      sigma2, out);
+}
+
+// C (p ns x p ns, column-major, by-outputs index o*ns + i) from the latent joint covariance S; T: (p ns) x (m ns) scratch.
+void launch_dense_cov(const double* S, int lds, int ns, int m, const double* Hm, int p, double jitter, double sigma2, double* T,
+                      double* out, hipStream_t st) {
+  const int na = p * ns;
+  hipLaunchKernelGGL(dense_cov_half_kernel, dim3((na + 255) / 256, m * ns), dim3(256), 0, st, S, lds, ns, m, Hm, p, jitter, T);
+  hipLaunchKernelGGL(dense_cov_full_kernel, dim3((na + 255) / 256, na), dim3(256), 0, st, T, ns, m, Hm, p, sigma2, out);
 }
 
 void launch_dense_assemble(const DenseArgs& a, hipStream_t st) {

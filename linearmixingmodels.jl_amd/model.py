@@ -443,8 +443,9 @@ def posterior(fx: FiniteGP, y):
     Ua, Sa, p, m = _H_args(f.H)
     l0, l1 = f.shard
     if f.f._post is not None:          # sequential conditioning of a posterior OILMM (same H: reference src/oilmm.jl:133)
-        if not f.is_oilmm:
-            raise NotImplementedError("sequential conditioning of the dense-H posterior")
+        if not f.is_oilmm:         # dense-H posterior: both projected data sets condition the prior (reference src/ilmm.jl:184-198)
+            L.check(lib.lmm_ilmm_post_condition(f.f._post.ptr, C.c_double(s2), xa.ptr, x.dim, x.n, ya.ptr, None, C.byref(handle)))
+            return ILMM(IndependentMOGP(f.f.fs, _PostHandle(handle, l0, l1)), f.H, shard=f.shard)
         L.check(lib.lmm_post_condition(f.f._post.ptr, Ua.ptr, Sa.ptr, p, m, C.c_double(s2), xa.ptr, x.dim, x.n, ya.ptr,
                                        C.byref(handle)))
         return ILMM(IndependentMOGP(f.f.fs, _PostHandle(handle, l0, l1)), f.H, shard=f.shard)
@@ -512,8 +513,12 @@ def mean_and_cov(fx: FiniteGP):
         jit = L.jitters((1e-9, 0.0, 0.0))          # cov(f, x) + Sigma_y: no latent jitter for a bare MOGP
     else:
         unpack(fx)
-        if not f.is_oilmm and f.f._post is not None:
-            raise NotImplementedError("full covariance of the dense-H posterior ILMM is not built")
+        if not f.is_oilmm and f.f._post is not None:      # coupled latents: reference src/ilmm.jl:132-139 on the PosteriorGP
+            n, p = x.n, f.H.shape[0]
+            mean, cov = np.empty(n * p), np.empty((n * p) * (n * p))
+            L.check(lib.lmm_ilmm_post_mean_and_cov(f.f._post.ptr, C.c_double(s2), xa.ptr, x.dim, n, None, L.Arr(mean, True).ptr,
+                                                   L.Arr(cov, True).ptr))
+            return mean, cov.reshape(n * p, n * p).T
         Ua, Sa, p, m = _H_args(f.H)
         post, descs, shard, jit = f.f._post, [g.desc() for g in f.f.fs], f.shard, None
     n = x.n

@@ -373,7 +373,33 @@ def ilmm_posterior(gps: Sequence[Dict], H: np.ndarray, x: np.ndarray, s2: float,
     mean, C = _ilmm_latent_joint(list(gps), x)
     L = np.linalg.cholesky(C + np.kron(ST, np.eye(n)))
     alpha = sla.cho_solve((L, True), Yproj - mean)
-    return {"gps": list(gps), "x": np.asarray(x, dtype=np.float64), "alpha": alpha, "L": L}
+    return {"gps": list(gps), "x": np.asarray(x, dtype=np.float64), "alpha": alpha, "L": L,
+            "delta": (Yproj - mean).reshape(len(gps), n), "noise": [(ST, n)]}
+
+
+def ilmm_posterior_condition(post: Dict, H: np.ndarray, x2: np.ndarray, s2: float, y2: np.ndarray) -> Dict:
+    """posterior(pi(x2, s2), y2) on the dense-H posterior ILMM: src/ilmm.jl:184-198 applied to the PosteriorGP latent
+    (AbstractGPs updates the Cholesky factor).  The result is the posterior of the PRIOR latents given both projected data
+    sets, batch k carrying the noise SigmaT_k (x) I -- restated here by refactorising the stacked system."""
+    gps = post["gps"]
+    m, n2 = len(gps), npoints(x2)
+    Y2 = reshape_y(y2, n2)
+    check_out_dim(Y2.shape[0], H)
+    T, ST = project_dense(H, s2)
+    x1 = post["x"]
+    xall = np.concatenate([x1, np.asarray(x2, dtype=np.float64)], axis=-1 if np.ndim(x1) == 1 else 1)
+    n = npoints(xall)
+    mean2 = np.array([float(g.get("mean", 0.0)) for g in gps])[:, None]
+    delta = np.concatenate([post["delta"], T @ Y2 - mean2], axis=1)            # m x n
+    noise = post["noise"] + [(ST, n2)]
+    _, C = _ilmm_latent_joint(list(gps), xall)
+    for a in range(m):
+        for b in range(m):
+            dvec = np.concatenate([np.full(nk, STk[a, b]) for STk, nk in noise])
+            C[a * n:(a + 1) * n, b * n:(b + 1) * n] += np.diag(dvec)
+    L = np.linalg.cholesky(C)
+    alpha = sla.cho_solve((L, True), delta.reshape(-1))
+    return {"gps": list(gps), "x": xall, "alpha": alpha, "L": L, "delta": delta, "noise": noise}
 
 
 def ilmm_mean_cov(latent, H: np.ndarray, x: np.ndarray, s2: float) -> Tuple[np.ndarray, np.ndarray]:

@@ -348,6 +348,46 @@ def test_ilmm_dense_mid(lmm):
     np.testing.assert_allclose(s, ref, rtol=1e-6, atol=1e-7)
 
 
+def test_ilmm_dense_posterior_cov_and_sequential_conditioning(lmm):
+    """AbstractGPs.TestUtils secondary interface on the dense-H posterior `pi` (reference test/ilmm.jl:34-37): cov /
+    mean_and_cov(pi) (src/ilmm.jl:132-147 on the PosteriorGP latent) and posterior(pi, y2) (src/ilmm.jl:184-198 again).
+    Checked against the oracle restatement and against the naive dense GP conditioned on both batches, each with its own
+    observation noise."""
+    rng = np.random.default_rng(4242)
+    m, p, n1, n2, ns = 3, 4, 40, 25, 9
+    x1, x2, xs = np.sort(rng.uniform(0, 6, n1)), np.sort(rng.uniform(0, 6, n2)), np.sort(rng.uniform(0, 6, ns))
+    gps = _gps(["se", "matern32", "matern52"], rng)
+    H = rng.uniform(0.2, 1.0, size=(p, m))
+    y1, y2 = rng.standard_normal(n1 * p), rng.standard_normal(n2 * p)
+    f = lmm.ILMM(_to_model(lmm, gps), H)
+    post = lmm.posterior(f(lmm.MOInputIsotopicByOutputs(x1, p), 0.1), y1)
+    po = O.ilmm_posterior(gps, H, x1, 0.1, y1)
+    xsin = lmm.MOInputIsotopicByOutputs(xs, p)
+    mu, Cg = lmm.mean_and_cov(post(xsin, 0.05))
+    mo, Co = O.ilmm_mean_cov(po, H, xs, 0.05)
+    np.testing.assert_allclose(mu, mo, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(Cg, Co, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(Cg, Cg.T, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(np.diag(Cg), lmm.mean_and_var(post(xsin, 0.05))[1], rtol=1e-9)
+    np.testing.assert_allclose(lmm.cov(post(xsin, 0.05)), Cg, rtol=0, atol=0)
+    # sequential conditioning with a different noise on the second batch
+    post2 = lmm.posterior(post(lmm.MOInputIsotopicByOutputs(x2, p), 0.3), y2)
+    po2 = O.ilmm_posterior_condition(po, H, x2, 0.3, y2)
+    mu2, v2 = lmm.mean_and_var(post2(xsin, 0.05))
+    mo2, vo2 = O.ilmm_mean_var(po2, H, xs, 0.05)
+    np.testing.assert_allclose(mu2, mo2, rtol=1e-8, atol=1e-10); np.testing.assert_allclose(v2, vo2, rtol=1e-8)
+    # naive dense GP over by-outputs stacked data: batch 1 with noise 0.1, batch 2 with noise 0.3
+    K11, K12, K22 = O.naive_cov(gps, H, x1), O.naive_cov(gps, H, x1, x2), O.naive_cov(gps, H, x2)
+    Kall = np.block([[K11 + 0.1 * np.eye(n1 * p), K12], [K12.T, K22 + 0.3 * np.eye(n2 * p)]])
+    Ks = np.vstack([O.naive_cov(gps, H, x1, xs), O.naive_cov(gps, H, x2, xs)])
+    yall = np.concatenate([y1 - O.naive_mean(gps, H, x1), y2 - O.naive_mean(gps, H, x2)])
+    mn = O.naive_mean(gps, H, xs) + Ks.T @ np.linalg.solve(Kall, yall)
+    vn = np.diag(O.naive_cov(gps, H, xs) - Ks.T @ np.linalg.solve(Kall, Ks)) + 0.05
+    np.testing.assert_allclose(mu2, mn, rtol=1e-5, atol=1e-6); np.testing.assert_allclose(v2, vn, rtol=1e-5)
+    # the first handle is still valid and unchanged
+    np.testing.assert_allclose(lmm.mean_and_cov(post(xsin, 0.05))[1], Cg, rtol=0, atol=0)
+
+
 def test_ilmm_identical_kernels_decoupled_equals_dense(lmm):
     """Dense-H ILMM whose latents share one kernel (BASELINE configs[1] shape): the decoupled shortcut (m independent
     n x n factorisations under the eigen-rotation of SigmaT) equals the reference's single (mn) x (mn) factorisation."""

@@ -184,3 +184,24 @@ def test_mogp_diagonal_noise_oracle_reduces_to_scalar_noise():
     gps = [{"kind": "se", "variance": 1.3, "lengthscale": 0.7, "mean": 0.2}, {"kind": "matern52", "variance": 0.6, "lengthscale": 1.1, "mean": -0.1}]
     y = rng.standard_normal(50)
     assert O.mogp_logpdf_diag(gps, x, np.full(50, 0.3), y) == pytest.approx(O.mogp_logpdf(gps, x, 0.3, y), rel=1e-12)
+
+
+def test_dense_ilmm_sequential_conditioning_matches_naive_two_batch_gp():
+    """oracle.ilmm_posterior_condition (reference src/ilmm.jl:184-198 applied to a posterior; TestUtils on `pi`,
+    test/ilmm.jl:34-37) == the naive dense GP conditioned on both batches, each with its own observation noise."""
+    rng = np.random.default_rng(1)
+    m, p, n1, n2, ns = 2, 3, 12, 7, 5
+    x1, x2, xs = np.sort(rng.uniform(0, 6, n1)), np.sort(rng.uniform(0, 6, n2)), np.sort(rng.uniform(0, 6, ns))
+    gps = [{"kind": "se", "variance": 1.2, "lengthscale": 0.8, "mean": 0.1}, {"kind": "matern32", "variance": 0.7, "lengthscale": 1.3, "mean": -0.2}]
+    H = rng.uniform(0.2, 1, (p, m))
+    y1, y2 = rng.standard_normal(n1 * p), rng.standard_normal(n2 * p)
+    po2 = O.ilmm_posterior_condition(O.ilmm_posterior(gps, H, x1, 0.1, y1), H, x2, 0.3, y2)
+    mo, vo = O.ilmm_mean_var(po2, H, xs, 0.05)
+    K11, K12, K22 = O.naive_cov(gps, H, x1), O.naive_cov(gps, H, x1, x2), O.naive_cov(gps, H, x2)
+    Kall = np.block([[K11 + 0.1 * np.eye(n1 * p), K12], [K12.T, K22 + 0.3 * np.eye(n2 * p)]])
+    Ks = np.vstack([O.naive_cov(gps, H, x1, xs), O.naive_cov(gps, H, x2, xs)])
+    yall = np.concatenate([y1 - O.naive_mean(gps, H, x1), y2 - O.naive_mean(gps, H, x2)])
+    mn = O.naive_mean(gps, H, xs) + Ks.T @ np.linalg.solve(Kall, yall)
+    vn = np.diag(O.naive_cov(gps, H, xs) - Ks.T @ np.linalg.solve(Kall, Ks)) + 0.05
+    np.testing.assert_allclose(mo, mn, rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(vo, vn, rtol=1e-7)
