@@ -202,6 +202,69 @@ function AbstractGPs.rand(rng::AbstractRNG, fx::FiniteGP{<:ILMM{<:IndependentMOG
     return _rand(rng, C_NULL, _gps(f.fs), Matrix{Float64}(H), Ptr{Cdouble}(C_NULL), p, m, σ², _xmat(x))
 end
 
+# ---- dense-H ILMM posterior (reference src/ilmm.jl:184-198 and the methods of :108-163 on its PosteriorGP latent): ONE
+# coupled (mn) x (mn) factorisation behind the handle ---------------------------------------------------------------
+const HIPPosteriorILMM = ILMM{<:HIPPosteriorMOGP,<:Matrix}
+
+function AbstractGPs.posterior(fx::FiniteGP{<:ILMM{<:IndependentMOGP,<:Matrix}}, y::AbstractVector{<:Real})
+    f, H, σ², x = unpack(fx)
+    X = _xmat(x); d, n = size(X); p, m = size(H)
+    gps = _gps(f.fs); Hm = Matrix{Float64}(H); yv = Vector{Float64}(y)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve X yv Hm gps check(ccall((:lmm_ilmm_posterior_create, liblmm), Cint,
+        (Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Cint, Cdouble, Ptr{LmmGp}, Ptr{LmmJitters},
+         Ref{Ptr{Cvoid}}), X, d, n, yv, p, Hm, m, σ², gps, C_NULL, h))
+    return ILMM(HIPPosteriorMOGP(f.fs, h[]), H)
+end
+
+# posterior(pi(x₂, σ²), y₂): AbstractGPs.TestUtils on `pi` (reference test/ilmm.jl:34-37)
+function AbstractGPs.posterior(fx::FiniteGP{<:HIPPosteriorILMM}, y::AbstractVector{<:Real})
+    X = _xmat(fx.x.x); d, n2 = size(X); yv = Vector{Float64}(y)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve X yv check(ccall((:lmm_ilmm_post_condition, liblmm), Cint,
+        (Ptr{Cvoid}, Cdouble, Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Ptr{LmmJitters}, Ref{Ptr{Cvoid}}),
+        fx.f.f.handle, noise_var(fx.Σy), X, d, n2, yv, C_NULL, h))
+    return ILMM(HIPPosteriorMOGP(fx.f.f.fs, h[]), fx.f.H)
+end
+
+function AbstractGPs.mean_and_var(fx::FiniteGP{<:HIPPosteriorILMM})
+    X = _xmat(fx.x.x); d, ns = size(X); p = size(fx.f.H, 1)
+    M = Vector{Float64}(undef, ns * p); V = similar(M)
+    GC.@preserve X M V check(ccall((:lmm_ilmm_post_mean_and_var, liblmm), Cint,
+        (Ptr{Cvoid}, Cdouble, Ptr{Cdouble}, Cint, Cint, Ptr{LmmJitters}, Ptr{Cdouble}, Ptr{Cdouble}),
+        fx.f.f.handle, noise_var(fx.Σy), X, d, ns, C_NULL, M, V))
+    return M, V
+end
+
+# replaces reference src/ilmm.jl:132-147 on the posterior
+function AbstractGPs.mean_and_cov(fx::FiniteGP{<:HIPPosteriorILMM})
+    X = _xmat(fx.x.x); d, ns = size(X); p = size(fx.f.H, 1)
+    M = Vector{Float64}(undef, ns * p); Cm = Matrix{Float64}(undef, ns * p, ns * p)
+    GC.@preserve X M Cm check(ccall((:lmm_ilmm_post_mean_and_cov, liblmm), Cint,
+        (Ptr{Cvoid}, Cdouble, Ptr{Cdouble}, Cint, Cint, Ptr{LmmJitters}, Ptr{Cdouble}, Ptr{Cdouble}),
+        fx.f.f.handle, noise_var(fx.Σy), X, d, ns, C_NULL, M, Cm))
+    return M, Cm
+end
+AbstractGPs.cov(fx::FiniteGP{<:HIPPosteriorILMM}) = mean_and_cov(fx)[2]
+
+function AbstractGPs.logpdf(fx::FiniteGP{<:HIPPosteriorILMM}, y::AbstractVector{<:Real})
+    X = _xmat(fx.x.x); d, ns = size(X); yv = Vector{Float64}(y)
+    out = Ref{Cdouble}(0.0)
+    GC.@preserve X yv check(ccall((:lmm_ilmm_post_logpdf, liblmm), Cint,
+        (Ptr{Cvoid}, Cdouble, Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Ptr{LmmJitters}, Ref{Cdouble}),
+        fx.f.f.handle, noise_var(fx.Σy), X, d, ns, yv, C_NULL, out))
+    return out[]
+end
+
+function AbstractGPs.rand(rng::AbstractRNG, fx::FiniteGP{<:HIPPosteriorILMM})
+    X = _xmat(fx.x.x); d, ns = size(X); p, m = size(fx.f.H)
+    z = randn(rng, ns * m); ε = randn(rng, ns * p); out = Vector{Float64}(undef, ns * p)
+    GC.@preserve X z ε out check(ccall((:lmm_ilmm_post_rand, liblmm), Cint,
+        (Ptr{Cvoid}, Cdouble, Cint, Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{LmmJitters}, Ptr{Cdouble}),
+        fx.f.f.handle, noise_var(fx.Σy), 1, X, d, ns, z, ε, C_NULL, out))
+    return out
+end
+
 # ---- gradients: ChainRulesCore.rrule around the ccall (reference tests: `gradient(logpdf, oilmmx, y) isa Tuple`,
 # test/oilmm.jl:31-32).  lmm_oilmm_logpdf_grad returns d/dy, d/dsigma2, d/dS, d/dU and per-latent (variance, lengthscale,
 # mean) cotangents in one pass; they are mapped back onto the reference's structs as Tangents. -------------------------
