@@ -481,11 +481,17 @@ __global__ __launch_bounds__(256) void diag64_kernel(BatchPtr Ab, size_t offA, i
 // blk of MFMA (u, v, s) is the 4x4 product of row group blk with column group (blk + s) mod 4: 4 rotations cover a
 // 16 x 16 tile.  Per k-step of 4: 4 + 4 TN ds_read_b64 feed 16 TN MFMAs (16 cycles each).
 // ---------------------------------------------------------------------------------------------------
+#ifdef LMM_CLOCK_PROBE
+__device__ unsigned long long g_clk_probe[4];     // tools/gemm_ablate: shader-clock vs 100 MHz real-time ticks of one tile
+#endif
 template <int BN, bool SET>
 __global__ __launch_bounds__(256, 2) void gemm44_kernel(BatchPtr Cb, size_t goffC, int ldc, BatchPtr Ab, size_t goffA, int lda,
                                                          BatchPtr Bb, size_t goffB, int ldb,
                                                          int M, int N, int K, int lower, int MT, int full_items,
                                                          int splitk, int kfrom_row) {
+#ifdef LMM_CLOCK_PROBE
+  const unsigned long long clk0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
   double* C = Cb.p[blockIdx.y] + goffC;
   const double* A = Ab.p[blockIdx.y] + goffA;
   const double* B = Bb.p[blockIdx.y] + goffB;
@@ -601,7 +607,9 @@ __global__ __launch_bounds__(256, 2) void gemm44_kernel(BatchPtr Cb, size_t goff
 #endif
 #ifndef LMM_ABLATE_NOMFMA
     if (active) {
-      __builtin_amdgcn_s_setprio(1);     // two workgroups share each SIMD: let the one in its MFMA phase issue first (+2 %)
+      // two workgroups share each SIMD: the one in its MFMA phase issues first (+2 %); odd work items one level higher, so
+      // that two co-resident workgroups do not trade the pipe instruction by instruction (+0.8 %)
+      if (blockIdx.x & 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
       const double* as = &As[buf][0];
       const double* bs = &Bs[buf][0];
 #pragma unroll
@@ -670,6 +678,11 @@ __global__ __launch_bounds__(256, 2) void gemm44_kernel(BatchPtr Cb, size_t goff
     }
     __builtin_amdgcn_wave_barrier();
   }
+#ifdef LMM_CLOCK_PROBE
+  if (blockIdx.x == 300 && threadIdx.x == 0) {
+    g_clk_probe[0] = __builtin_readcyclecounter() - clk0; g_clk_probe[1] = __builtin_amdgcn_s_memrealtime() - rt0;
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1111,6 +1124,9 @@ __global__ void reorder_kernel(const double* __restrict__ in, int n, int p, int 
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mfma_f64_peak_kernel(double* out, int iters) {
   // v_mfma_f64_4x4x4_4b_f64 with the update kernel's operand pattern: 4 A-fragments x 16 B-fragments, 64 accumulators
+#ifdef LMM_CLOCK_PROBE
+  const unsigned long long clk0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
   double acc[64], a[4], b[16];
 #pragma unroll
   for (int q = 0; q < 64; ++q) acc[q] = 0.0;
@@ -1128,6 +1144,11 @@ __global__ __launch_bounds__(256) void mfma_f64_peak_kernel(double* out, int ite
 #pragma unroll
   for (int q = 0; q < 64; ++q) s += acc[q];
   out[blockIdx.x * 256 + threadIdx.x] = s;
+#ifdef LMM_CLOCK_PROBE
+  if (blockIdx.x == 100 && threadIdx.x == 0) {
+    g_clk_probe[2] = __builtin_readcyclecounter() - clk0; g_clk_probe[3] = __builtin_amdgcn_s_memrealtime() - rt0;
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------

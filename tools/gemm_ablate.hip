@@ -28,7 +28,21 @@ int main(int argc, char** argv) {
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
     double fl = lower ? 2.0 * K * ((double)N * (N + 1) / 2 + (double)(M - N) * N) : 2.0 * M * N * (double)K;
+#ifdef LMM_CLOCK_PROBE
+    { unsigned long long h[4]; hipMemcpyFromSymbol(h, HIP_SYMBOL(g_clk_probe), sizeof h);
+      printf("  tile of block 300: %llu shader clocks in %llu ticks of 100 MHz -> %.0f MHz\n", h[0], h[1], h[1] ? 100.0 * h[0] / h[1] : 0.0); }
+#endif
     printf("%s rnd=%d M=%d N=%d K=%d lower=%d: %.3f ms  %.2f TFLOP/s (algorithmic)\n", which ? "mfma16x16x4" : "mfma4x4x4_4b", rnd, M, N, K, lower, ms, fl / ms / 1e9);
   }
+#ifdef LMM_CLOCK_PROBE
+  { double* o; hipMalloc(&o, 256 * 256 * 8);
+    for (int iters : {20000, 200000}) {
+      hipEventRecord(e0); launch_mfma_peak(o, 256, iters, 0); hipEventRecord(e1); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      unsigned long long h[4]; hipMemcpyFromSymbol(h, HIP_SYMBOL(g_clk_probe), sizeof h);
+      printf("mfma peak probe iters=%d: %.3f ms  %.2f TF;  %llu shader clocks in %llu ticks -> %.0f MHz\n", iters, ms,
+             256.0 * 4 * iters * 64.0 * 512.0 / ms / 1e9, h[2], h[3], h[3] ? 100.0 * h[2] / h[3] : 0.0);
+    } }
+#endif
   return 0;
 }
