@@ -616,12 +616,20 @@ __global__ __launch_bounds__(256, 2) void gemm44_kernel(BatchPtr Cb, size_t goff
       for (int s4 = 0; s4 < BK / 4; ++s4) {
         double fa[TM];
 #pragma unroll
+#ifdef LMM_ABLATE_NOLDSREAD
+        for (int u = 0; u < TM; ++u) fa[u] = __builtin_amdgcn_readfirstlane(kt) * 1e-9 + u + s4;   // operands from registers (ablation)
+#else
         for (int u = 0; u < TM; ++u) fa[u] = as[offA + 4 * s4 * SA + 16 * u];
+#endif
 #pragma unroll
         for (int v = 0; v < TN; ++v) {
           double fb[4];
 #pragma unroll
+#ifdef LMM_ABLATE_NOLDSREAD
+          for (int s = 0; s < 4; ++s) fb[s] = lane * 1e-9 + s + v;
+#else
           for (int s = 0; s < 4; ++s) fb[s] = bs[offB[s] + 4 * s4 * SB + 16 * v];
+#endif
 #pragma unroll
           for (int u = 0; u < TM; ++u)
 #pragma unroll
