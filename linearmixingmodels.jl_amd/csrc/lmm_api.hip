@@ -266,6 +266,20 @@ void trsm_rec(double* R, int ldr, int nr, const double* L, int ld, const double*
   trsm_rec(R, ldr, nr, L, ld, W, j0 + h, w - h, st, tri);
 }
 
+// The same solve for a batch of (R_j, L_j, W_j) of identical shapes in lock-step launches (blockIdx.y = matrix).
+void trsm_rec(const BatchPtr& R, int ldr, int nr, const BatchPtr& L, int ld, const BatchPtr& W, int nb, int j0, int w,
+              hipStream_t st) {
+  if (w <= 64) {
+    launch_gemm_nt(R, (size_t)j0 * ldr, ldr, R, (size_t)j0 * ldr, ldr, W, (size_t)(j0 / 64) * 4096, 64, nr, 64, 64, 0, true, nb, st);
+    return;
+  }
+  const int h = split(w);
+  trsm_rec(R, ldr, nr, L, ld, W, nb, j0, h, st);
+  launch_gemm_nt(R, (size_t)(j0 + h) * ldr, ldr, R, (size_t)j0 * ldr, ldr, L, (size_t)j0 * ld + (j0 + h), ld, nr, w - h, h, 0, false,
+                 nb, st);
+  trsm_rec(R, ldr, nr, L, ld, W, nb, j0 + h, w - h, st);
+}
+
 // alpha (in place over z = L^-1 delta) <- L^-T z for one factor matrix
 void backsolve1(const double* L, int ld, const double* W, int nblk, double* z, hipStream_t st) {
   BatchPtr Lb{}, Wb{}, zb{};
@@ -1495,6 +1509,16 @@ int lmm_post_destroy(lmm_post_t* post) {
   return LMM_OK;
 }
 
+// Rk (nsr x NC, ldr) = K(xs, x): the cross-Gram of a posterior latent's training inputs as rider rows (rows beyond ns zero).
+static void cross_gram(const lmm_post* P, const lmm_gp_t& gp, const double* xsd, int d, int ns, double* Rk, int ldr, int nsr,
+                       hipStream_t st) {
+  GramArgs r{};
+  r.A = Rk; r.ld = ldr; r.nrows = P->NC + nsr; r.ncols = P->NC; r.row_tile0 = P->NC / 64; r.row_shift = P->NC; r.full = 1;
+  r.x = P->x.p; r.d = d; r.n = P->n; r.kind = gp.kind; r.var = gp.variance; r.inv_ls = 1.0 / gp.lengthscale;
+  r.xs = xsd; r.ns = ns;
+  launch_gram(r, st);
+}
+
 // Latent marginals (mean, var) of latents [l0, l1) at xs into device arrays (ns per latent).
 // post != NULL: posterior latents; else prior latents gps[l0..l1).  Caller holds g_mu.
 static int latent_marginals_dev(const lmm_post* P, const lmm_gp_t* gps_shard, int ms, const double* xsd, int d, int ns,
@@ -1512,24 +1536,34 @@ static int latent_marginals_dev(const lmm_post* P, const lmm_gp_t* gps_shard, in
   }
   if (P->d != d) return fail(LMM_ERR_DIM, "input dimension mismatch: posterior has d=%d, xs has d=%d", P->d, d);
   const int nsr = rup(ns, 64);
-  const int nslots = std::min(ms, g.nstreams);
   int ldr = nsr; if ((ldr % 512) == 0) ldr += 16;
-  std::vector<Buf<double>> R, part;
-  for (int s = 0; s < nslots; ++s) { R.emplace_back((size_t)ldr * P->NC); part.emplace_back(strip_partial_elems(nsr, P->NC, 2)); }
+  int nb_per = 1, nslots = 1;
+  batch_plan(ms, &nb_per, &nslots, (double)ldr * P->NC * sizeof(double));
+  std::vector<std::vector<Buf<double>>> R(nslots);
+  std::vector<Buf<double>> part;
+  for (int s = 0; s < nslots; ++s) {
+    for (int j = 0; j < nb_per; ++j) R[s].emplace_back((size_t)ldr * P->NC);
+    part.emplace_back(strip_partial_elems(nsr, P->NC, 2));
+  }
   fork_slots(nslots);
-  for (int k = 0; k < ms; ++k) {
-    hipStream_t st = g.streams[k % nslots];
-    double* Rk = R[k % nslots].p;
-    const lmm_gp_t& gp = P->gps[P->l0 + k];
-    GramArgs a{};
-    a.A = Rk; a.ld = ldr; a.nrows = P->NC + nsr; a.ncols = P->NC; a.row_tile0 = P->NC / 64; a.row_shift = P->NC; a.full = 1;
-    a.x = P->x.p; a.d = d; a.n = P->n; a.kind = gp.kind; a.var = gp.variance; a.inv_ls = 1.0 / gp.lengthscale;
-    a.diag_add = 0.0; a.pad_diag = 0.0; a.xs = xsd; a.ns = ns;
-    launch_gram(a, st);
-    trsm_rec(Rk, ldr, nsr, P->L[k].p, P->ld, P->W[k].p, 0, P->NC, st);
-    // mean = mu + K(x*,x) alpha = mu + R' (L^-1 delta);  var = kappa(0) - colsumsq(R)   (one pass over R)
-    launch_rider_stats(Rk, ldr, ns, P->n, P->z[k].p, gp.mean, gp.variance, part[k % nslots].p, mean_lat + (size_t)k * ns,
-                       var_lat + (size_t)k * ns, st);
+  int bi = 0;
+  for (int k0 = 0; k0 < ms; k0 += nb_per, ++bi) {
+    const int s = bi % nslots, nb = std::min(nb_per, ms - k0);
+    hipStream_t st = g.streams[s];
+    BatchPtr Rb{}, Lb{}, Wb{};
+    for (int j = 0; j < nb; ++j) {
+      const int k = k0 + j;
+      cross_gram(P, P->gps[P->l0 + k], xsd, d, ns, R[s][j].p, ldr, nsr, st);
+      Rb.p[j] = R[s][j].p; Lb.p[j] = P->L[k].p; Wb.p[j] = P->W[k].p;
+    }
+    trsm_rec(Rb, ldr, nsr, Lb, P->ld, Wb, nb, 0, P->NC, st);       // R_j <- K(x*, x) L_j^-T for the whole batch
+    for (int j = 0; j < nb; ++j) {
+      const int k = k0 + j;
+      const lmm_gp_t& gp = P->gps[P->l0 + k];
+      // mean = mu + K(x*,x) alpha = mu + R' (L^-1 delta);  var = kappa(0) - colsumsq(R)   (one pass over R)
+      launch_rider_stats(R[s][j].p, ldr, ns, P->n, P->z[k].p, gp.mean, gp.variance, part[s].p, mean_lat + (size_t)k * ns,
+                         var_lat + (size_t)k * ns, st);
+    }
   }
   join_slots(nslots);
   HIPCHK(hipStreamSynchronize(g.streams[0]));   // R buffers are released on return
@@ -1589,11 +1623,7 @@ int lmm_oilmm_mean_and_var(const lmm_post_t* post, const lmm_gp_t* gps, const do
 // R (nsr x NC, ldr) = K(xs, x) L^-T for latent k of the posterior: the riders of the cross-Gram solved against the factor.
 static void cross_solve(const lmm_post* P, int k, const lmm_gp_t& gp, const double* xsd, int d, int ns, double* Rk, int ldr,
                         int nsr, hipStream_t st) {
-  GramArgs r{};
-  r.A = Rk; r.ld = ldr; r.nrows = P->NC + nsr; r.ncols = P->NC; r.row_tile0 = P->NC / 64; r.row_shift = P->NC; r.full = 1;
-  r.x = P->x.p; r.d = d; r.n = P->n; r.kind = gp.kind; r.var = gp.variance; r.inv_ls = 1.0 / gp.lengthscale;
-  r.xs = xsd; r.ns = ns;
-  launch_gram(r, st);
+  cross_gram(P, gp, xsd, d, ns, Rk, ldr, nsr, st);
   trsm_rec(Rk, ldr, nsr, P->L[k].p, P->ld, P->W[k].p, 0, P->NC, st);
 }
 
@@ -1611,25 +1641,36 @@ static void cov_at_xs(const lmm_post* P, const lmm_gp_t& gp, const double* xsd, 
 }
 
 // Working buffers of the batched "covariance at xs" loops (rand, posterior logpdf): per stream slot nb_per factor matrices
-// with their inverse blocks, means and riders, ONE cross-solve block R and one reduction scratch (reused latent after latent
-// in stream order).
+// with their inverse blocks, means, riders and cross-solve blocks R, and one reduction scratch (reused latent after latent in
+// stream order).
 struct XsSlots {
   int nb_per = 1, nslots = 1, ldr = 0, nsr = 0;
-  std::vector<std::vector<Buf<double>>> B, WB, mu, rid;
-  std::vector<Buf<double>> R, part;
+  std::vector<std::vector<Buf<double>>> B, WB, mu, rid, R;
+  std::vector<Buf<double>> part;
   XsSlots(const lmm_post* P, int ms, int ns, const Dims& Ds) {
     nsr = rup(ns, 64);
     ldr = nsr; if ((ldr % 512) == 0) ldr += 16;
-    batch_plan(std::max(ms, 1), &nb_per, &nslots, (double)Ds.elems() * sizeof(double));
-    B.resize(nslots); WB.resize(nslots); mu.resize(nslots); rid.resize(nslots);
+    batch_plan(std::max(ms, 1), &nb_per, &nslots, ((double)Ds.elems() + (P ? (double)ldr * P->NC : 0.0)) * sizeof(double));
+    B.resize(nslots); WB.resize(nslots); mu.resize(nslots); rid.resize(nslots); R.resize(nslots);
     for (int s = 0; s < nslots; ++s) {
       for (int j = 0; j < nb_per; ++j) {
         B[s].emplace_back(Ds.elems()); WB[s].emplace_back((size_t)(Ds.NC / 64) * 4096);
         mu[s].emplace_back((size_t)ns); rid[s].emplace_back((size_t)ns);
+        R[s].emplace_back(P ? (size_t)ldr * P->NC : 1);
       }
-      R.emplace_back(P ? (size_t)ldr * P->NC : 1);
       part.emplace_back(std::max(strip_partial_elems(nsr, P ? P->NC : 1, 1), strip_partial_elems(ns, ns, 1)));
     }
+  }
+  // R[s][j] <- K(xs, x) L_k^-T and mu[s][j] <- mean_k(xs) for the latents k0..k0+nb-1 of the posterior's shard (one batched solve)
+  void cross_solve_batch(const lmm_post* P, int s, int k0, int nb, const double* xsd, int d, int ns, hipStream_t st) {
+    BatchPtr Rb{}, Lb{}, Wb{};
+    for (int j = 0; j < nb; ++j) {
+      cross_gram(P, P->gps[P->l0 + k0 + j], xsd, d, ns, R[s][j].p, ldr, nsr, st);
+      Rb.p[j] = R[s][j].p; Lb.p[j] = P->L[k0 + j].p; Wb.p[j] = P->W[k0 + j].p;
+    }
+    trsm_rec(Rb, ldr, nsr, Lb, P->ld, Wb, nb, 0, P->NC, st);
+    for (int j = 0; j < nb; ++j)
+      launch_rider_stats(R[s][j].p, ldr, ns, P->n, P->z[k0 + j].p, P->gps[P->l0 + k0 + j].mean, 0.0, part[s].p, mu[s][j].p, nullptr, st);
   }
 };
 
@@ -1733,13 +1774,12 @@ int lmm_oilmm_post_logpdf(const lmm_post_t* post, const double* U, const double*
     const int s = bi % nslots, nb = std::min(X.nb_per, ms - k0);
     hipStream_t st = g.streams[s];
     Batch Bt;
+    X.cross_solve_batch(P, s, k0, nb, xsd.p, d, ns, st);
     for (int j = 0; j < nb; ++j) {
       const int k = k0 + j;
       const lmm_gp_t& gp = P->gps[l0 + k];
-      cross_solve(P, k, gp, xsd.p, d, ns, X.R[s].p, X.ldr, X.nsr, st);
-      launch_rider_stats(X.R[s].p, X.ldr, ns, P->n, P->z[k].p, gp.mean, 0.0, X.part[s].p, X.mu[s][j].p, nullptr, st);
       launch_vec_lin(Ty_shard + (size_t)k * ns, X.mu[s][j].p, -1.0, ns, X.rid[s][j].p, st);
-      cov_at_xs(P, gp, xsd.p, d, ns, ST[l0 + k], X.rid[s][j].p, Ds, X.B[s][j].p, X.R[s].p, X.ldr, st);
+      cov_at_xs(P, gp, xsd.p, d, ns, ST[l0 + k], X.rid[s][j].p, Ds, X.B[s][j].p, X.R[s][j].p, X.ldr, st);
       Bt.add(X.B[s][j].p, X.WB[s][j].p, info.p + k);
     }
     potrf_rec(Bt, Ds.ld, Ds.NR, 0, Ds.NC, ns, st);
@@ -1801,14 +1841,11 @@ int lmm_lmm_rand_multi(const lmm_post_t* post, const lmm_gp_t* gps, const double
     const int s = bi % nslots, nb = std::min(Xs.nb_per, ms - k0);
     hipStream_t st = g.streams[s];
     Batch Bt;
+    if (P) Xs.cross_solve_batch(P, s, k0, nb, xsd.p, d, ns, st);      // posterior: R_k and the mean vectors (sample = mean + L z)
     for (int j = 0; j < nb; ++j) {
       const int k = k0 + j;
       const lmm_gp_t& gp = P ? P->gps[l0 + k] : gps[l0 + k];
-      if (P) {   // posterior mean vector: sample = mean(xs) + L z
-        cross_solve(P, k, gp, xsd.p, d, ns, Xs.R[s].p, Xs.ldr, Xs.nsr, st);
-        launch_rider_stats(Xs.R[s].p, Xs.ldr, ns, P->n, P->z[k].p, gp.mean, 0.0, Xs.part[s].p, Xs.mu[s][j].p, nullptr, st);
-      }
-      cov_at_xs(P, gp, xsd.p, d, ns, jitter, nullptr, Ds, Xs.B[s][j].p, Xs.R[s].p, Xs.ldr, st);
+      cov_at_xs(P, gp, xsd.p, d, ns, jitter, nullptr, Ds, Xs.B[s][j].p, Xs.R[s][j].p, Xs.ldr, st);
       Bt.add(Xs.B[s][j].p, Xs.WB[s][j].p, info.p + k);
     }
     potrf_rec(Bt, Ds.ld, Ds.NR, 0, Ds.NC, ns, st);      // ONE factorisation per latent, nsamples triangular products
