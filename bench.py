@@ -68,6 +68,7 @@ def cpu_baseline(P, orthogonal, budget_latents=2):
     k = min(budget_latents, m)
     T, ST = O.project_orthogonal(P["U"], P["S"], P["s2"])
     Ty = T @ O.reshape_y(P["y"], n)
+    np.linalg.cholesky(np.eye(256) * 2.0)      # BLAS thread-pool start-up is not part of the sample
     t0 = time.perf_counter()
     t_gram = 0.0
     for l in range(k):
