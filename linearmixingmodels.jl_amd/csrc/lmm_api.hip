@@ -43,7 +43,7 @@ struct Ctx {
   int err_latent = -1, err_info = 0;
   // measurement hooks
   bool prof = false, prof_serial = false;
-  struct ProfRec { int cls; double work, bytes; hipEvent_t e0, e1; int M, N, K; };
+  struct ProfRec { int cls; double work, bytes; hipEvent_t e0, e1; int M, N, K, count; };
   std::vector<ProfRec> prof_recs;
   std::vector<hipEvent_t> ev_pool;
 };
@@ -148,10 +148,10 @@ inline int rup(int v, int m) { return (v + m - 1) / m * m; }
 // Brackets one launch with events when profiling is on (lmm_profile_begin); otherwise just launches.
 struct ProfScope {
   bool on; hipStream_t st; size_t idx;
-  ProfScope(int cls, double work, hipStream_t st_, int M = 0, int N = 0, int K = 0, double bytes = 0.0)
-      : on(g.prof), st(st_), idx(0) {
+  ProfScope(int cls, double work, hipStream_t st_, int M = 0, int N = 0, int K = 0, double bytes = 0.0, int count = 1)
+      : on(g.prof), st(st_), idx(0) {      // count: launches bracketed by this one event pair
     if (!on) return;
-    Ctx::ProfRec r; r.cls = cls; r.work = work; r.bytes = bytes; r.M = M; r.N = N; r.K = K;
+    Ctx::ProfRec r; r.cls = cls; r.work = work; r.bytes = bytes; r.M = M; r.N = N; r.K = K; r.count = count;
     for (hipEvent_t* e : {&r.e0, &r.e1}) {
       if (!g.ev_pool.empty()) { *e = g.ev_pool.back(); g.ev_pool.pop_back(); }
       else HIPCHK(hipEventCreate(e));
@@ -508,6 +508,10 @@ int latent_lmls(const double* xd, int d, int n, const lmm_gp_t* gps, const doubl
     Slot& s = slots[bi % nslots];
     const int nb = std::min(nb_per, ms - k0);
     Batch B;
+    {
+    // the batch's Gram launches share one event pair (back-to-back launches: the event overhead is not charged per launch)
+    const double gb = (double)n * ((double)n + 1.0) / 2.0 * 8.0;
+    ProfScope ps(LMM_PROF_GRAM, nb * gb, s.st, 0, 0, 0, nb * gb, nb);
     for (int j = 0; j < nb; ++j) {
       const int k = k0 + j;
       const lmm_gp_t& gp = gps[l0 + k];
@@ -517,8 +521,9 @@ int latent_lmls(const double* xd, int d, int n, const lmm_gp_t* gps, const doubl
       a.diag_add = noisevec ? 0.0 : noise[l0 + k]; a.pad_diag = 1.0;
       a.diag_vec = noisevec ? noisevec + (size_t)k * n : nullptr;      // per-point noise of latent k (device, n values)
       a.rider = delta + (size_t)k * nrhs * n; a.rider_ld = n; a.nrider = nrhs; a.xs = nullptr; a.ns = 0;
-      { const double gb = (double)n * ((double)n + 1.0) / 2.0 * 8.0; ProfScope ps(LMM_PROF_GRAM, gb, s.st, 0, 0, 0, gb); launch_gram(a, s.st); }
+      launch_gram(a, s.st);
       B.add(s.A[j].p, s.W[j].p, info.p + k);
+    }
     }
     potrf_rec(B, D.ld, D.NR, 0, D.NC, n, s.st);
     for (int j = 0; j < nb; ++j) launch_lml_reduce(s.A[j].p, D.ld, n, D.NC, nrhs, out.p + (size_t)(k0 + j) * nrhs, s.st);
@@ -1939,7 +1944,7 @@ int lmm_profile_end(lmm_prof_entry_t* out) {
   for (auto& r : g.prof_recs) {
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, r.e0, r.e1));
-    out[r.cls].launches += 1; out[r.cls].ms += ms; out[r.cls].work += r.work; out[r.cls].bytes += r.bytes;
+    out[r.cls].launches += r.count; out[r.cls].ms += ms; out[r.cls].work += r.work; out[r.cls].bytes += r.bytes;
     if (getenv("LMM_PROF_DUMP") && r.M > 0)
       fprintf(stderr, "[prof] cls=%d M=%d N=%d K=%d ms=%.4f tflops=%.2f\n", r.cls, r.M, r.N, r.K, ms, r.work / (ms * 1e-3) / 1e12);
     g.ev_pool.push_back(r.e0); g.ev_pool.push_back(r.e1);
