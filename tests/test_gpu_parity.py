@@ -388,6 +388,28 @@ def test_ilmm_dense_posterior_cov_and_sequential_conditioning(lmm):
     np.testing.assert_allclose(lmm.mean_and_cov(post(xsin, 0.05))[1], Cg, rtol=0, atol=0)
 
 
+def _golden_cases():
+    import json, os
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_fixtures.json")))["cases"]
+
+
+@pytest.mark.parametrize("case", _golden_cases(), ids=lambda c: c["name"])
+def test_golden_fixtures(lmm, case):
+    """The HIP path against the committed fixture vectors (tests/golden/oracle_fixtures.json: frozen oracle values with
+    their full inputs): logpdf, posterior marginals at x*, logpdf of the posterior at (x*, y*).  rtol 1e-6 is the bar."""
+    x, xs, y, ys, s2, p = np.array(case["x"]), np.array(case["xs"]), np.array(case["y"]), np.array(case["ys"]), case["sigma2"], case["p"]
+    H = lmm.Orthogonal(np.array(case["U"]), np.array(case["S"])) if case["orthogonal"] else np.array(case["H"])
+    f = lmm.ILMM(_to_model(lmm, case["gps"]), H)
+    fx = f(lmm.MOInputIsotopicByOutputs(x, p), s2)
+    assert lmm.logpdf(fx, y) == pytest.approx(case["logpdf"], rel=1e-9)
+    post = lmm.posterior(fx, y)
+    pix = post(lmm.MOInputIsotopicByOutputs(xs, p), s2)
+    mu, var = lmm.mean_and_var(pix)
+    np.testing.assert_allclose(mu, case["post_mean"], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(var, case["post_var"], rtol=1e-7)
+    assert lmm.logpdf(pix, ys) == pytest.approx(case["post_logpdf"], rel=1e-7)
+
+
 def test_ilmm_identical_kernels_decoupled_equals_dense(lmm):
     """Dense-H ILMM whose latents share one kernel (BASELINE configs[1] shape): the decoupled shortcut (m independent
     n x n factorisations under the eigen-rotation of SigmaT) equals the reference's single (mn) x (mn) factorisation."""

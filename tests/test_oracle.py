@@ -205,3 +205,29 @@ def test_dense_ilmm_sequential_conditioning_matches_naive_two_batch_gp():
     vn = np.diag(O.naive_cov(gps, H, xs) - Ks.T @ np.linalg.solve(Kall, Ks)) + 0.05
     np.testing.assert_allclose(mo, mn, rtol=1e-7, atol=1e-8)
     np.testing.assert_allclose(vo, vn, rtol=1e-7)
+
+
+def _fixture_cases():
+    return json.load(open(os.path.join(HERE, "golden", "oracle_fixtures.json")))["cases"]
+
+
+@pytest.mark.parametrize("case", _fixture_cases(), ids=lambda c: c["name"])
+def test_oracle_reproduces_committed_fixtures(case):
+    """tests/golden/oracle_fixtures.json (written by tests/golden/make_oracle_fixtures.py) freezes the oracle's values on
+    small seeded problems; the same file is the fixed target of tests/test_gpu_parity.py::test_golden_fixtures."""
+    x, xs, y, ys, s2, gps = (np.array(case["x"]), np.array(case["xs"]), np.array(case["y"]), np.array(case["ys"]),
+                             case["sigma2"], case["gps"])
+    if case["orthogonal"]:
+        U, S = np.array(case["U"]), np.array(case["S"])
+        assert O.oilmm_logpdf(gps, U, S, x, s2, y) == pytest.approx(case["logpdf"], rel=1e-12)
+        post = O.oilmm_posterior(gps, U, S, x, s2, y)
+        mu, var = O.oilmm_mean_var(post, U, S, xs, s2)
+        assert O.oilmm_logpdf(post, U, S, xs, s2, ys) == pytest.approx(case["post_logpdf"], rel=1e-10)
+    else:
+        H = np.array(case["H"])
+        assert O.ilmm_logpdf(gps, H, x, s2, y) == pytest.approx(case["logpdf"], rel=1e-12)
+        post = O.ilmm_posterior(gps, H, x, s2, y)
+        mu, var = O.ilmm_mean_var(post, H, xs, s2)
+        assert O.ilmm_logpdf(post, H, xs, s2, ys) == pytest.approx(case["post_logpdf"], rel=1e-10)
+    np.testing.assert_allclose(mu, case["post_mean"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(var, case["post_var"], rtol=1e-10)
