@@ -94,6 +94,19 @@ __device__ __forceinline__ double scaled_dist2(const double* __restrict__ a, con
   return s;
 }
 
+// sqrt for the d > 1 Matern distances: v_rsq_f64 seed, two Newton steps on 1/sqrt, one Heron correction (<= 1 ulp-ish for
+// normal arguments; 0 -> 0 exactly).  The library sqrt carries scaling for subnormal / huge arguments that scaled squared
+// distances never need and costs about twice as much.
+__device__ __forceinline__ double sqrt_dist(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double h = 0.5 * x;
+  y = y * __builtin_fma(-h * y, y, 1.5);
+  y = y * __builtin_fma(-h * y, y, 1.5);
+  double r = x * y;
+  r = __builtin_fma(0.5 * y, __builtin_fma(-r, r, x), r);
+  return (x > 1e-300) ? r : 0.0;
+}
+
 template <int KIND>
 __device__ __forceinline__ double kappa_t(double var, double r, double r2) {
 #ifdef LMM_ABLATE_NOMATH
@@ -190,20 +203,37 @@ __device__ __forceinline__ double exp_any(double x) {
 // column factors), so the per-element cost drops from a full exp (~20 f64 ops) to 2 multiplies and a min; the 4 row and
 // 2 x 64 column exponentials are amortised over 64 elements per thread.  Guard: |a (x - c)| <= 40 inside the strip (else
 // the direct per-element exp is used, e.g. for unsorted inputs).  Relative error of the product form <= ~1e-14.
-template <int KIND>
+template <int KIND, bool ND>      // ND: the 1 < d <= 8 fast path is compiled in (kept out of the d == 1 kernel's register budget)
 __global__ __launch_bounds__(256) void gram_kernel(GramArgs a) {
+  constexpr int DMAX = 8;                                     // input dimensions with a fast path (d > DMAX: generic tiles)
   __shared__ double colE[64], colF[64], colX[64];
+  __shared__ double colP[ND ? 64 * DMAX : 1];
   const int ti = blockIdx.x + a.row_tile0, sy = blockIdx.y;   // (a 1-D grid over the non-empty strips measured 4 % slower)
   const int t = threadIdx.x;
   const int i0 = ti * 64 + 2 * (t & 31);
   const int cg = t >> 5;
-  const bool rows_interior = (a.d == 1) && (ti * 64 + 63 < a.n);
+  // Row source of this strip when all 64 rows are points: training inputs x (rows < n) or the cross-Gram inputs xs
+  // (rider rows ncols .. ncols + ns - 1 of the predict path); otherwise the strip mixes kinds and takes the generic tiles.
+  const double* rsrc = nullptr;
+  int rbase = 0;
+  if (ti * 64 + 63 < a.n) { rsrc = a.x; }
+  else if (a.xs != nullptr && ti * 64 >= a.ncols && ti * 64 + 63 - a.ncols < a.ns) { rsrc = a.xs; rbase = a.ncols; }
+  const bool rows_interior = (a.d == 1) && rsrc != nullptr;
+  const bool rows_nd = ND && (a.d > 1) && (a.d <= DMAX) && rsrc != nullptr;
+  double xr0[DMAX], xr1[DMAX];                                // d > 1: this thread's two row points, pre-scaled by 1/lengthscale
+  if (ND && rows_nd) {
+#pragma unroll
+    for (int k = 0; k < DMAX; ++k) {
+      xr0[k] = (k < a.d) ? rsrc[(size_t)(i0 - rbase) * a.d + k] * a.inv_ls : 0.0;
+      xr1[k] = (k < a.d) ? rsrc[(size_t)(i0 + 1 - rbase) * a.d + k] * a.inv_ls : 0.0;
+    }
+  }
   constexpr bool SEP = (KIND != LMM_KERNEL_SE);
   const double aS = (KIND == LMM_KERNEL_MATERN32 ? 1.7320508075688772 : 2.23606797749979) * a.inv_ls;
   double x0 = 0.0, x1 = 0.0, cr = 0.0, E0 = 0.0, F0 = 0.0, E1 = 0.0, F1 = 0.0;
   bool rows_ok = false;
   if (rows_interior) {
-    x0 = a.x[i0]; x1 = a.x[i0 + 1]; cr = a.x[ti * 64];
+    x0 = rsrc[i0 - rbase]; x1 = rsrc[i0 + 1 - rbase]; cr = rsrc[ti * 64 - rbase];
     if (SEP) {
       const double u0 = aS * (x0 - cr), u1 = aS * (x1 - cr);
       rows_ok = fabs(u0) <= 40.0 && fabs(u1) <= 40.0;
@@ -214,9 +244,40 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs a) {
     const int tj = sy * 4 + c4;
     if (tj * 64 >= a.ncols) break;
     if (!a.full && ti < tj) break;                          // lower tiles only
-    const bool interior = rows_interior && (tj * 64 + 63 < a.n);
-    if (!interior) { gram_tile_generic(a, ti, tj); continue; }
+    const bool cols_in = (tj * 64 + 63 < a.n);
     double* out = a.A + (size_t)(tj * 64 + cg) * a.ld + (i0 - a.row_shift);
+    if (ND && rows_nd && cols_in) {                         // d > 1 interior tile: column points staged (pre-scaled) in LDS
+      __syncthreads();
+      for (int e = t; e < 64 * a.d; e += 256) colP[e] = a.x[(size_t)tj * 64 * a.d + e] * a.inv_ls;
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int jl = cg + 8 * q;
+        const double* cp = colP + jl * a.d;
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < DMAX; ++k) {
+          if (k < a.d) {
+            const double c = cp[k];
+            const double t0 = xr0[k] - c, t1 = xr1[k] - c;
+            s0 = __builtin_fma(t0, t0, s0); s1 = __builtin_fma(t1, t1, s1);
+          }
+        }
+        d2 v;
+        v.x = kappa_t<KIND>(a.var, KIND == LMM_KERNEL_SE ? 0.0 : sqrt_dist(s0), s0);
+        v.y = kappa_t<KIND>(a.var, KIND == LMM_KERNEL_SE ? 0.0 : sqrt_dist(s1), s1);
+        if (ti == tj) {
+          const int j = tj * 64 + jl;
+          const double da = a.diag_add + (a.diag_vec ? a.diag_vec[j] : 0.0);
+          if (i0 == j) v.x += da;
+          if (i0 + 1 == j) v.y += da;
+        }
+        *reinterpret_cast<d2*>(out + (size_t)(8 * q) * a.ld) = v;
+      }
+      continue;
+    }
+    const bool interior = rows_interior && cols_in;
+    if (!interior) { gram_tile_generic(a, ti, tj); continue; }
     bool sep = false;
     if (SEP) {
       __syncthreads();                                      // previous tile's readers are done with colE/colF/colX
@@ -1164,9 +1225,16 @@ __global__ __launch_bounds__(256) void mfma_f64_peak_kernel(double* out, int ite
 // ---------------------------------------------------------------------------------------------------
 void launch_gram(const GramArgs& a, hipStream_t st) {
   dim3 grid(a.nrows / 64 - a.row_tile0, (a.ncols / 64 + 3) / 4);
-  if (a.kind == LMM_KERNEL_SE) hipLaunchKernelGGL((gram_kernel<LMM_KERNEL_SE>), grid, dim3(256), 0, st, a);
-  else if (a.kind == LMM_KERNEL_MATERN32) hipLaunchKernelGGL((gram_kernel<LMM_KERNEL_MATERN32>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((gram_kernel<LMM_KERNEL_MATERN52>), grid, dim3(256), 0, st, a);
+  const bool nd = (a.d > 1 && a.d <= 8);
+#define LMM_GRAM_LAUNCH(K)                                                                          \
+  do {                                                                                              \
+    if (nd) hipLaunchKernelGGL((gram_kernel<K, true>), grid, dim3(256), 0, st, a);                  \
+    else hipLaunchKernelGGL((gram_kernel<K, false>), grid, dim3(256), 0, st, a);                    \
+  } while (0)
+  if (a.kind == LMM_KERNEL_SE) LMM_GRAM_LAUNCH(LMM_KERNEL_SE);
+  else if (a.kind == LMM_KERNEL_MATERN32) LMM_GRAM_LAUNCH(LMM_KERNEL_MATERN32);
+  else LMM_GRAM_LAUNCH(LMM_KERNEL_MATERN52);
+#undef LMM_GRAM_LAUNCH
 }
 
 void launch_dense_cross(double* R, int ldr, int nrows, int ncols, const double* xs, int ns, const double* x, int n, int d,
