@@ -20,6 +20,7 @@
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ d2 mk2(double x, double y) { d2 v; v.x = x; v.y = y; return v; }
 
 #define LOG2PI 1.8378770664093453
 
@@ -444,67 +445,136 @@ __global__ void dense_var_finish_kernel(const double* __restrict__ partial, int 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// K2a: 64x64 diagonal block: Cholesky factor L and its inverse W = L^-1 in one symmetric Gaussian
-// elimination of [A | I] held in LDS (one barrier per pivot).  One workgroup, latency bound.
-//   after eliminating column j with multipliers A_ij/d_j:  [A | I] -> [D L1' | L1^-1];
-//   L = L1 D^1/2,  W = D^-1/2 L1^-1.
+// K2a: 64x64 diagonal block: Cholesky factor L and its inverse W = L^-1 in one symmetric Gaussian elimination of [A | I]
+// held in registers: after eliminating the columns,  [A | I] -> [D L1' | L1^-1];  L = L1 D^1/2,  W = D^-1/2 L1^-1.
+// One workgroup per matrix of the batch, latency bound.
 // ---------------------------------------------------------------------------------------------------
+// Rank-4, 4x4-register-block form: four pivots per barrier, and thread (a, b) owns the 4x4 blocks
+// (rows 4a..4a+3, columns 4b..4b+3) of the S part and of the W part, so a step needs only 4 + 4 + 4 + 4 four-double LDS rows
+// per thread (its rows of the pivot columns, the pivot block, its columns of the pivot rows of both parts) instead of the
+// 64 + 64 values of a row-per-thread layout.  The owners of block column J/4 publish the four current columns J..J+3 (raw,
+// and masked to the rows below the block: by symmetry the pivot rows); the owners of block row J/4 publish rows J..J+3 of the
+// W part; every thread factors the 4x4 pivot block P = Lp Lp' redundantly, forms y = B Lp^-T for its four rows (the final L
+// entries in these columns) and the multipliers m = y Lp^-1, and applies one rank-4 update to its 16 + 16 register values.
+// Rows inside the block finish their W rows as Lp^-1 Wtop.  s holds L sqrt(d), w holds sqrt(d) L^-1, dd the pivots.
 __global__ __launch_bounds__(256) void diag64_kernel(BatchPtr Ab, size_t offA, int ld, BatchPtr Wb, size_t offW,
                                                      int gcol0, int n_real, BatchInfo infob) {
   double* __restrict__ A = Ab.p[blockIdx.x] + offA;
   double* __restrict__ W = Wb.p[blockIdx.x] + offW;
   int* __restrict__ info = infob.p[blockIdx.x];
-  // Register-resident elimination: thread (i = t & 63, q = t >> 6) owns row i, columns 16q..16q+15 of both the
-  // S part (the block being factored) and the W part (identity -> L1^-1).  Per pivot j the owners publish, through
-  // double-buffered LDS, column j (colb: every row's multiplier numerator; cmsk: the same masked to rows > j, which by
-  // symmetry is the pivot row of the S part) and row j of the W part; one barrier per pivot; all register indices are
-  // compile-time (inner 16 pivots unrolled), so nothing spills to scratch.
-  __shared__ __attribute__((aligned(16))) double colb[2][64];
-  __shared__ __attribute__((aligned(16))) double cmsk[2][64];
-  __shared__ __attribute__((aligned(16))) double roww[2][64];
+  __shared__ __attribute__((aligned(16))) double cb[2][4][64];     // raw columns J..J+3 (all rows)
+  __shared__ __attribute__((aligned(16))) double cm[2][4][64];     // the same, zero for rows <= J+3
+  __shared__ __attribute__((aligned(16))) double rw[2][4][64];     // rows J..J+3 of the W part
   __shared__ double dd[64];
-  const int t = threadIdx.x, i = t & 63, q = t >> 6;
-  double s[16], w[16];
+  const int t = threadIdx.x, a = t & 15, b = t >> 4;
+  double s[4][4], w[4][4];
 #pragma unroll
-  for (int c = 0; c < 16; ++c) {
-    const int k = 16 * q + c;
-    s[c] = (i >= k) ? A[(size_t)k * ld + i] : 0.0;
-    w[c] = (i == k) ? 1.0 : 0.0;
+  for (int c = 0; c < 4; ++c) {
+    const int k = 4 * b + c;
+    const d2* src = reinterpret_cast<const d2*>(A + (size_t)k * ld + 4 * a);
+    d2 v0 = mk2(0.0, 0.0), v1 = v0;
+    if (a >= b) { v0 = src[0]; v1 = src[1]; }
+    const double col[4] = {v0.x, v0.y, v1.x, v1.y};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      s[r][c] = (4 * a + r >= k) ? col[r] : 0.0;
+      w[r][c] = (4 * a + r == k) ? 1.0 : 0.0;
+    }
   }
-  for (int jb = 0; jb < 4; ++jb) {
+  auto rsq = [](double x) {          // 1/sqrt(x): v_rsq_f64 + two Newton steps
+    double y = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    y = y * __builtin_fma(-h * y, y, 1.5);
+    y = y * __builtin_fma(-h * y, y, 1.5);
+    return y;
+  };
+  for (int st = 0; st < 16; ++st) {
+    const int J = 4 * st, bf = st & 1;
+    if (b == st) {                       // owners of columns J..J+3: column r' holds s[.][r'] for rows 4a..4a+3
 #pragma unroll
-    for (int jj = 0; jj < 16; ++jj) {
-      const int j = 16 * jb + jj, b = jj & 1;
-      if (q == jb) {                       // owners of column j (wave-uniform)
-        colb[b][i] = s[jj];
-        cmsk[b][i] = (i > j) ? s[jj] : 0.0;
+      for (int rp = 0; rp < 4; ++rp) {
+        d2* o = reinterpret_cast<d2*>(&cb[bf][rp][4 * a]);
+        d2* om = reinterpret_cast<d2*>(&cm[bf][rp][4 * a]);
+        const d2 lo = mk2(s[0][rp], s[1][rp]), hi = mk2(s[2][rp], s[3][rp]);
+        const d2 z = mk2(0.0, 0.0);
+        o[0] = lo; o[1] = hi;
+        om[0] = (a > st) ? lo : z; om[1] = (a > st) ? hi : z;
       }
-      if (i == j) {                        // owners of row j of the W part
+    }
+    if (a == st) {                       // owners of rows J..J+3 of the W part
 #pragma unroll
-        for (int c = 0; c < 16; ++c) roww[b][16 * q + c] = w[c];
+      for (int r = 0; r < 4; ++r) {
+        d2* o = reinterpret_cast<d2*>(&rw[bf][r][4 * b]);
+        o[0] = mk2(w[r][0], w[r][1]); o[1] = mk2(w[r][2], w[r][3]);
       }
-      __syncthreads();
-      const double dj = colb[b][j];
-      const double ci = colb[b][i];
-      const d2* rs = reinterpret_cast<const d2*>(&cmsk[b][16 * q]);
-      const d2* rw = reinterpret_cast<const d2*>(&roww[b][16 * q]);
-      d2 ps[8], pw[8];
+    }
+    __syncthreads();
+    double Bv[4][4], Pv[4][4], Rv[4][4], Wv[4][4];     // [column or pivot r'][row / col within my block]
 #pragma unroll
-      for (int c2 = 0; c2 < 8; ++c2) { ps[c2] = rs[c2]; pw[c2] = rw[c2]; }     // issued before the reciprocal: overlaps it
-      if (t == 0) dd[j] = dj;
-      // 1/d_j by v_rcp_f64 + two Newton steps (<= 1-2 ulp; an IEEE division is ~3x the dependent latency on the
-      // pivot-to-pivot critical path); non-positive pivots are detected after the loop from dd[].
-      double rinv = __builtin_amdgcn_rcp(dj);
-      rinv = __builtin_fma(__builtin_fma(-dj, rinv, 1.0), rinv, rinv);
-      rinv = __builtin_fma(__builtin_fma(-dj, rinv, 1.0), rinv, rinv);
-      const double mult = (i > j) ? ci * rinv : 0.0;
+    for (int rp = 0; rp < 4; ++rp) {
+      const d2* pb = reinterpret_cast<const d2*>(&cb[bf][rp][4 * a]);
+      const d2* pp = reinterpret_cast<const d2*>(&cb[bf][rp][J]);
+      const d2* pr = reinterpret_cast<const d2*>(&cm[bf][rp][4 * b]);
+      const d2* pw = reinterpret_cast<const d2*>(&rw[bf][rp][4 * b]);
+      const d2 b0 = pb[0], b1 = pb[1], p0 = pp[0], p1 = pp[1], r0 = pr[0], r1 = pr[1], w0 = pw[0], w1 = pw[1];
+      Bv[rp][0] = b0.x; Bv[rp][1] = b0.y; Bv[rp][2] = b1.x; Bv[rp][3] = b1.y;
+      Pv[rp][0] = p0.x; Pv[rp][1] = p0.y; Pv[rp][2] = p1.x; Pv[rp][3] = p1.y;
+      Rv[rp][0] = r0.x; Rv[rp][1] = r0.y; Rv[rp][2] = r1.x; Rv[rp][3] = r1.y;
+      Wv[rp][0] = w0.x; Wv[rp][1] = w0.y; Wv[rp][2] = w1.x; Wv[rp][3] = w1.y;
+    }
+    // 4x4 Cholesky of the pivot block (Pv[c][r] = P[r][c], lower part used)
+    const double d0 = Pv[0][0], r0 = rsq(d0);
+    const double l10 = Pv[0][1] * r0, l20 = Pv[0][2] * r0, l30 = Pv[0][3] * r0;
+    const double d1 = __builtin_fma(-l10, l10, Pv[1][1]), r1 = rsq(d1);
+    const double l21 = __builtin_fma(-l20, l10, Pv[1][2]) * r1, l31 = __builtin_fma(-l30, l10, Pv[1][3]) * r1;
+    const double d2v = __builtin_fma(-l21, l21, __builtin_fma(-l20, l20, Pv[2][2])), r2 = rsq(d2v);
+    const double l32 = __builtin_fma(-l31, l21, __builtin_fma(-l30, l20, Pv[2][3])) * r2;
+    const double d3 = __builtin_fma(-l32, l32, __builtin_fma(-l31, l31, __builtin_fma(-l30, l30, Pv[3][3]))), r3 = rsq(d3);
+    const double l00 = d0 * r0, l11 = d1 * r1, l22 = d2v * r2, l33 = d3 * r3;
+    if (t == 0) { dd[J] = d0; dd[J + 1] = d1; dd[J + 2] = d2v; dd[J + 3] = d3; }
+    const bool below = (a > st), inblk = (a == st);
+    // coefficients of the W-part update of my four rows: below the block -m; inside it l_rr * (Lp^-1)[r][.]; above: none
+    double cf[4][4], keep = 1.0;
+    double y[4][4];
 #pragma unroll
-      for (int c2 = 0; c2 < 8; ++c2) {
-        s[2 * c2] = __builtin_fma(-mult, ps[c2].x, s[2 * c2]);
-        s[2 * c2 + 1] = __builtin_fma(-mult, ps[c2].y, s[2 * c2 + 1]);
-        w[2 * c2] = __builtin_fma(-mult, pw[c2].x, w[2 * c2]);
-        w[2 * c2 + 1] = __builtin_fma(-mult, pw[c2].y, w[2 * c2 + 1]);
-      }
+    for (int r = 0; r < 4; ++r) {
+      // y = B_row Lp^-T (forward), m = y Lp^-1 (backward)
+      y[r][0] = Bv[0][r] * r0;
+      y[r][1] = __builtin_fma(-y[r][0], l10, Bv[1][r]) * r1;
+      y[r][2] = __builtin_fma(-y[r][1], l21, __builtin_fma(-y[r][0], l20, Bv[2][r])) * r2;
+      y[r][3] = __builtin_fma(-y[r][2], l32, __builtin_fma(-y[r][1], l31, __builtin_fma(-y[r][0], l30, Bv[3][r]))) * r3;
+      const double m3 = y[r][3] * r3;
+      const double m2 = __builtin_fma(-m3, l32, y[r][2]) * r2;
+      const double m1 = __builtin_fma(-m3, l31, __builtin_fma(-m2, l21, y[r][1])) * r1;
+      const double m0 = __builtin_fma(-m3, l30, __builtin_fma(-m2, l20, __builtin_fma(-m1, l10, y[r][0]))) * r0;
+      cf[r][0] = below ? -m0 : 0.0; cf[r][1] = below ? -m1 : 0.0; cf[r][2] = below ? -m2 : 0.0; cf[r][3] = below ? -m3 : 0.0;
+    }
+    // S part: only rows below the block change (cf = -m there, 0 elsewhere)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        s[r][c] = __builtin_fma(cf[r][3], Rv[3][c], __builtin_fma(cf[r][2], Rv[2][c], __builtin_fma(cf[r][1], Rv[1][c],
+                  __builtin_fma(cf[r][0], Rv[0][c], s[r][c]))));
+    if (inblk) {                         // rows J..J+3: w <- l_rr * (Lp^-1 Wtop)[r]
+      keep = 0.0;
+      const double i10 = -l10 * r0 * r1;
+      const double i20 = -(l20 * r0 + l21 * i10) * r2, i21 = -l21 * r1 * r2;
+      const double i30 = -(l30 * r0 + l31 * i10 + l32 * i20) * r3, i31 = -(l31 * r1 + l32 * i21) * r3, i32 = -l32 * r2 * r3;
+      cf[0][0] = l00 * r0; cf[0][1] = 0.0; cf[0][2] = 0.0; cf[0][3] = 0.0;
+      cf[1][0] = l11 * i10; cf[1][1] = l11 * r1; cf[1][2] = 0.0; cf[1][3] = 0.0;
+      cf[2][0] = l22 * i20; cf[2][1] = l22 * i21; cf[2][2] = l22 * r2; cf[2][3] = 0.0;
+      cf[3][0] = l33 * i30; cf[3][1] = l33 * i31; cf[3][2] = l33 * i32; cf[3][3] = l33 * r3;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        w[r][c] = __builtin_fma(cf[r][3], Wv[3][c], __builtin_fma(cf[r][2], Wv[2][c], __builtin_fma(cf[r][1], Wv[1][c],
+                  __builtin_fma(cf[r][0], Wv[0][c], keep * w[r][c]))));
+    if (b == st) {                       // my rows' final entries in columns J..J+3, in the s = L sqrt(d) convention
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s[r][0] = y[r][0] * l00; s[r][1] = y[r][1] * l11; s[r][2] = y[r][2] * l22; s[r][3] = y[r][3] * l33; }
     }
   }
   __syncthreads();
@@ -514,15 +584,29 @@ __global__ __launch_bounds__(256) void diag64_kernel(BatchPtr Ab, size_t offA, i
     if (t == 0 && mask != 0ull) atomicCAS(info, 0, gcol0 + __builtin_ctzll(mask) + 1);
   }
   __syncthreads();
-  const double rsi = 1.0 / sqrt(dd[i]);           // row scale of W = D^-1/2 L1^-1
+  double rsr[4];                                   // row scales of W = D^-1/2 L1^-1
 #pragma unroll
-  for (int c = 0; c < 16; ++c) {
-    const int k = 16 * q + c;
-    if (i >= k) {
-      const double lk = sqrt(dd[k]);
-      A[(size_t)k * ld + i] = (i == k) ? lk : s[c] / lk;
+  for (int r = 0; r < 4; ++r) rsr[r] = rsq(dd[4 * a + r]);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int k = 4 * b + c;
+    const double dk = dd[k], lki = rsq(dk);
+    double ao[4], wo[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 4 * a + r;
+      ao[r] = (i == k) ? dk * lki : s[r][c] * lki;
+      wo[r] = (i >= k) ? w[r][c] * rsr[r] : 0.0;
     }
-    W[k * 64 + i] = (i >= k) ? w[c] * rsi : 0.0;
+    if (a > b) {
+      d2* o = reinterpret_cast<d2*>(A + (size_t)k * ld + 4 * a);
+      o[0] = mk2(ao[0], ao[1]); o[1] = mk2(ao[2], ao[3]);
+    } else if (a == b) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) if (r >= c) A[(size_t)k * ld + 4 * a + r] = ao[r];
+    }
+    d2* ow = reinterpret_cast<d2*>(W + k * 64 + 4 * a);
+    ow[0] = mk2(wo[0], wo[1]); ow[1] = mk2(wo[2], wo[3]);
   }
 }
 
