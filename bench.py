@@ -6,7 +6,7 @@ HBM.  Default workload = BASELINE.json configs[2] (the configuration north_star 
 OILMM, Orthogonal(U,S) 64x32, 32 Matern52 latents, n = 16384, Float64.  It fits one GPU, so the same problem is
 run at every N with the 32 latents sharded over the ranks (strong scaling; one scalar all-reduce per step).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c1|c0|small]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c1|c1dense|c0|small|notebook|c3]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -33,6 +33,11 @@ WORKLOADS = {
                                           "single (mn)x(mn) factorisation, shortcut disabled)"),
     "c0": (3, 5, 200, "se", True, "configs[0]: OILMM, 3 SEKernel latents, p=5, n=200, f64"),
     "small": (8, 16, 2048, "matern52", True, "reduced smoke workload (NOT a BASELINE config)"),
+    # secondary metric: one step = posterior(fx, y) + marginals at n* = n test points, latents sharded, ONE
+    # all-reduce of the p x n* partial means / variances per step.  Float64 (the bf16-projection variant of
+    # configs[3] is not built).
+    "c3": (64, 128, 8192, "matern52", True, "configs[3] shape in f64: OILMM posterior predictive, H 128x64, n_train = n_test = 8192 "
+                                            "(step = posterior + mean_and_var at x*)"),
     # the reference notebook's timing shape (examples/oilmm_and_ilmm.ipynb:124-129, 226-235): the only published number
     "notebook": (20, 600, 552, "matern52", True, "reference notebook: OILMM logpdf, p=600, m=20, n=552 Matern52, sigma2=1e-6, f64"),
 }
@@ -82,6 +87,22 @@ def cpu_baseline(P, orthogonal, budget_latents=2):
     return {"value": 1.0 / est, "unit": "evals/s", "cores": cores, "kind": "port",
             "sample": f"oracle per-latent logpdf (NumPy Gram + LAPACK potrf/trtrs) for {k} of {m} latents at n={n}: "
                       f"{dt:.2f} s ({t_gram:.2f} s of it Gram assembly), extrapolated x{m}/{k}"}
+
+
+def cpu_baseline_predictive(P):
+    """Oracle posterior + marginals (LAPACK potrf, trtrs on the n x n* cross-Gram) for ONE latent at full size, extrapolated to
+    the m independent latents."""
+    from oracle import lmm_oracle as O
+    m, n = P["m"], P["n"]
+    T, ST = O.project_orthogonal(P["U"], P["S"], P["s2"])
+    Ty0 = T[0] @ O.reshape_y(P["y"], n)
+    xs = P["x"] + 0.5 * 20.0 / 575.0
+    np.linalg.cholesky(np.eye(256) * 2.0)
+    t0 = time.perf_counter()
+    O.gp_mean_var(O.gp_posterior(P["gps"][0], P["x"], ST[0], Ty0), xs)
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / (dt * m), "unit": "evals/s", "cores": os.cpu_count() or 1, "kind": "port",
+            "sample": f"oracle posterior + marginals of 1 of {m} latents at n = n* = {n}: {dt:.2f} s, extrapolated x{m}"}
 
 
 def main():
@@ -146,7 +167,18 @@ def main():
     rdev = dev if backend == "nccl" else torch.device("cpu")      # where the collectives' tensors live
     red = torch.zeros(1, dtype=torch.float64, device=rdev)
 
+    predictive = (args.workload == "c3")
+    if predictive:
+        xs_in = lmm_amd.MOInputIsotopicByOutputs(xd + 0.5 * 20.0 / 575.0, p)      # test points between the training points
+
+    def step_predictive():
+        post = lmm_amd.posterior(fx, yd)                                            # this rank's latents only
+        mean, var = lmm_amd.sharded_mean_and_var(post(xs_in, s2))                   # one all-reduce of 2 x p x n* doubles
+        return float(mean[0])
+
     def step():
+        if predictive:
+            return step_predictive()
         part = lmm_amd.logpdf(fx, yd, rank == 0)
         if world > 1 and orth:
             red[0] = part
@@ -179,7 +211,7 @@ def main():
 
     roof = None
     extra = {}
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and not args.no_roofline and not predictive:
         # Roofline leg: one more evaluation of one batch of latents of the same workload with every launch of the hot
         # kernels bracketed by HIP events on its stream; the batch runs on ONE stream so that an event pair times its
         # kernel alone (the timed region above runs several batches on concurrent streams).  DESIGN.md "Measurement".
@@ -225,11 +257,11 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(P, orth)
+        cpu = cpu_baseline_predictive(P) if predictive else cpu_baseline(P, orth)
 
     if rank == 0:
         line = {
-            "metric": "logpdf evals/sec", "value": evals_per_s, "unit": "evals/s",
+            "metric": "posterior + marginals evals/sec" if predictive else "logpdf evals/sec", "value": evals_per_s, "unit": "evals/s",
             "obs_per_s": evals_per_s * n * p if evals_per_s else None,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if orth else "replicas",
@@ -237,7 +269,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc, "m": m, "p": p, "n": n, "kernel": kind, "sigma2": s2,
                        "latents_per_gpu": (shard[1] - shard[0]), "parallelism": f"latent-shard x{world}" if orth else "replicas"},
-            "logpdf": val,
+            ("first_predictive_mean" if predictive else "logpdf"): val,
             "roofline": roof, "cpu_baseline": cpu,
         }
         line.update(extra)
