@@ -293,9 +293,13 @@ void backsolve1(const double* L, int ld, const double* W, int nblk, double* z, h
 void batch_plan(int ms, int* nb_per, int* nstreams_used, double bytes_per_latent = 0.0) {
   static int bmax = -1;
   if (bmax < 0) { const char* e = getenv("LMM_BATCH"); bmax = e ? atoi(e) : 8; if (bmax < 1) bmax = 1; if (bmax > LMM_MAX_BATCH) bmax = LMM_MAX_BATCH; }
-  static int minb = -1;
-  if (minb < 0) { const char* e = getenv("LMM_MIN_BATCHES"); minb = e ? atoi(e) : 2; if (minb < 1) minb = 1; }
-  int b = std::min(bmax, std::max(1, ms / minb));       // keep at least minb (2) batches in flight when ms >= 2
+  // Batches kept in flight for small shards: factor matrices up to n = 8192 do best as ONE lock-step batch (fewer, fuller
+  // launches: n = 2048, m = 8: 2.82 -> 2.51 ms); larger ones as two batches on two streams, so one batch's leaf chain hides
+  // behind the other's updates (C2 share of 4 latents: 108 vs 110 ms).  LMM_MIN_BATCHES overrides.
+  static int minb_env = -2;
+  if (minb_env == -2) { const char* e = getenv("LMM_MIN_BATCHES"); minb_env = e ? std::max(1, atoi(e)) : -1; }
+  const int minb = minb_env > 0 ? minb_env : ((bytes_per_latent > 0.0 && bytes_per_latent <= 6e8) ? 1 : 2);
+  int b = std::min(bmax, std::max(1, ms / minb));
   if (g.prof && g.prof_serial) b = std::min(bmax, ms);  // instrumented pass: production-sized batches on ONE stream
   int nbatches = (ms + b - 1) / b;
   int ns = std::max(1, std::min(nbatches, eff_streams()));
@@ -1091,7 +1095,7 @@ static int posterior_create_common(const double* xd, int d, int n, const lmm_gp_
     Buf<int> info(std::max(ms, 1));
     HIPCHK(hipMemsetAsync(info.p, 0, std::max(ms, 1) * sizeof(int), g.streams[0]));
     int nb_per = 1, nslots = 1;
-    batch_plan(std::max(ms, 1), &nb_per, &nslots);
+    batch_plan(std::max(ms, 1), &nb_per, &nslots, (double)D.elems() * sizeof(double));
     for (int k = 0; k < ms; ++k) {
       P->L.emplace_back((size_t)D.elems());
       P->W.emplace_back((size_t)(D.NC / 64) * 4096);
