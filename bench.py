@@ -246,7 +246,8 @@ def main():
             extra["roofline_gram"] = {"bound": "hbm", "kernel": "gram_kernel (lower-triangular f64 write)",
                                       "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                       "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
-                                      "launches": gr["launches"], "avg_launch_ms": round(gr["ms"] / gr["launches"], 4)}
+                                      "matrices": gr["launches"], "avg_ms_per_matrix": round(gr["ms"] / gr["launches"], 4),
+                                      "note": "the matrices of a batch are assembled by one launch (blockIdx.z = latent)"}
         extra["kernel_classes_ms"] = {c: round(v["ms"], 3) for c, v in prof.items()}
         tf = C.c_double()
         if lib.lmm_dev_mfma_f64_peak(C.byref(tf)) == 0:

@@ -516,6 +516,7 @@ int latent_lmls(const double* xd, int d, int n, const lmm_gp_t* gps, const doubl
     // the batch's Gram launches share one event pair (back-to-back launches: the event overhead is not charged per launch)
     const double gb = (double)n * ((double)n + 1.0) / 2.0 * 8.0;
     ProfScope ps(LMM_PROF_GRAM, nb * gb, s.st, 0, 0, 0, nb * gb, nb);
+    GramArgs ga[LMM_MAX_BATCH];
     for (int j = 0; j < nb; ++j) {
       const int k = k0 + j;
       const lmm_gp_t& gp = gps[l0 + k];
@@ -525,9 +526,10 @@ int latent_lmls(const double* xd, int d, int n, const lmm_gp_t* gps, const doubl
       a.diag_add = noisevec ? 0.0 : noise[l0 + k]; a.pad_diag = 1.0;
       a.diag_vec = noisevec ? noisevec + (size_t)k * n : nullptr;      // per-point noise of latent k (device, n values)
       a.rider = delta + (size_t)k * nrhs * n; a.rider_ld = n; a.nrider = nrhs; a.xs = nullptr; a.ns = 0;
-      launch_gram(a, s.st);
+      ga[j] = a;
       B.add(s.A[j].p, s.W[j].p, info.p + k);
     }
+    launch_gram_batch(ga, nb, s.st);       // one launch per run of equal kernel kinds (blockIdx.z = latent)
     }
     potrf_rec(B, D.ld, D.NR, 0, D.NC, n, s.st);
     for (int j = 0; j < nb; ++j) launch_lml_reduce(s.A[j].p, D.ld, n, D.NC, nrhs, out.p + (size_t)(k0 + j) * nrhs, s.st);
@@ -1113,6 +1115,7 @@ static int posterior_create_common(const double* xd, int d, int n, const lmm_gp_
       hipStream_t st = g.streams[bi % nslots];
       const int nb = std::min(nb_per, ms - k0);
       Batch B;
+      GramArgs ga[LMM_MAX_BATCH];
       for (int j = 0; j < nb; ++j) {
         const int k = k0 + j;
         const lmm_gp_t& gp = gps[l0 + k];
@@ -1121,9 +1124,10 @@ static int posterior_create_common(const double* xd, int d, int n, const lmm_gp_
         a.kind = gp.kind; a.var = gp.variance; a.inv_ls = 1.0 / gp.lengthscale; a.pad_diag = 1.0;
         a.diag_add = 0.0; a.diag_vec = P->noisev[k].p;
         a.rider = delta + (size_t)k * n; a.rider_ld = n; a.nrider = 1;
-        launch_gram(a, st);
+        ga[j] = a;
         B.add(P->L[k].p, P->W[k].p, info.p + k);
       }
+      launch_gram_batch(ga, nb, st);
       potrf_rec(B, D.ld, D.NR, 0, D.NC, n, st);
       BatchPtr ab{};
       for (int j = 0; j < nb; ++j) {
@@ -1519,13 +1523,17 @@ int lmm_post_destroy(lmm_post_t* post) {
 }
 
 // Rk (nsr x NC, ldr) = K(xs, x): the cross-Gram of a posterior latent's training inputs as rider rows (rows beyond ns zero).
-static void cross_gram(const lmm_post* P, const lmm_gp_t& gp, const double* xsd, int d, int ns, double* Rk, int ldr, int nsr,
-                       hipStream_t st) {
+static GramArgs cross_gram_args(const lmm_post* P, const lmm_gp_t& gp, const double* xsd, int d, int ns, double* Rk, int ldr,
+                                int nsr) {
   GramArgs r{};
   r.A = Rk; r.ld = ldr; r.nrows = P->NC + nsr; r.ncols = P->NC; r.row_tile0 = P->NC / 64; r.row_shift = P->NC; r.full = 1;
   r.x = P->x.p; r.d = d; r.n = P->n; r.kind = gp.kind; r.var = gp.variance; r.inv_ls = 1.0 / gp.lengthscale;
   r.xs = xsd; r.ns = ns;
-  launch_gram(r, st);
+  return r;
+}
+static void cross_gram(const lmm_post* P, const lmm_gp_t& gp, const double* xsd, int d, int ns, double* Rk, int ldr, int nsr,
+                       hipStream_t st) {
+  launch_gram(cross_gram_args(P, gp, xsd, d, ns, Rk, ldr, nsr), st);
 }
 
 // Latent marginals (mean, var) of latents [l0, l1) at xs into device arrays (ns per latent).
@@ -1560,11 +1568,13 @@ static int latent_marginals_dev(const lmm_post* P, const lmm_gp_t* gps_shard, in
     const int s = bi % nslots, nb = std::min(nb_per, ms - k0);
     hipStream_t st = g.streams[s];
     BatchPtr Rb{}, Lb{}, Wb{};
+    GramArgs ga[LMM_MAX_BATCH];
     for (int j = 0; j < nb; ++j) {
       const int k = k0 + j;
-      cross_gram(P, P->gps[P->l0 + k], xsd, d, ns, R[s][j].p, ldr, nsr, st);
+      ga[j] = cross_gram_args(P, P->gps[P->l0 + k], xsd, d, ns, R[s][j].p, ldr, nsr);
       Rb.p[j] = R[s][j].p; Lb.p[j] = P->L[k].p; Wb.p[j] = P->W[k].p;
     }
+    launch_gram_batch(ga, nb, st);
     trsm_rec(Rb, ldr, nsr, Lb, P->ld, Wb, nb, 0, P->NC, st);       // R_j <- K(x*, x) L_j^-T for the whole batch
     for (int j = 0; j < nb; ++j) {
       const int k = k0 + j;
@@ -1638,15 +1648,25 @@ static void cross_solve(const lmm_post* P, int k, const lmm_gp_t& gp, const doub
 
 // Per-latent posterior (or prior) covariance at xs as a factor matrix B (NRs x NCs): gram(xs) + diag_add - R R' (posterior,
 // R from cross_solve), rider row = rider_vec.  Not factorised here (the caller batches potrf_rec).  Caller holds g_mu.
-static void cov_at_xs(const lmm_post* P, const lmm_gp_t& gp, const double* xsd, int d, int ns, double diag_add,
-                      const double* rider_vec, const Dims& Ds, double* B, const double* Rk, int ldr, hipStream_t st) {
+static GramArgs cov_args(const lmm_gp_t& gp, const double* xsd, int d, int ns, double diag_add, const double* rider_vec,
+                         const Dims& Ds, double* B) {
   GramArgs a{};
   a.A = B; a.ld = Ds.ld; a.nrows = Ds.NR; a.ncols = Ds.NC; a.x = xsd; a.d = d; a.n = ns;
   a.kind = gp.kind; a.var = gp.variance; a.inv_ls = 1.0 / gp.lengthscale; a.diag_add = diag_add; a.pad_diag = 1.0;
   a.rider = rider_vec; a.rider_ld = ns; a.nrider = rider_vec ? 1 : 0;
-  launch_gram(a, st);
+  return a;
+}
+static void cov_at_xs(const lmm_post* P, const lmm_gp_t& gp, const double* xsd, int d, int ns, double diag_add,
+                      const double* rider_vec, const Dims& Ds, double* B, const double* Rk, int ldr, hipStream_t st) {
+  launch_gram(cov_args(gp, xsd, d, ns, diag_add, rider_vec, Ds, B), st);
   // Schur complement on the leading NCs x NCs block (rows of R beyond ns are zero)
   if (P != nullptr) launch_gemm_nt(B, Ds.ld, Rk, ldr, Rk, ldr, Ds.NC, Ds.NC, P->NC, 1, false, st);
+}
+// The same for the nb latents of a batch: one Gram launch per run of equal kinds, ONE batched Schur-complement GEMM.
+static void cov_at_xs_batch(const lmm_post* P, const GramArgs* ga, int nb, const Dims& Ds, const BatchPtr& Bb, const BatchPtr& Rb,
+                            int ldr, hipStream_t st) {
+  launch_gram_batch(ga, nb, st);
+  if (P != nullptr) launch_gemm_nt(Bb, 0, Ds.ld, Rb, 0, ldr, Rb, 0, ldr, Ds.NC, Ds.NC, P->NC, 1, false, nb, st);
 }
 
 // Working buffers of the batched "covariance at xs" loops (rand, posterior logpdf): per stream slot nb_per factor matrices
@@ -1673,10 +1693,12 @@ struct XsSlots {
   // R[s][j] <- K(xs, x) L_k^-T and mu[s][j] <- mean_k(xs) for the latents k0..k0+nb-1 of the posterior's shard (one batched solve)
   void cross_solve_batch(const lmm_post* P, int s, int k0, int nb, const double* xsd, int d, int ns, hipStream_t st) {
     BatchPtr Rb{}, Lb{}, Wb{};
+    GramArgs ga[LMM_MAX_BATCH];
     for (int j = 0; j < nb; ++j) {
-      cross_gram(P, P->gps[P->l0 + k0 + j], xsd, d, ns, R[s][j].p, ldr, nsr, st);
+      ga[j] = cross_gram_args(P, P->gps[P->l0 + k0 + j], xsd, d, ns, R[s][j].p, ldr, nsr);
       Rb.p[j] = R[s][j].p; Lb.p[j] = P->L[k0 + j].p; Wb.p[j] = P->W[k0 + j].p;
     }
+    launch_gram_batch(ga, nb, st);
     trsm_rec(Rb, ldr, nsr, Lb, P->ld, Wb, nb, 0, P->NC, st);
     for (int j = 0; j < nb; ++j)
       launch_rider_stats(R[s][j].p, ldr, ns, P->n, P->z[k0 + j].p, P->gps[P->l0 + k0 + j].mean, 0.0, part[s].p, mu[s][j].p, nullptr, st);
@@ -1784,13 +1806,17 @@ int lmm_oilmm_post_logpdf(const lmm_post_t* post, const double* U, const double*
     hipStream_t st = g.streams[s];
     Batch Bt;
     X.cross_solve_batch(P, s, k0, nb, xsd.p, d, ns, st);
+    GramArgs ga[LMM_MAX_BATCH];
+    BatchPtr Bb{}, Rb{};
     for (int j = 0; j < nb; ++j) {
       const int k = k0 + j;
       const lmm_gp_t& gp = P->gps[l0 + k];
       launch_vec_lin(Ty_shard + (size_t)k * ns, X.mu[s][j].p, -1.0, ns, X.rid[s][j].p, st);
-      cov_at_xs(P, gp, xsd.p, d, ns, ST[l0 + k], X.rid[s][j].p, Ds, X.B[s][j].p, X.R[s][j].p, X.ldr, st);
+      ga[j] = cov_args(gp, xsd.p, d, ns, ST[l0 + k], X.rid[s][j].p, Ds, X.B[s][j].p);
+      Bb.p[j] = X.B[s][j].p; Rb.p[j] = X.R[s][j].p;
       Bt.add(X.B[s][j].p, X.WB[s][j].p, info.p + k);
     }
+    cov_at_xs_batch(P, ga, nb, Ds, Bb, Rb, X.ldr, st);
     potrf_rec(Bt, Ds.ld, Ds.NR, 0, Ds.NC, ns, st);
     for (int j = 0; j < nb; ++j) launch_lml_reduce(X.B[s][j].p, Ds.ld, ns, Ds.NC, 1, outd.p + k0 + j, st);
   }
@@ -1851,12 +1877,16 @@ int lmm_lmm_rand_multi(const lmm_post_t* post, const lmm_gp_t* gps, const double
     hipStream_t st = g.streams[s];
     Batch Bt;
     if (P) Xs.cross_solve_batch(P, s, k0, nb, xsd.p, d, ns, st);      // posterior: R_k and the mean vectors (sample = mean + L z)
+    GramArgs ga[LMM_MAX_BATCH];
+    BatchPtr Bb{}, Rb{};
     for (int j = 0; j < nb; ++j) {
       const int k = k0 + j;
       const lmm_gp_t& gp = P ? P->gps[l0 + k] : gps[l0 + k];
-      cov_at_xs(P, gp, xsd.p, d, ns, jitter, nullptr, Ds, Xs.B[s][j].p, Xs.R[s][j].p, Xs.ldr, st);
+      ga[j] = cov_args(gp, xsd.p, d, ns, jitter, nullptr, Ds, Xs.B[s][j].p);
+      Bb.p[j] = Xs.B[s][j].p; Rb.p[j] = Xs.R[s][j].p;
       Bt.add(Xs.B[s][j].p, Xs.WB[s][j].p, info.p + k);
     }
+    cov_at_xs_batch(P, ga, nb, Ds, Bb, Rb, Xs.ldr, st);
     potrf_rec(Bt, Ds.ld, Ds.NR, 0, Ds.NC, ns, st);      // ONE factorisation per latent, nsamples triangular products
     for (int j = 0; j < nb; ++j) {
       const int k = k0 + j;

@@ -26,6 +26,16 @@ struct GramArgs {
   const double* xs; int ns;                    // rows ncols + r  <- kappa(xs_r, x_j)
 };
 
+// The same assembly for up to LMM_MAX_BATCH same-shaped matrices in ONE launch (blockIdx.z = matrix): everything in `base`
+// is shared; the fields below replace base's per matrix.  All matrices of a launch have base.kind.
+struct GramBatchArgs {
+  GramArgs base;
+  double* A[LMM_MAX_BATCH];
+  double var[LMM_MAX_BATCH], inv_ls[LMM_MAX_BATCH], diag_add[LMM_MAX_BATCH];
+  const double* diag_vec[LMM_MAX_BATCH];
+  const double* rider[LMM_MAX_BATCH];
+};
+
 struct DenseArgs {
   double* A; int ld, nrows, ncols;
   const double* x; int d, n, m;
@@ -36,6 +46,8 @@ struct DenseArgs {
 };
 
 void launch_gram(const GramArgs& a, hipStream_t st);
+// nb same-shaped assemblies (differing only in A, kind, var, inv_ls, diag_add, diag_vec, rider): one launch per run of equal kinds
+void launch_gram_batch(const GramArgs* args, int nb, hipStream_t st);
 void launch_dense_assemble(const DenseArgs& a, hipStream_t st);
 void launch_dense_cov(const double* S, int lds, int ns, int m, const double* Hm, int p, double jitter, double sigma2, double* T,
                       double* out, hipStream_t st);

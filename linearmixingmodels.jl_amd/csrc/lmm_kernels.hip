@@ -205,7 +205,7 @@ __device__ __forceinline__ double exp_any(double x) {
 // 2 x 64 column exponentials are amortised over 64 elements per thread.  Guard: |a (x - c)| <= 40 inside the strip (else
 // the direct per-element exp is used, e.g. for unsorted inputs).  Relative error of the product form <= ~1e-14.
 template <int KIND, bool ND>      // ND: the 1 < d <= 8 fast path is compiled in (kept out of the d == 1 kernel's register budget)
-__global__ __launch_bounds__(256) void gram_kernel(GramArgs a) {
+__device__ __forceinline__ void gram_body(const GramArgs& a) {
   constexpr int DMAX = 8;                                     // input dimensions with a fast path (d > DMAX: generic tiles)
   __shared__ double colE[64], colF[64], colX[64];
   __shared__ double colP[ND ? 64 * DMAX : 1];
@@ -337,6 +337,17 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs a) {
       }
     }
   }
+}
+
+template <int KIND, bool ND>
+__global__ __launch_bounds__(256) void gram_kernel(GramArgs a) { gram_body<KIND, ND>(a); }
+
+template <int KIND, bool ND>
+__global__ __launch_bounds__(256) void gram_batch_kernel(GramBatchArgs b) {
+  GramArgs a = b.base;
+  const int z = blockIdx.z;
+  a.A = b.A[z]; a.var = b.var[z]; a.inv_ls = b.inv_ls[z]; a.diag_add = b.diag_add[z]; a.diag_vec = b.diag_vec[z]; a.rider = b.rider[z];
+  gram_body<KIND, ND>(a);
 }
 
 // K8: dense ILMM latent covariance  blockdiag(K_1..K_m) + SigmaT (x) I_n  (+ mean-free rider row):
@@ -1319,6 +1330,35 @@ void launch_gram(const GramArgs& a, hipStream_t st) {
   else if (a.kind == LMM_KERNEL_MATERN32) LMM_GRAM_LAUNCH(LMM_KERNEL_MATERN32);
   else LMM_GRAM_LAUNCH(LMM_KERNEL_MATERN52);
 #undef LMM_GRAM_LAUNCH
+}
+
+void launch_gram_batch(const GramArgs* args, int nb, hipStream_t st) {
+  int j0 = 0;
+  while (j0 < nb) {
+    int j1 = j0 + 1;
+    while (j1 < nb && args[j1].kind == args[j0].kind) ++j1;
+    if (j1 - j0 == 1) { launch_gram(args[j0], st); j0 = j1; continue; }
+    GramBatchArgs b{};
+    b.base = args[j0];
+    for (int j = j0; j < j1; ++j) {
+      const GramArgs& a = args[j];
+      b.A[j - j0] = a.A; b.var[j - j0] = a.var; b.inv_ls[j - j0] = a.inv_ls; b.diag_add[j - j0] = a.diag_add;
+      b.diag_vec[j - j0] = a.diag_vec; b.rider[j - j0] = a.rider;
+    }
+    const GramArgs& a = b.base;
+    dim3 grid(a.nrows / 64 - a.row_tile0, (a.ncols / 64 + 3) / 4, j1 - j0);
+    const bool nd = (a.d > 1 && a.d <= 8);
+#define LMM_GRAM_LAUNCH(K)                                                                          \
+    do {                                                                                            \
+      if (nd) hipLaunchKernelGGL((gram_batch_kernel<K, true>), grid, dim3(256), 0, st, b);          \
+      else hipLaunchKernelGGL((gram_batch_kernel<K, false>), grid, dim3(256), 0, st, b);            \
+    } while (0)
+    if (a.kind == LMM_KERNEL_SE) LMM_GRAM_LAUNCH(LMM_KERNEL_SE);
+    else if (a.kind == LMM_KERNEL_MATERN32) LMM_GRAM_LAUNCH(LMM_KERNEL_MATERN32);
+    else LMM_GRAM_LAUNCH(LMM_KERNEL_MATERN52);
+#undef LMM_GRAM_LAUNCH
+    j0 = j1;
+  }
 }
 
 void launch_dense_cross(double* R, int ldr, int nrows, int ncols, const double* xs, int ns, const double* x, int n, int d,
