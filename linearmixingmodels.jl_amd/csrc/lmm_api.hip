@@ -37,6 +37,10 @@ struct Ctx {
   hipStream_t streams[kMaxStreams];
   hipEvent_t ev_main;
   hipEvent_t ev_slot[kMaxStreams];
+  // pinned host arena for the small per-call uploads / read-backs (projection matrices, per-latent results): copies from / to
+  // pinned memory are truly asynchronous, pageable ones stall the calling thread until the stream has drained
+  char* pin = nullptr;
+  size_t pin_cap = 0, pin_off = 0;
   std::multimap<size_t, void*> pool;   // cached device blocks (size -> ptr)
   std::map<void*, size_t> live;
   std::string err;
@@ -66,6 +70,15 @@ int fail(int code, const char* fmt, ...) {
     if (e_ != hipSuccess) throw fail(LMM_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
                                      __FILE__, __LINE__);                                         \
   } while (0)
+
+// bytes from the pinned arena (valid until the next API call), or nullptr when it is full / absent
+void* pin_take(size_t bytes) {
+  bytes = (bytes + 63) & ~size_t(63);
+  if (g.pin == nullptr || g.pin_off + bytes > g.pin_cap) return nullptr;
+  void* p = g.pin + g.pin_off;
+  g.pin_off += bytes;
+  return p;
+}
 
 void* dev_alloc(size_t bytes) {
   if (bytes == 0) bytes = 256;
@@ -473,7 +486,9 @@ struct Uploaded {   // small host arrays staged on the device
   Buf<double> buf;
   Uploaded() = default;
   Uploaded(const std::vector<double>& v, hipStream_t st) : buf(v.size()) {
-    HIPCHK(hipMemcpyAsync(buf.p, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    const void* src = v.data();
+    if (void* pp = pin_take(v.size() * sizeof(double))) { std::memcpy(pp, v.data(), v.size() * sizeof(double)); src = pp; }
+    HIPCHK(hipMemcpyAsync(buf.p, src, v.size() * sizeof(double), hipMemcpyHostToDevice, st));
   }
 };
 
@@ -536,9 +551,13 @@ int latent_lmls(const double* xd, int d, int n, const lmm_gp_t* gps, const doubl
   }
   join_slots(nslots);
   std::vector<int> hinfo(ms);
-  HIPCHK(hipMemcpyAsync(lml.data(), out.p, (size_t)ms * nrhs * sizeof(double), hipMemcpyDeviceToHost, g.streams[0]));
-  HIPCHK(hipMemcpyAsync(hinfo.data(), info.p, ms * sizeof(int), hipMemcpyDeviceToHost, g.streams[0]));
+  double* plml = static_cast<double*>(pin_take((size_t)ms * nrhs * sizeof(double)));
+  int* pinfo = static_cast<int*>(pin_take((size_t)ms * sizeof(int)));
+  HIPCHK(hipMemcpyAsync(plml ? plml : lml.data(), out.p, (size_t)ms * nrhs * sizeof(double), hipMemcpyDeviceToHost, g.streams[0]));
+  HIPCHK(hipMemcpyAsync(pinfo ? pinfo : hinfo.data(), info.p, ms * sizeof(int), hipMemcpyDeviceToHost, g.streams[0]));
   HIPCHK(hipStreamSynchronize(g.streams[0]));
+  if (plml) std::memcpy(lml.data(), plml, (size_t)ms * nrhs * sizeof(double));
+  if (pinfo) std::memcpy(hinfo.data(), pinfo, (size_t)ms * sizeof(int));
   return check_info(hinfo, l0);
 }
 
@@ -576,8 +595,9 @@ struct lmm_post {
   catch (int code) { return code; }                 \
   catch (const std::exception& e) { return fail(LMM_ERR_HIP, "exception: %s", e.what()); }
 
-#define REQUIRE_INIT() \
-  if (!g.init) return fail(LMM_ERR_ARG, "lmm_init() has not been called")
+#define REQUIRE_INIT()                                                           \
+  if (!g.init) return fail(LMM_ERR_ARG, "lmm_init() has not been called");      \
+  g.pin_off = 0
 
 extern "C" {
 
@@ -600,6 +620,8 @@ int lmm_init(int device) {
     HIPCHK(hipEventCreateWithFlags(&g.ev_slot[s], hipEventDisableTiming));
   }
   HIPCHK(hipEventCreateWithFlags(&g.ev_main, hipEventDisableTiming));
+  g.pin_cap = 1u << 20;
+  if (hipHostMalloc((void**)&g.pin, g.pin_cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); g.pin = nullptr; g.pin_cap = 0; }
   g.device = device;
   g.init = true;
   return LMM_OK;
@@ -614,6 +636,7 @@ int lmm_shutdown(void) {
   g.pool.clear();
   for (int s = 0; s < kMaxStreams; ++s) { (void)hipStreamDestroy(g.streams[s]); (void)hipEventDestroy(g.ev_slot[s]); }
   (void)hipEventDestroy(g.ev_main);
+  if (g.pin) { (void)hipHostFree(g.pin); g.pin = nullptr; g.pin_cap = 0; }
   g.init = false;
   return LMM_OK;
 }
@@ -684,7 +707,10 @@ int lmm_oilmm_logpdf(const double* x, int d, int n, const double* y, int p, cons
   // projection (+ residual for the regulariser, which needs T*Y for all m latents)
   const int c0 = with_regulariser ? 0 : l0, C = with_regulariser ? m : ms;
   Buf<double> Ty((size_t)n * std::max(C, 1));
-  double resid = 0.0;
+  double resid_pageable = 0.0;
+  double* resid = static_cast<double*>(pin_take(sizeof(double)));      // pinned: the read-back below does not stall the host
+  if (resid == nullptr) resid = &resid_pageable;
+  *resid = 0.0;
   Buf<double> resid_dev(1);
   if (C > 0) project_on_device(yd.p, n, p, Td.buf, m, c0, C, nullptr, Ty.p, st0);
   Uploaded Hd;                 // function scope: the residual kernels run asynchronously until latent_lmls' final sync
@@ -694,7 +720,7 @@ int lmm_oilmm_logpdf(const double* x, int d, int n, const double* y, int p, cons
     partial = Buf<double>(tall_skinny_partials(n, p));
     // reference src/oilmm.jl:112: sum(abs2, (I - U U') Y)  ==  |Y - H T Y|_F^2 since H T = U U'
     residual_on_device(yd.p, n, p, Ty.p, m, Hd.buf, partial.p, resid_dev.p, st0);
-    HIPCHK(hipMemcpyAsync(&resid, resid_dev.p, sizeof(double), hipMemcpyDeviceToHost, st0));   // read after latent_lmls' sync
+    HIPCHK(hipMemcpyAsync(resid, resid_dev.p, sizeof(double), hipMemcpyDeviceToHost, st0));    // read after latent_lmls' sync
   }
   // delta_l = (T y)_l - mean_l
   Buf<double> delta((size_t)n * std::max(ms, 1));
@@ -707,7 +733,7 @@ int lmm_oilmm_logpdf(const double* x, int d, int n, const double* y, int p, cons
     // reference src/oilmm.jl:101-113
     double logdetS = 0.0;
     for (int l = 0; l < m; ++l) logdetS += std::log(S[l]);
-    total += -((double)n * (logdetS + (double)(p - m) * std::log(2.0 * M_PI * sigma2)) + resid / sigma2) / 2.0;
+    total += -((double)n * (logdetS + (double)(p - m) * std::log(2.0 * M_PI * sigma2)) + *resid / sigma2) / 2.0;
   }
   *out = total;
   return LMM_OK;
