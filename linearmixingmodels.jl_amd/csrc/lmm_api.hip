@@ -547,7 +547,7 @@ int latent_lmls(const double* xd, int d, int n, const lmm_gp_t* gps, const doubl
     launch_gram_batch(ga, nb, s.st);       // one launch per run of equal kernel kinds (blockIdx.z = latent)
     }
     potrf_rec(B, D.ld, D.NR, 0, D.NC, n, s.st);
-    for (int j = 0; j < nb; ++j) launch_lml_reduce(s.A[j].p, D.ld, n, D.NC, nrhs, out.p + (size_t)(k0 + j) * nrhs, s.st);
+    launch_lml_reduce(B.A, nb, D.ld, n, D.NC, nrhs, out.p + (size_t)k0 * nrhs, s.st);
   }
   join_slots(nslots);
   std::vector<int> hinfo(ms);
@@ -1844,7 +1844,7 @@ int lmm_oilmm_post_logpdf(const lmm_post_t* post, const double* U, const double*
     }
     cov_at_xs_batch(P, ga, nb, Ds, Bb, Rb, X.ldr, st);
     potrf_rec(Bt, Ds.ld, Ds.NR, 0, Ds.NC, ns, st);
-    for (int j = 0; j < nb; ++j) launch_lml_reduce(X.B[s][j].p, Ds.ld, ns, Ds.NC, 1, outd.p + k0 + j, st);
+    launch_lml_reduce(Bt.A, nb, Ds.ld, ns, Ds.NC, 1, outd.p + k0, st);
   }
   join_slots(nslots);
   std::vector<double> lml(std::max(ms, 1), 0.0);

@@ -63,6 +63,7 @@ void launch_gemm_nt(const BatchPtr& C, size_t offC, int ldc, const BatchPtr& A, 
 void launch_gemm_nt(double* C, int ldc, const double* A, int lda, const double* B, int ldb, int M, int N, int K,
                     int lower, bool set, hipStream_t st);
 void launch_lml_reduce(const double* A, int ld, int n, int rider_row0, int nrhs, double* out, hipStream_t st);
+void launch_lml_reduce(const BatchPtr& A, int nb, int ld, int n, int rider_row0, int nrhs, double* out, hipStream_t st);   // out[b*nrhs + r]
 void launch_extract_row(const double* A, int ld, int row, int n, double* out, hipStream_t st);
 int strip_kc(int nk);
 size_t strip_partial_elems(int nr, int nk, int nv);

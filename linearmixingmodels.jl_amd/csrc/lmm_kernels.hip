@@ -854,8 +854,11 @@ __global__ __launch_bounds__(256, 2) void gemm44_kernel(BatchPtr Cb, size_t goff
 // z = rider row `rider_row` (= (L^-1 delta)').  One workgroup; wavefront shuffle reductions.
 // Also used with nrhs > 1 riders (matrix-Y): out[r].
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void lml_reduce_kernel(const double* __restrict__ A, int ld, int n,
+// One workgroup per matrix of the batch (blockIdx.x); matrix b writes out[b * nrhs + r].
+__global__ __launch_bounds__(256) void lml_reduce_kernel(BatchPtr Ab, int ld, int n,
                                                          int rider_row0, int nrhs, double* __restrict__ out) {
+  const double* __restrict__ A = Ab.p[blockIdx.x];
+  out += (size_t)blockIdx.x * nrhs;
   __shared__ double sh[4];
   double sl = 0.0;
   for (int k = threadIdx.x; k < n; k += 256) sl += log(A[(size_t)k * ld + k]);
@@ -1457,8 +1460,13 @@ void launch_gemm_nt(double* C, int ldc, const double* A, int lda, const double* 
   launch_gemm_nt(c, 0, ldc, a, 0, lda, b, 0, ldb, M, N, K, lower, set, 1, st);
 }
 
+void launch_lml_reduce(const BatchPtr& A, int nb, int ld, int n, int rider_row0, int nrhs, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(lml_reduce_kernel, dim3(nb), dim3(256), 0, st, A, ld, n, rider_row0, nrhs, out);
+}
 void launch_lml_reduce(const double* A, int ld, int n, int rider_row0, int nrhs, double* out, hipStream_t st) {
-  hipLaunchKernelGGL(lml_reduce_kernel, dim3(1), dim3(256), 0, st, A, ld, n, rider_row0, nrhs, out);
+  BatchPtr b{};
+  b.p[0] = const_cast<double*>(A);
+  launch_lml_reduce(b, 1, ld, n, rider_row0, nrhs, out, st);
 }
 
 void launch_extract_row(const double* A, int ld, int row, int n, double* out, hipStream_t st) {
