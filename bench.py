@@ -64,7 +64,7 @@ def cpu_baseline(P, orthogonal, budget_latents=2):
     cores = os.cpu_count() or 1
     if not orthogonal:
         # dense ILMM: (mn)^3/3 does not subsample by latents; time a reduced n and scale by the cubic flop count
-        ns = max(64, n // 8)
+        ns = max(64, n // 2)      # (m n/2)^3/3 flops: seconds of LAPACK at C1, large enough that fixed overheads do not dominate
         Ps = O.synthetic_problem(m, P["p"], ns, P["gps"][0]["kind"], False, P["s2"], seed=0)
         t0 = time.perf_counter(); O.ilmm_logpdf(Ps["gps"], Ps["H"], Ps["x"], Ps["s2"], Ps["y"]); dt = time.perf_counter() - t0
         est = dt * (n / ns) ** 3
