@@ -281,16 +281,18 @@ void trsm_rec(double* R, int ldr, int nr, const double* L, int ld, const double*
 
 // The same solve for a batch of (R_j, L_j, W_j) of identical shapes in lock-step launches (blockIdx.y = matrix).
 void trsm_rec(const BatchPtr& R, int ldr, int nr, const BatchPtr& L, int ld, const BatchPtr& W, int nb, int j0, int w,
-              hipStream_t st) {
+              hipStream_t st, bool tri = false) {
   if (w <= 64) {
-    launch_gemm_nt(R, (size_t)j0 * ldr, ldr, R, (size_t)j0 * ldr, ldr, W, (size_t)(j0 / 64) * 4096, 64, nr, 64, 64, 0, true, nb, st);
+    const int rows = tri ? std::min(nr, j0 + 64) : nr;
+    launch_gemm_nt(R, (size_t)j0 * ldr, ldr, R, (size_t)j0 * ldr, ldr, W, (size_t)(j0 / 64) * 4096, 64, rows, 64, 64, 0, true, nb, st);
     return;
   }
   const int h = split(w);
-  trsm_rec(R, ldr, nr, L, ld, W, nb, j0, h, st);
-  launch_gemm_nt(R, (size_t)(j0 + h) * ldr, ldr, R, (size_t)j0 * ldr, ldr, L, (size_t)j0 * ld + (j0 + h), ld, nr, w - h, h, 0, false,
+  trsm_rec(R, ldr, nr, L, ld, W, nb, j0, h, st, tri);
+  const int rows = tri ? std::min(nr, j0 + h) : nr;
+  launch_gemm_nt(R, (size_t)(j0 + h) * ldr, ldr, R, (size_t)j0 * ldr, ldr, L, (size_t)j0 * ld + (j0 + h), ld, rows, w - h, h, 0, false,
                  nb, st);
-  trsm_rec(R, ldr, nr, L, ld, W, nb, j0 + h, w - h, st);
+  trsm_rec(R, ldr, nr, L, ld, W, nb, j0 + h, w - h, st, tri);
 }
 
 // alpha (in place over z = L^-1 delta) <- L^-T z for one factor matrix
@@ -771,35 +773,54 @@ int lmm_oilmm_logpdf_grad(const double* x, int d, int n, const double* y, int p,
   if (ms > 0) project_on_device(yd.p, n, p, Td.buf, m, l0, ms, meansd.buf.p + l0, delta.p, st0);
   // per-latent factorisation, alpha, inverse, contractions
   Dims D(n, 1);
-  const int nslots = std::max(1, std::min(ms, eff_streams()));
-  std::vector<Buf<double>> Am, Wm, Rm, part;
+  int nb_per = 1, nslots = 1;
+  batch_plan(std::max(ms, 1), &nb_per, &nslots, 2.0 * (double)D.elems() * sizeof(double));     // factor + inverse-factor matrices
+  std::vector<std::vector<Buf<double>>> Am(nslots), Wm(nslots), Rm(nslots);
+  std::vector<Buf<double>> part;
   for (int s = 0; s < nslots; ++s) {
-    Am.emplace_back(D.elems()); Wm.emplace_back((size_t)(D.NC / 64) * 4096);
-    Rm.emplace_back((size_t)D.ld * D.NC); part.emplace_back((size_t)grad_partials(n));
+    for (int j = 0; j < nb_per; ++j) {
+      Am[s].emplace_back(D.elems()); Wm[s].emplace_back((size_t)(D.NC / 64) * 4096); Rm[s].emplace_back((size_t)D.ld * D.NC);
+    }
+    part.emplace_back((size_t)grad_partials(n));
   }
   Buf<double> alpha((size_t)D.NC * std::max(ms, 1)), lmld(std::max(ms, 1)), red((size_t)5 * std::max(ms, 1));
   Buf<int> info(std::max(ms, 1));
   HIPCHK(hipMemsetAsync(info.p, 0, std::max(ms, 1) * sizeof(int), st0));
   HIPCHK(hipMemsetAsync(alpha.p, 0, (size_t)D.NC * std::max(ms, 1) * sizeof(double), st0));
   fork_slots(nslots);
-  for (int k = 0; k < ms; ++k) {
-    const int s = k % nslots;
+  int bi = 0;
+  for (int k0 = 0; k0 < ms; k0 += nb_per, ++bi) {
+    const int s = bi % nslots, nb = std::min(nb_per, ms - k0);
     hipStream_t st = g.streams[s];
-    const lmm_gp_t& gp = gps[l0 + k];
-    double* al = alpha.p + (size_t)k * D.NC;
-    GramArgs a{};
-    a.A = Am[s].p; a.ld = D.ld; a.nrows = D.NR; a.ncols = D.NC; a.x = xd.p; a.d = d; a.n = n;
-    a.kind = gp.kind; a.var = gp.variance; a.inv_ls = 1.0 / gp.lengthscale; a.diag_add = ST[l0 + k]; a.pad_diag = 1.0;
-    a.rider = delta.p + (size_t)k * n; a.rider_ld = n; a.nrider = 1;
-    launch_gram(a, st);
-    potrf_rec(Am[s].p, D.ld, D.NR, 0, D.NC, Wm[s].p, n, info.p + k, st);
-    launch_lml_reduce(Am[s].p, D.ld, n, D.NC, 1, lmld.p + k, st);
-    launch_extract_row(Am[s].p, D.ld, D.NC, n, al, st);
-    backsolve1(Am[s].p, D.ld, Wm[s].p, D.NC / 64, al, st);
-    launch_set_identity(Rm[s].p, D.ld, D.NC, st);
-    trsm_rec(Rm[s].p, D.ld, D.NC, Am[s].p, D.ld, Wm[s].p, 0, D.NC, st, true);     // R = L^-T (upper triangular)
-    launch_syrk_upper_set(Am[s].p, D.ld, Rm[s].p, D.ld, D.NC, st);                  // lower(A) = L^-T L^-1 = Kt^-1
-    launch_grad_reduce(Am[s].p, D.ld, n, al, delta.p + (size_t)k * n, xd.p, d, to_dev(gp), part[s].p, red.p + (size_t)5 * k, st);
+    Batch B;
+    BatchPtr Rb{}, alb{};
+    GramArgs ga[LMM_MAX_BATCH];
+    for (int j = 0; j < nb; ++j) {
+      const int k = k0 + j;
+      const lmm_gp_t& gp = gps[l0 + k];
+      GramArgs a{};
+      a.A = Am[s][j].p; a.ld = D.ld; a.nrows = D.NR; a.ncols = D.NC; a.x = xd.p; a.d = d; a.n = n;
+      a.kind = gp.kind; a.var = gp.variance; a.inv_ls = 1.0 / gp.lengthscale; a.diag_add = ST[l0 + k]; a.pad_diag = 1.0;
+      a.rider = delta.p + (size_t)k * n; a.rider_ld = n; a.nrider = 1;
+      ga[j] = a;
+      B.add(Am[s][j].p, Wm[s][j].p, info.p + k);
+      Rb.p[j] = Rm[s][j].p; alb.p[j] = alpha.p + (size_t)k * D.NC;
+    }
+    launch_gram_batch(ga, nb, st);
+    potrf_rec(B, D.ld, D.NR, 0, D.NC, n, st);
+    launch_lml_reduce(B.A, nb, D.ld, n, D.NC, 1, lmld.p + k0, st);
+    for (int j = 0; j < nb; ++j) {
+      launch_extract_row(Am[s][j].p, D.ld, D.NC, n, alb.p[j], st);
+      launch_set_identity(Rm[s][j].p, D.ld, D.NC, st);
+    }
+    launch_backsolve(B.A, D.ld, B.W, D.NC / 64, alb, nb, st);
+    trsm_rec(Rb, D.ld, D.NC, B.A, D.ld, B.W, nb, 0, D.NC, st, true);        // R = L^-T (upper triangular), whole batch
+    launch_syrk_upper_set(B.A, D.ld, Rb, D.ld, D.NC, nb, st);                // lower(A) = L^-T L^-1 = Kt^-1
+    for (int j = 0; j < nb; ++j) {
+      const int k = k0 + j;
+      launch_grad_reduce(Am[s][j].p, D.ld, n, alb.p[j], delta.p + (size_t)k * n, xd.p, d, to_dev(gps[l0 + k]), part[s].p,
+                         red.p + (size_t)5 * k, st);
+    }
   }
   join_slots(nslots);
   std::vector<double> lml(std::max(ms, 1), 0.0), hred((size_t)5 * std::max(ms, 1), 0.0);

@@ -84,6 +84,7 @@ void launch_cov_mix(const BatchPtr& Cl, int ldcl, int nl, const double* Hs, int 
 void launch_trmv_lower(const double* L, int ld, int n, const double* z, double mu, double* partial, double* out,
                        hipStream_t st);
 void launch_syrk_upper_set(double* C, int ldc, const double* X, int ldx, int N, hipStream_t st);
+void launch_syrk_upper_set(const BatchPtr& C, int ldc, const BatchPtr& X, int ldx, int N, int nb, hipStream_t st);
 void launch_set_identity(double* R, int ld, int nc, hipStream_t st);
 int grad_partials(int n);
 void launch_grad_reduce(const double* Kinv, int ld, int n, const double* alpha, const double* delta, const double* x, int d,

@@ -1442,15 +1442,18 @@ void launch_gemm_nt(const BatchPtr& C, size_t offC, int ldc, const BatchPtr& A, 
 }
 
 // C (lower triangle, N x N) = X X' for an upper-triangular X (N x N): the inverse K^-1 = L^-T L^-1 from X = L^-T.
-void launch_syrk_upper_set(double* C, int ldc, const double* X, int ldx, int N, hipStream_t st) {
-  if (N <= 0) return;
+void launch_syrk_upper_set(const BatchPtr& C, int ldc, const BatchPtr& X, int ldx, int N, int nb, hipStream_t st) {
+  if (N <= 0 || nb <= 0) return;
   const int MT = (N + 127) / 128, NT = (N + 127) / 128;
   long long T = 0;
   for (int tj = 0; tj < NT; ++tj) T += MT - tj;
+  hipLaunchKernelGGL((gemm44_kernel<128, true>), dim3((int)T, nb), dim3(256), 0, st, C, (size_t)0, ldc, X, (size_t)0, ldx, X, (size_t)0, ldx,
+                     N, N, N, 1, MT, (int)T, 1, 1);
+}
+void launch_syrk_upper_set(double* C, int ldc, const double* X, int ldx, int N, hipStream_t st) {
   BatchPtr c{}, a{};
   c.p[0] = C; a.p[0] = const_cast<double*>(X);
-  hipLaunchKernelGGL((gemm44_kernel<128, true>), dim3((int)T, 1), dim3(256), 0, st, c, (size_t)0, ldc, a, (size_t)0, ldx, a, (size_t)0, ldx,
-                     N, N, N, 1, MT, (int)T, 1, 1);
+  launch_syrk_upper_set(c, ldc, a, ldx, N, 1, st);
 }
 
 void launch_gemm_nt(double* C, int ldc, const double* A, int lda, const double* B, int ldb, int M, int N, int K,
