@@ -495,15 +495,23 @@ struct Uploaded {   // small host arrays staged on the device
 };
 
 // Ty (n x C, ld n) = In (n x K) * Mx' - sub;  optionally residual sum of squares |Ref - Ty * Hm'|_F^2.
+void project_on_device(const double* Y, int n, int p, const double* Td, int m, int c0, int C,
+                       const double* sub_dev, double* Ty, hipStream_t st) {
+  launch_tall_skinny(Y, n, n, p, Td + c0, m, C, Ty, n, sub_dev, nullptr, 0, nullptr, 0, st);
+}
 void project_on_device(const double* Y, int n, int p, const Buf<double>& Td, int m, int c0, int C,
                        const double* sub_dev, double* Ty, hipStream_t st) {
-  launch_tall_skinny(Y, n, n, p, Td.p + c0, m, C, Ty, n, sub_dev, nullptr, 0, nullptr, 0, st);
+  project_on_device(Y, n, p, Td.p, m, c0, C, sub_dev, Ty, st);
 }
 
+void residual_on_device(const double* Y, int n, int p, const double* Ty_all, int m, const double* Hd,
+                        double* partial, double* out1, hipStream_t st) {
+  launch_tall_skinny(Ty_all, n, n, m, Hd, p, p, nullptr, 0, nullptr, Y, n, partial, 1, st);
+  launch_sum_partials(partial, tall_skinny_partials(n, p), out1, st);
+}
 void residual_on_device(const double* Y, int n, int p, const double* Ty_all, int m, const Buf<double>& Hd,
                         double* partial, double* out1, hipStream_t st) {
-  launch_tall_skinny(Ty_all, n, n, m, Hd.p, p, p, nullptr, 0, nullptr, Y, n, partial, 1, st);
-  launch_sum_partials(partial, tall_skinny_partials(n, p), out1, st);
+  residual_on_device(Y, n, p, Ty_all, m, Hd.p, partial, out1, st);
 }
 
 // Core: per-latent log marginal likelihoods for latents [l0, l1) given the device rider vectors
@@ -511,7 +519,8 @@ void residual_on_device(const double* Y, int n, int p, const double* Ty_all, int
 // right-hand sides (matrix-Y logpdf) ride one factorisation.  noisevec ([latent of the shard][n], device) replaces the
 // scalar per-latent noise by a per-point diagonal.
 int latent_lmls(const double* xd, int d, int n, const lmm_gp_t* gps, const double* noise, int l0, int l1,
-                const double* delta, std::vector<double>& lml, int nrhs = 1, const double* noisevec = nullptr) {
+                const double* delta, std::vector<double>& lml, int nrhs = 1, const double* noisevec = nullptr,
+                const double* rider_sub = nullptr) {       // rider_sub[latent] (host): subtracted from that latent's riders
   const int ms = l1 - l0;
   lml.assign((size_t)ms * nrhs, 0.0);
   if (ms == 0) return LMM_OK;
@@ -543,6 +552,7 @@ int latent_lmls(const double* xd, int d, int n, const lmm_gp_t* gps, const doubl
       a.diag_add = noisevec ? 0.0 : noise[l0 + k]; a.pad_diag = 1.0;
       a.diag_vec = noisevec ? noisevec + (size_t)k * n : nullptr;      // per-point noise of latent k (device, n values)
       a.rider = delta + (size_t)k * nrhs * n; a.rider_ld = n; a.nrider = nrhs; a.xs = nullptr; a.ns = 0;
+      a.rider_sub = rider_sub ? rider_sub[l0 + k] : 0.0;
       ga[j] = a;
       B.add(s.A[j].p, s.W[j].p, info.p + k);
     }
@@ -701,34 +711,34 @@ int lmm_oilmm_logpdf(const double* x, int d, int n, const double* y, int p, cons
   std::vector<double> T, ST, H;
   project_orthogonal(U, S, p, m, sigma2, T, ST, H);
   DevIn xd(x, (size_t)d * n, st0), yd(y, (size_t)n * p, st0);
-  Uploaded Td(T, st0);
   std::vector<double> means(m);
   for (int l = 0; l < m; ++l) means[l] = gps[l].mean;
-  Uploaded meansd(means, st0);
   const int l0 = latent_begin, l1 = latent_end, ms = l1 - l0;
-  // projection (+ residual for the regulariser, which needs T*Y for all m latents)
-  const int c0 = with_regulariser ? 0 : l0, C = with_regulariser ? m : ms;
-  Buf<double> Ty((size_t)n * std::max(C, 1));
   double resid_pageable = 0.0;
   double* resid = static_cast<double*>(pin_take(sizeof(double)));      // pinned: the read-back below does not stall the host
   if (resid == nullptr) resid = &resid_pageable;
   *resid = 0.0;
-  Buf<double> resid_dev(1);
-  if (C > 0) project_on_device(yd.p, n, p, Td.buf, m, c0, C, nullptr, Ty.p, st0);
-  Uploaded Hd;                 // function scope: the residual kernels run asynchronously until latent_lmls' final sync
-  Buf<double> partial;
-  if (with_regulariser) {
-    Hd = Uploaded(H, st0);
-    partial = Buf<double>(tall_skinny_partials(n, p));
-    // reference src/oilmm.jl:112: sum(abs2, (I - U U') Y)  ==  |Y - H T Y|_F^2 since H T = U U'
-    residual_on_device(yd.p, n, p, Ty.p, m, Hd.buf, partial.p, resid_dev.p, st0);
-    HIPCHK(hipMemcpyAsync(resid, resid_dev.p, sizeof(double), hipMemcpyDeviceToHost, st0));    // read after latent_lmls' sync
-  }
-  // delta_l = (T y)_l - mean_l
-  Buf<double> delta((size_t)n * std::max(ms, 1));
-  if (ms > 0) project_on_device(yd.p, n, p, Td.buf, m, l0, ms, meansd.buf.p + l0, delta.p, st0);
   std::vector<double> lml;
-  if (int rc = latent_lmls(xd.p, d, n, gps, ST.data(), l0, l1, delta.p, lml)) return rc;
+  if (with_regulariser) {
+    // ONE upload [T | H]; ONE projection T*Y of all m latents serves the regulariser's residual and, through rider rows that
+    // subtract the latent mean inside the Gram kernel, the per-latent right-hand sides delta_l = (T y)_l - mean_l
+    std::vector<double> pack(T);
+    pack.insert(pack.end(), H.begin(), H.end());
+    Uploaded THd(pack, st0);
+    const double* Tdev = THd.buf.p;
+    const double* Hdev = THd.buf.p + (size_t)m * p;
+    Buf<double> Ty((size_t)n * m), resid_dev(1), partial(tall_skinny_partials(n, p));
+    project_on_device(yd.p, n, p, Tdev, m, 0, m, nullptr, Ty.p, st0);
+    // reference src/oilmm.jl:112: sum(abs2, (I - U U') Y)  ==  |Y - H T Y|_F^2 since H T = U U'
+    residual_on_device(yd.p, n, p, Ty.p, m, Hdev, partial.p, resid_dev.p, st0);
+    HIPCHK(hipMemcpyAsync(resid, resid_dev.p, sizeof(double), hipMemcpyDeviceToHost, st0));    // read after latent_lmls' sync
+    if (int rc = latent_lmls(xd.p, d, n, gps, ST.data(), l0, l1, Ty.p + (size_t)l0 * n, lml, 1, nullptr, means.data())) return rc;
+  } else {
+    Uploaded Td(T, st0), meansd(means, st0);
+    Buf<double> delta((size_t)n * std::max(ms, 1));
+    if (ms > 0) project_on_device(yd.p, n, p, Td.buf, m, l0, ms, meansd.buf.p + l0, delta.p, st0);
+    if (int rc = latent_lmls(xd.p, d, n, gps, ST.data(), l0, l1, delta.p, lml)) return rc;
+  }
   double total = 0.0;
   for (int k = 0; k < ms; ++k) total += lml[k];
   if (with_regulariser) {

@@ -22,7 +22,8 @@ struct GramArgs {
   const double* x; int d, n;
   int kind; double var, inv_ls, diag_add, pad_diag;
   const double* diag_vec;                      // optional per-point diagonal term (length n), added to diag_add
-  const double* rider; int rider_ld, nrider;   // rows ncols + r  <- rider[r*rider_ld + j]
+  const double* rider; int rider_ld, nrider;   // rows ncols + r  <- rider[r*rider_ld + j] - rider_sub
+  double rider_sub;                            // constant subtracted from the rider rows (latent mean: delta = T y - mean)
   const double* xs; int ns;                    // rows ncols + r  <- kappa(xs_r, x_j)
 };
 
@@ -34,6 +35,7 @@ struct GramBatchArgs {
   double var[LMM_MAX_BATCH], inv_ls[LMM_MAX_BATCH], diag_add[LMM_MAX_BATCH];
   const double* diag_vec[LMM_MAX_BATCH];
   const double* rider[LMM_MAX_BATCH];
+  double rider_sub[LMM_MAX_BATCH];
 };
 
 struct DenseArgs {

@@ -164,7 +164,7 @@ __device__ __forceinline__ void gram_tile_generic(const GramArgs& a, int ti, int
           val = kappa(a.kind, a.var, r, r2);
           if (rtype[e] == 0 && i0 + e == j) val += a.diag_add + (a.diag_vec ? a.diag_vec[j] : 0.0);
         } else if (rtype[e] == 2) {
-          val = rpt[e][j];
+          val = rpt[e][j] - a.rider_sub;
         }
         out[e] = val;
       }
@@ -346,7 +346,7 @@ template <int KIND, bool ND>
 __global__ __launch_bounds__(256) void gram_batch_kernel(GramBatchArgs b) {
   GramArgs a = b.base;
   const int z = blockIdx.z;
-  a.A = b.A[z]; a.var = b.var[z]; a.inv_ls = b.inv_ls[z]; a.diag_add = b.diag_add[z]; a.diag_vec = b.diag_vec[z]; a.rider = b.rider[z];
+  a.A = b.A[z]; a.var = b.var[z]; a.inv_ls = b.inv_ls[z]; a.diag_add = b.diag_add[z]; a.diag_vec = b.diag_vec[z]; a.rider = b.rider[z]; a.rider_sub = b.rider_sub[z];
   gram_body<KIND, ND>(a);
 }
 
@@ -1346,7 +1346,7 @@ void launch_gram_batch(const GramArgs* args, int nb, hipStream_t st) {
     for (int j = j0; j < j1; ++j) {
       const GramArgs& a = args[j];
       b.A[j - j0] = a.A; b.var[j - j0] = a.var; b.inv_ls[j - j0] = a.inv_ls; b.diag_add[j - j0] = a.diag_add;
-      b.diag_vec[j - j0] = a.diag_vec; b.rider[j - j0] = a.rider;
+      b.diag_vec[j - j0] = a.diag_vec; b.rider[j - j0] = a.rider; b.rider_sub[j - j0] = a.rider_sub;
     }
     const GramArgs& a = b.base;
     dim3 grid(a.nrows / 64 - a.row_tile0, (a.ncols / 64 + 3) / 4, j1 - j0);
