@@ -25,6 +25,8 @@
 #ifndef LMM_HIP_H
 #define LMM_HIP_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -240,6 +242,10 @@ int lmm_dev_gemm_nt_sub(double* C, int ldc, const double* A, int lda, const doub
 /* Gram assembly of one latent into a padded factor matrix (lower triangle + pad identity). */
 int lmm_dev_gram(double* A, int ld, int nrows, int ncols, const double* x, int d, int n,
                  const lmm_gp_t* gp, double diag_add);
+/* Standard normals generated on the device (Philox4x32-10 counter RNG + Box-Muller, Float64): out[j] for j < count is a
+ * function of (seed, stream, j) only.  Optional companion of lmm_lmm_rand*: the reference draws its normals on the host with
+ * the caller's rng (src/oilmm.jl:47,53), and the shim keeps doing so when the reference's random stream matters. */
+int lmm_normals(unsigned long long seed, unsigned long long stream, size_t count, double* out);
 /* ---- measurement hooks (bench.py roofline leg) ------------------------------------------------ */
 /* Between lmm_profile_begin and lmm_profile_end every launch of the classes below is bracketed by HIP events
  * on the stream it is launched on.  serial != 0 forces all latents onto ONE stream, so an event pair times its

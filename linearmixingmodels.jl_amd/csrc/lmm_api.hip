@@ -1975,6 +1975,24 @@ int lmm_lmm_rand(const lmm_post_t* post, const lmm_gp_t* gps, const double* U, c
   return lmm_lmm_rand_multi(post, gps, U, S, p, m, latent_begin, latent_end, sigma2, add_noise, xs, d, ns, 1, z_lat, eps, jit, out);
 }
 
+// Standard normals on the device (Philox4x32-10 + Box-Muller, Float64): out[j], j < count, reproducible for (seed, stream).
+// out may be a host or a device pointer.  Optional companion of lmm_lmm_rand / lmm_lmm_rand_multi, whose normals are
+// caller-supplied: the Julia shim draws them from the reference's rng on the host; this generator serves callers that do not
+// need that stream (SURVEY.md section 8a, K7 "optional Philox").
+int lmm_normals(unsigned long long seed, unsigned long long stream, size_t count, double* out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  REQUIRE_INIT();
+  LMM_TRY
+  if (!out && count > 0) return fail(LMM_ERR_ARG, "out is NULL");
+  hipStream_t st0 = g.streams[0];
+  DevOut od(out, count);
+  launch_normals(seed, stream, count, od.p, st0);
+  od.finish(st0);
+  HIPCHK(hipStreamSynchronize(st0));
+  return LMM_OK;
+  LMM_CATCH
+}
+
 // ------------------------------------------------------------------------------------------------
 // building blocks (device pointers) for tests / profiling
 // ------------------------------------------------------------------------------------------------

@@ -95,4 +95,5 @@ void launch_atb(const double* X, int ldx, const double* Z, int ldz, int n, int n
 void launch_fill(double* p, int n, double v, hipStream_t st);
 void launch_reorder(const double* in, int n, int p, int to_outputs, double* out, hipStream_t st);
 void launch_vec_lin(const double* a, const double* b, double sb, int n, double* out, hipStream_t st);  // out = a + sb*b
+void launch_normals(unsigned long long seed, unsigned long long stream, size_t count, double* out, hipStream_t st);
 void launch_mfma_peak(double* out, int blocks, int iters, hipStream_t st);

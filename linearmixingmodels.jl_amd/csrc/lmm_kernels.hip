@@ -1287,6 +1287,38 @@ __global__ void reorder_kernel(const double* __restrict__ in, int n, int p, int 
 }
 
 // ---------------------------------------------------------------------------------------------------
+// K7 (optional): standard normals on the device -- Philox4x32-10 counter RNG (Salmon et al. 2011) + Box-Muller in Float64.
+// Normal 2j and 2j+1 come from counter (j, stream) under key `seed`, so a buffer is reproducible for (seed, stream) whatever
+// the launch shape.  The reference draws with Julia's MersenneTwister on the host; this is for callers that do not need
+// the reference's random stream (the draw ORDER of rand is kept by the caller: latent normals first, then noise normals).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(unsigned int c[4], unsigned int k0, unsigned int k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0], p1 = (unsigned long long)0xCD9E8D57u * c[2];
+    const unsigned int hi0 = (unsigned int)(p0 >> 32), lo0 = (unsigned int)p0, hi1 = (unsigned int)(p1 >> 32), lo1 = (unsigned int)p1;
+    const unsigned int n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+    c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+
+__global__ void normals_kernel(unsigned long long seed, unsigned long long stream, size_t count, double* __restrict__ out) {
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // pair index
+  if (2 * j >= count) return;
+  unsigned int c[4] = {(unsigned int)j, (unsigned int)(j >> 32), (unsigned int)stream, (unsigned int)(stream >> 32)};
+  philox4x32_10(c, (unsigned int)seed, (unsigned int)(seed >> 32));
+  // two uniforms in (0, 1] / [0, 1) with 53 random bits each
+  const double u1 = ((double)(((unsigned long long)(c[0] >> 5) << 26) | (c[1] >> 6)) + 1.0) * (1.0 / 9007199254740992.0);
+  const double u2 = (double)(((unsigned long long)(c[2] >> 5) << 26) | (c[3] >> 6)) * (1.0 / 9007199254740992.0);
+  const double rad = sqrt(-2.0 * log(u1));
+  double sn, cs;
+  sincospi(2.0 * u2, &sn, &cs);
+  out[2 * j] = rad * cs;
+  if (2 * j + 1 < count) out[2 * j + 1] = rad * sn;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // f64 MFMA issue-rate microbenchmark (the guide gives no FP64 matrix peak).
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mfma_f64_peak_kernel(double* out, int iters) {
@@ -1587,6 +1619,12 @@ void launch_reorder(const double* in, int n, int p, int to_outputs, double* out,
 
 void launch_vec_lin(const double* a, const double* b, double sb, int n, double* out, hipStream_t st) {
   hipLaunchKernelGGL(vec_lin_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a, b, sb, n, out);
+}
+
+void launch_normals(unsigned long long seed, unsigned long long stream, size_t count, double* out, hipStream_t st) {
+  if (count == 0) return;
+  const size_t pairs = (count + 1) / 2;
+  hipLaunchKernelGGL(normals_kernel, dim3((unsigned int)((pairs + 255) / 256)), dim3(256), 0, st, seed, stream, count, out);
 }
 
 void launch_mfma_peak(double* out, int blocks, int iters, hipStream_t st) {

@@ -550,6 +550,32 @@ def marginals(fx: FiniteGP) -> Normal:
     return Normal(m, v ** 0.5)
 
 
+class DeviceNormals:
+    """Standard normals generated on the GPU (lmm_normals: Philox4x32-10 + Box-Muller, Float64).  Pass it to `rand` in place of
+    a numpy Generator when the reference's host random stream is not needed: the draw ORDER of the reference is kept (latent
+    normals, then noise normals), the buffers never leave the device, and the sample comes back as a device tensor."""
+
+    def __init__(self, seed: int):
+        self.seed, self.stream = int(seed), 0
+
+    def standard_normal(self, count: int):
+        import torch
+        L.ensure_init()
+        out = torch.empty(int(count), dtype=torch.float64, device="cuda")
+        L.check(L.load().lmm_normals(C.c_ulonglong(self.seed), C.c_ulonglong(self.stream), C.c_size_t(int(count)),
+                                     C.c_void_p(out.data_ptr())))
+        self.stream += 1
+        return out
+
+
+def _empty_for(rng, *shape):
+    """Result / staging buffer on the side the normals live on."""
+    if isinstance(rng, DeviceNormals):
+        import torch
+        return torch.empty(*shape, dtype=torch.float64, device="cuda")
+    return np.empty(shape)
+
+
 def rand(rng, fx: FiniteGP, N: Optional[int] = None, jitters=None, add_noise: bool = True):
     """rand(rng, fx[, N]): reference src/oilmm.jl:40-54, src/ilmm.jl:78-92, src/independent_mogp.jl:83-96.
     `rng` is a numpy Generator; standard normals are drawn on the host in the reference's order (m blocks of n
@@ -575,12 +601,12 @@ def rand(rng, fx: FiniteGP, N: Optional[int] = None, jitters=None, add_noise: bo
             unpack(fx)
             Ua, Sa, p, m = _H_args(f.H)
             descs, post, shard, jit, noise = [g.desc() for g in f.f.fs], f.f._post, f.shard, L.jitters(jitters), int(add_noise)
-        z = np.empty((N, m * n)); eps = np.empty((N, n * p))
+        z = _empty_for(rng, N, m * n); eps = _empty_for(rng, N, n * p)
         for q in range(N):
             z[q] = rng.standard_normal(m * n)
             if not isinstance(f, IndependentMOGP):
                 eps[q] = rng.standard_normal(n * p)
-        out = np.empty((N, n * p))
+        out = _empty_for(rng, N, n * p)
         L.check(lib.lmm_lmm_rand_multi(post.ptr if post is not None else None, L.gps_array(descs), Ua.ptr,
                                        Sa.ptr if Sa is not None else None, p, m, shard[0], shard[1], C.c_double(s2), noise, xa.ptr,
                                        x.dim, n, N, L.Arr(z).ptr, L.Arr(eps).ptr if noise else None, jit, L.Arr(out, True).ptr))
@@ -589,7 +615,7 @@ def rand(rng, fx: FiniteGP, N: Optional[int] = None, jitters=None, add_noise: bo
         # vcat(rand(rng, f_l(x, s2))): latent jitter = s2, H = I, no extra noise term
         m = len(f.fs)
         z = rng.standard_normal(m * n)
-        out = np.empty(n * m)
+        out = _empty_for(rng, n * m)
         gps = L.gps_array([g.desc() for g in f.fs])
         post = f._post.ptr if f._post is not None else None
         Ua = L.Arr(L.colmajor(np.eye(m)))
@@ -601,7 +627,7 @@ def rand(rng, fx: FiniteGP, N: Optional[int] = None, jitters=None, add_noise: bo
     Ua, Sa, p, m = _H_args(f.H)
     z = rng.standard_normal(m * n)
     eps = rng.standard_normal(n * p)
-    out = np.empty(n * p)
+    out = _empty_for(rng, n * p)
     if not f.is_oilmm and f.f._post is not None:      # dense-H posterior: coupled latents, reference src/ilmm.jl:78-87
         L.check(lib.lmm_ilmm_post_rand(f.f._post.ptr, C.c_double(s2), int(add_noise), xa.ptr, x.dim, n, L.Arr(z).ptr,
                                        L.Arr(eps).ptr, L.jitters(jitters), L.Arr(out, True).ptr))

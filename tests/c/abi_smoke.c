@@ -13,7 +13,7 @@ int main(int argc, char** argv) {
     void* syms[] = {(void*)lmm_init, (void*)lmm_oilmm_logpdf, (void*)lmm_ilmm_logpdf, (void*)lmm_mogp_logpdf, (void*)lmm_mogp_logpdf_diag,
                     (void*)lmm_oilmm_posterior_create, (void*)lmm_post_destroy, (void*)lmm_oilmm_mean_and_var,
                     (void*)lmm_lmm_rand, (void*)lmm_oilmm_logpdf_grad, (void*)lmm_lmm_mean_and_cov,
-                    (void*)lmm_ilmm_post_mean_and_cov, (void*)lmm_ilmm_post_condition};
+                    (void*)lmm_ilmm_post_mean_and_cov, (void*)lmm_ilmm_post_condition, (void*)lmm_normals};
     printf("linked %zu symbols\n", sizeof syms / sizeof *syms);
     return 0;
   }

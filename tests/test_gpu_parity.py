@@ -485,6 +485,43 @@ def test_mogp_heteroscedastic_diagonal_noise(lmm):
                    rng.standard_normal(4 * n))
 
 
+def test_device_normals_and_device_rand(lmm):
+    """lmm_normals (Philox4x32-10 + Box-Muller on the device; SURVEY.md 8a K7 'optional Philox'): reproducible per (seed, stream),
+    standard-normal moments, and rand() fed from it equals rand() fed the same numbers from the host."""
+    import torch
+    g1, g2 = lmm.DeviceNormals(1234), lmm.DeviceNormals(1234)
+    a, b = g1.standard_normal(200001), g2.standard_normal(200001)
+    assert torch.equal(a, b)
+    c = g1.standard_normal(200001)                       # next stream: different numbers
+    assert not torch.equal(a, c)
+    x = torch.cat([a, c]).cpu().numpy()
+    assert abs(x.mean()) < 0.01 and abs(x.var() - 1.0) < 0.01 and abs((x ** 3).mean()) < 0.03 and abs((x ** 4).mean() - 3.0) < 0.08
+    assert np.isfinite(x).all() and np.abs(x).max() < 7.0
+    host = np.empty(1001)                                 # host output pointer, odd count
+    from lmm_amd import _lib as L
+    import ctypes as C
+    L.check(lmm.load().lmm_normals(C.c_ulonglong(1234), C.c_ulonglong(0), C.c_size_t(1001), L.Arr(host, True).ptr))
+    np.testing.assert_array_equal(host, a[:1001].cpu().numpy())
+    # a sample drawn with device normals == the same normals handed over from the host
+    rng = np.random.default_rng(5)
+    n, p, m = 90, 4, 3
+    xx = np.sort(rng.uniform(0, 5, n))
+    gps = _gps(["se", "matern32", "matern52"], rng)
+    U, S = _orth(rng, p, m)
+    fx = lmm.ILMM(_to_model(lmm, gps), lmm.Orthogonal(U, S))(lmm.MOInputIsotopicByOutputs(xx, p), 0.1)
+    s_dev = lmm.rand(lmm.DeviceNormals(77), fx, jitters=(1e-9, 1e-8, 1e-8))
+    gd = lmm.DeviceNormals(77)
+    z, eps = gd.standard_normal(m * n).cpu().numpy(), gd.standard_normal(n * p).cpu().numpy()
+
+    class Replay:
+        def __init__(self, bufs): self.bufs = list(bufs)
+        def standard_normal(self, k): v = self.bufs.pop(0); assert len(v) == k; return v
+    s_host = lmm.rand(Replay([z, eps]), fx, jitters=(1e-9, 1e-8, 1e-8))
+    np.testing.assert_allclose(s_dev.cpu().numpy(), s_host, rtol=1e-12, atol=1e-13)
+    S3 = lmm.rand(lmm.DeviceNormals(9), fx, 3, jitters=(1e-9, 1e-8, 1e-8))
+    assert tuple(S3.shape) == (n * p, 3) and bool(torch.isfinite(S3).all())
+
+
 def test_matrix_y_logpdf_and_rand_n(lmm):
     """logpdf(fx, Y::Matrix) and rand(rng, fx, N) (AbstractGPs.TestUtils primary interface; SURVEY.md 8f next #3): one
     factorisation per latent serves every column / sample; values equal the per-column reference answers."""
