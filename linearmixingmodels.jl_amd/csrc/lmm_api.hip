@@ -1186,15 +1186,10 @@ static int posterior_create_common(const double* xd, int d, int n, const lmm_gp_
       }
       launch_gram_batch(ga, nb, st);
       potrf_rec(B, D.ld, D.NR, 0, D.NC, n, st);
-      BatchPtr ab{};
-      for (int j = 0; j < nb; ++j) {
-        const int k = k0 + j;
-        // alpha = L^-T (L^-1 delta): the rider row is z = L^-1 delta
-        HIPCHK(hipMemsetAsync(P->alpha[k].p, 0, (size_t)D.NC * sizeof(double), st));
-        launch_extract_row(P->L[k].p, D.ld, D.NC, n, P->alpha[k].p, st);
-        HIPCHK(hipMemcpyAsync(P->z[k].p, P->alpha[k].p, (size_t)D.NC * sizeof(double), hipMemcpyDeviceToDevice, st));
-        ab.p[j] = P->alpha[k].p;
-      }
+      // alpha = L^-T (L^-1 delta): the rider row is z = L^-1 delta (kept as P->z, zero-padded to NC)
+      BatchPtr ab{}, zb{};
+      for (int j = 0; j < nb; ++j) { ab.p[j] = P->alpha[k0 + j].p; zb.p[j] = P->z[k0 + j].p; }
+      launch_extract_rows(B.A, nb, D.ld, D.NC, n, D.NC, ab, zb, st);
       launch_backsolve(B.A, D.ld, B.W, D.NC / 64, ab, nb, st);
     }
     join_slots(nslots);

@@ -67,6 +67,8 @@ void launch_gemm_nt(double* C, int ldc, const double* A, int lda, const double* 
 void launch_lml_reduce(const double* A, int ld, int n, int rider_row0, int nrhs, double* out, hipStream_t st);
 void launch_lml_reduce(const BatchPtr& A, int nb, int ld, int n, int rider_row0, int nrhs, double* out, hipStream_t st);   // out[b*nrhs + r]
 void launch_extract_row(const double* A, int ld, int row, int n, double* out, hipStream_t st);
+void launch_extract_rows(const BatchPtr& A, int nb, int ld, int row, int n, int nfill, const BatchPtr& o1, const BatchPtr& o2,
+                         hipStream_t st);
 int strip_kc(int nk);
 size_t strip_partial_elems(int nr, int nk, int nv);
 void launch_rider_stats(const double* R, int ld, int nr, int nk, const double* z, double mu, double base, double* partial,

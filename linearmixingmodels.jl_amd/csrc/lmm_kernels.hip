@@ -883,6 +883,16 @@ __global__ void extract_row_kernel(const double* __restrict__ A, int ld, int row
   if (k < n) out[k] = A[(size_t)k * ld + row];
 }
 
+// The same for the matrices of a batch (blockIdx.y), zero-filled up to nfill, into two destinations per matrix (alpha, which
+// the back substitution then overwrites, and the kept copy z = L^-1 delta).
+__global__ void extract_rows_kernel(BatchPtr Ab, int ld, int row, int n, int nfill, BatchPtr o1, BatchPtr o2) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nfill) return;
+  const double v = (k < n) ? Ab.p[blockIdx.y][(size_t)k * ld + row] : 0.0;
+  o1.p[blockIdx.y][k] = v;
+  o2.p[blockIdx.y][k] = v;
+}
+
 // Strip reductions over a column-major block M (rows r contiguous in memory, columns k, stride ld): for the 64-row strip
 // blockIdx.x and the k-chunk blockIdx.y (kc columns) of this workgroup
 //   dot[r] = sum_k M[r,k] v[k]        and, SQ:  sq[r] = sum_k M[r,k]^2       (TRI: only k <= r, i.e. the product L z)
@@ -1506,6 +1516,11 @@ void launch_lml_reduce(const double* A, int ld, int n, int rider_row0, int nrhs,
 
 void launch_extract_row(const double* A, int ld, int row, int n, double* out, hipStream_t st) {
   hipLaunchKernelGGL(extract_row_kernel, dim3((n + 255) / 256), dim3(256), 0, st, A, ld, row, n, out);
+}
+
+void launch_extract_rows(const BatchPtr& A, int nb, int ld, int row, int n, int nfill, const BatchPtr& o1, const BatchPtr& o2,
+                         hipStream_t st) {
+  hipLaunchKernelGGL(extract_rows_kernel, dim3((nfill + 255) / 256, nb), dim3(256), 0, st, A, ld, row, n, nfill, o1, o2);
 }
 
 // k-chunk width of the strip reductions: at most 64 chunks, a multiple of 256 columns
