@@ -590,8 +590,10 @@ struct lmm_post {
   std::vector<Buf<double>> W; // inverse diagonal blocks
   std::vector<Buf<double>> alpha;     // C \\ delta
   std::vector<Buf<double>> z;         // per latent: L^-1 delta (contiguous copy of the rider row)
-  std::vector<Buf<double>> delta;     // per latent: projected residuals (T y)_l - mean_l   (kept for sequential conditioning)
-  std::vector<Buf<double>> noisev;    // per latent: per-point projected noise
+  // kept for sequential conditioning: projected residuals (T y)_l - mean_l, [latent of the shard][n], and the projected noise:
+  // one scalar per latent after a first conditioning, per-point values ([latent][n]) once batches with different noise mix
+  Buf<double> delta_all, noise_all;
+  std::vector<double> noise_scalar;
   // dense ILMM (kind 1): L[0] is the (mn) x (mn) factor, alpha[0] the (mn) weights
   int p = 0;
   Buf<double> ddelta;           // (mn): projected residuals [latent][point]  (kept for sequential conditioning)
@@ -1160,11 +1162,14 @@ static int posterior_create_common(const double* xd, int d, int n, const lmm_gp_
       P->W.emplace_back((size_t)(D.NC / 64) * 4096);
       P->alpha.emplace_back((size_t)D.NC);
       P->z.emplace_back((size_t)D.NC);
-      P->delta.emplace_back((size_t)n);
-      P->noisev.emplace_back((size_t)n);
-      HIPCHK(hipMemcpyAsync(P->delta[k].p, delta + (size_t)k * n, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, g.streams[0]));
-      if (noisevec) HIPCHK(hipMemcpyAsync(P->noisev[k].p, noisevec + (size_t)k * n, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, g.streams[0]));
-      else launch_fill(P->noisev[k].p, n, noise[l0 + k], g.streams[0]);
+    }
+    P->delta_all = Buf<double>((size_t)n * std::max(ms, 1));
+    if (ms > 0) HIPCHK(hipMemcpyAsync(P->delta_all.p, delta, (size_t)n * ms * sizeof(double), hipMemcpyDeviceToDevice, g.streams[0]));
+    if (noisevec) {
+      P->noise_all = Buf<double>((size_t)n * std::max(ms, 1));
+      if (ms > 0) HIPCHK(hipMemcpyAsync(P->noise_all.p, noisevec, (size_t)n * ms * sizeof(double), hipMemcpyDeviceToDevice, g.streams[0]));
+    } else {
+      P->noise_scalar.assign(noise + l0, noise + l1);
     }
     fork_slots(nslots);
     int bi = 0;
@@ -1179,7 +1184,8 @@ static int posterior_create_common(const double* xd, int d, int n, const lmm_gp_
         GramArgs a{};
         a.A = P->L[k].p; a.ld = D.ld; a.nrows = D.NR; a.ncols = D.NC; a.x = P->x.p; a.d = d; a.n = n;
         a.kind = gp.kind; a.var = gp.variance; a.inv_ls = 1.0 / gp.lengthscale; a.pad_diag = 1.0;
-        a.diag_add = 0.0; a.diag_vec = P->noisev[k].p;
+        a.diag_add = noisevec ? 0.0 : noise[l0 + k];
+        a.diag_vec = noisevec ? P->noise_all.p + (size_t)k * n : nullptr;
         a.rider = delta + (size_t)k * n; a.rider_ld = n; a.nrider = 1;
         ga[j] = a;
         B.add(P->L[k].p, P->W[k].p, info.p + k);
@@ -1257,9 +1263,11 @@ int lmm_post_condition(const lmm_post_t* post, const double* U, const double* S,
   HIPCHK(hipMemcpyAsync(xall.p + (size_t)d * n1, x2d.p, (size_t)d * n2 * sizeof(double), hipMemcpyDeviceToDevice, st0));
   if (ms > 0) project_on_device(y2d.p, n2, p, Td.buf, m, l0, ms, meansd.buf.p + l0, d2buf.p, st0);
   for (int k = 0; k < ms; ++k) {
-    HIPCHK(hipMemcpyAsync(delta.p + (size_t)k * n, P->delta[k].p, (size_t)n1 * sizeof(double), hipMemcpyDeviceToDevice, st0));
+    HIPCHK(hipMemcpyAsync(delta.p + (size_t)k * n, P->delta_all.p + (size_t)k * n1, (size_t)n1 * sizeof(double), hipMemcpyDeviceToDevice, st0));
     HIPCHK(hipMemcpyAsync(delta.p + (size_t)k * n + n1, d2buf.p + (size_t)k * n2, (size_t)n2 * sizeof(double), hipMemcpyDeviceToDevice, st0));
-    HIPCHK(hipMemcpyAsync(nv.p + (size_t)k * n, P->noisev[k].p, (size_t)n1 * sizeof(double), hipMemcpyDeviceToDevice, st0));
+    if (P->noise_all.p != nullptr)
+      HIPCHK(hipMemcpyAsync(nv.p + (size_t)k * n, P->noise_all.p + (size_t)k * n1, (size_t)n1 * sizeof(double), hipMemcpyDeviceToDevice, st0));
+    else launch_fill(nv.p + (size_t)k * n, n1, P->noise_scalar[k], st0);
     launch_fill(nv.p + (size_t)k * n + n1, n2, ST[l0 + k], st0);
   }
   return posterior_create_common(xall.p, d, n, P->gps.data(), m, ST.data(), l0, l1, delta.p, out, nv.p);
