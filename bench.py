@@ -65,7 +65,8 @@ def cpu_baseline(P, orthogonal, budget_latents=2):
     if not orthogonal:
         # dense ILMM: (mn)^3/3 does not subsample by latents; time a reduced n and scale by the cubic flop count
         ns = max(64, n // 2)      # (m n/2)^3/3 flops: seconds of LAPACK at C1, large enough that fixed overheads do not dominate
-        Ps = O.synthetic_problem(m, P["p"], ns, P["gps"][0]["kind"], False, P["s2"], seed=0)
+        from lmm_amd.workloads import synthetic_problem
+        Ps = synthetic_problem(m, P["p"], ns, P["gps"][0]["kind"], False, P["s2"], seed=0)
         t0 = time.perf_counter(); O.ilmm_logpdf(Ps["gps"], Ps["H"], Ps["x"], Ps["s2"], Ps["y"]); dt = time.perf_counter() - t0
         est = dt * (n / ns) ** 3
         return {"value": 1.0 / est, "unit": "evals/s", "cores": cores, "kind": "port",
@@ -138,7 +139,7 @@ def main():
 
     import lmm_amd
     from lmm_amd import _lib as L
-    from oracle import lmm_oracle as O      # synthetic problem generator + cpu_baseline leg only
+    from lmm_amd.workloads import synthetic_problem      # input generation only; the oracle is imported by the cpu_baseline leg alone
     lmm_amd.init(local_rank)
     dev = torch.device("cuda", local_rank)
     from lmm_amd import model as lmm_model
@@ -146,7 +147,7 @@ def main():
 
     m, p, n, kind, orth, desc = WORKLOADS[args.workload]
     s2 = 0.1
-    P = O.synthetic_problem(m, p, n, kind, orth, s2=s2, seed=0)
+    P = synthetic_problem(m, p, n, kind, orth, s2=s2, seed=0)
     if args.workload == "notebook":      # x = 552 of 576 grid points on [0, 20]; S = singular values of rand(600, 20); sigma2 = 1e-6
         s2 = 1e-6
         keep = np.sort(np.random.default_rng(1).permutation(576)[:552])

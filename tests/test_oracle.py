@@ -231,3 +231,18 @@ def test_oracle_reproduces_committed_fixtures(case):
         assert O.ilmm_logpdf(post, H, xs, s2, ys) == pytest.approx(case["post_logpdf"], rel=1e-10)
     np.testing.assert_allclose(mu, case["post_mean"], rtol=1e-10, atol=1e-12)
     np.testing.assert_allclose(var, case["post_var"], rtol=1e-10)
+
+
+def test_workload_generator_matches_oracle_copy():
+    """linearmixingmodels.jl_amd/workloads.py (what bench.py feeds the HIP path) == the oracle's own generator."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("lmm_workloads", os.path.join(HERE, "..", "linearmixingmodels.jl_amd", "workloads.py"))
+    W = importlib.util.module_from_spec(spec); spec.loader.exec_module(W)
+    for orth in (True, False):
+        a, b = W.synthetic_problem(3, 5, 40, "matern52", orth, s2=0.2, seed=4), O.synthetic_problem(3, 5, 40, "matern52", orth, s2=0.2, seed=4)
+        assert a.keys() == b.keys()
+        for k in a:
+            if isinstance(a[k], np.ndarray):
+                np.testing.assert_array_equal(a[k], b[k])
+            else:
+                assert a[k] == b[k]
