@@ -1,7 +1,7 @@
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np, torch, lmm_amd
-from oracle import lmm_oracle as O
+from lmm_amd import workloads as O      # input generation only
 lmm_amd.init(0)
 ml = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 16384

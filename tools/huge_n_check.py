@@ -3,7 +3,7 @@
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np, torch, lmm_amd
-from oracle import lmm_oracle as O
+from lmm_amd import workloads as O      # input generation only
 lmm_amd.init(0)
 n, p, m = 65536, 8, 8
 P = O.synthetic_problem(m, p, n, "matern52", True, s2=0.1, seed=0)

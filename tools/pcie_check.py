@@ -2,7 +2,7 @@
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np, torch, lmm_amd
-from oracle import lmm_oracle as O
+from lmm_amd import workloads as O      # input generation only
 lmm_amd.init(0)
 P = O.synthetic_problem(32, 64, 16384, "matern52", True, s2=0.1, seed=0)
 fs = lmm_amd.independent_mogp([lmm_amd.GP(lmm_amd.Matern52Kernel()) for _ in range(32)])

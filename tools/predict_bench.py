@@ -2,7 +2,7 @@
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np, torch, lmm_amd
-from oracle import lmm_oracle as O
+from lmm_amd import workloads as O      # input generation only
 lmm_amd.init(0)
 m, p, n, ns, ml = 64, 128, 8192, 8192, int(sys.argv[1]) if len(sys.argv) > 1 else 8
 P = O.synthetic_problem(m, p, n, "matern52", True, s2=0.1, seed=0)

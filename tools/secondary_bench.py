@@ -7,7 +7,7 @@ import json, sys, time
 sys.path.insert(0, '.')
 import numpy as np, torch, lmm_amd
 from lmm_amd import _lib as L
-from oracle import lmm_oracle as O      # synthetic problem generator only
+from lmm_amd import workloads as O      # input generation only
 
 lmm_amd.init(0)
 lib = lmm_amd.load()

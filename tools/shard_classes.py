@@ -3,7 +3,7 @@ import sys, ctypes as C
 sys.path.insert(0, '.')
 import numpy as np, torch, lmm_amd
 from lmm_amd import _lib as L
-from oracle import lmm_oracle as O
+from lmm_amd import workloads as O      # input generation only
 lmm_amd.init(0); lib = lmm_amd.load()
 B = int(sys.argv[1])
 P = O.synthetic_problem(32, 64, 16384, "matern52", True, s2=0.1, seed=0)
