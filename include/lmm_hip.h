@@ -184,7 +184,8 @@ int lmm_latent_marginals(const lmm_post_t* post, const lmm_gp_t* gps, int m_shar
  * H = U sqrt(S) (pass S == NULL to give a dense H in U: the diagonal-covariance mixing of an ILMM whose
  * latents are independent).  Outputs are the shard's PARTIAL sums over its latents, length ns*p,
  * by-outputs; sigma2 (+ default jitter per latent) is added iff add_noise != 0.
- * post == NULL => prior latents `gps` (m_shard of them, starting at latent_begin). */
+ * post == NULL => prior latents `gps` (m_shard of them, starting at latent_begin).
+ * var_out == NULL => means only (AbstractGPs.mean(fx), src/ilmm.jl:142): mu + K(x*, x) alpha per latent, no triangular solve. */
 int lmm_oilmm_mean_and_var(const lmm_post_t* post, const lmm_gp_t* gps,
                            const double* U, const double* S, int p, int m,
                            int latent_begin, int latent_end, double sigma2, int add_noise,

@@ -1673,7 +1673,7 @@ int lmm_oilmm_mean_and_var(const lmm_post_t* post, const lmm_gp_t* gps, const do
   std::lock_guard<std::mutex> lk(g_mu);
   REQUIRE_INIT();
   LMM_TRY
-  if (!U || !xs || !mean_out || !var_out || d <= 0 || ns <= 0 || p <= 0 || m <= 0) return fail(LMM_ERR_ARG, "bad arguments");
+  if (!U || !xs || !mean_out || d <= 0 || ns <= 0 || p <= 0 || m <= 0) return fail(LMM_ERR_ARG, "bad arguments");
   if (!jit) jit = &kDefaultJit;
   int l0 = latent_begin, l1 = latent_end;
   if (post) { l0 = post->l0; l1 = post->l1; if (post->m != m) return fail(LMM_ERR_DIM, "posterior has %d latents, H has %d", post->m, m); }
@@ -1688,6 +1688,22 @@ int lmm_oilmm_mean_and_var(const lmm_post_t* post, const lmm_gp_t* gps, const do
   Uploaded Hd(Hs, st0);
   DevIn xsd(xs, (size_t)d * ns, st0);
   Buf<double> ml((size_t)ns * std::max(ms, 1)), vl((size_t)ns * std::max(ms, 1));
+  if (var_out == nullptr) {
+    // mean only (AbstractGPs.mean(fx), reference src/ilmm.jl:142 -> mean_and_var(fx)[1]): the posterior latent means are
+    // mu + K(x*, x) alpha -- n n* kernel evaluations, no triangular solve (the reference pays for the variances it discards)
+    if (post && post->d != d) return fail(LMM_ERR_DIM, "input dimension mismatch: posterior has d=%d, xs has d=%d", post->d, d);
+    Buf<double> pm_part(post ? post_mean_partial_elems(ns, post->n) : 1);
+    for (int k = 0; k < ms; ++k) {
+      const lmm_gp_t& gp = post ? post->gps[l0 + k] : gps[l0 + k];
+      launch_post_mean(xsd.p, ns, post ? post->x.p : nullptr, post ? post->n : 0, d, post ? post->alpha[k].p : nullptr, to_dev(gp),
+                       pm_part.p, ml.p + (size_t)k * ns, st0);
+    }
+    DevOut mo(mean_out, (size_t)ns * p);
+    launch_mix(ml.p, ns, ms, Hd.buf.p, p, 1, 0.0, 0.0, nullptr, 0.0, mo.p, st0);
+    mo.finish(st0);
+    HIPCHK(hipStreamSynchronize(st0));
+    return LMM_OK;
+  }
   if (int rc = latent_marginals_dev(post, post ? nullptr : gps + l0, ms, xsd.p, d, ns, ml.p, vl.p)) return rc;
   DevOut mo(mean_out, (size_t)ns * p), vo(var_out, (size_t)ns * p);
   // reference src/oilmm.jl:69,72: M = H M_latent;  V = abs2.(H) V_latent .+ sigma2   (V_latent carries the 1e-18 jitter)

@@ -535,7 +535,20 @@ def cov(fx: FiniteGP):
 
 
 def mean(fx: FiniteGP):
-    """reference src/ilmm.jl:142."""
+    """reference src/ilmm.jl:142 (mean_and_var(fx)[1]).  For an OILMM (prior or posterior, by-outputs inputs) the means alone
+    are computed -- mu + K(x*, x) alpha per latent, no triangular solve for variances that would be discarded."""
+    f, x = fx.f, fx.x
+    if isinstance(f, ILMM) and isinstance(x, MOInputIsotopicByOutputs) and (f.is_oilmm or f.f._post is None):
+        L.ensure_init()
+        unpack(fx)
+        Ua, Sa, p, m = _H_args(f.H)
+        l0, l1 = f.shard
+        out = _alloc_like(x.x, x.n * p)
+        post = f.f._post.ptr if f.f._post is not None else None
+        L.check(L.load().lmm_oilmm_mean_and_var(post, L.gps_array([g.desc() for g in f.f.fs]), Ua.ptr,
+                                               Sa.ptr if Sa is not None else None, p, m, l0, l1, C.c_double(fx.sigma2), 0,
+                                               x.carr().ptr, x.dim, x.n, None, L.Arr(out, True).ptr, None))
+        return out
     return mean_and_var(fx)[0]
 
 

@@ -485,6 +485,27 @@ def test_mogp_heteroscedastic_diagonal_noise(lmm):
                    rng.standard_normal(4 * n))
 
 
+def test_mean_only_path(lmm):
+    """mean(fx) (reference src/ilmm.jl:142) through the means-only entry (var_out = NULL: mu + K(x*,x) alpha, no solve) equals
+    mean_and_var(fx)[0] and the oracle, prior and posterior, d = 1 and 2."""
+    rng = np.random.default_rng(31)
+    for d in (1, 2):
+        n, ns, p, m = 120, 37, 4, 3
+        x = np.sort(rng.uniform(0, 5, n)) if d == 1 else rng.uniform(0, 3, (d, n))
+        xs = np.sort(rng.uniform(0, 5, ns)) if d == 1 else rng.uniform(0, 3, (d, ns))
+        gps = _gps(["se", "matern32", "matern52"], rng)
+        U, S = _orth(rng, p, m)
+        f = lmm.ILMM(_to_model(lmm, gps), lmm.Orthogonal(U, S))
+        y = rng.standard_normal(n * p)
+        xin, xsin = lmm.MOInputIsotopicByOutputs(x, p), lmm.MOInputIsotopicByOutputs(xs, p)
+        np.testing.assert_allclose(lmm.mean(f(xsin, 0.1)), O.oilmm_mean_var(gps, U, S, xs, 0.1)[0], rtol=1e-12, atol=1e-13)
+        post = lmm.posterior(f(xin, 0.1), y)
+        mo = O.oilmm_mean_var(O.oilmm_posterior(gps, U, S, x, 0.1, y), U, S, xs, 0.1)[0]
+        got = lmm.mean(post(xsin, 0.1))
+        np.testing.assert_allclose(got, mo, rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(got, lmm.mean_and_var(post(xsin, 0.1))[0], rtol=1e-9, atol=1e-10)
+
+
 def test_device_normals_and_device_rand(lmm):
     """lmm_normals (Philox4x32-10 + Box-Muller on the device; SURVEY.md 8a K7 'optional Philox'): reproducible per (seed, stream),
     standard-normal moments, and rand() fed from it equals rand() fed the same numbers from the host."""

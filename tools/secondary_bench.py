@@ -52,6 +52,7 @@ def run(tag, m, p, n, ns, share):
     cfg = {"config": f"{tag}: one GPU's {share} of {m} latents, p={p}, n={n}, n*={ns}, f64"}
     post = timed(f"{tag} posterior(fx, y)", lambda: lmm_amd.posterior(f(xin, 0.1), yd), share * n ** 3 / 3.0, cfg)
     timed(f"{tag} marginals(post(x*))", lambda: lmm_amd.mean_and_var(post(xsin, 0.1)), share * float(n) ** 2 * ns, cfg)
+    timed(f"{tag} mean(post(x*)) [means only]", lambda: lmm_amd.mean(post(xsin, 0.1)), 0.0, cfg)
     timed(f"{tag} marginals(prior(x))", lambda: lmm_amd.mean_and_var(f(xin, 0.1)), 0.0, cfg)
     rng = np.random.default_rng(0)      # normals are drawn on the host in the reference's order (part of the timed call)
     timed(f"{tag} rand(prior(x))", lambda: lmm_amd.rand(rng, f(xin, 0.1), jitters=(1e-9, 1e-8, 1e-8)),
