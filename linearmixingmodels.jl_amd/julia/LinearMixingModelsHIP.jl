@@ -156,7 +156,18 @@ function AbstractGPs.mean_and_var(fx::FiniteGP{<:HIPPosteriorOILMM})
         post.handle, C_NULL, U, S, p, m, 0, m, σ², 1, X, d, ns, C_NULL, M, V))
     return M, V
 end
-AbstractGPs.mean(fx::FiniteGP{<:HIPPosteriorOILMM}) = mean_and_var(fx)[1]
+# mean alone: var_out = C_NULL selects mu + K(x*, x) alpha per latent (no triangular solve for variances that would be discarded)
+function AbstractGPs.mean(fx::FiniteGP{<:HIPPosteriorOILMM})
+    H = fx.f.H; post = fx.f.f
+    X = _xmat(fx.x.x); d, ns = size(X); p, m = size(H.U)
+    S = Vector{Float64}(H.S.diag); U = Matrix{Float64}(H.U)
+    M = Vector{Float64}(undef, ns * p)
+    GC.@preserve X U S M check(ccall((:lmm_oilmm_mean_and_var, liblmm), Cint,
+        (Ptr{Cvoid}, Ptr{LmmGp}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Cint, Cint, Cdouble, Cint, Ptr{Cdouble},
+         Cint, Cint, Ptr{LmmJitters}, Ptr{Cdouble}, Ptr{Cdouble}),
+        post.handle, C_NULL, U, S, p, m, 0, m, noise_var(fx.Σy), 0, X, d, ns, C_NULL, M, C_NULL))
+    return M
+end
 AbstractGPs.var(fx::FiniteGP{<:HIPPosteriorOILMM}) = mean_and_var(fx)[2]
 
 # logpdf(po(x*, σ²), y*) (reference test/oilmm.jl:25)
