@@ -116,17 +116,34 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU) through
+        # torch.distributed.run.  This parent has not imported torch and never touches a GPU; it only relays the exit code.
+        import socket
+        import subprocess
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        print(f"[bench] --gpus {args.gpus} without WORLD_SIZE: launching {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.call(cmd, env=env))
+
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        sys.exit(f"[bench] --gpus {args.gpus} does not match WORLD_SIZE {world}: refusing to report a number for the wrong rank count")
     # Rehearsal switches (not used by the driver): LMM_BENCH_BACKEND=gloo reduces over CPU tensors and
     # LMM_BENCH_SHARE_GPU=1 puts every rank on GPU 0, so the N > 1 path can be exercised on a one-GPU box.
     backend = os.environ.get("LMM_BENCH_BACKEND", "nccl")
     if os.environ.get("LMM_BENCH_SHARE_GPU") == "1":
         local_rank = 0
+    elif local_rank >= torch.cuda.device_count():
+        sys.exit(f"[bench] rank {rank}: local rank {local_rank} but only {torch.cuda.device_count()} GPU(s) visible "
+                 "(one process per GPU; LMM_BENCH_SHARE_GPU=1 + LMM_BENCH_BACKEND=gloo rehearses N ranks on one GPU)")
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
@@ -134,14 +151,18 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
-
     import lmm_amd
     from lmm_amd import _lib as L
     from lmm_amd.workloads import synthetic_problem      # input generation only; the oracle is imported by the cpu_baseline leg alone
     lmm_amd.init(local_rank)
     dev = torch.device("cuda", local_rank)
+    # The data-path collective is the C ABI's own RCCL communicator (lmm_allreduce_sum_f64: what a Julia / C caller binds);
+    # torch.distributed is kept for the rendezvous (it ships the RCCL unique id), the fence barrier and the max-over-ranks clock.
+    abi_comm = world > 1 and backend == "nccl"
+    if abi_comm:
+        L.comm_init_from_torch()
+        if L.comm_world() != world:
+            sys.exit(f"[bench] ABI communicator has {L.comm_world()} ranks, expected {world}")
     from lmm_amd import model as lmm_model
     lmm_model.ILMM_ALLOW_DECOUPLED = (args.workload != "c1dense")
 
@@ -167,6 +188,7 @@ def main():
     fx = f(xin, s2)
     rdev = dev if backend == "nccl" else torch.device("cpu")      # where the collectives' tensors live
     red = torch.zeros(1, dtype=torch.float64, device=rdev)
+    red_host = np.zeros(1)
 
     predictive = (args.workload == "c3")
     if predictive:
@@ -182,8 +204,12 @@ def main():
             return step_predictive()
         part = lmm_amd.logpdf(fx, yd, rank == 0)
         if world > 1 and orth:
+            if abi_comm:
+                red_host[0] = part
+                L.allreduce_sum(red_host)    # ONE scalar RCCL all-reduce per evaluation, inside liblmm_hip.so
+                return float(red_host[0])
             red[0] = part
-            dist.all_reduce(red)             # ONE scalar RCCL all-reduce per evaluation
+            dist.all_reduce(red)             # gloo rehearsal (LMM_BENCH_BACKEND=gloo)
             return float(red[0])
         return part
 
@@ -263,14 +289,18 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "posterior + marginals evals/sec" if predictive else "logpdf evals/sec", "value": evals_per_s, "unit": "evals/s",
+            "metric": ("posterior + marginals evals/sec" if predictive else "logpdf evals/sec") +
+                      ("" if orth or world == 1 else " (independent replicas: the dense-H path does not shard)"),
+            "value": evals_per_s, "unit": "evals/s",
             "obs_per_s": evals_per_s * n * p if evals_per_s else None,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if orth else "replicas",
             "vs_baseline": (evals_per_s / NOTEBOOK_PUBLISHED_EVALS_PER_S) if (args.workload == "notebook" and evals_per_s) else None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc, "m": m, "p": p, "n": n, "kernel": kind, "sigma2": s2,
-                       "latents_per_gpu": (shard[1] - shard[0]), "parallelism": f"latent-shard x{world}" if orth else "replicas"},
+                       "latents_per_gpu": (shard[1] - shard[0]), "parallelism": f"latent-shard x{world}" if orth else "replicas",
+                       "collective": ("lmm_allreduce_sum_f64 (RCCL inside liblmm_hip.so)" if abi_comm else
+                                      ("torch.distributed/" + backend if world > 1 else None))},
             ("first_predictive_mean" if predictive else "logpdf"): val,
             "roofline": roof, "cpu_baseline": cpu,
         }
@@ -278,6 +308,8 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
+        if abi_comm:
+            L.comm_destroy()
         dist.destroy_process_group()
 
 

@@ -21,6 +21,11 @@
  *     lmm_last_error_detail() the failing latent and LAPACK-style pivot `info`
  *     (-> Julia `PosDefException(info)`).  Nothing is ever NaN-and-continue.
  *   - calls are blocking; the library never keeps a caller pointer after returning.
+ *   - threading: one context per process (= one GPU).  Every entry point takes the context lock, so calls from several
+ *     threads are safe but execute one at a time (the context owns ONE set of HIP streams, one device-memory pool and one
+ *     pinned staging arena, which concurrent calls would have to share).  Concurrency across GPUs = one process per GPU.
+ *   - device pointers produced by another stream (e.g. a PyTorch tensor still being written by torch's stream): call
+ *     lmm_stream_wait_caller(that stream) first; the library's streams then order themselves behind it.
  */
 #ifndef LMM_HIP_H
 #define LMM_HIP_H
@@ -38,7 +43,8 @@ typedef enum {
   LMM_ERR_NOT_PD = 3,          /* PosDefException from cholesky                                         */
   LMM_ERR_HIP = 4,
   LMM_ERR_ARG = 5,
-  LMM_ERR_UNSUPPORTED = 6
+  LMM_ERR_UNSUPPORTED = 6,
+  LMM_ERR_RCCL = 7             /* a collective failed (lmm_last_error_string carries ncclGetErrorString)             */
 } lmm_status;
 
 typedef enum { LMM_KERNEL_SE = 0, LMM_KERNEL_MATERN32 = 1, LMM_KERNEL_MATERN52 = 2 } lmm_kernel_kind;
@@ -68,6 +74,25 @@ const char* lmm_last_error_string(void);
 int lmm_last_error_detail(int* latent, int* info);
 int lmm_device_synchronize(void);
 int lmm_release_cached_memory(void);      /* return the caching device-memory pool (factor-matrix slots) to HIP */
+/* Order the library's streams behind everything queued so far on `hip_stream` (a hipStream_t; NULL = the legacy default
+ * stream): the NEXT entry point may then be handed device pointers that stream is still producing, or output buffers it is
+ * still reading.  Entry points are blocking, so no ordering is needed in the other direction. */
+int lmm_stream_wait_caller(void* hip_stream);
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI -----------------------------------------
+ * The reference has no parallelism; latents shard over ranks (latent_begin/latent_end above) with NO data-path collective,
+ * and ONE sum all-reduce finishes logpdf (8 bytes), marginals (2 p n* doubles) or a sample (n p doubles).
+ *   rank 0:  lmm_comm_get_unique_id(id)  -> ship the LMM_UNIQUE_ID_BYTES bytes to the other ranks out of band
+ *            (MPI.bcast in Julia, a file, torch.distributed's store, ...)
+ *   all   :  lmm_comm_init_rank(id, rank, world)   after lmm_init(device); world == 1 is valid (all-reduce = identity)
+ *   all   :  lmm_allreduce_sum_f64(buf, count)     in place; buf host or device; blocking                                  */
+#define LMM_UNIQUE_ID_BYTES 128
+int lmm_comm_get_unique_id(void* id_out);
+int lmm_comm_init_rank(const void* id, int rank, int world);
+int lmm_comm_info(int* rank, int* world);              /* world = 0 when no communicator exists */
+int lmm_allreduce_sum_f64(double* buf, size_t count);
+int lmm_allreduce_max_f64(double* buf, size_t count);  /* e.g. max-over-ranks timing */
+int lmm_comm_destroy(void);
 
 /* ---- Orthogonal(U, S) validation: reference src/orthogonal_matrix.jl:21-23 -------------- */
 int lmm_orthogonal_validate(const double* U, int p, int m);
@@ -264,7 +289,8 @@ typedef struct { long long launches; double ms; double work; double bytes; /* al
 int lmm_profile_begin(int serial);
 int lmm_profile_end(lmm_prof_entry_t* out /* LMM_PROF_COUNT entries */);
 
-/* f64 MFMA issue-rate microbenchmark: returns measured TFLOP/s of v_mfma_f64_16x16x4_f64. */
+/* f64 MFMA issue-rate microbenchmark: returns measured TFLOP/s of v_mfma_f64_4x4x4_4b_f64 (the form the update kernel
+ * issues; its 4 A x 16 B operand pattern). */
 int lmm_dev_mfma_f64_peak(double* tflops);
 
 #ifdef __cplusplus

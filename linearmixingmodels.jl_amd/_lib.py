@@ -11,12 +11,15 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblmm_hip.so")
 
-LMM_OK, LMM_ERR_DIM, LMM_ERR_NOT_ORTHOGONAL, LMM_ERR_NOT_PD, LMM_ERR_HIP, LMM_ERR_ARG, LMM_ERR_UNSUPPORTED = range(7)
+LMM_OK, LMM_ERR_DIM, LMM_ERR_NOT_ORTHOGONAL, LMM_ERR_NOT_PD, LMM_ERR_HIP, LMM_ERR_ARG, LMM_ERR_UNSUPPORTED, LMM_ERR_RCCL = range(8)
+UNIQUE_ID_BYTES = 128
 KERNEL_KINDS = {"se": 0, "matern32": 1, "matern52": 2}
 
 # Every symbol include/lmm_hip.h declares (tests/test_abi.py checks the library exports each one).
 SYMBOLS = [
     "lmm_init", "lmm_shutdown", "lmm_last_error_string", "lmm_last_error_detail", "lmm_device_synchronize", "lmm_release_cached_memory",
+    "lmm_stream_wait_caller", "lmm_comm_get_unique_id", "lmm_comm_init_rank", "lmm_comm_info", "lmm_allreduce_sum_f64", "lmm_allreduce_max_f64",
+    "lmm_comm_destroy",
     "lmm_orthogonal_validate", "lmm_oilmm_logpdf", "lmm_oilmm_logpdf_grad", "lmm_oilmm_logpdf_multi", "lmm_reorder", "lmm_ilmm_logpdf", "lmm_ilmm_logpdf_ex", "lmm_mogp_logpdf", "lmm_mogp_logpdf_diag",
     "lmm_oilmm_posterior_create", "lmm_mogp_posterior_create", "lmm_post_condition", "lmm_ilmm_posterior_create", "lmm_post_destroy", "lmm_ilmm_post_mean_and_var", "lmm_ilmm_post_mean_and_cov", "lmm_ilmm_post_condition", "lmm_ilmm_post_logpdf", "lmm_ilmm_post_rand",
     "lmm_latent_marginals", "lmm_oilmm_mean_and_var", "lmm_lmm_mean_and_cov", "lmm_oilmm_post_logpdf", "lmm_lmm_rand", "lmm_lmm_rand_multi", "lmm_normals",
@@ -135,6 +138,8 @@ class Arr:
             self.owner = a
             self.ptr = C.c_void_p(a.data_ptr())
             self.size = a.numel()
+            if a.is_cuda:
+                order_after_torch()
         else:
             if writable:
                 if not (isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags.c_contiguous):
@@ -144,6 +149,64 @@ class Arr:
             self.owner = a
             self.ptr = a.ctypes.data_as(C.c_void_p)
             self.size = a.size
+
+
+def order_after_torch() -> None:
+    """The library runs on its own non-blocking HIP streams; torch produces (and recycles) device tensors asynchronously on ITS
+    current stream.  Before a device pointer crosses the ABI, make the library's streams wait for everything torch has queued
+    (lmm_stream_wait_caller: one event record + one stream wait, no host stall).  Skipped when torch's stream is already idle."""
+    import torch
+    st = torch.cuda.current_stream()
+    if st.query():
+        return
+    ensure_init()
+    check(load().lmm_stream_wait_caller(C.c_void_p(st.cuda_stream)))
+
+
+# ---- RCCL communicator of the C ABI (one process per GPU) ---------------------------------------------------------
+def comm_world() -> int:
+    """World size of the ABI's RCCL communicator (0: none)."""
+    if _lib is None or _initialised_device is None:
+        return 0
+    r, w = C.c_int(), C.c_int()
+    check(_lib.lmm_comm_info(C.byref(r), C.byref(w)))
+    return w.value
+
+
+def comm_get_unique_id() -> bytes:
+    buf = C.create_string_buffer(UNIQUE_ID_BYTES)
+    check(load().lmm_comm_get_unique_id(buf))
+    return buf.raw
+
+
+def comm_init_rank(uid: bytes, rank: int, world: int) -> None:
+    ensure_init()
+    if len(uid) != UNIQUE_ID_BYTES:
+        raise ValueError("unique id must be %d bytes" % UNIQUE_ID_BYTES)
+    check(load().lmm_comm_init_rank(C.create_string_buffer(uid, UNIQUE_ID_BYTES), C.c_int(rank), C.c_int(world)))
+
+
+def comm_init_from_torch() -> None:
+    """Create the ABI's RCCL communicator for the ranks of torch.distributed's default group: rank 0 draws the unique id and
+    ships it through the group's store-backed object broadcast (the out-of-band step a Julia caller does with MPI.bcast)."""
+    import torch.distributed as dist
+    rank, world = dist.get_rank(), dist.get_world_size()
+    box = [comm_get_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    comm_init_rank(box[0], rank, world)
+
+
+def comm_destroy() -> None:
+    if _lib is not None:
+        check(_lib.lmm_comm_destroy())
+
+
+def allreduce_sum(a, op: str = "sum"):
+    """In-place sum (or max) all-reduce of a float64 NumPy array or CUDA tensor over the ABI communicator."""
+    arr = Arr(a, True)
+    fn = load().lmm_allreduce_sum_f64 if op == "sum" else load().lmm_allreduce_max_f64
+    check(fn(arr.ptr, C.c_size_t(arr.size)))
+    return a
 
 
 def gps_array(gps: Sequence[dict]):

@@ -11,6 +11,7 @@
 // per level (log2(n/64) levels) instead of once per panel.  Leaves (64 columns): diag64 (factor + inverse
 // of the diagonal block) then TRSM as a GEMM with the inverse.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <cmath>
@@ -45,6 +46,10 @@ struct Ctx {
   std::map<void*, size_t> live;
   std::string err;
   int err_latent = -1, err_info = 0;
+  // multi-GPU: one RCCL communicator per process (rank = this GPU)
+  ncclComm_t comm = nullptr;
+  int comm_rank = 0, comm_world = 0;
+  hipEvent_t ev_caller = nullptr;
   // measurement hooks
   bool prof = false, prof_serial = false;
   struct ProfRec { int cls; double work, bytes; hipEvent_t e0, e1; int M, N, K, count; };
@@ -523,7 +528,12 @@ int latent_lmls(const double* xd, int d, int n, const lmm_gp_t* gps, const doubl
                 const double* rider_sub = nullptr) {       // rider_sub[latent] (host): subtracted from that latent's riders
   const int ms = l1 - l0;
   lml.assign((size_t)ms * nrhs, 0.0);
-  if (ms == 0) return LMM_OK;
+  if (ms == 0) {
+    // callers read pinned results (regulariser residual) and release their device buffers after this returns: the main stream
+    // must be drained even when this rank holds no latent
+    HIPCHK(hipStreamSynchronize(g.streams[0]));
+    return LMM_OK;
+  }
   Dims D(n, nrhs);
   int nb_per = 1, nslots = 1;
   batch_plan(ms, &nb_per, &nslots, (double)D.elems() * sizeof(double));
@@ -575,6 +585,10 @@ int latent_lmls(const double* xd, int d, int n, const lmm_gp_t* gps, const doubl
 
 const lmm_jitters_t kDefaultJit = {1e-9, 1e-12, 1e-18};
 
+void drain_after_error() {
+  if (g.init) { (void)hipDeviceSynchronize(); (void)hipGetLastError(); }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -604,10 +618,12 @@ struct lmm_post {
 };
 
 #define LMM_TRY try {
+// A throw unwinds through Buf destructors, which hand device blocks back to the caching pool while slot streams may still be
+// running kernels on them: drain the device before the caller can issue the next call (which could be given those blocks).
 #define LMM_CATCH                                   \
   }                                                 \
-  catch (int code) { return code; }                 \
-  catch (const std::exception& e) { return fail(LMM_ERR_HIP, "exception: %s", e.what()); }
+  catch (int code) { drain_after_error(); return code; }                 \
+  catch (const std::exception& e) { drain_after_error(); return fail(LMM_ERR_HIP, "exception: %s", e.what()); }
 
 #define REQUIRE_INIT()                                                           \
   if (!g.init) return fail(LMM_ERR_ARG, "lmm_init() has not been called");      \
@@ -646,6 +662,8 @@ int lmm_shutdown(void) {
   std::lock_guard<std::mutex> lk(g_mu);
   if (!g.init) return LMM_OK;
   (void)hipDeviceSynchronize();
+  if (g.comm) { (void)ncclCommDestroy(g.comm); g.comm = nullptr; g.comm_world = 0; }
+  if (g.ev_caller) { (void)hipEventDestroy(g.ev_caller); g.ev_caller = nullptr; }
   for (auto& kv : g.pool) (void)hipFree(kv.second);
   g.pool.clear();
   for (int s = 0; s < kMaxStreams; ++s) { (void)hipStreamDestroy(g.streams[s]); (void)hipEventDestroy(g.ev_slot[s]); }
@@ -672,7 +690,100 @@ int lmm_release_cached_memory(void) {
   return LMM_OK;
 }
 
+int lmm_stream_wait_caller(void* hip_stream) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  REQUIRE_INIT();
+  LMM_TRY
+  if (!g.ev_caller) HIPCHK(hipEventCreateWithFlags(&g.ev_caller, hipEventDisableTiming));
+  HIPCHK(hipEventRecord(g.ev_caller, static_cast<hipStream_t>(hip_stream)));
+  HIPCHK(hipStreamWaitEvent(g.streams[0], g.ev_caller, 0));      // slot streams fork from streams[0] (fork_slots)
+  return LMM_OK;
+  LMM_CATCH
+}
+
+// ---- RCCL (the ONE exchange step of the sharded paths) -------------------------------------------
+#define NCCLCHK(expr)                                                                                  \
+  do {                                                                                                 \
+    ncclResult_t r_ = (expr);                                                                          \
+    if (r_ != ncclSuccess) throw fail(LMM_ERR_RCCL, "%s failed: %s (%s:%d)", #expr, ncclGetErrorString(r_), __FILE__, __LINE__); \
+  } while (0)
+
+int lmm_comm_get_unique_id(void* id_out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  LMM_TRY
+  if (!id_out) return fail(LMM_ERR_ARG, "id_out is NULL");
+  static_assert(sizeof(ncclUniqueId) == LMM_UNIQUE_ID_BYTES, "LMM_UNIQUE_ID_BYTES must match ncclUniqueId");
+  ncclUniqueId id;
+  NCCLCHK(ncclGetUniqueId(&id));
+  std::memcpy(id_out, &id, sizeof id);
+  return LMM_OK;
+  LMM_CATCH
+}
+
+int lmm_comm_init_rank(const void* id, int rank, int world) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  REQUIRE_INIT();
+  LMM_TRY
+  if (!id || world < 1 || rank < 0 || rank >= world) return fail(LMM_ERR_ARG, "bad arguments");
+  if (g.comm) return fail(LMM_ERR_ARG, "a communicator already exists (rank %d of %d): lmm_comm_destroy first", g.comm_rank, g.comm_world);
+  ncclUniqueId uid;
+  std::memcpy(&uid, id, sizeof uid);
+  HIPCHK(hipSetDevice(g.device));
+  NCCLCHK(ncclCommInitRank(&g.comm, world, uid, rank));
+  g.comm_rank = rank; g.comm_world = world;
+  return LMM_OK;
+  LMM_CATCH
+}
+
+int lmm_comm_info(int* rank, int* world) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (rank) *rank = g.comm ? g.comm_rank : 0;
+  if (world) *world = g.comm ? g.comm_world : 0;
+  return LMM_OK;
+}
+
+static int allreduce_f64(double* buf, size_t count, ncclRedOp_t op) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  REQUIRE_INIT();
+  LMM_TRY
+  if (!g.comm) return fail(LMM_ERR_ARG, "no communicator: call lmm_comm_init_rank first");
+  if (count == 0) return LMM_OK;
+  if (!buf) return fail(LMM_ERR_ARG, "buf is NULL");
+  hipStream_t st0 = g.streams[0];
+  if (is_device_ptr(buf)) {
+    NCCLCHK(ncclAllReduce(buf, buf, count, ncclDouble, op, g.comm, st0));
+    HIPCHK(hipStreamSynchronize(st0));
+    return LMM_OK;
+  }
+  // host buffer: stage through the pinned arena when it fits (the scalar logpdf sum always does)
+  Buf<double> dev(count);
+  double* pin = static_cast<double*>(pin_take(count * sizeof(double)));
+  if (pin) std::memcpy(pin, buf, count * sizeof(double));
+  HIPCHK(hipMemcpyAsync(dev.p, pin ? pin : buf, count * sizeof(double), hipMemcpyHostToDevice, st0));
+  NCCLCHK(ncclAllReduce(dev.p, dev.p, count, ncclDouble, op, g.comm, st0));
+  HIPCHK(hipMemcpyAsync(pin ? pin : buf, dev.p, count * sizeof(double), hipMemcpyDeviceToHost, st0));
+  HIPCHK(hipStreamSynchronize(st0));
+  if (pin) std::memcpy(buf, pin, count * sizeof(double));
+  return LMM_OK;
+  LMM_CATCH
+}
+int lmm_allreduce_sum_f64(double* buf, size_t count) { return allreduce_f64(buf, count, ncclSum); }
+int lmm_allreduce_max_f64(double* buf, size_t count) { return allreduce_f64(buf, count, ncclMax); }
+
+int lmm_comm_destroy(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  LMM_TRY
+  if (g.comm) {
+    if (g.init) (void)hipDeviceSynchronize();
+    NCCLCHK(ncclCommDestroy(g.comm));
+    g.comm = nullptr; g.comm_world = 0; g.comm_rank = 0;
+  }
+  return LMM_OK;
+  LMM_CATCH
+}
+
 int lmm_device_synchronize(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
   REQUIRE_INIT();
   LMM_TRY
   HIPCHK(hipDeviceSynchronize());
@@ -682,6 +793,7 @@ int lmm_device_synchronize(void) {
 
 // reference src/orthogonal_matrix.jl:21-23: isapprox(U'U, I) (Frobenius norm, rtol = sqrt(eps)).
 int lmm_orthogonal_validate(const double* U, int p, int m) {
+  std::lock_guard<std::mutex> lk(g_mu);
   if (!U || p <= 0 || m <= 0) return fail(LMM_ERR_ARG, "bad arguments");
   double diff2 = 0.0, g2 = 0.0;
   for (int a = 0; a < m; ++a)
@@ -770,6 +882,7 @@ int lmm_oilmm_logpdf_grad(const double* x, int d, int n, const double* y, int p,
   if (m > p) return fail(LMM_ERR_DIM, "out dim of x != out dim of f.");
   if (latent_begin < 0 || latent_end > m || latent_begin > latent_end) return fail(LMM_ERR_ARG, "bad latent shard");
   if (int rc = check_gps(gps, m)) return rc;
+  if (!(sigma2 > 0.0)) return fail(LMM_ERR_ARG, "sigma2 must be > 0");
   hipStream_t st0 = g.streams[0];
   const int l0 = latent_begin, l1 = latent_end, ms = l1 - l0;
   std::vector<double> T, ST, H;
@@ -1203,7 +1316,7 @@ static int posterior_create_common(const double* xd, int d, int n, const lmm_gp_
     HIPCHK(hipMemcpyAsync(hinfo.data(), info.p, std::max(ms, 1) * sizeof(int), hipMemcpyDeviceToHost, g.streams[0]));
     HIPCHK(hipStreamSynchronize(g.streams[0]));
     if (int rc = check_info(hinfo, l0)) { delete P; return rc; }
-  } catch (int code) { delete P; return code; }
+  } catch (int code) { drain_after_error(); delete P; return code; }
   *out = P;
   return LMM_OK;
 }
@@ -1338,7 +1451,7 @@ static int dense_posterior_build(const double* xd, int d, int n, const double* H
     HIPCHK(hipMemcpyAsync(&hinfo, info.p, sizeof(int), hipMemcpyDeviceToHost, st0));
     HIPCHK(hipStreamSynchronize(st0));
     if (int rc = check_info(std::vector<int>{hinfo}, 0)) { delete P; return rc; }
-  } catch (int code) { delete P; return code; }
+  } catch (int code) { drain_after_error(); delete P; return code; }
   *out = P;
   return LMM_OK;
 }
@@ -1655,6 +1768,7 @@ int lmm_latent_marginals(const lmm_post_t* post, const lmm_gp_t* gps, int m_shar
   REQUIRE_INIT();
   LMM_TRY
   if (!xs || !mean_lat || !var_lat || d <= 0 || ns <= 0) return fail(LMM_ERR_ARG, "bad arguments");
+  if (post && post->kind != 0) return fail(LMM_ERR_UNSUPPORTED, "per-latent marginals of the dense-H posterior (coupled latents): use lmm_ilmm_post_mean_and_var");
   const int ms = post ? (post->l1 - post->l0) : m_shard;
   if (!post) { if (int rc = check_gps(gps, m_shard)) return rc; }
   hipStream_t st0 = g.streams[0];
@@ -1674,6 +1788,7 @@ int lmm_oilmm_mean_and_var(const lmm_post_t* post, const lmm_gp_t* gps, const do
   REQUIRE_INIT();
   LMM_TRY
   if (!U || !xs || !mean_out || d <= 0 || ns <= 0 || p <= 0 || m <= 0) return fail(LMM_ERR_ARG, "bad arguments");
+  if (post && post->kind != 0) return fail(LMM_ERR_UNSUPPORTED, "dense-H posterior handle: use lmm_ilmm_post_mean_and_var");
   if (!jit) jit = &kDefaultJit;
   int l0 = latent_begin, l1 = latent_end;
   if (post) { l0 = post->l0; l1 = post->l1; if (post->m != m) return fail(LMM_ERR_DIM, "posterior has %d latents, H has %d", post->m, m); }
@@ -1849,8 +1964,11 @@ int lmm_oilmm_post_logpdf(const lmm_post_t* post, const double* U, const double*
   LMM_TRY
   if (!post || !U || !S || !xs || !ys || !out || d <= 0 || ns <= 0) return fail(LMM_ERR_ARG, "bad arguments");
   const lmm_post* P = post;
+  if (P->kind != 0) return fail(LMM_ERR_UNSUPPORTED, "dense-H posterior handle: use lmm_ilmm_post_logpdf");
   if (P->m != m) return fail(LMM_ERR_DIM, "posterior has %d latents, H has %d", P->m, m);
   if (P->d != d) return fail(LMM_ERR_DIM, "input dimension mismatch");
+  if (m > p) return fail(LMM_ERR_DIM, "out dim of x != out dim of f.");
+  if (!(sigma2 > 0.0)) return fail(LMM_ERR_ARG, "sigma2 must be > 0");
   hipStream_t st0 = g.streams[0];
   const int l0 = P->l0, l1 = P->l1, ms = l1 - l0;
   std::vector<double> T, ST, H;
@@ -1926,8 +2044,12 @@ int lmm_lmm_rand_multi(const lmm_post_t* post, const lmm_gp_t* gps, const double
   if (!jit) jit = &kDefaultJit;
   const lmm_post* P = post;
   int l0 = latent_begin, l1 = latent_end;
-  if (P) { l0 = P->l0; l1 = P->l1; if (P->m != m) return fail(LMM_ERR_DIM, "posterior has %d latents, H has %d", P->m, m); }
-  else if (int rc = check_gps(gps, m)) return rc;
+  if (P) {
+    if (P->kind != 0) return fail(LMM_ERR_UNSUPPORTED, "dense-H posterior handle: use lmm_ilmm_post_rand");
+    l0 = P->l0; l1 = P->l1;
+    if (P->m != m) return fail(LMM_ERR_DIM, "posterior has %d latents, H has %d", P->m, m);
+    if (P->d != d) return fail(LMM_ERR_DIM, "input dimension mismatch");
+  } else if (int rc = check_gps(gps, m)) return rc;
   if (l0 < 0 || l1 > m || l0 > l1) return fail(LMM_ERR_ARG, "bad latent shard");
   const int ms = l1 - l0;
   // OILMM: f(x) default jitter 1e-18 (reference src/oilmm.jl:47); dense-H ILMM: 1e-12 (src/ilmm.jl:84)

@@ -73,6 +73,11 @@ class IndependentMOGP:
 
     def __call__(self, x: "MOInputIsotopicByOutputs", sigma2=1e-18) -> "FiniteGP":
         """f(x, sigma2) or f(x, diag) with the diagonal of a general Diagonal noise (length n*p, ordered like x)."""
+        if self._post is not None and self._post.dense:
+            # get_latent_gp(posterior(ilmm_dense(x, s2), y)): the latents of a dense-H posterior are COUPLED (one (mn) x (mn)
+            # state); the per-latent entry points would index past its single factor.  Use the ILMM posterior itself.
+            raise NotImplementedError("the latent GP of a dense-H ILMM posterior is a coupled PosteriorGP; query the ILMM "
+                                      "posterior (mean_and_var / rand / logpdf on posterior(fx, y)(x*, s2)) instead")
         if np.isscalar(sigma2) or getattr(sigma2, "ndim", 1) == 0:
             return FiniteGP(self, x, float(sigma2))
         return FiniteGP(self, x, sigma2)
@@ -177,8 +182,8 @@ class _PostHandle:
     """Owns an lmm_post_t* (device-resident posterior state); freed with the Python object, as the Julia
     shim does with a finalizer."""
 
-    def __init__(self, ptr: C.c_void_p, l0: int, l1: int):
-        self.ptr, self.l0, self.l1 = ptr, l0, l1
+    def __init__(self, ptr: C.c_void_p, l0: int, l1: int, dense: bool = False):
+        self.ptr, self.l0, self.l1, self.dense = ptr, l0, l1, dense      # dense: coupled (mn) x (mn) state of a dense-H ILMM
 
     def __del__(self):
         try:
@@ -445,7 +450,7 @@ def posterior(fx: FiniteGP, y):
     if f.f._post is not None:          # sequential conditioning of a posterior OILMM (same H: reference src/oilmm.jl:133)
         if not f.is_oilmm:         # dense-H posterior: both projected data sets condition the prior (reference src/ilmm.jl:184-198)
             L.check(lib.lmm_ilmm_post_condition(f.f._post.ptr, C.c_double(s2), xa.ptr, x.dim, x.n, ya.ptr, None, C.byref(handle)))
-            return ILMM(IndependentMOGP(f.f.fs, _PostHandle(handle, l0, l1)), f.H, shard=f.shard)
+            return ILMM(IndependentMOGP(f.f.fs, _PostHandle(handle, l0, l1, dense=True)), f.H, shard=f.shard)
         L.check(lib.lmm_post_condition(f.f._post.ptr, Ua.ptr, Sa.ptr, p, m, C.c_double(s2), xa.ptr, x.dim, x.n, ya.ptr,
                                        C.byref(handle)))
         return ILMM(IndependentMOGP(f.f.fs, _PostHandle(handle, l0, l1)), f.H, shard=f.shard)
@@ -456,7 +461,7 @@ def posterior(fx: FiniteGP, y):
     else:
         L.check(lib.lmm_ilmm_posterior_create(xa.ptr, x.dim, x.n, ya.ptr, p, Ua.ptr, m, C.c_double(s2), gps, None,
                                               C.byref(handle)))
-    return ILMM(IndependentMOGP(f.f.fs, _PostHandle(handle, l0, l1)), f.H, shard=f.shard)
+    return ILMM(IndependentMOGP(f.f.fs, _PostHandle(handle, l0, l1, dense=not f.is_oilmm)), f.H, shard=f.shard)
 
 
 def mean_and_var(fx: FiniteGP, add_noise: bool = True):

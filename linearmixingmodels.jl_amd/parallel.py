@@ -6,6 +6,9 @@ from __future__ import annotations
 
 from typing import Callable, Optional, Tuple
 
+import numpy as np
+
+from . import _lib as L
 from . import model as M
 
 
@@ -21,24 +24,51 @@ def _dist():
     return dist if dist.is_available() and dist.is_initialized() else None
 
 
+def _abi_comm() -> Tuple[int, int]:
+    """(rank, world) of the C ABI's own RCCL communicator (lmm_comm_init_rank); world 0 when there is none."""
+    if L._lib is None or L._initialised_device is None:
+        return 0, 0
+    import ctypes as C
+    r, w = C.c_int(), C.c_int()
+    L.check(L._lib.lmm_comm_info(C.byref(r), C.byref(w)))
+    return r.value, w.value
+
+
 def _world() -> Tuple[int, int]:
+    r, w = _abi_comm()
+    if w > 0:
+        return r, w
     d = _dist()
     return (d.get_rank(), d.get_world_size()) if d else (0, 1)
 
 
 def _all_reduce_sum(t):
+    """Sum over ranks, in place.  The product path is lmm_allreduce_sum_f64 -- RCCL inside liblmm_hip.so, the same call a Julia
+    or C caller makes -- whenever the ABI communicator exists; torch.distributed (gloo in the CPU tests) otherwise."""
+    if _abi_comm()[1] > 0:
+        if L._is_torch(t) and not t.is_cuda:
+            a = t.numpy()                      # shares memory with t
+            L.allreduce_sum(a)
+        else:
+            L.allreduce_sum(t)
+        return t
     d = _dist()
     if d is not None and d.get_world_size() > 1:
         d.all_reduce(t, op=d.ReduceOp.SUM)
     return t
 
 
-def _reduce_device():
+def _reduce_tensor(a):
+    """`a` as a float64 tensor on the side the active collective reduces on: the ABI communicator takes host or device
+    pointers (so the data stays where the HIP path left it); torch's nccl backend needs device tensors, gloo host tensors."""
     import torch
+    t = torch.as_tensor(a, dtype=torch.float64)
+    if _abi_comm()[1] > 0:
+        return t if t.is_contiguous() else t.contiguous()
     d = _dist()
     if d is not None and d.get_backend() == "nccl":
-        return torch.device("cuda", torch.cuda.current_device())
-    return torch.device("cpu")
+        return t.to(torch.device("cuda", torch.cuda.current_device()))
+    return t.cpu()
 
 
 def sharded_logpdf(f: M.ILMM, x: M.MOInputIsotopicByOutputs, sigma2: float, y,
@@ -55,7 +85,7 @@ def sharded_logpdf(f: M.ILMM, x: M.MOInputIsotopicByOutputs, sigma2: float, y,
     part = fn(fx, y, rank == 0)
     if not reduce:
         return part
-    t = torch.tensor([part], dtype=torch.float64, device=_reduce_device())
+    t = _reduce_tensor(np.array([part]))
     return float(_all_reduce_sum(t)[0])
 
 
@@ -67,8 +97,7 @@ def sharded_mean_and_var(fx_shard: M.FiniteGP, local_fn: Optional[Callable] = No
     rank, _ = _world()
     fn = local_fn or M.mean_and_var
     mean, var = fn(fx_shard, rank == 0)
-    dev = _reduce_device()
-    t = torch.stack([torch.as_tensor(mean, dtype=torch.float64), torch.as_tensor(var, dtype=torch.float64)]).to(dev)
+    t = _reduce_tensor(torch.stack([torch.as_tensor(mean, dtype=torch.float64), torch.as_tensor(var, dtype=torch.float64)]))
     _all_reduce_sum(t)
     return t[0], t[1]
 
@@ -89,5 +118,4 @@ def sharded_rand(rng, fx_shard: M.FiniteGP, local_fn: Optional[Callable] = None,
     rank, _ = _world()
     fn = local_fn or (lambda fx, add_noise: M.rand(rng, fx, None, jitters, add_noise))
     part = fn(fx_shard, rank == 0)
-    t = torch.as_tensor(part, dtype=torch.float64).to(_reduce_device())
-    return _all_reduce_sum(t)
+    return _all_reduce_sum(_reduce_tensor(part))

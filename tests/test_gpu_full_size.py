@@ -99,25 +99,48 @@ def test_c3_shape_posterior_predictive(lmm):
 
 
 def test_c4_shape_rand_marginals(lmm):
-    """configs[4] shape in Float64: p = 256 outputs, 128 latents, n = 32768 -- two of one GPU's 16 latents: prior marginals
-    (closed form), posterior marginals bounded by the prior, a posterior sample given normals is finite and has the mixing
-    structure (sample - mean lies in span(H_shard) before noise)."""
+    """configs[4] shape in Float64: p = 256 outputs, 128 latents, n = 32768 -- one full lock-step batch (8 of one GPU's 16
+    latents): prior marginals (closed form); posterior marginals bounded by the prior AND latent 0's marginals against host
+    LAPACK (32768^3/3 flops on the host cores: tens of seconds); a posterior sample given normals has the mixing structure
+    (sample - mean lies in span(H_shard) before noise) and latent 0's sample equals the oracle's on the same normals."""
     import torch
-    n, p, m = 32768, 256, 128
+    from lmm_amd import _lib as L
+    n, p, m, nl, ns = 32768, 256, 128, 8, 2048
     P = O.synthetic_problem(m, p, n, "matern52", True, s2=0.1, seed=0)
     fs, H = _model(lmm, P["gps"]), lmm.Orthogonal(P["U"], P["S"])
-    f = lmm.ILMM(fs, H, shard=(0, 2))
+    f = lmm.ILMM(fs, H, shard=(0, nl))
     xd = torch.from_numpy(P["x"]).cuda()
     xin = lmm.MOInputIsotopicByOutputs(xd, p)
     mu, v = lmm.mean_and_var(f(xin, 0.1))                       # prior: mean 0, var = sum_l H[o,l]^2 (1 + 1e-18) + 0.1
-    Hs = O.orthogonal_dense(P["U"], P["S"])[:, :2]
+    Hs = O.orthogonal_dense(P["U"], P["S"])[:, :nl]
     assert float(mu.abs().max()) == 0.0
     np.testing.assert_allclose(v.cpu().numpy().reshape(p, n)[:, 0], (Hs * Hs).sum(1) + 0.1, rtol=1e-12)
-    post = lmm.posterior(f(xin, 0.1), torch.from_numpy(P["y"]).cuda())
-    xs = P["x"][:2048] + 0.01
-    mup, vp = lmm.mean_and_var(post(lmm.MOInputIsotopicByOutputs(xs, p), 0.1))
-    assert np.all(np.isfinite(mup)) and np.all(vp > 0.1) and np.all(vp <= v.cpu().numpy().reshape(p, n)[:, :2048].reshape(-1) + 1e-12)
-    s = lmm.rand(np.random.default_rng(0), post(lmm.MOInputIsotopicByOutputs(xs, p), 0.1), jitters=(1e-9, 1e-8, 1e-8), add_noise=False)
-    R = (s - mup).reshape(p, 2048)
+    yd = torch.from_numpy(P["y"]).cuda()
+    post = lmm.posterior(f(xin, 0.1), yd)
+    xs = P["x"][:ns] + 0.01
+    xsin = lmm.MOInputIsotopicByOutputs(xs, p)
+    mup, vp = lmm.mean_and_var(post(xsin, 0.1))
+    assert np.all(np.isfinite(mup)) and np.all(vp > 0.1) and np.all(vp <= v.cpu().numpy().reshape(p, n)[:, :ns].reshape(-1) + 1e-12)
+    # latent marginals of the batch; latent 0 against host LAPACK
+    ml, vl = np.empty(nl * ns), np.empty(nl * ns)
+    L.check(lmm.load().lmm_latent_marginals(post.f._post.ptr, None, nl, L.Arr(xs).ptr, 1, ns, L.Arr(ml, True).ptr, L.Arr(vl, True).ptr))
+    T, ST = O.project_orthogonal(P["U"], P["S"], 0.1)
+    po0 = O.gp_posterior(P["gps"][0], P["x"], ST[0], T[0] @ O.reshape_y(P["y"], n))
+    mo, vo = O.gp_mean_var(po0, xs)
+    np.testing.assert_allclose(ml[:ns], mo, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(vl[:ns], vo, rtol=1e-6, atol=1e-10)
+    np.testing.assert_allclose(mup, (Hs @ ml.reshape(nl, ns)).reshape(-1), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(vp, ((Hs * Hs) @ (vl.reshape(nl, ns) + 1e-18)).reshape(-1) + 0.1, rtol=1e-10)
+    # posterior sample of the batch given normals: mixing structure
+    jit = (1e-9, 1e-8, 1e-8)
+    s = lmm.rand(np.random.default_rng(0), post(xsin, 0.1), jitters=jit, add_noise=False)
+    R = (s - mup).reshape(p, ns)
     resid = R - Hs @ np.linalg.lstsq(Hs, R, rcond=None)[0]
     assert np.abs(resid).max() < 1e-9 * max(1.0, np.abs(R).max())
+    # latent 0's contribution on its own (a one-latent shard of the same model) against the oracle on the same normals
+    del post
+    post0 = lmm.posterior(lmm.ILMM(fs, H, shard=(0, 1))(xin, 0.1), yd)
+    s0 = lmm.rand(np.random.default_rng(0), post0(xsin, 0.1), jitters=jit, add_noise=False)
+    z0 = np.random.default_rng(0).standard_normal(m * ns)[:ns]                     # latent 0's block of the reference's draw order
+    ref0 = O.gp_rand(po0, xs, 1e-8, z0)
+    np.testing.assert_allclose(s0.reshape(p, ns), Hs[:, :1] * ref0[None, :], rtol=1e-6, atol=1e-8)
