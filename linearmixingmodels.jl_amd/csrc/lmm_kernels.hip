@@ -640,7 +640,30 @@ __global__ __launch_bounds__(256) void diag64_kernel(BatchPtr Ab, size_t offA, i
 #ifdef LMM_CLOCK_PROBE
 __device__ unsigned long long g_clk_probe[4];     // tools/gemm_ablate: shader-clock vs 100 MHz real-time ticks of one tile
 #endif
-template <int BN, bool SET>
+
+// ---- LDS-flag synchronisation (FLAGS variant of gemm44_kernel) ----------------------------------------------------------
+// s_barrier makes the four waves of a workgroup meet once per k-stage, so every stage pays the arrival skew of waves whose
+// SIMD partners (the other resident workgroup) progress unevenly.  The FLAGS main loop replaces it by two monotonic LDS
+// counters: "published" (a wave has written its share of the NEXT stage's operands) and "retired" (a wave has finished
+// reading the CURRENT stage).  A wave publishes in the middle of a stage and polls the counters half a stage later, so up to
+// half a stage of skew between the waves costs nothing.  LDS operations of one wave execute in issue order (they return in
+// order: lgkmcnt), so a ds_add issued after the wave's ds_writes / ds_reads is performed after them.
+__device__ __forceinline__ unsigned lds_off(const void* p) {
+  return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+__device__ __forceinline__ void lds_signal(unsigned off) {
+  asm volatile("ds_add_u32 %0, %1" ::"v"(off), "v"(1u) : "memory");
+}
+__device__ __forceinline__ void lds_wait_ge(unsigned off, unsigned target) {
+  for (;;) {
+    unsigned v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(off) : "memory");
+    if ((int)(__builtin_amdgcn_readfirstlane(v) - target) >= 0) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+template <int BN, bool SET, bool FLAGS = false>
 __global__ __launch_bounds__(256, 2) void gemm44_kernel(BatchPtr Cb, size_t goffC, int ldc, BatchPtr Ab, size_t goffA, int lda,
                                                          BatchPtr Bb, size_t goffB, int ldb,
                                                          int M, int N, int K, int lower, int MT, int full_items,
@@ -662,6 +685,8 @@ __global__ __launch_bounds__(256, 2) void gemm44_kernel(BatchPtr Cb, size_t goff
   __shared__ __attribute__((aligned(16))) double smem[STAGE > EPI ? STAGE : EPI];   // staging, then epilogue transpose
   double (*As)[BK * SA] = reinterpret_cast<double (*)[BK * SA]>(smem);
   double (*Bs)[BK * SB] = reinterpret_cast<double (*)[BK * SB]>(smem + 2 * BK * SA);
+  __shared__ unsigned sync_cnt[FLAGS ? 2 : 1];          // FLAGS: [0] stages published, [1] stages retired (x 4 waves)
+  if (FLAGS && threadIdx.x == 0) { sync_cnt[0] = 0; sync_cnt[1] = 0; }        // visible after the prologue barrier
 
   // Work item -> (tile, k-part).  Tiles on/below the diagonal are enumerated column by column; the first
   // `full_items` tiles run their whole K range, the remaining ones (the last, partial round of workgroups over the
@@ -749,12 +774,75 @@ __global__ __launch_bounds__(256, 2) void gemm44_kernel(BatchPtr Cb, size_t goff
   for (int s = 0; s < 4; ++s) offB[s] = lk * SB + wc + ((l15 + 4 * s) & 15);
 
   const int nk = kc1 - kc0;
+  if constexpr (FLAGS) {
+    const unsigned off_pub = lds_off(&sync_cnt[0]), off_ret = lds_off(&sync_cnt[1]);
+    if (nk > 1) {                                  // stage 1 into registers (stage 0 is in LDS, published by the prologue barrier)
+      const double* pa = ga0 + (size_t)BK * lda;
+      const double* pb = gb0 + (size_t)BK * ldb;
+#pragma unroll
+      for (int q = 0; q < NLA; ++q) ra[q] = *reinterpret_cast<const d2*>(pa + (size_t)(4 * q) * lda);
+#pragma unroll
+      for (int q = 0; q < NLB; ++q) rb[q] = *reinterpret_cast<const d2*>(pb + (size_t)(KSB * q) * ldb);
+    }
+    if (blockIdx.x & 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = kt & 1;
+      if (kt > 0) lds_wait_ge(off_pub, 4u * kt);   // every wave has published its share of stage kt (written during stage kt-1)
+      const double* as = &As[buf][0];
+      const double* bs = &Bs[buf][0];
+#pragma unroll
+      for (int s4 = 0; s4 < BK / 4; ++s4) {
+        if (active) {
+          double fa[TM];
+#pragma unroll
+          for (int u = 0; u < TM; ++u) fa[u] = as[offA + 4 * s4 * SA + 16 * u];
+#pragma unroll
+          for (int v = 0; v < TN; ++v) {
+            double fb[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) fb[s] = bs[offB[s] + 4 * s4 * SB + 16 * v];
+#pragma unroll
+            for (int u = 0; u < TM; ++u)
+#pragma unroll
+              for (int s = 0; s < 4; ++s)
+                acc[u][v][s] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[u], fb[s], acc[u][v][s], 0, 0, 0);
+          }
+        }
+        if (s4 == 1 && kt + 1 < nk) {
+          // mid-stage: the other buffer was read during stage kt-1 -- wait until all four waves retired it, then write stage
+          // kt+1 (in registers since the middle of stage kt-1), publish, and start the loads of stage kt+2
+          lds_wait_ge(off_ret, 4u * kt);
+#pragma unroll
+          for (int q = 0; q < NLA; ++q) *reinterpret_cast<d2*>(&As[buf ^ 1][sa0 + 4 * q * SA]) = ra[q];
+#pragma unroll
+          for (int q = 0; q < NLB; ++q) *reinterpret_cast<d2*>(&Bs[buf ^ 1][sb0 + KSB * q * SB]) = rb[q];
+          if (lane == 0) lds_signal(off_pub);
+          if (kt + 2 < nk) {
+            const double* pa = ga0 + (size_t)(kt + 2) * BK * lda;
+            const double* pb = gb0 + (size_t)(kt + 2) * BK * ldb;
+#pragma unroll
+            for (int q = 0; q < NLA; ++q) ra[q] = *reinterpret_cast<const d2*>(pa + (size_t)(4 * q) * lda);
+#pragma unroll
+            for (int q = 0; q < NLB; ++q) rb[q] = *reinterpret_cast<const d2*>(pb + (size_t)(KSB * q) * ldb);
+          }
+        }
+      }
+      if (lane == 0) lds_signal(off_ret);          // this wave's reads of stage kt are issued (LDS runs a wave's ops in order)
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __syncthreads();                               // the epilogue reuses the staging memory as transpose scratch
+  } else
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
 #ifndef LMM_ABLATE_NOLOAD
     if (kt + 1 < nk) {
-      const double* pa = ga0 + (size_t)(kt + 1) * BK * lda;
-      const double* pb = gb0 + (size_t)(kt + 1) * BK * ldb;
+#ifdef LMM_ABLATE_L2HOT
+      const int ktl = (kt + 1) & 3;      // ablation: operand loads always hit the same 4 k-stages (L2-resident)
+#else
+      const int ktl = kt + 1;
+#endif
+      const double* pa = ga0 + (size_t)ktl * BK * lda;
+      const double* pb = gb0 + (size_t)ktl * BK * ldb;
 #pragma unroll
       for (int q = 0; q < NLA; ++q) ra[q] = *reinterpret_cast<const d2*>(pa + (size_t)(4 * q) * lda);
 #pragma unroll
@@ -802,7 +890,9 @@ __global__ __launch_bounds__(256, 2) void gemm44_kernel(BatchPtr Cb, size_t goff
 #pragma unroll
       for (int q = 0; q < NLB; ++q) *reinterpret_cast<d2*>(&Bs[buf ^ 1][sb0 + KSB * q * SB]) = rb[q];
     }
+#ifndef LMM_ABLATE_NOBARRIER
     __syncthreads();
+#endif
   }
 
   if (!active) return;
@@ -1444,9 +1534,14 @@ void launch_diag64(const BatchPtr& A, size_t offA, int ld, const BatchPtr& W, si
   hipLaunchKernelGGL(diag64_kernel, dim3(nb), dim3(256), 0, st, A, offA, ld, W, offW, gcol0, n_real, info);
 }
 
+// Update-kernel variant: 0 = one s_barrier per k-stage (default), 1 = LDS-flag synchronised main loop (correct, but measured
+// 3-6 % SLOWER: tools/gemm_ab, profiles/r02/gemm_ab_flags_vs_barrier.log -- the s_barrier is not what limits this kernel).
+// LMM_GEMM_FLAGS overrides; tools/gemm_ab flips it between timed rounds of one process.
+int g_gemm_flags = -1;
 void launch_gemm_nt(const BatchPtr& C, size_t offC, int ldc, const BatchPtr& A, size_t offA, int lda, const BatchPtr& B,
                     size_t offB, int ldb, int M, int N, int K, int lower, bool set, int nb, hipStream_t st) {
   if (M <= 0 || N <= 0 || K <= 0 || nb <= 0) return;
+  if (g_gemm_flags < 0) { const char* e = getenv("LMM_GEMM_FLAGS"); g_gemm_flags = e ? (atoi(e) != 0) : 0; }
   const bool narrow = (N <= 64);
   const int MT = (M + 127) / 128;
   if (set) {   // in-place TRSM by inverse: one block column, no K split
@@ -1479,6 +1574,8 @@ void launch_gemm_nt(const BatchPtr& C, size_t offC, int ldc, const BatchPtr& A, 
   const int items = full_items + (int)(T - full_items) * splitk;
   if (narrow) hipLaunchKernelGGL((gemm44_kernel<64, false>), dim3(items, nb), dim3(256), 0, st, C, offC, ldc, A, offA, lda, B, offB,
                                  ldb, M, N, K, lower, MT, full_items, splitk, 0);
+  else if (g_gemm_flags) hipLaunchKernelGGL((gemm44_kernel<128, false, true>), dim3(items, nb), dim3(256), 0, st, C, offC, ldc, A, offA, lda,
+                                            B, offB, ldb, M, N, K, lower, MT, full_items, splitk, 0);
   else hipLaunchKernelGGL((gemm44_kernel<128, false>), dim3(items, nb), dim3(256), 0, st, C, offC, ldc, A, offA, lda, B, offB,
                           ldb, M, N, K, lower, MT, full_items, splitk, 0);
 }
