@@ -117,6 +117,24 @@ int lmm_oilmm_logpdf_grad(const double* x, int d, int n, const double* y, int p,
                           double* out_logpdf, double* grad_y, double* grad_sigma2, double* grad_S, double* grad_U,
                           lmm_gp_grad_t* grad_gps);
 
+/* Value and TOTAL gradient of the predictive logpdf  logpdf(posterior(f(x, sigma2), y)(xs, sigma2_s), ys)  of an OILMM or (U = I,
+ * S = 1, with_regulariser = 0) an IndependentMOGP: what the reference differentiates with Zygote.gradient(logpdf, po_x, y*) on its
+ * posterior models (test/oilmm.jl:32, test/independent_mogp.jl:66), with the derivatives carried through the posterior
+ * (alpha, the factor, the Schur complement).  Gradients w.r.t. y (n*p), ys (ns*p), sigma2 (training noise), sigma2_s (predictive
+ * noise), S, U and each latent's (variance, lengthscale, mean).  Any grad pointer may be NULL; partial sums over the shard. */
+int lmm_oilmm_post_logpdf_grad(const double* x, int d, int n, const double* y, const double* xs, int ns, const double* ys, int p,
+                               const double* U, const double* S, int m, double sigma2, double sigma2_s, const lmm_gp_t* gps,
+                               int latent_begin, int latent_end, int with_regulariser, double* out_logpdf, double* grad_y,
+                               double* grad_ys, double* grad_sigma2, double* grad_sigma2_s, double* grad_S, double* grad_U,
+                               lmm_gp_grad_t* grad_gps);
+
+/* Value and gradient of logpdf(fx::FiniteGP{<:ILMM}, y) for a dense H (reference src/ilmm.jl:150-181; Zygote.gradient(logpdf,
+ * ilmmx, y) in test/ilmm.jl:31) w.r.t. y, sigma2, H (p x m, column-major) and each latent's (variance, lengthscale, mean).
+ * The reference's dense operation plus the explicit (mn) x (mn) inverse; m*n <= 46000.  Does not shard. */
+int lmm_ilmm_logpdf_grad(const double* x, int d, int n, const double* y, int p, const double* H, int m, double sigma2,
+                         const lmm_gp_t* gps, const lmm_jitters_t* jit, double* out_logpdf, double* grad_y, double* grad_sigma2,
+                         double* grad_H, lmm_gp_grad_t* grad_gps);
+
 /* logpdf(fx, Y::AbstractMatrix): one value per column of Y ((n p) x ncol, column-major) from ONE factorisation per latent
  * (the extra columns ride the factorisation as rider rows).  The reference does not overload this (it falls to AbstractGPs'
  * dense generic path); AbstractGPs.TestUtils calls it.  out: ncol values. */

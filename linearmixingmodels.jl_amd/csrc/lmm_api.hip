@@ -866,37 +866,46 @@ int lmm_oilmm_logpdf(const double* x, int d, int n, const double* y, int p, cons
   LMM_CATCH
 }
 
-// Value and gradient of logpdf(fx::FiniteGP{<:OILMM}, y) (reference src/oilmm.jl:79-93; what the reference's
-// Zygote.gradient(logpdf, fx, y) differentiates, test/oilmm.jl:31-32) w.r.t. y, sigma2, S, U and every latent's
-// (variance, lengthscale, mean).  Per latent: factor, alpha = Kt^-1 delta, Kt^-1 = L^-T L^-1 (triangular solve of identity
-// riders + an upper-triangular SYRK on the MFMA kernels), then one fused contraction kernel; the chain rule through
-// T = S^-1/2 U', SigmaT = sigma2 / S and the regulariser is small host algebra.  Partial sums over the shard.
-int lmm_oilmm_logpdf_grad(const double* x, int d, int n, const double* y, int p, const double* U, const double* S, int m,
-                          double sigma2, const lmm_gp_t* gps, int latent_begin, int latent_end, int with_regulariser,
-                          double* out_logpdf, double* grad_y, double* grad_sigma2, double* grad_S, double* grad_U,
-                          lmm_gp_grad_t* grad_gps) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  REQUIRE_INIT();
-  LMM_TRY
-  if (!x || !y || !U || !S || !out_logpdf || d <= 0 || n <= 0 || p <= 0 || m <= 0) return fail(LMM_ERR_ARG, "bad arguments");
-  if (m > p) return fail(LMM_ERR_DIM, "out dim of x != out dim of f.");
-  if (latent_begin < 0 || latent_end > m || latent_begin > latent_end) return fail(LMM_ERR_ARG, "bad latent shard");
-  if (int rc = check_gps(gps, m)) return rc;
-  if (!(sigma2 > 0.0)) return fail(LMM_ERR_ARG, "sigma2 must be > 0");
+}  // extern "C"
+
+namespace {
+
+struct OilmmGrad {          // host results of oilmm_grad_core (partial sums over the latent shard)
+  double value = 0.0, gs2a = 0.0, gs2b = 0.0;
+  std::vector<double> gS, gU;
+  std::vector<lmm_gp_grad_t> ggps;
+};
+
+// Value and gradient of the OILMM logpdf (reference src/oilmm.jl:79-113 differentiated) over N points whose first `nsplit`
+// carry observation noise s2a and the rest s2b (nsplit == N: the plain logpdf; nsplit < N: the joint density of training and
+// test points that the predictive logpdf is the difference of).  Per latent: factor, alpha = Kt^-1 delta, Kt^-1 = L^-T L^-1
+// (triangular solve of identity riders + an upper-triangular SYRK on the MFMA kernels), one fused contraction kernel; the chain
+// rule through T = S^-1/2 U', the projected noise s2/S and the regulariser is small host algebra.
+// xd: d x N (device), yd: N x p column-major (device), gy_dev: N x p device output or nullptr.  Caller holds g_mu.
+int oilmm_grad_core(const double* xd, int d, int N, int nsplit, const double* yd, int p, const double* U, const double* S, int m,
+                    double s2a, double s2b, const lmm_gp_t* gps, int l0, int l1, int with_regulariser, OilmmGrad& G,
+                    double* gy_dev) {
   hipStream_t st0 = g.streams[0];
-  const int l0 = latent_begin, l1 = latent_end, ms = l1 - l0;
-  std::vector<double> T, ST, H;
-  project_orthogonal(U, S, p, m, sigma2, T, ST, H);
-  DevIn xd(x, (size_t)d * n, st0), yd(y, (size_t)n * p, st0);
+  const int ms = l1 - l0, n = N;
+  const bool two = nsplit < N;
+  std::vector<double> T, STa, H;
+  project_orthogonal(U, S, p, m, s2a, T, STa, H);
+  std::vector<double> STb(m);
+  for (int l = 0; l < m; ++l) STb[l] = s2b / S[l];
   Uploaded Td(T, st0);
   std::vector<double> means(m);
   for (int l = 0; l < m; ++l) means[l] = gps[l].mean;
   Uploaded meansd(means, st0);
-  // projections: Ty (all m, for the regulariser and dS), delta for the shard
+  // projections: Ty (all m, for dS), delta for the shard
   Buf<double> Ty((size_t)n * m), delta((size_t)n * std::max(ms, 1));
-  project_on_device(yd.p, n, p, Td.buf, m, 0, m, nullptr, Ty.p, st0);
-  if (ms > 0) project_on_device(yd.p, n, p, Td.buf, m, l0, ms, meansd.buf.p + l0, delta.p, st0);
-  // per-latent factorisation, alpha, inverse, contractions
+  project_on_device(yd, n, p, Td.buf, m, 0, m, nullptr, Ty.p, st0);
+  if (ms > 0) project_on_device(yd, n, p, Td.buf, m, l0, ms, meansd.buf.p + l0, delta.p, st0);
+  Buf<double> nv(two ? (size_t)n * std::max(ms, 1) : 1);          // per-point projected noise of the shard's latents
+  if (two)
+    for (int k = 0; k < ms; ++k) {
+      launch_fill(nv.p + (size_t)k * n, nsplit, STa[l0 + k], st0);
+      launch_fill(nv.p + (size_t)k * n + nsplit, n - nsplit, STb[l0 + k], st0);
+    }
   Dims D(n, 1);
   int nb_per = 1, nslots = 1;
   batch_plan(std::max(ms, 1), &nb_per, &nslots, 2.0 * (double)D.elems() * sizeof(double));     // factor + inverse-factor matrices
@@ -908,7 +917,8 @@ int lmm_oilmm_logpdf_grad(const double* x, int d, int n, const double* y, int p,
     }
     part.emplace_back((size_t)grad_partials(n));
   }
-  Buf<double> alpha((size_t)D.NC * std::max(ms, 1)), lmld(std::max(ms, 1)), red((size_t)5 * std::max(ms, 1));
+  const int NGR = LMM_NGRAD;
+  Buf<double> alpha((size_t)D.NC * std::max(ms, 1)), lmld(std::max(ms, 1)), red((size_t)NGR * std::max(ms, 1));
   Buf<int> info(std::max(ms, 1));
   HIPCHK(hipMemsetAsync(info.p, 0, std::max(ms, 1) * sizeof(int), st0));
   HIPCHK(hipMemsetAsync(alpha.p, 0, (size_t)D.NC * std::max(ms, 1) * sizeof(double), st0));
@@ -924,8 +934,10 @@ int lmm_oilmm_logpdf_grad(const double* x, int d, int n, const double* y, int p,
       const int k = k0 + j;
       const lmm_gp_t& gp = gps[l0 + k];
       GramArgs a{};
-      a.A = Am[s][j].p; a.ld = D.ld; a.nrows = D.NR; a.ncols = D.NC; a.x = xd.p; a.d = d; a.n = n;
-      a.kind = gp.kind; a.var = gp.variance; a.inv_ls = 1.0 / gp.lengthscale; a.diag_add = ST[l0 + k]; a.pad_diag = 1.0;
+      a.A = Am[s][j].p; a.ld = D.ld; a.nrows = D.NR; a.ncols = D.NC; a.x = xd; a.d = d; a.n = n;
+      a.kind = gp.kind; a.var = gp.variance; a.inv_ls = 1.0 / gp.lengthscale; a.pad_diag = 1.0;
+      a.diag_add = two ? 0.0 : STa[l0 + k];
+      a.diag_vec = two ? nv.p + (size_t)k * n : nullptr;
       a.rider = delta.p + (size_t)k * n; a.rider_ld = n; a.nrider = 1;
       ga[j] = a;
       B.add(Am[s][j].p, Wm[s][j].p, info.p + k);
@@ -943,48 +955,57 @@ int lmm_oilmm_logpdf_grad(const double* x, int d, int n, const double* y, int p,
     launch_syrk_upper_set(B.A, D.ld, Rb, D.ld, D.NC, nb, st);                // lower(A) = L^-T L^-1 = Kt^-1
     for (int j = 0; j < nb; ++j) {
       const int k = k0 + j;
-      launch_grad_reduce(Am[s][j].p, D.ld, n, alb.p[j], delta.p + (size_t)k * n, xd.p, d, to_dev(gps[l0 + k]), part[s].p,
-                         red.p + (size_t)5 * k, st);
+      launch_grad_reduce(Am[s][j].p, D.ld, n, nsplit, alb.p[j], delta.p + (size_t)k * n, xd, d, to_dev(gps[l0 + k]), part[s].p,
+                         red.p + (size_t)NGR * k, st);
     }
   }
   join_slots(nslots);
-  std::vector<double> lml(std::max(ms, 1), 0.0), hred((size_t)5 * std::max(ms, 1), 0.0);
+  std::vector<double> lml(std::max(ms, 1), 0.0), hred((size_t)NGR * std::max(ms, 1), 0.0);
   std::vector<int> hinfo(std::max(ms, 1), 0);
   HIPCHK(hipMemcpyAsync(lml.data(), lmld.p, std::max(ms, 1) * sizeof(double), hipMemcpyDeviceToHost, st0));
-  HIPCHK(hipMemcpyAsync(hred.data(), red.p, (size_t)5 * std::max(ms, 1) * sizeof(double), hipMemcpyDeviceToHost, st0));
+  HIPCHK(hipMemcpyAsync(hred.data(), red.p, (size_t)NGR * std::max(ms, 1) * sizeof(double), hipMemcpyDeviceToHost, st0));
   HIPCHK(hipMemcpyAsync(hinfo.data(), info.p, std::max(ms, 1) * sizeof(int), hipMemcpyDeviceToHost, st0));
-  // small dense products needed by the chain rule: YA = Y' alpha (p x ms), aTy = alpha_l . (T y)_l, M2 = Y Y' (p x p)
-  Buf<double> YAd((size_t)p * std::max(ms, 1)), aTyd((size_t)std::max(ms, 1) * m), M2d((size_t)p * p);
+  // small dense products needed by the chain rule: YA = Y' alpha (p x ms), aTy = alpha_l . (T y)_l, M2 = Y Y' (p x p) per noise block
+  Buf<double> YAd((size_t)p * std::max(ms, 1)), aTyd((size_t)std::max(ms, 1) * m), M2ad((size_t)p * p), M2bd((size_t)p * p);
   if (ms > 0) {
-    launch_atb(yd.p, n, alpha.p, D.NC, n, p, ms, YAd.p, st0);
+    launch_atb(yd, n, alpha.p, D.NC, n, p, ms, YAd.p, st0);
     launch_atb(alpha.p, D.NC, Ty.p, n, n, ms, m, aTyd.p, st0);       // [k, l]; only l = l0 + k is used
   }
-  if (with_regulariser) launch_atb(yd.p, n, yd.p, n, n, p, p, M2d.p, st0);
-  std::vector<double> YA((size_t)p * std::max(ms, 1), 0.0), aTy((size_t)std::max(ms, 1) * m, 0.0), M2((size_t)p * p, 0.0);
+  std::vector<double> YA((size_t)p * std::max(ms, 1), 0.0), aTy((size_t)std::max(ms, 1) * m, 0.0), M2a((size_t)p * p, 0.0), M2b((size_t)p * p, 0.0);
+  if (with_regulariser) {
+    launch_atb(yd, n, yd, n, nsplit, p, p, M2ad.p, st0);
+    HIPCHK(hipMemcpyAsync(M2a.data(), M2ad.p, M2a.size() * sizeof(double), hipMemcpyDeviceToHost, st0));
+    if (two) {
+      launch_atb(yd + nsplit, n, yd + nsplit, n, n - nsplit, p, p, M2bd.p, st0);
+      HIPCHK(hipMemcpyAsync(M2b.data(), M2bd.p, M2b.size() * sizeof(double), hipMemcpyDeviceToHost, st0));
+    }
+  }
   HIPCHK(hipMemcpyAsync(YA.data(), YAd.p, YA.size() * sizeof(double), hipMemcpyDeviceToHost, st0));
   HIPCHK(hipMemcpyAsync(aTy.data(), aTyd.p, aTy.size() * sizeof(double), hipMemcpyDeviceToHost, st0));
-  if (with_regulariser) HIPCHK(hipMemcpyAsync(M2.data(), M2d.p, M2.size() * sizeof(double), hipMemcpyDeviceToHost, st0));
   HIPCHK(hipStreamSynchronize(st0));
   if (int rc = check_info(hinfo, l0)) return rc;
 
   // ---- host chain rule ----
-  double total = 0.0, gs2 = 0.0;
-  std::vector<double> gS(m, 0.0), gU((size_t)p * m, 0.0);
-  if (grad_gps) for (int l = 0; l < m; ++l) { grad_gps[l].variance = 0.0; grad_gps[l].lengthscale = 0.0; grad_gps[l].mean = 0.0; }
+  double total = 0.0;
+  G.gs2a = G.gs2b = 0.0;
+  G.gS.assign(m, 0.0); G.gU.assign((size_t)p * m, 0.0);
+  G.ggps.assign(m, lmm_gp_grad_t{0.0, 0.0, 0.0});
+  const double na = nsplit, nbk = n - nsplit;
   for (int k = 0; k < ms; ++k) {
     const int l = l0 + k;
     total += lml[k];
-    const double cl = hred[5 * k + 0], trinv = hred[5 * k + 1], aa = hred[5 * k + 2], ad = hred[5 * k + 3], sa = hred[5 * k + 4];
-    const double s = ST[l], v = gps[l].variance;
-    const double g_s = 0.5 * (aa - trinv);                       // d lml / d noise_l
-    if (grad_gps) {
-      grad_gps[l].variance = 0.5 * ((ad - s * aa) - ((double)n - s * trinv)) / v;     // 1/2 tr((aa' - Kinv) K) / v
-      grad_gps[l].lengthscale = cl;                              // sum_{i>j} (a_i a_j - Kinv_ij) dK_ij/dl (x2 / 2)
-      grad_gps[l].mean = sa;
-    }
-    gs2 += g_s / S[l];
-    gS[l] += -g_s * sigma2 / (S[l] * S[l]) + 0.5 * aTy[k + (size_t)l * ms] / S[l];
-    for (int o = 0; o < p; ++o) gU[o + (size_t)l * p] += -YA[o + (size_t)k * p] / std::sqrt(S[l]);
+    const double* r = &hred[(size_t)NGR * k];
+    const double cl = r[0], tra = r[1], aaa = r[2], ad = r[3], sa = r[4], trb = r[5], aab = r[6];
+    const double sA = STa[l], sB = STb[l], v = gps[l].variance;
+    const double g_sa = 0.5 * (aaa - tra), g_sb = 0.5 * (aab - trb);           // d lml / d noise of block a, b
+    // 1/2 tr((aa' - Kt^-1) K) / v  with K = Kt - D:  a'delta - a'Da - (n - tr(Kt^-1 D))
+    G.ggps[l].variance = 0.5 * ((ad - (sA * aaa + sB * aab)) - ((double)n - (sA * tra + sB * trb))) / v;
+    G.ggps[l].lengthscale = cl;                                                // sum_{i>j} (a_i a_j - Kinv_ij) dK_ij/dl (x2 / 2)
+    G.ggps[l].mean = sa;
+    G.gs2a += g_sa / S[l];
+    G.gs2b += g_sb / S[l];
+    G.gS[l] += -(g_sa * s2a + g_sb * s2b) / (S[l] * S[l]) + 0.5 * aTy[k + (size_t)l * ms] / S[l];
+    for (int o = 0; o < p; ++o) G.gU[o + (size_t)l * p] += -YA[o + (size_t)k * p] / std::sqrt(S[l]);
   }
   std::vector<double> PtP;       // P'P for the regulariser's dY
   if (with_regulariser) {
@@ -1001,25 +1022,26 @@ int lmm_oilmm_logpdf_grad(const double* x, int d, int n, const double* y, int p,
       return Cc;
     };
     PtP = matmul(Pm, p, p, Pm, p);                               // P symmetric: P'P = P P
-    double Rn = 0.0;                                             // |P Y|_F^2 = tr(P'P Y Y')
-    for (int a1 = 0; a1 < p; ++a1) for (int b1 = 0; b1 < p; ++b1) Rn += PtP[a1 + (size_t)b1 * p] * M2[b1 + (size_t)a1 * p];
     double logdetS = 0.0;
     for (int l = 0; l < m; ++l) logdetS += std::log(S[l]);
-    total += -((double)n * (logdetS + (double)(p - m) * std::log(2.0 * M_PI * sigma2)) + Rn / sigma2) / 2.0;   // src/oilmm.jl:101-113
-    for (int l = 0; l < m; ++l) gS[l] += -(double)n / (2.0 * S[l]);
-    gs2 += -0.5 * ((double)n * (double)(p - m) / sigma2 - Rn / (sigma2 * sigma2));
     std::vector<double> Uv(U, U + (size_t)p * m);
-    std::vector<double> M2U = matmul(M2, p, p, Uv, m), PU = matmul(Pm, p, p, Uv, m);
-    std::vector<double> t1 = matmul(Pm, p, p, M2U, m), t2 = matmul(M2, p, p, PU, m);
-    for (size_t q = 0; q < gU.size(); ++q) gU[q] += (t1[q] + t2[q]) / sigma2;
+    std::vector<double> PU = matmul(Pm, p, p, Uv, m);
+    for (int blk = 0; blk < (two ? 2 : 1); ++blk) {               // reference src/oilmm.jl:101-113, once per noise block
+      const std::vector<double>& M2 = blk ? M2b : M2a;
+      const double s2 = blk ? s2b : s2a, cnt = blk ? nbk : na;
+      double Rn = 0.0;                                           // |P Y|_F^2 = tr(P'P Y Y')
+      for (int a1 = 0; a1 < p; ++a1) for (int b1 = 0; b1 < p; ++b1) Rn += PtP[a1 + (size_t)b1 * p] * M2[b1 + (size_t)a1 * p];
+      total += -(cnt * (logdetS + (double)(p - m) * std::log(2.0 * M_PI * s2)) + Rn / s2) / 2.0;
+      for (int l = 0; l < m; ++l) G.gS[l] += -cnt / (2.0 * S[l]);
+      (blk ? G.gs2b : G.gs2a) += -0.5 * (cnt * (double)(p - m) / s2 - Rn / (s2 * s2));
+      std::vector<double> M2U = matmul(M2, p, p, Uv, m);
+      std::vector<double> t1 = matmul(Pm, p, p, M2U, m), t2 = matmul(M2, p, p, PU, m);
+      for (size_t q = 0; q < G.gU.size(); ++q) G.gU[q] += (t1[q] + t2[q]) / s2;
+    }
   }
-  *out_logpdf = total;
-  if (grad_sigma2) *grad_sigma2 = gs2;
-  if (grad_S) std::copy(gS.begin(), gS.end(), grad_S);
-  if (grad_U) std::copy(gU.begin(), gU.end(), grad_U);
-  if (grad_y) {
-    // dL/dY[o, i] = - sum_l T[l, o] alpha_l[i]  - (P'P Y)[o, i] / sigma2
-    DevOut gy(grad_y, (size_t)n * p);
+  G.value = total;
+  if (gy_dev) {
+    // dL/dY[o, i] = - sum_l T[l, o] alpha_l[i]  - (P'P Y)[o, i] / sigma2(i)
     std::vector<double> negTt((size_t)p * std::max(ms, 1), 0.0);
     for (int k = 0; k < ms; ++k) for (int o = 0; o < p; ++o) negTt[o + (size_t)k * p] = -T[(l0 + k) + (size_t)o * m];
     Uploaded nT(negTt, st0);
@@ -1027,16 +1049,119 @@ int lmm_oilmm_logpdf_grad(const double* x, int d, int n, const double* y, int p,
     // mix reads lat[l*ns + s] with ns = n: alpha is stored with stride NC -> compact copy first
     Buf<double> ac((size_t)n * std::max(ms, 1));
     for (int k = 0; k < ms; ++k) HIPCHK(hipMemcpyAsync(ac.p + (size_t)k * n, alpha.p + (size_t)k * D.NC, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st0));
-    launch_mix(ac.p, n, ms, nT.buf.p, p, 1, 0.0, 0.0, nullptr, 0.0, ga.p, st0);
+    launch_mix(ac.p, n, ms, nT.buf.p, p, 1, 0.0, 0.0, nullptr, 0.0, with_regulariser ? ga.p : gy_dev, st0);
     if (with_regulariser) {
       Uploaded Qd(PtP, st0);
       Buf<double> gr((size_t)n * p);
-      launch_tall_skinny(yd.p, n, n, p, Qd.buf.p, p, p, gr.p, n, nullptr, nullptr, 0, nullptr, 0, st0);   // (Y' (P'P)')' rows
-      launch_vec_lin(ga.p, gr.p, -1.0 / sigma2, n * p, gy.p, st0);
+      launch_tall_skinny(yd, n, n, p, Qd.buf.p, p, p, gr.p, n, nullptr, nullptr, 0, nullptr, 0, st0);   // (Y' (P'P)')' rows
+      launch_vec_lin2(ga.p, gr.p, -1.0 / s2a, -1.0 / s2b, nsplit, n, (size_t)n * p, gy_dev, st0);
+      HIPCHK(hipStreamSynchronize(st0));       // ga, gr, Qd are released on return
     } else {
-      HIPCHK(hipMemcpyAsync(gy.p, ga.p, (size_t)n * p * sizeof(double), hipMemcpyDeviceToDevice, st0));
+      HIPCHK(hipStreamSynchronize(st0));
     }
+  }
+  return LMM_OK;
+}
+
+void write_oilmm_grad(const OilmmGrad& G, int m, int p, double* out_logpdf, double* grad_sigma2, double* grad_S, double* grad_U,
+                      lmm_gp_grad_t* grad_gps) {
+  *out_logpdf = G.value;
+  if (grad_sigma2) *grad_sigma2 = G.gs2a + G.gs2b;
+  if (grad_S) std::copy(G.gS.begin(), G.gS.end(), grad_S);
+  if (grad_U) std::copy(G.gU.begin(), G.gU.end(), grad_U);
+  if (grad_gps) std::copy(G.ggps.begin(), G.ggps.end(), grad_gps);
+  (void)m; (void)p;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Value and gradient of logpdf(fx::FiniteGP{<:OILMM}, y) (reference src/oilmm.jl:79-93; what the reference's
+// Zygote.gradient(logpdf, fx, y) differentiates, test/oilmm.jl:31-32) w.r.t. y, sigma2, S, U and every latent's
+// (variance, lengthscale, mean).  Partial sums over the shard.
+int lmm_oilmm_logpdf_grad(const double* x, int d, int n, const double* y, int p, const double* U, const double* S, int m,
+                          double sigma2, const lmm_gp_t* gps, int latent_begin, int latent_end, int with_regulariser,
+                          double* out_logpdf, double* grad_y, double* grad_sigma2, double* grad_S, double* grad_U,
+                          lmm_gp_grad_t* grad_gps) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  REQUIRE_INIT();
+  LMM_TRY
+  if (!x || !y || !U || !S || !out_logpdf || d <= 0 || n <= 0 || p <= 0 || m <= 0) return fail(LMM_ERR_ARG, "bad arguments");
+  if (m > p) return fail(LMM_ERR_DIM, "out dim of x != out dim of f.");
+  if (latent_begin < 0 || latent_end > m || latent_begin > latent_end) return fail(LMM_ERR_ARG, "bad latent shard");
+  if (int rc = check_gps(gps, m)) return rc;
+  if (!(sigma2 > 0.0)) return fail(LMM_ERR_ARG, "sigma2 must be > 0");
+  hipStream_t st0 = g.streams[0];
+  DevIn xd(x, (size_t)d * n, st0), yd(y, (size_t)n * p, st0);
+  DevOut gy(grad_y, (size_t)n * p);
+  OilmmGrad G;
+  if (int rc = oilmm_grad_core(xd.p, d, n, n, yd.p, p, U, S, m, sigma2, sigma2, gps, latent_begin, latent_end, with_regulariser, G, gy.p))
+    return rc;
+  write_oilmm_grad(G, m, p, out_logpdf, grad_sigma2, grad_S, grad_U, grad_gps);
+  if (grad_y) { gy.finish(st0); HIPCHK(hipStreamSynchronize(st0)); }
+  return LMM_OK;
+  LMM_CATCH
+}
+
+// Value and gradient of the predictive logpdf  logpdf(posterior(f(x, sigma2), y)(xs, sigma2_s), ys)  of an OILMM (or, with
+// U = I, S = 1, an IndependentMOGP) -- the reference takes Zygote.gradient(logpdf, po_x, y*) on the posterior models
+// (test/oilmm.jl:32, test/independent_mogp.jl:66).  Exact conditioning gives, latent by latent and for the regulariser,
+//     log p(ys | y) = log p(y, ys) - log p(y),
+// so value and TOTAL derivatives (through alpha, the factor and the Schur complement of the posterior) are the difference of
+// two evaluations of the prior-logpdf gradient: the joint over [x; xs] with per-block noise, and the marginal over x.
+int lmm_oilmm_post_logpdf_grad(const double* x, int d, int n, const double* y, const double* xs, int ns, const double* ys, int p,
+                               const double* U, const double* S, int m, double sigma2, double sigma2_s, const lmm_gp_t* gps,
+                               int latent_begin, int latent_end, int with_regulariser, double* out_logpdf, double* grad_y,
+                               double* grad_ys, double* grad_sigma2, double* grad_sigma2_s, double* grad_S, double* grad_U,
+                               lmm_gp_grad_t* grad_gps) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  REQUIRE_INIT();
+  LMM_TRY
+  if (!x || !y || !xs || !ys || !U || !S || !out_logpdf || d <= 0 || n <= 0 || ns <= 0 || p <= 0 || m <= 0)
+    return fail(LMM_ERR_ARG, "bad arguments");
+  if (m > p) return fail(LMM_ERR_DIM, "out dim of x != out dim of f.");
+  if (latent_begin < 0 || latent_end > m || latent_begin > latent_end) return fail(LMM_ERR_ARG, "bad latent shard");
+  if (int rc = check_gps(gps, m)) return rc;
+  if (!(sigma2 > 0.0) || !(sigma2_s > 0.0)) return fail(LMM_ERR_ARG, "sigma2 must be > 0");
+  hipStream_t st0 = g.streams[0];
+  const int N = n + ns;
+  DevIn xd(x, (size_t)d * n, st0), yd(y, (size_t)n * p, st0), xsd(xs, (size_t)d * ns, st0), ysd(ys, (size_t)ns * p, st0);
+  Buf<double> xj((size_t)d * N), yj((size_t)N * p), gj((size_t)N * p), gm((size_t)n * p);
+  HIPCHK(hipMemcpyAsync(xj.p, xd.p, (size_t)d * n * sizeof(double), hipMemcpyDeviceToDevice, st0));
+  HIPCHK(hipMemcpyAsync(xj.p + (size_t)d * n, xsd.p, (size_t)d * ns * sizeof(double), hipMemcpyDeviceToDevice, st0));
+  HIPCHK(hipMemcpy2DAsync(yj.p, (size_t)N * sizeof(double), yd.p, (size_t)n * sizeof(double), (size_t)n * sizeof(double), p, hipMemcpyDeviceToDevice, st0));
+  HIPCHK(hipMemcpy2DAsync(yj.p + n, (size_t)N * sizeof(double), ysd.p, (size_t)ns * sizeof(double), (size_t)ns * sizeof(double), p, hipMemcpyDeviceToDevice, st0));
+  const bool want_gy = grad_y != nullptr || grad_ys != nullptr;
+  OilmmGrad GJ, GM;
+  if (int rc = oilmm_grad_core(xj.p, d, N, n, yj.p, p, U, S, m, sigma2, sigma2_s, gps, latent_begin, latent_end, with_regulariser, GJ,
+                               want_gy ? gj.p : nullptr)) return rc;
+  if (int rc = oilmm_grad_core(xd.p, d, n, n, yd.p, p, U, S, m, sigma2, sigma2, gps, latent_begin, latent_end, with_regulariser, GM,
+                               grad_y ? gm.p : nullptr)) return rc;
+  *out_logpdf = GJ.value - GM.value;
+  if (grad_sigma2) *grad_sigma2 = GJ.gs2a - (GM.gs2a + GM.gs2b);
+  if (grad_sigma2_s) *grad_sigma2_s = GJ.gs2b;
+  for (int l = 0; l < m; ++l) {
+    if (grad_S) grad_S[l] = GJ.gS[l] - GM.gS[l];
+    if (grad_gps) {
+      grad_gps[l].variance = GJ.ggps[l].variance - GM.ggps[l].variance;
+      grad_gps[l].lengthscale = GJ.ggps[l].lengthscale - GM.ggps[l].lengthscale;
+      grad_gps[l].mean = GJ.ggps[l].mean - GM.ggps[l].mean;
+    }
+  }
+  if (grad_U) for (size_t q = 0; q < (size_t)p * m; ++q) grad_U[q] = GJ.gU[q] - GM.gU[q];
+  if (grad_y) {
+    DevOut gy(grad_y, (size_t)n * p);
+    Buf<double> top((size_t)n * p);
+    HIPCHK(hipMemcpy2DAsync(top.p, (size_t)n * sizeof(double), gj.p, (size_t)N * sizeof(double), (size_t)n * sizeof(double), p, hipMemcpyDeviceToDevice, st0));
+    launch_vec_lin(top.p, gm.p, -1.0, n * p, gy.p, st0);
     gy.finish(st0);
+    HIPCHK(hipStreamSynchronize(st0));
+  }
+  if (grad_ys) {
+    DevOut gys(grad_ys, (size_t)ns * p);
+    HIPCHK(hipMemcpy2DAsync(gys.p, (size_t)ns * sizeof(double), gj.p + n, (size_t)N * sizeof(double), (size_t)ns * sizeof(double), p, hipMemcpyDeviceToDevice, st0));
+    gys.finish(st0);
     HIPCHK(hipStreamSynchronize(st0));
   }
   return LMM_OK;
@@ -1248,6 +1373,186 @@ int lmm_ilmm_logpdf_ex(const double* x, int d, int n, const double* y, int p, co
 int lmm_ilmm_logpdf(const double* x, int d, int n, const double* y, int p, const double* H, int m, double sigma2,
                     const lmm_gp_t* gps, const lmm_jitters_t* jit, double* out) {
   return lmm_ilmm_logpdf_ex(x, d, n, y, p, H, m, sigma2, gps, jit, 1, nullptr, out);
+}
+
+// Value and gradient of logpdf(fx::FiniteGP{<:ILMM}, y) with a dense H (reference src/ilmm.jl:150-181 differentiated; the
+// reference's tests take Zygote.gradient(logpdf, ilmmx, y), test/ilmm.jl:31) w.r.t. y, sigma2, H (p x m) and every latent's
+// (variance, lengthscale, mean).  The reference's own operation: ONE (mn) x (mn) factorisation of blockdiag(K_l) + SigmaT (x) I;
+// here additionally its explicit inverse (triangular solve of identity riders + upper-triangular SYRK on the MFMA kernels),
+// per-latent contractions on the diagonal blocks of the inverse, and the chain rule through project(H, sigma2)
+// (src/ilmm.jl:61-68) and the regulariser (src/ilmm.jl:171-181) as small host algebra.  Does not shard.
+int lmm_ilmm_logpdf_grad(const double* x, int d, int n, const double* y, int p, const double* H, int m, double sigma2,
+                         const lmm_gp_t* gps, const lmm_jitters_t* jit, double* out_logpdf, double* grad_y, double* grad_sigma2,
+                         double* grad_H, lmm_gp_grad_t* grad_gps) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  REQUIRE_INIT();
+  LMM_TRY
+  if (!x || !y || !H || !out_logpdf || d <= 0 || n <= 0 || p <= 0 || m <= 0) return fail(LMM_ERR_ARG, "bad arguments");
+  if (int rc = check_gps(gps, m)) return rc;
+  if (!(sigma2 > 0.0)) return fail(LMM_ERR_ARG, "sigma2 must be > 0");
+  if (!jit) jit = &kDefaultJit;
+  if ((long long)m * n > 46000) return fail(LMM_ERR_UNSUPPORTED, "m*n too large for the dense gradient (explicit (mn)^2 inverse)");
+  hipStream_t st0 = g.streams[0];
+  const double s = 1.0 / sigma2;
+  std::vector<double> T, ST;
+  double logdetST = 0.0;
+  if (int rc = project_dense(H, p, m, sigma2, jit->project_jitter, T, ST, &logdetST)) return rc;
+  // host copies in the layouts the kernels read: Tt = T' (p x m), Ht = H' (m x p)
+  std::vector<double> Hv(H, H + (size_t)p * m), Tt((size_t)p * m), Ht((size_t)m * p), means(m);
+  for (int l = 0; l < m; ++l) {
+    means[l] = gps[l].mean;
+    for (int o = 0; o < p; ++o) { Tt[o + (size_t)l * p] = T[l + (size_t)o * m]; Ht[l + (size_t)o * m] = H[o + (size_t)l * p]; }
+  }
+  std::vector<LatentDev> lat(m);
+  for (int l = 0; l < m; ++l) lat[l] = to_dev(gps[l]);
+  DevIn xd(x, (size_t)d * n, st0), yd(y, (size_t)n * p, st0);
+  Uploaded Td(T, st0), STd(ST, st0), Hd(Hv, st0), Ttd(Tt, st0), Htd(Ht, st0), meansd(means, st0);
+  Buf<LatentDev> latd(m);
+  HIPCHK(hipMemcpyAsync(latd.p, lat.data(), m * sizeof(LatentDev), hipMemcpyHostToDevice, st0));
+  const int N = m * n;
+  Buf<double> Ty((size_t)N), delta((size_t)N), partial(tall_skinny_partials(n, p)), resid_dev(1);
+  project_on_device(yd.p, n, p, Td.buf, m, 0, m, nullptr, Ty.p, st0);
+  project_on_device(yd.p, n, p, Td.buf, m, 0, m, meansd.buf.p, delta.p, st0);
+  residual_on_device(yd.p, n, p, Ty.p, m, Hd.buf, partial.p, resid_dev.p, st0);
+  Dims D(N, 1);
+  Buf<double> A(D.elems()), W((size_t)(D.NC / 64) * 4096), R((size_t)D.ld * D.NC), alpha((size_t)D.NC), lml_dev(1);
+  Buf<int> info(1);
+  HIPCHK(hipMemsetAsync(info.p, 0, sizeof(int), st0));
+  HIPCHK(hipMemsetAsync(alpha.p, 0, (size_t)D.NC * sizeof(double), st0));
+  DenseArgs a{};
+  a.A = A.p; a.ld = D.ld; a.nrows = D.NR; a.ncols = D.NC; a.x = xd.p; a.d = d; a.n = n; a.m = m;
+  a.lat = latd.p; a.sigmaT = STd.buf.p; a.rider = delta.p; a.rider_ld = N; a.nrider = 1;
+  launch_dense_assemble(a, st0);
+  potrf_rec(A.p, D.ld, D.NR, 0, D.NC, W.p, N, info.p, st0);
+  launch_lml_reduce(A.p, D.ld, N, D.NC, 1, lml_dev.p, st0);
+  launch_extract_row(A.p, D.ld, D.NC, N, alpha.p, st0);
+  backsolve1(A.p, D.ld, W.p, D.NC / 64, alpha.p, st0);
+  launch_set_identity(R.p, D.ld, D.NC, st0);
+  trsm_rec(R.p, D.ld, D.NC, A.p, D.ld, W.p, 0, D.NC, st0, true);                 // R = L^-T
+  launch_syrk_upper_set(A.p, D.ld, R.p, D.ld, D.NC, st0);                         // lower(A) = Sigma^-1
+  const int NGR = LMM_NGRAD;
+  Buf<double> red((size_t)NGR * m), gpart((size_t)grad_partials(n)), Btr((size_t)m * m), AAt((size_t)m * m), AY((size_t)m * p);
+  for (int l = 0; l < m; ++l)
+    launch_grad_reduce(A.p + (size_t)l * n * D.ld + (size_t)l * n, D.ld, n, n, alpha.p + (size_t)l * n, delta.p + (size_t)l * n, xd.p, d,
+                       lat[l], gpart.p, red.p + (size_t)NGR * l, st0);
+  launch_block_trace(A.p, D.ld, n, m, Btr.p, st0);
+  launch_atb(alpha.p, n, alpha.p, n, n, m, m, AAt.p, st0);                         // (alpha_l . alpha_l')
+  launch_atb(alpha.p, n, yd.p, n, n, m, p, AY.p, st0);                             // sum_i alpha_l[i] Y[i, o]   (m x p)
+  // regulariser pieces: Rm = Y - (T Y)' H' (n x p), RH = Rm H (n x m), Rm' Ty (p x m), RH' Y (m x p)
+  Buf<double> HTY((size_t)n * p), Rm((size_t)n * p), RH((size_t)N), RtTy((size_t)p * m), RHtY((size_t)m * p);
+  launch_tall_skinny(Ty.p, n, n, m, Hd.buf.p, p, p, HTY.p, n, nullptr, nullptr, 0, nullptr, 0, st0);
+  launch_vec_lin(yd.p, HTY.p, -1.0, n * p, Rm.p, st0);
+  launch_tall_skinny(Rm.p, n, n, p, Htd.buf.p, m, m, RH.p, n, nullptr, nullptr, 0, nullptr, 0, st0);
+  launch_atb(Rm.p, n, Ty.p, n, n, p, m, RtTy.p, st0);
+  launch_atb(RH.p, n, yd.p, n, n, m, p, RHtY.p, st0);
+  std::vector<double> hred((size_t)NGR * m), hB((size_t)m * m), hAAt((size_t)m * m), hAY((size_t)m * p), hRtTy((size_t)p * m), hRHtY((size_t)m * p);
+  double lml = 0.0, resid = 0.0;
+  int hinfo = 0;
+  HIPCHK(hipMemcpyAsync(&lml, lml_dev.p, sizeof(double), hipMemcpyDeviceToHost, st0));
+  HIPCHK(hipMemcpyAsync(&resid, resid_dev.p, sizeof(double), hipMemcpyDeviceToHost, st0));
+  HIPCHK(hipMemcpyAsync(&hinfo, info.p, sizeof(int), hipMemcpyDeviceToHost, st0));
+  HIPCHK(hipMemcpyAsync(hred.data(), red.p, hred.size() * sizeof(double), hipMemcpyDeviceToHost, st0));
+  HIPCHK(hipMemcpyAsync(hB.data(), Btr.p, hB.size() * sizeof(double), hipMemcpyDeviceToHost, st0));
+  HIPCHK(hipMemcpyAsync(hAAt.data(), AAt.p, hAAt.size() * sizeof(double), hipMemcpyDeviceToHost, st0));
+  HIPCHK(hipMemcpyAsync(hAY.data(), AY.p, hAY.size() * sizeof(double), hipMemcpyDeviceToHost, st0));
+  HIPCHK(hipMemcpyAsync(hRtTy.data(), RtTy.p, hRtTy.size() * sizeof(double), hipMemcpyDeviceToHost, st0));
+  HIPCHK(hipMemcpyAsync(hRHtY.data(), RHtY.p, hRHtY.size() * sizeof(double), hipMemcpyDeviceToHost, st0));
+  HIPCHK(hipStreamSynchronize(st0));
+  if (int rc = check_info(std::vector<int>{hinfo}, 0)) return rc;
+  // value: reference src/ilmm.jl:150-163 + :171-181
+  *out_logpdf = lml - ((double)n * ((double)(p - m) * kLog2Pi + ((double)p * std::log(sigma2) - logdetST)) + resid / sigma2) / 2.0;
+  // ---- kernel-parameter gradients: 1/2 tr((aa' - Sigma^-1) dSigma/dtheta_l), dSigma = E_ll (x) dK_l ----
+  if (grad_gps)
+    for (int l = 0; l < m; ++l) {
+      const double* r = &hred[(size_t)NGR * l];
+      grad_gps[l].lengthscale = r[0];
+      grad_gps[l].variance = (r[7] + 0.5 * gps[l].variance * (r[2] - r[1])) / gps[l].variance;     // K_ii = variance
+      grad_gps[l].mean = r[4];
+    }
+  auto at = [](std::vector<double>& M, int rows, int i, int j) -> double& { return M[i + (size_t)j * rows]; };
+  // ---- cotangents of T (m x p) and SigmaT (m x m) ----
+  std::vector<double> Tb((size_t)m * p, 0.0), Gs((size_t)m * m, 0.0), Hb((size_t)p * m, 0.0);
+  double s2b = 0.0;
+  for (int l = 0; l < m; ++l)
+    for (int o = 0; o < p; ++o) Tb[l + (size_t)o * m] = -hAY[l + (size_t)o * m] + s * hRHtY[l + (size_t)o * m];   // lml + regulariser (residual)
+  // SigmaT^-1 for the +n/2 logdet SigmaT term of the regulariser
+  std::vector<double> STc = ST, STinv((size_t)m * m, 0.0);
+  if (!host_cholesky(STc, m)) return fail(LMM_ERR_NOT_PD, "PosDefException: SigmaT not PD");
+  for (int c = 0; c < m; ++c) {       // solve (L L') col = e_c
+    std::vector<double> v(m, 0.0);
+    for (int aI = 0; aI < m; ++aI) { double t = (aI == c) ? 1.0 : 0.0; for (int k = 0; k < aI; ++k) t -= STc[aI + (size_t)k * m] * v[k]; v[aI] = t / STc[aI + (size_t)aI * m]; }
+    for (int aI = m - 1; aI >= 0; --aI) { double t = v[aI]; for (int k = aI + 1; k < m; ++k) t -= STc[k + (size_t)aI * m] * v[k]; v[aI] = t / STc[aI + (size_t)aI * m]; }
+    for (int aI = 0; aI < m; ++aI) STinv[aI + (size_t)c * m] = v[aI];
+  }
+  for (int aI = 0; aI < m; ++aI)
+    for (int b = 0; b < m; ++b) Gs[aI + (size_t)b * m] = 0.5 * (hAAt[aI + (size_t)b * m] - hB[aI + (size_t)b * m]) + 0.5 * (double)n * STinv[aI + (size_t)b * m];
+  // explicit sigma2 of the regulariser and explicit H of the residual
+  s2b += -0.5 * ((double)n * (double)p / sigma2 - resid / (sigma2 * sigma2));
+  for (int o = 0; o < p; ++o) for (int l = 0; l < m; ++l) Hb[o + (size_t)l * p] += s * hRtTy[o + (size_t)l * p];
+  // ---- backward through project(H, sigma2): P = s H'H + eps I,  T = P^-1 H' s,  SigmaT = sigma2 T T' ----
+  // SigmaT = sigma2 T T':  Tb += sigma2 (Gs + Gs') T;  s2b += <Gs, T T'>
+  for (int aI = 0; aI < m; ++aI)
+    for (int o = 0; o < p; ++o) {
+      double acc = 0.0;
+      for (int b = 0; b < m; ++b) acc += (Gs[aI + (size_t)b * m] + Gs[b + (size_t)aI * m]) * T[b + (size_t)o * m];
+      Tb[aI + (size_t)o * m] += sigma2 * acc;
+    }
+  for (int aI = 0; aI < m; ++aI)
+    for (int b = 0; b < m; ++b) {
+      double tt = 0.0;
+      for (int o = 0; o < p; ++o) tt += T[aI + (size_t)o * m] * T[b + (size_t)o * m];
+      s2b += Gs[aI + (size_t)b * m] * tt;
+    }
+  // P and its Cholesky
+  std::vector<double> HtH((size_t)m * m, 0.0), P((size_t)m * m, 0.0);
+  for (int aI = 0; aI < m; ++aI)
+    for (int b = 0; b < m; ++b) {
+      double acc = 0.0;
+      for (int o = 0; o < p; ++o) acc += H[o + (size_t)aI * p] * H[o + (size_t)b * p];
+      HtH[aI + (size_t)b * m] = acc;
+      P[aI + (size_t)b * m] = s * acc + (aI == b ? jit->project_jitter : 0.0);
+    }
+  if (!host_cholesky(P, m)) return fail(LMM_ERR_NOT_PD, "PosDefException in project(H, sigma2)");
+  // Mb = P^-1 Tb (m x p);  Pb = -Mb T'
+  std::vector<double> Mb((size_t)m * p, 0.0), Pb((size_t)m * m, 0.0);
+  for (int o = 0; o < p; ++o) {
+    std::vector<double> v(m);
+    for (int aI = 0; aI < m; ++aI) { double t = Tb[aI + (size_t)o * m]; for (int k = 0; k < aI; ++k) t -= P[aI + (size_t)k * m] * v[k]; v[aI] = t / P[aI + (size_t)aI * m]; }
+    for (int aI = m - 1; aI >= 0; --aI) { double t = v[aI]; for (int k = aI + 1; k < m; ++k) t -= P[k + (size_t)aI * m] * v[k]; v[aI] = t / P[aI + (size_t)aI * m]; }
+    for (int aI = 0; aI < m; ++aI) Mb[aI + (size_t)o * m] = v[aI];
+  }
+  for (int aI = 0; aI < m; ++aI)
+    for (int b = 0; b < m; ++b) {
+      double acc = 0.0;
+      for (int o = 0; o < p; ++o) acc += Mb[aI + (size_t)o * m] * T[b + (size_t)o * m];
+      Pb[aI + (size_t)b * m] = -acc;
+    }
+  double sb = 0.0;       // cotangent of s = 1 / sigma2
+  for (int o = 0; o < p; ++o)
+    for (int l = 0; l < m; ++l) {
+      Hb[o + (size_t)l * p] += s * Mb[l + (size_t)o * m];                      // M = H' s
+      sb += Mb[l + (size_t)o * m] * H[o + (size_t)l * p];
+      double acc = 0.0;                                                        // P = s H'H: Hb += s H (Pb + Pb')
+      for (int b = 0; b < m; ++b) acc += H[o + (size_t)b * p] * (Pb[b + (size_t)l * m] + Pb[l + (size_t)b * m]);
+      Hb[o + (size_t)l * p] += s * acc;
+    }
+  for (int aI = 0; aI < m; ++aI) for (int b = 0; b < m; ++b) sb += Pb[aI + (size_t)b * m] * HtH[aI + (size_t)b * m];
+  s2b += -sb * s * s;
+  (void)at;
+  if (grad_sigma2) *grad_sigma2 = s2b;
+  if (grad_H) std::copy(Hb.begin(), Hb.end(), grad_H);
+  if (grad_y) {
+    // dL/dY (n x p) = -((alpha - RH / sigma2) T) - Rm / sigma2     (alpha as the n x m matrix [point][latent])
+    DevOut gy(grad_y, (size_t)n * p);
+    Buf<double> Z((size_t)N), ZT((size_t)n * p);
+    launch_vec_lin(alpha.p, RH.p, -s, N, Z.p, st0);
+    launch_tall_skinny(Z.p, n, n, m, Ttd.buf.p, p, p, ZT.p, n, nullptr, nullptr, 0, nullptr, 0, st0);
+    launch_vec_axpby(ZT.p, -1.0, Rm.p, -s, (size_t)n * p, gy.p, st0);
+    gy.finish(st0);
+    HIPCHK(hipStreamSynchronize(st0));
+  }
+  return LMM_OK;
+  LMM_CATCH
 }
 
 // ------------------------------------------------------------------------------------------------

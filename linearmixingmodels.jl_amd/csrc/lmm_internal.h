@@ -91,8 +91,12 @@ void launch_syrk_upper_set(double* C, int ldc, const double* X, int ldx, int N, 
 void launch_syrk_upper_set(const BatchPtr& C, int ldc, const BatchPtr& X, int ldx, int N, int nb, hipStream_t st);
 void launch_set_identity(double* R, int ld, int nc, hipStream_t st);
 int grad_partials(int n);
-void launch_grad_reduce(const double* Kinv, int ld, int n, const double* alpha, const double* delta, const double* x, int d,
-                        LatentDev g, double* partial, double* out5, hipStream_t st);
+#define LMM_NGRAD 8
+void launch_grad_reduce(const double* Kinv, int ld, int n, int nsplit, const double* alpha, const double* delta, const double* x, int d,
+                        LatentDev g, double* partial, double* out7, hipStream_t st);
+void launch_vec_axpby(const double* a, double sa, const double* b, double sb, size_t n, double* out, hipStream_t st);
+void launch_block_trace(const double* Minv, int ld, int n, int m, double* out, hipStream_t st);
+void launch_vec_lin2(const double* a, const double* b, double sa, double sb, int nsplit, int N, size_t count, double* out, hipStream_t st);
 void launch_atb(const double* X, int ldx, const double* Z, int ldz, int n, int na, int nb, double* out, hipStream_t st);
 void launch_fill(double* p, int n, double v, hipStream_t st);
 void launch_reorder(const double* in, int n, int p, int to_outputs, double* out, hipStream_t st);

@@ -1290,6 +1290,10 @@ __global__ void vec_lin_kernel(const double* a, const double* b, double sb, int 
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k < n) out[k] = a[k] + sb * b[k];
 }
+__global__ void vec_axpby_kernel(const double* a, double sa, const double* b, double sb, size_t n, double* out) {
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) out[k] = sa * a[k] + sb * b[k];
+}
 
 // R = I on an nc x nc block (ld), zero elsewhere: the riders whose triangular solve gives L^-T.
 __global__ void set_identity_kernel(double* __restrict__ R, int ld, int nc) {
@@ -1308,10 +1312,14 @@ __device__ __forceinline__ double dkappa_dell(int kind, double var, double inv_l
 }
 
 // Gradient contractions of one latent: per 64x64 lower tile (ti >= tj) of Kinv
-//   partial[5*tile + 0] = sum_{i>j in tile} (alpha_i alpha_j - Kinv_ij) dK_ij/d ell        (lengthscale)
-//   partial[5*tile + 1] = sum_{i in tile, diagonal tiles} Kinv_ii                           (trace of the inverse)
-//   partial[5*tile + 2..4] = alpha.alpha, alpha.delta, sum alpha over the tile's rows (diagonal tiles only)
-__global__ __launch_bounds__(256) void grad_reduce_kernel(const double* __restrict__ Kinv, int ld, int n,
+//   partial[NG*tile + 0] = sum_{i>j in tile} (alpha_i alpha_j - Kinv_ij) dK_ij/d ell        (lengthscale)
+//   partial[NG*tile + 1], [5] = sum_i Kinv_ii over the tile's rows i < nsplit, i >= nsplit    (trace of the inverse, per noise block)
+//   partial[NG*tile + 2], [6] = alpha.alpha over the same two row ranges
+//   partial[NG*tile + 3..4]   = alpha.delta, sum alpha over the tile's rows                   (diagonal tiles only)
+//   partial[NG*tile + 7]      = sum_{i>j in tile} (alpha_i alpha_j - Kinv_ij) K_ij            (variance, when Kinv is a block of a larger inverse)
+// The split at nsplit serves the predictive logpdf (joint of training and test points, each block with its own noise).
+#define LMM_NG 8
+__global__ __launch_bounds__(256) void grad_reduce_kernel(const double* __restrict__ Kinv, int ld, int n, int nsplit,
                                                           const double* __restrict__ alpha, const double* __restrict__ delta,
                                                           const double* __restrict__ x, int d, LatentDev g, int nt,
                                                           double* __restrict__ partial) {
@@ -1321,7 +1329,7 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const double* __restri
   const int t = threadIdx.x;
   const int i0 = ti * 64 + (t & 63);
   const int cg = t >> 6;
-  double acc = 0.0;
+  double acc = 0.0, acck = 0.0;
   if (i0 < n) {
     const double ai = alpha[i0];
     for (int q = 0; q < 16; ++q) {
@@ -1330,36 +1338,60 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const double* __restri
         double r, r2;
         if (d == 1) { r = fabs(x[i0] - x[j]) * g.inv_ls; r2 = r * r; }
         else { r2 = scaled_dist2(x + (size_t)i0 * d, x + (size_t)j * d, d, g.inv_ls); r = sqrt(r2); }
-        acc = __builtin_fma(ai * alpha[j] - Kinv[(size_t)j * ld + i0], dkappa_dell(g.kind, g.var, g.inv_ls, r, r2), acc);
+        const double w = ai * alpha[j] - Kinv[(size_t)j * ld + i0];
+        acc = __builtin_fma(w, dkappa_dell(g.kind, g.var, g.inv_ls, r, r2), acc);
+        acck = __builtin_fma(w, kappa(g.kind, g.var, r, r2), acck);
       }
     }
   }
   const int tile = ti * nt + tj;
   const double tl = block_sum_256(acc, sh);
-  double tr = 0.0, aa = 0.0, ad = 0.0, sa = 0.0;
+  const double tk = block_sum_256(acck, sh);
+  double tra = 0.0, aaa = 0.0, trb = 0.0, aab = 0.0, ad = 0.0, sa = 0.0;
   if (ti == tj && t < 64 && i0 < n) {
-    const double ai = alpha[i0];
-    tr = Kinv[(size_t)i0 * ld + i0]; aa = ai * ai; ad = ai * delta[i0]; sa = ai;
+    const double ai = alpha[i0], kii = Kinv[(size_t)i0 * ld + i0];
+    if (i0 < nsplit) { tra = kii; aaa = ai * ai; } else { trb = kii; aab = ai * ai; }
+    ad = ai * delta[i0]; sa = ai;
   }
-  const double s1 = block_sum_256(tr, sh), s2 = block_sum_256(aa, sh), s3 = block_sum_256(ad, sh), s4 = block_sum_256(sa, sh);
+  const double s1 = block_sum_256(tra, sh), s2 = block_sum_256(aaa, sh), s3 = block_sum_256(ad, sh), s4 = block_sum_256(sa, sh);
+  const double s5 = block_sum_256(trb, sh), s6 = block_sum_256(aab, sh);
   if (t == 0) {
-    partial[5 * tile + 0] = tl; partial[5 * tile + 1] = s1; partial[5 * tile + 2] = s2; partial[5 * tile + 3] = s3;
-    partial[5 * tile + 4] = s4;
+    double* o = partial + (size_t)LMM_NG * tile;
+    o[0] = tl; o[1] = s1; o[2] = s2; o[3] = s3; o[4] = s4; o[5] = s5; o[6] = s6; o[7] = tk;
   }
 }
 
-// out[c] = sum over the nt*nt tile partials of component c (c < 5); upper tiles were never written -> skip them.
+// out[c] = sum over the nt*nt tile partials of component c (c < LMM_NG); upper tiles were never written -> skip them.
 __global__ __launch_bounds__(256) void grad_finish_kernel(const double* __restrict__ partial, int nt, double* __restrict__ out) {
   __shared__ double sh[4];
-  for (int c = 0; c < 5; ++c) {
+  for (int c = 0; c < LMM_NG; ++c) {
     double s = 0.0;
     for (int k = threadIdx.x; k < nt * nt; k += 256) {
       const int ti = k / nt, tj = k - ti * nt;
-      if (ti >= tj) s += partial[5 * k + c];
+      if (ti >= tj) s += partial[(size_t)LMM_NG * k + c];
     }
     const double tot = block_sum_256(s, sh);
     if (threadIdx.x == 0) out[c] = tot;
   }
+}
+
+// out[l + l2*m] = sum_i Minv[(l n + i), (l2 n + i)]  for l >= l2 (mirrored into l < l2): the m x m matrix of traces of the diagonals of
+// the n x n blocks of a symmetric (m n) x (m n) matrix whose lower triangle is stored (dense-H ILMM gradient: dL/dSigmaT).
+__global__ __launch_bounds__(256) void block_trace_kernel(const double* __restrict__ Minv, int ld, int n, int m,
+                                                          double* __restrict__ out) {
+  __shared__ double sh[4];
+  const int l = blockIdx.x, l2 = blockIdx.y;
+  if (l < l2) return;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += Minv[(size_t)(l2 * n + i) * ld + (l * n + i)];
+  const double tot = block_sum_256(s, sh);
+  if (threadIdx.x == 0) { out[l + (size_t)l2 * m] = tot; out[l2 + (size_t)l * m] = tot; }
+}
+
+// out[k] = a[k] + (row(k) < nsplit ? sa : sb) * b[k]  with row(k) = k mod N  (column-major N x p operands)
+__global__ void vec_lin2_kernel(const double* a, const double* b, double sa, double sb, int nsplit, int N, size_t count, double* out) {
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < count) out[k] = a[k] + (((int)(k % N) < nsplit) ? sa : sb) * b[k];
 }
 
 // out[a + b*na] = sum_i X[i + a*ldx] Z[i + b*ldz]   (X' Z for tall-skinny X (n x na), Z (n x nb)); one block per (a, b).
@@ -1708,13 +1740,27 @@ void launch_set_identity(double* R, int ld, int nc, hipStream_t st) {
   hipLaunchKernelGGL(set_identity_kernel, dim3((nc + 255) / 256, nc), dim3(256), 0, st, R, ld, nc);
 }
 
-int grad_partials(int n) { const int nt = (n + 63) / 64; return 5 * nt * nt; }
+int grad_partials(int n) { const int nt = (n + 63) / 64; return LMM_NG * nt * nt; }
 
-void launch_grad_reduce(const double* Kinv, int ld, int n, const double* alpha, const double* delta, const double* x, int d,
-                        LatentDev g, double* partial, double* out5, hipStream_t st) {
+// out8: [dl/d ell, tr Kinv (rows < nsplit), a.a (rows < nsplit), a.delta, sum a, tr Kinv (rows >= nsplit), a.a (rows >= nsplit),
+//        sum_{i>j} (a_i a_j - Kinv_ij) K_ij]
+void launch_grad_reduce(const double* Kinv, int ld, int n, int nsplit, const double* alpha, const double* delta, const double* x, int d,
+                        LatentDev g, double* partial, double* out7, hipStream_t st) {
   const int nt = (n + 63) / 64;
-  hipLaunchKernelGGL(grad_reduce_kernel, dim3(nt, nt), dim3(256), 0, st, Kinv, ld, n, alpha, delta, x, d, g, nt, partial);
-  hipLaunchKernelGGL(grad_finish_kernel, dim3(1), dim3(256), 0, st, partial, nt, out5);
+  hipLaunchKernelGGL(grad_reduce_kernel, dim3(nt, nt), dim3(256), 0, st, Kinv, ld, n, nsplit, alpha, delta, x, d, g, nt, partial);
+  hipLaunchKernelGGL(grad_finish_kernel, dim3(1), dim3(256), 0, st, partial, nt, out7);
+}
+
+void launch_vec_axpby(const double* a, double sa, const double* b, double sb, size_t n, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(vec_axpby_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, sa, b, sb, n, out);
+}
+
+void launch_block_trace(const double* Minv, int ld, int n, int m, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(block_trace_kernel, dim3(m, m), dim3(256), 0, st, Minv, ld, n, m, out);
+}
+
+void launch_vec_lin2(const double* a, const double* b, double sa, double sb, int nsplit, int N, size_t count, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(vec_lin2_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, a, b, sa, sb, nsplit, N, count, out);
 }
 
 void launch_atb(const double* X, int ldx, const double* Z, int ldz, int n, int na, int nb, double* out, hipStream_t st) {

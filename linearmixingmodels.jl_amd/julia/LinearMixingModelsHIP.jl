@@ -1,17 +1,26 @@
 # LinearMixingModelsHIP.jl -- the Julia-side binding a LinearMixingModels.jl maintainer would add to route the
 # ILMM/OILMM inference hot path through liblmm_hip.so (include/lmm_hip.h).
 #
-# NOT EXECUTED IN THIS REPOSITORY'S CI: Julia is absent from the build image and from the GPU box (SURVEY.md
-# section 8c).  The file is argument marshalling only -- every method body is one `ccall`, so there is no
-# arithmetic here to get wrong; parity is proven through the same C ABI from Python (tests/test_gpu_parity.py).
+# NOT EXECUTED IN THIS REPOSITORY: Julia is absent from the build image and from the GPU box (SURVEY.md section 8c).
+# The file is argument marshalling only -- every method body is one `ccall`, so there is no arithmetic here to get
+# wrong; parity is proven through the same C ABI from Python (tests/test_gpu_parity*.py).
 #
-# It keeps the reference's own types (`ILMM`, `IndependentMOGP`, `Orthogonal`; reference
-# src/LinearMixingModels.jl:21-24) and overrides the method bodies cited next to each definition.
+# Design: NO method of LinearMixingModels is overwritten (overwriting another module's methods breaks precompilation on
+# Julia >= 1.10).  The reference's types `ILMM` and `Orthogonal` are kept; the opt-in is the latent container: `hip(f)`
+# swaps the `IndependentMOGP` inside an ILMM for a `HIPMOGP` (same `fs` field, plus a device handle once conditioned), and
+# every method below dispatches on `FiniteGP{<:ILMM{<:HIPMOGP, ...}}` -- strictly more specific than the reference's
+# `FiniteGP{<:ILMM}` / `FiniteGP{<:OILMM}` signatures, so Julia picks it without ambiguity:
+#
+#     f  = hip(ILMM(independent_mogp(fs), Orthogonal(U, S)))     # or ILMM(hip(independent_mogp(fs)), H)
+#     fx = f(MOInputIsotopicByOutputs(x, p), σ²)
+#     logpdf(fx, y); po = posterior(fx, y); marginals(po(xs, σ²)); rand(rng, fx); Zygote.gradient(logpdf, fx, y)
 module LinearMixingModelsHIP
 
-using AbstractGPs, KernelFunctions, LinearAlgebra, Random, FillArrays
+using AbstractGPs, KernelFunctions, LinearAlgebra, Random, FillArrays, ChainRulesCore
 using LinearMixingModels
-using LinearMixingModels: ILMM, OILMM, IndependentMOGP, Orthogonal, unpack, noise_var
+using LinearMixingModels: ILMM, IndependentMOGP, Orthogonal, unpack, noise_var
+
+export hip, HIPMOGP
 
 const liblmm = get(ENV, "LMM_HIP_LIB", "liblmm_hip.so")
 
@@ -22,7 +31,11 @@ struct LmmGp            # lmm_gp_t
     lengthscale::Cdouble
     mean::Cdouble
 end
-
+struct LmmGpGrad        # lmm_gp_grad_t
+    variance::Cdouble
+    lengthscale::Cdouble
+    mean::Cdouble
+end
 struct LmmJitters       # lmm_jitters_t
     project_jitter::Cdouble
     ilmm_rand_jitter::Cdouble
@@ -40,12 +53,34 @@ function check(rc::Cint)
         lat = Ref{Cint}(0); info = Ref{Cint}(0)
         ccall((:lmm_last_error_detail, liblmm), Cint, (Ref{Cint}, Ref{Cint}), lat, info)
         throw(PosDefException(info[]))
-    else
+    else                                         # LMM_ERR_HIP / _ARG / _UNSUPPORTED / _RCCL
         error(msg)
     end
 end
 
 __init__() = check(ccall((:lmm_init, liblmm), Cint, (Cint,), parse(Cint, get(ENV, "LOCAL_RANK", "0"))))
+
+# ---- the opt-in latent container ----------------------------------------------------------------------------------
+# Prior: handle == C_NULL.  Posterior: lmm_post_t* (device-resident factors, alpha, x) + the data it was built from
+# (train: needed for TOTAL derivatives of the predictive logpdf; nothing after sequential conditioning).
+mutable struct HIPMOGP{Tfs<:Vector{<:AbstractGP}} <: AbstractGPs.AbstractGP
+    fs::Tfs
+    handle::Ptr{Cvoid}
+    train::Any               # nothing | (X::Matrix{Float64}, σ²::Float64, y::Vector{Float64})
+    function HIPMOGP(fs::Tfs, h::Ptr{Cvoid}=C_NULL, train=nothing) where {Tfs<:Vector{<:AbstractGP}}
+        obj = new{Tfs}(fs, h, train)
+        h == C_NULL || finalizer(o -> ccall((:lmm_post_destroy, liblmm), Cint, (Ptr{Cvoid},), o.handle), obj)
+        return obj
+    end
+end
+hip(f::IndependentMOGP) = HIPMOGP(f.fs)
+hip(f::ILMM) = ILMM(hip(f.f), f.H)
+LinearMixingModels.get_latent_gp(f::ILMM{<:HIPMOGP}) = f.f
+
+const HIPOILMM = ILMM{<:HIPMOGP,<:Orthogonal}
+const HIPDenseILMM = ILMM{<:HIPMOGP,<:Matrix}
+const ByOutputsFill{F} = FiniteGP{<:F,<:MOInputIsotopicByOutputs,<:Diagonal{<:Real,<:Fill}}
+isposterior(f::HIPMOGP) = f.handle != C_NULL
 
 # ---- latent descriptors: kernel -> (kind, variance, lengthscale) ---------------------------------------------
 _kind(::SEKernel) = Cint(0)
@@ -56,56 +91,91 @@ _desc(k::ScaledKernel) = ((kd, v, l) = _desc(k.kernel); (kd, v * only(k.σ²), l
 _desc(k::TransformedKernel{<:Kernel,<:ScaleTransform}) = ((kd, v, l) = _desc(k.kernel); (kd, v, l / only(k.transform.s)))
 _mean(::AbstractGPs.ZeroMean) = 0.0
 _mean(m::AbstractGPs.ConstMean) = Float64(m.c)
-function _gps(fs::Vector{<:AbstractGP})
-    return [begin (kd, v, l) = _desc(f.kernel); LmmGp(kd, v, l, _mean(f.mean)) end for f in fs]
-end
+_gps(fs::Vector{<:AbstractGP}) = [begin (kd, v, l) = _desc(f.kernel); LmmGp(kd, v, l, _mean(f.mean)) end for f in fs]
 
 # x as a d x n column-major matrix: Vector{Float64} => 1 x n; ColVecs => its X; RowVecs => transposed copy.
 _xmat(x::AbstractVector{<:Real}) = reshape(collect(Float64, x), 1, :)
 _xmat(x::ColVecs) = Matrix{Float64}(x.X)
 _xmat(x::RowVecs) = Matrix{Float64}(x.X')
 
-# ---- logpdf(fx::FiniteGP{<:OILMM}, y): replaces reference src/oilmm.jl:79-93 ---------------------------------
-function AbstractGPs.logpdf(fx::FiniteGP{<:OILMM}, y::AbstractVector{<:Real})
+# (U, S-or-NULL, p, m) of the mixing matrix: Orthogonal passes U and diag(S) -- never collect(H), whose getindex
+# materialises U sqrt(S) per element (reference src/orthogonal_matrix.jl:27-30)
+_hargs(H::Orthogonal) = (Matrix{Float64}(H.U), Vector{Float64}(H.S.diag), size(H.U)...)
+_hargs(H::AbstractMatrix) = (Matrix{Float64}(H), nothing, size(H)...)
+_ptr(::Nothing) = Ptr{Cdouble}(C_NULL)
+_ptr(a::Array{Float64}) = pointer(a)
+
+# ---- logpdf -------------------------------------------------------------------------------------------------------
+# reference src/oilmm.jl:79-93 (prior) and test/oilmm.jl:25 (posterior: the posterior is again an OILMM, src/oilmm.jl:133)
+function AbstractGPs.logpdf(fx::ByOutputsFill{HIPOILMM}, y::AbstractVector{<:Real})
     fs, H, σ², x = unpack(fx)                       # keeps the reference's out-dim check (src/ilmm.jl:45-54)
-    X = _xmat(x); d, n = size(X); p, m = size(H.U)
-    gps = _gps(fs.fs); S = Vector{Float64}(H.S.diag); U = Matrix{Float64}(H.U); yv = Vector{Float64}(y)
+    X = _xmat(x); d, n = size(X); U, S, p, m = _hargs(H); yv = Vector{Float64}(y)
     out = Ref{Cdouble}(0.0)
-    GC.@preserve X yv U S gps check(ccall((:lmm_oilmm_logpdf, liblmm), Cint,
-        (Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cdouble, Ptr{LmmGp},
-         Cint, Cint, Cint, Ref{Cdouble}),
-        X, d, n, yv, p, U, S, m, σ², gps, 0, m, 1, out))
+    if isposterior(fs)
+        GC.@preserve X U S yv check(ccall((:lmm_oilmm_post_logpdf, liblmm), Cint,
+            (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Cdouble, Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Cint, Ref{Cdouble}),
+            fs.handle, U, S, p, m, σ², X, d, n, yv, 1, out))
+    else
+        gps = _gps(fs.fs)
+        GC.@preserve X yv U S gps check(ccall((:lmm_oilmm_logpdf, liblmm), Cint,
+            (Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cdouble, Ptr{LmmGp}, Cint, Cint, Cint, Ref{Cdouble}),
+            X, d, n, yv, p, U, S, m, σ², gps, 0, m, 1, out))
+    end
     return out[]
 end
 
-# ---- logpdf(fx::FiniteGP{<:ILMM}, y), dense H: replaces reference src/ilmm.jl:150-163 -----------------------------
-function AbstractGPs.logpdf(fx::FiniteGP{<:ILMM{<:IndependentMOGP,<:Matrix}}, y::AbstractVector{<:Real})
+# logpdf(fx, Y::AbstractMatrix): one value per column from ONE factorisation per latent (AbstractGPs.TestUtils calls it)
+function AbstractGPs.logpdf(fx::ByOutputsFill{HIPOILMM}, Y::AbstractMatrix{<:Real})
+    fs, H, σ², x = unpack(fx)
+    isposterior(fs) && return [logpdf(fx, Y[:, c]) for c in axes(Y, 2)]
+    X = _xmat(x); d, n = size(X); U, S, p, m = _hargs(H); Ym = Matrix{Float64}(Y); gps = _gps(fs.fs)
+    out = Vector{Float64}(undef, size(Ym, 2))
+    GC.@preserve X Ym U S gps out check(ccall((:lmm_oilmm_logpdf_multi, liblmm), Cint,
+        (Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cdouble, Ptr{LmmGp}, Cint, Cint, Cint, Ptr{Cdouble}),
+        X, d, n, Ym, p, size(Ym, 2), U, S, m, σ², gps, 0, m, 1, out))
+    return out
+end
+
+# reference src/ilmm.jl:150-163 (prior) and test/ilmm.jl:25 (posterior), dense H
+function AbstractGPs.logpdf(fx::ByOutputsFill{HIPDenseILMM}, y::AbstractVector{<:Real})
     f, H, σ², x = unpack(fx)
-    X = _xmat(x); d, n = size(X); p, m = size(H)
-    gps = _gps(f.fs); Hm = Matrix{Float64}(H); yv = Vector{Float64}(y)
+    X = _xmat(x); d, n = size(X); p, m = size(H); yv = Vector{Float64}(y)
     out = Ref{Cdouble}(0.0)
-    GC.@preserve X yv Hm gps check(ccall((:lmm_ilmm_logpdf, liblmm), Cint,
-        (Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Cint, Cdouble, Ptr{LmmGp}, Ptr{LmmJitters},
-         Ref{Cdouble}), X, d, n, yv, p, Hm, m, σ², gps, C_NULL, out))
+    if isposterior(f)
+        GC.@preserve X yv check(ccall((:lmm_ilmm_post_logpdf, liblmm), Cint,
+            (Ptr{Cvoid}, Cdouble, Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Ptr{LmmJitters}, Ref{Cdouble}),
+            f.handle, σ², X, d, n, yv, C_NULL, out))
+    else
+        gps = _gps(f.fs); Hm = Matrix{Float64}(H)
+        GC.@preserve X yv Hm gps check(ccall((:lmm_ilmm_logpdf, liblmm), Cint,
+            (Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Cint, Cdouble, Ptr{LmmGp}, Ptr{LmmJitters}, Ref{Cdouble}),
+            X, d, n, yv, p, Hm, m, σ², gps, C_NULL, out))
+    end
     return out[]
 end
 
-# ---- logpdf(ft::IsotropicByOutputsFiniteIndependentMOGP, y): replaces reference src/independent_mogp.jl:74-80 -----
-function AbstractGPs.logpdf(ft::LinearMixingModels.IsotropicByOutputsFiniteIndependentMOGP, y::AbstractVector{<:Real})
-    X = _xmat(ft.x.x); d, n = size(X); m = length(ft.f.fs)
-    gps = _gps(ft.f.fs); yv = Vector{Float64}(y)
+# reference src/independent_mogp.jl:74-80 (by-outputs, scalar noise); posterior MOGP == posterior OILMM with U = I, S = 1
+function AbstractGPs.logpdf(ft::ByOutputsFill{HIPMOGP}, y::AbstractVector{<:Real})
+    X = _xmat(ft.x.x); d, n = size(X); m = length(ft.f.fs); yv = Vector{Float64}(y); σ² = noise_var(ft.Σy)
+    ft.x.out_dim == m || throw(ErrorException("out dim of x != out dim of f."))
     out = Ref{Cdouble}(0.0)
-    GC.@preserve X yv gps check(ccall((:lmm_mogp_logpdf, liblmm), Cint,
-        (Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Cint, Cdouble, Ptr{LmmGp}, Cint, Cint, Ref{Cdouble}),
-        X, d, n, yv, m, Float64(ft.Σy[1]), gps, 0, m, out))
+    if isposterior(ft.f)
+        U = Matrix{Float64}(I, m, m); S = ones(m)
+        GC.@preserve X U S yv check(ccall((:lmm_oilmm_post_logpdf, liblmm), Cint,
+            (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Cdouble, Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Cint, Ref{Cdouble}),
+            ft.f.handle, U, S, m, m, σ², X, d, n, yv, 0, out))
+    else
+        gps = _gps(ft.f.fs)
+        GC.@preserve X yv gps check(ccall((:lmm_mogp_logpdf, liblmm), Cint,
+            (Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Cint, Cdouble, Ptr{LmmGp}, Cint, Cint, Ref{Cdouble}),
+            X, d, n, yv, m, σ², gps, 0, m, out))
+    end
     return out[]
 end
 
-# ---- general Diagonal noise on a by-outputs IndependentMOGP (what reference src/independent_mogp.jl:222-229 reaches after
-# reorder_by_outputs, :149-159): per-point noise variances ride the Gram diagonal ------------------------------------
-function AbstractGPs.logpdf(
-    ft::FiniteGP{<:IndependentMOGP,<:MOInputIsotopicByOutputs,<:Diagonal{<:Real,<:Vector}}, y::AbstractVector{<:Real}
-)
+# general Diagonal noise on a by-outputs IndependentMOGP (what reference src/independent_mogp.jl:222-229 reaches after
+# reorder_by_outputs, :149-159): per-point noise variances ride the Gram diagonal
+function AbstractGPs.logpdf(ft::FiniteGP{<:HIPMOGP,<:MOInputIsotopicByOutputs,<:Diagonal{<:Real,<:Vector}}, y::AbstractVector{<:Real})
     X = _xmat(ft.x.x); d, n = size(X); m = length(ft.f.fs)
     gps = _gps(ft.f.fs); yv = Vector{Float64}(y); nv = Vector{Float64}(ft.Σy.diag)
     out = Ref{Cdouble}(0.0)
@@ -115,198 +185,303 @@ function AbstractGPs.logpdf(
     return out[]
 end
 
-# ---- posterior: device-resident state behind an opaque handle ---------------------------------------------------
-# The reference returns ILMM(independent_mogp(posteriors), H) (src/oilmm.jl:133).  The shim returns the same ILMM
-# whose latent container is a `HIPPosteriorMOGP` (an AbstractGP holding the handle), so `post(x*, σ²)` builds a
-# FiniteGP on which the methods below dispatch.
-mutable struct HIPPosteriorMOGP{Tfs<:Vector{<:AbstractGP}} <: AbstractGP
-    fs::Tfs                  # the prior latents (kept for get_latent_gp / printing)
-    handle::Ptr{Cvoid}       # lmm_post_t*
-    function HIPPosteriorMOGP(fs::Tfs, h::Ptr{Cvoid}) where {Tfs}
-        obj = new{Tfs}(fs, h)
-        finalizer(o -> ccall((:lmm_post_destroy, liblmm), Cint, (Ptr{Cvoid},), o.handle), obj)
-        return obj
-    end
-end
-
-# replaces reference src/oilmm.jl:116-134
-function AbstractGPs.posterior(fx::FiniteGP{<:OILMM}, y::AbstractVector{<:Real})
+# ---- posterior ----------------------------------------------------------------------------------------------------
+# reference src/oilmm.jl:116-134; on a posterior: sequential conditioning (TestUtils on `po`, test/oilmm.jl:34-37)
+function AbstractGPs.posterior(fx::ByOutputsFill{HIPOILMM}, y::AbstractVector{<:Real})
     fs, H, σ², x = unpack(fx)
-    X = _xmat(x); d, n = size(X); p, m = size(H.U)
-    gps = _gps(fs.fs); S = Vector{Float64}(H.S.diag); U = Matrix{Float64}(H.U); yv = Vector{Float64}(y)
+    X = _xmat(x); d, n = size(X); U, S, p, m = _hargs(H); yv = Vector{Float64}(y)
     h = Ref{Ptr{Cvoid}}(C_NULL)
+    if isposterior(fs)
+        GC.@preserve X yv U S check(ccall((:lmm_post_condition, liblmm), Cint,
+            (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Cdouble, Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Ref{Ptr{Cvoid}}),
+            fs.handle, U, S, p, m, σ², X, d, n, yv, h))
+        return ILMM(HIPMOGP(fs.fs, h[], nothing), H)
+    end
+    gps = _gps(fs.fs)
     GC.@preserve X yv U S gps check(ccall((:lmm_oilmm_posterior_create, liblmm), Cint,
-        (Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cdouble, Ptr{LmmGp},
-         Cint, Cint, Ref{Ptr{Cvoid}}), X, d, n, yv, p, U, S, m, σ², gps, 0, m, h))
-    return ILMM(HIPPosteriorMOGP(fs.fs, h[]), H)
+        (Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cdouble, Ptr{LmmGp}, Cint, Cint, Ref{Ptr{Cvoid}}),
+        X, d, n, yv, p, U, S, m, σ², gps, 0, m, h))
+    return ILMM(HIPMOGP(fs.fs, h[], (X, Float64(σ²), yv)), H)      # again an ILMM with the same H (src/oilmm.jl:133)
 end
 
-const HIPPosteriorOILMM = ILMM{<:HIPPosteriorMOGP,<:Orthogonal}
+# reference src/independent_mogp.jl:119-126; on a posterior: sequential conditioning (test/independent_mogp.jl:68-76)
+function AbstractGPs.posterior(ft::ByOutputsFill{HIPMOGP}, y::AbstractVector{<:Real})
+    X = _xmat(ft.x.x); d, n = size(X); m = length(ft.f.fs); yv = Vector{Float64}(y); σ² = noise_var(ft.Σy)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    if isposterior(ft.f)
+        U = Matrix{Float64}(I, m, m); S = ones(m)
+        GC.@preserve X yv U S check(ccall((:lmm_post_condition, liblmm), Cint,
+            (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Cdouble, Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Ref{Ptr{Cvoid}}),
+            ft.f.handle, U, S, m, m, σ², X, d, n, yv, h))
+        return HIPMOGP(ft.f.fs, h[], nothing)
+    end
+    gps = _gps(ft.f.fs)
+    GC.@preserve X yv gps check(ccall((:lmm_mogp_posterior_create, liblmm), Cint,
+        (Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Cint, Cdouble, Ptr{LmmGp}, Cint, Cint, Ref{Ptr{Cvoid}}),
+        X, d, n, yv, m, σ², gps, 0, m, h))
+    return HIPMOGP(ft.f.fs, h[], (X, Float64(σ²), yv))
+end
 
-# mean_and_var / marginals of the posterior OILMM at x*: replaces reference src/oilmm.jl:57-76
-function AbstractGPs.mean_and_var(fx::FiniteGP{<:HIPPosteriorOILMM})
-    H = fx.f.H; σ² = noise_var(fx.Σy); post = fx.f.f
-    X = _xmat(fx.x.x); d, ns = size(X); p, m = size(H.U)
-    fx.x.out_dim == p || throw(error("out dim of x != out dim of f."))
-    S = Vector{Float64}(H.S.diag); U = Matrix{Float64}(H.U)
-    M = Vector{Float64}(undef, ns * p); V = similar(M)
-    GC.@preserve X U S M V check(ccall((:lmm_oilmm_mean_and_var, liblmm), Cint,
-        (Ptr{Cvoid}, Ptr{LmmGp}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Cint, Cint, Cdouble, Cint, Ptr{Cdouble},
-         Cint, Cint, Ptr{LmmJitters}, Ptr{Cdouble}, Ptr{Cdouble}),
-        post.handle, C_NULL, U, S, p, m, 0, m, σ², 1, X, d, ns, C_NULL, M, V))
+# reference src/ilmm.jl:184-198 (one coupled (mn) x (mn) factorisation); on a posterior: TestUtils on `pi` (test/ilmm.jl:34-37)
+function AbstractGPs.posterior(fx::ByOutputsFill{HIPDenseILMM}, y::AbstractVector{<:Real})
+    f, H, σ², x = unpack(fx)
+    X = _xmat(x); d, n = size(X); p, m = size(H); yv = Vector{Float64}(y)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    if isposterior(f)
+        GC.@preserve X yv check(ccall((:lmm_ilmm_post_condition, liblmm), Cint,
+            (Ptr{Cvoid}, Cdouble, Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Ptr{LmmJitters}, Ref{Ptr{Cvoid}}),
+            f.handle, σ², X, d, n, yv, C_NULL, h))
+        return ILMM(HIPMOGP(f.fs, h[], nothing), H)
+    end
+    gps = _gps(f.fs); Hm = Matrix{Float64}(H)
+    GC.@preserve X yv Hm gps check(ccall((:lmm_ilmm_posterior_create, liblmm), Cint,
+        (Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Cint, Cdouble, Ptr{LmmGp}, Ptr{LmmJitters}, Ref{Ptr{Cvoid}}),
+        X, d, n, yv, p, Hm, m, σ², gps, C_NULL, h))
+    return ILMM(HIPMOGP(f.fs, h[], (X, Float64(σ²), yv)), H)
+end
+
+# ---- mean_and_var / marginals / mean / var / mean_and_cov / cov --------------------------------------------------------
+# Independent latents (OILMM prior or posterior, dense-H prior): reference src/oilmm.jl:57-76, src/ilmm.jl:108-145.
+# want_var = false: means only -- mu + K(x*, x) alpha per latent, no triangular solve (the reference computes and discards
+# the variances, src/ilmm.jl:142).
+function _mean_var(fx, want_var::Bool)
+    f, H, σ², x = unpack(fx)
+    X = _xmat(x); d, ns = size(X); U, S, p, m = _hargs(H)
+    gps = isposterior(f) ? LmmGp[] : _gps(f.fs)
+    M = Vector{Float64}(undef, ns * p); V = want_var ? similar(M) : Float64[]
+    GC.@preserve X U S gps M V check(ccall((:lmm_oilmm_mean_and_var, liblmm), Cint,
+        (Ptr{Cvoid}, Ptr{LmmGp}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Cint, Cint, Cdouble, Cint, Ptr{Cdouble}, Cint, Cint,
+         Ptr{LmmJitters}, Ptr{Cdouble}, Ptr{Cdouble}),
+        f.handle, isposterior(f) ? Ptr{LmmGp}(C_NULL) : pointer(gps), U, _ptr(S), p, m, 0, m, σ², 1, X, d, ns, C_NULL,
+        M, want_var ? pointer(V) : Ptr{Cdouble}(C_NULL)))
     return M, V
 end
-# mean alone: var_out = C_NULL selects mu + K(x*, x) alpha per latent (no triangular solve for variances that would be discarded)
-function AbstractGPs.mean(fx::FiniteGP{<:HIPPosteriorOILMM})
-    H = fx.f.H; post = fx.f.f
-    X = _xmat(fx.x.x); d, ns = size(X); p, m = size(H.U)
-    S = Vector{Float64}(H.S.diag); U = Matrix{Float64}(H.U)
-    M = Vector{Float64}(undef, ns * p)
-    GC.@preserve X U S M check(ccall((:lmm_oilmm_mean_and_var, liblmm), Cint,
-        (Ptr{Cvoid}, Ptr{LmmGp}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Cint, Cint, Cdouble, Cint, Ptr{Cdouble},
-         Cint, Cint, Ptr{LmmJitters}, Ptr{Cdouble}, Ptr{Cdouble}),
-        post.handle, C_NULL, U, S, p, m, 0, m, noise_var(fx.Σy), 0, X, d, ns, C_NULL, M, C_NULL))
-    return M
-end
-AbstractGPs.var(fx::FiniteGP{<:HIPPosteriorOILMM}) = mean_and_var(fx)[2]
+AbstractGPs.mean_and_var(fx::ByOutputsFill{HIPOILMM}) = _mean_var(fx, true)
+AbstractGPs.mean(fx::ByOutputsFill{HIPOILMM}) = _mean_var(fx, false)[1]
+AbstractGPs.var(fx::ByOutputsFill{HIPOILMM}) = _mean_var(fx, true)[2]
 
-# logpdf(po(x*, σ²), y*) (reference test/oilmm.jl:25)
-function AbstractGPs.logpdf(fx::FiniteGP{<:HIPPosteriorOILMM}, y::AbstractVector{<:Real})
-    H = fx.f.H; σ² = noise_var(fx.Σy); post = fx.f.f
-    X = _xmat(fx.x.x); d, ns = size(X); p, m = size(H.U)
-    S = Vector{Float64}(H.S.diag); U = Matrix{Float64}(H.U); yv = Vector{Float64}(y)
-    out = Ref{Cdouble}(0.0)
-    GC.@preserve X U S yv check(ccall((:lmm_oilmm_post_logpdf, liblmm), Cint,
-        (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Cdouble, Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Cint,
-         Ref{Cdouble}), post.handle, U, S, p, m, σ², X, d, ns, yv, 1, out))
-    return out[]
-end
-
-# ---- rand: the normals are drawn HERE, in the reference's order (src/oilmm.jl:47,53: m blocks of n latent draws,
-# then n*p noise draws), so the same `rng` gives the same sample as the reference -----------------------------------
-function _rand(rng::AbstractRNG, handle, gps, U, S, p, m, σ², X)
-    d, ns = size(X)
-    z = randn(rng, ns * m); ε = randn(rng, ns * p)
-    out = Vector{Float64}(undef, ns * p)
-    GC.@preserve X U S gps z ε out check(ccall((:lmm_lmm_rand, liblmm), Cint,
-        (Ptr{Cvoid}, Ptr{LmmGp}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Cint, Cint, Cdouble, Cint, Ptr{Cdouble}, Cint,
-         Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{LmmJitters}, Ptr{Cdouble}),
-        handle, gps, U, S, p, m, 0, m, σ², 1, X, d, ns, z, ε, C_NULL, out))
-    return out
-end
-
-# replaces reference src/oilmm.jl:40-54
-function AbstractGPs.rand(rng::AbstractRNG, fx::FiniteGP{<:OILMM})
-    fs, H, σ², x = unpack(fx)
-    p, m = size(H.U)
-    return _rand(rng, C_NULL, _gps(fs.fs), Matrix{Float64}(H.U), Vector{Float64}(H.S.diag), p, m, σ², _xmat(x))
-end
-function AbstractGPs.rand(rng::AbstractRNG, fx::FiniteGP{<:HIPPosteriorOILMM})
-    H = fx.f.H; p, m = size(H.U)
-    return _rand(rng, fx.f.f.handle, Ptr{LmmGp}(C_NULL), Matrix{Float64}(H.U), Vector{Float64}(H.S.diag), p, m,
-                 noise_var(fx.Σy), _xmat(fx.x.x))
-end
-# replaces reference src/ilmm.jl:78-87 (dense H: S == NULL selects the 1e-12 latent jitter of src/ilmm.jl:84)
-function AbstractGPs.rand(rng::AbstractRNG, fx::FiniteGP{<:ILMM{<:IndependentMOGP,<:Matrix}})
-    f, H, σ², x = unpack(fx)
-    p, m = size(H)
-    return _rand(rng, C_NULL, _gps(f.fs), Matrix{Float64}(H), Ptr{Cdouble}(C_NULL), p, m, σ², _xmat(x))
-end
-
-# ---- dense-H ILMM posterior (reference src/ilmm.jl:184-198 and the methods of :108-163 on its PosteriorGP latent): ONE
-# coupled (mn) x (mn) factorisation behind the handle ---------------------------------------------------------------
-const HIPPosteriorILMM = ILMM{<:HIPPosteriorMOGP,<:Matrix}
-
-function AbstractGPs.posterior(fx::FiniteGP{<:ILMM{<:IndependentMOGP,<:Matrix}}, y::AbstractVector{<:Real})
-    f, H, σ², x = unpack(fx)
-    X = _xmat(x); d, n = size(X); p, m = size(H)
-    gps = _gps(f.fs); Hm = Matrix{Float64}(H); yv = Vector{Float64}(y)
-    h = Ref{Ptr{Cvoid}}(C_NULL)
-    GC.@preserve X yv Hm gps check(ccall((:lmm_ilmm_posterior_create, liblmm), Cint,
-        (Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Cint, Cdouble, Ptr{LmmGp}, Ptr{LmmJitters},
-         Ref{Ptr{Cvoid}}), X, d, n, yv, p, Hm, m, σ², gps, C_NULL, h))
-    return ILMM(HIPPosteriorMOGP(f.fs, h[]), H)
-end
-
-# posterior(pi(x₂, σ²), y₂): AbstractGPs.TestUtils on `pi` (reference test/ilmm.jl:34-37)
-function AbstractGPs.posterior(fx::FiniteGP{<:HIPPosteriorILMM}, y::AbstractVector{<:Real})
-    X = _xmat(fx.x.x); d, n2 = size(X); yv = Vector{Float64}(y)
-    h = Ref{Ptr{Cvoid}}(C_NULL)
-    GC.@preserve X yv check(ccall((:lmm_ilmm_post_condition, liblmm), Cint,
-        (Ptr{Cvoid}, Cdouble, Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Ptr{LmmJitters}, Ref{Ptr{Cvoid}}),
-        fx.f.f.handle, noise_var(fx.Σy), X, d, n2, yv, C_NULL, h))
-    return ILMM(HIPPosteriorMOGP(fx.f.f.fs, h[]), fx.f.H)
-end
-
-function AbstractGPs.mean_and_var(fx::FiniteGP{<:HIPPosteriorILMM})
+function AbstractGPs.mean_and_var(fx::ByOutputsFill{HIPDenseILMM})
+    f = fx.f.f
+    isposterior(f) || return _mean_var(fx, true)             # prior latents are independent: same mixing as the OILMM form
+    unpack(fx)
     X = _xmat(fx.x.x); d, ns = size(X); p = size(fx.f.H, 1)
     M = Vector{Float64}(undef, ns * p); V = similar(M)
     GC.@preserve X M V check(ccall((:lmm_ilmm_post_mean_and_var, liblmm), Cint,
         (Ptr{Cvoid}, Cdouble, Ptr{Cdouble}, Cint, Cint, Ptr{LmmJitters}, Ptr{Cdouble}, Ptr{Cdouble}),
-        fx.f.f.handle, noise_var(fx.Σy), X, d, ns, C_NULL, M, V))
+        f.handle, noise_var(fx.Σy), X, d, ns, C_NULL, M, V))
     return M, V
 end
+AbstractGPs.mean(fx::ByOutputsFill{HIPDenseILMM}) = isposterior(fx.f.f) ? mean_and_var(fx)[1] : _mean_var(fx, false)[1]
+AbstractGPs.var(fx::ByOutputsFill{HIPDenseILMM}) = mean_and_var(fx)[2]
 
-# replaces reference src/ilmm.jl:132-147 on the posterior
-function AbstractGPs.mean_and_cov(fx::FiniteGP{<:HIPPosteriorILMM})
-    X = _xmat(fx.x.x); d, ns = size(X); p = size(fx.f.H, 1)
+# reference src/independent_mogp.jl:50,55: vcat of the latent marginals (+ Σy on the variances)
+function AbstractGPs.mean_and_var(ft::ByOutputsFill{HIPMOGP})
+    X = _xmat(ft.x.x); d, ns = size(X); m = length(ft.f.fs)
+    gps = isposterior(ft.f) ? LmmGp[] : _gps(ft.f.fs)
+    M = Vector{Float64}(undef, ns * m); V = similar(M)
+    GC.@preserve X gps M V check(ccall((:lmm_latent_marginals, liblmm), Cint,
+        (Ptr{Cvoid}, Ptr{LmmGp}, Cint, Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}),
+        ft.f.handle, isposterior(ft.f) ? Ptr{LmmGp}(C_NULL) : pointer(gps), m, X, d, ns, M, V))
+    return M, V .+ noise_var(ft.Σy)
+end
+AbstractGPs.mean(ft::ByOutputsFill{HIPMOGP}) = mean_and_var(ft)[1]
+AbstractGPs.var(ft::ByOutputsFill{HIPMOGP}) = mean_and_var(ft)[2]
+
+# reference src/ilmm.jl:132-147: full (p n*) x (p n*) covariance, small n* only (as in the reference)
+function AbstractGPs.mean_and_cov(fx::Union{ByOutputsFill{HIPOILMM},ByOutputsFill{HIPDenseILMM}})
+    f, H, σ², x = unpack(fx)
+    X = _xmat(x); d, ns = size(X); U, S, p, m = _hargs(H)
     M = Vector{Float64}(undef, ns * p); Cm = Matrix{Float64}(undef, ns * p, ns * p)
-    GC.@preserve X M Cm check(ccall((:lmm_ilmm_post_mean_and_cov, liblmm), Cint,
-        (Ptr{Cvoid}, Cdouble, Ptr{Cdouble}, Cint, Cint, Ptr{LmmJitters}, Ptr{Cdouble}, Ptr{Cdouble}),
-        fx.f.f.handle, noise_var(fx.Σy), X, d, ns, C_NULL, M, Cm))
+    if isposterior(f) && S === nothing                         # coupled latents of the dense-H posterior
+        GC.@preserve X M Cm check(ccall((:lmm_ilmm_post_mean_and_cov, liblmm), Cint,
+            (Ptr{Cvoid}, Cdouble, Ptr{Cdouble}, Cint, Cint, Ptr{LmmJitters}, Ptr{Cdouble}, Ptr{Cdouble}),
+            f.handle, σ², X, d, ns, C_NULL, M, Cm))
+        return M, Cm
+    end
+    gps = isposterior(f) ? LmmGp[] : _gps(f.fs)
+    GC.@preserve X U S gps M Cm check(ccall((:lmm_lmm_mean_and_cov, liblmm), Cint,
+        (Ptr{Cvoid}, Ptr{LmmGp}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Cint, Cint, Cdouble, Cint, Ptr{Cdouble}, Cint, Cint,
+         Ptr{LmmJitters}, Ptr{Cdouble}, Ptr{Cdouble}),
+        f.handle, isposterior(f) ? Ptr{LmmGp}(C_NULL) : pointer(gps), U, _ptr(S), p, m, 0, m, σ², 1, X, d, ns, C_NULL, M, Cm))
     return M, Cm
 end
-AbstractGPs.cov(fx::FiniteGP{<:HIPPosteriorILMM}) = mean_and_cov(fx)[2]
+AbstractGPs.cov(fx::Union{ByOutputsFill{HIPOILMM},ByOutputsFill{HIPDenseILMM}}) = mean_and_cov(fx)[2]
 
-function AbstractGPs.logpdf(fx::FiniteGP{<:HIPPosteriorILMM}, y::AbstractVector{<:Real})
-    X = _xmat(fx.x.x); d, ns = size(X); yv = Vector{Float64}(y)
-    out = Ref{Cdouble}(0.0)
-    GC.@preserve X yv check(ccall((:lmm_ilmm_post_logpdf, liblmm), Cint,
-        (Ptr{Cvoid}, Cdouble, Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Ptr{LmmJitters}, Ref{Cdouble}),
-        fx.f.f.handle, noise_var(fx.Σy), X, d, ns, yv, C_NULL, out))
-    return out[]
-end
-
-function AbstractGPs.rand(rng::AbstractRNG, fx::FiniteGP{<:HIPPosteriorILMM})
-    X = _xmat(fx.x.x); d, ns = size(X); p, m = size(fx.f.H)
-    z = randn(rng, ns * m); ε = randn(rng, ns * p); out = Vector{Float64}(undef, ns * p)
-    GC.@preserve X z ε out check(ccall((:lmm_ilmm_post_rand, liblmm), Cint,
-        (Ptr{Cvoid}, Cdouble, Cint, Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{LmmJitters}, Ptr{Cdouble}),
-        fx.f.f.handle, noise_var(fx.Σy), 1, X, d, ns, z, ε, C_NULL, out))
+# ---- rand: the normals are drawn HERE, in the reference's order (src/oilmm.jl:47,53: m blocks of n latent draws, then
+# n*p noise draws; N samples = N repeats, src/ilmm.jl:90-92), so the same `rng` gives the same samples as the reference;
+# ONE factorisation per latent serves all N samples (lmm_lmm_rand_multi) --------------------------------------------------
+function _rand(rng::AbstractRNG, fx, N::Int)
+    f, H, σ², x = unpack(fx)
+    X = _xmat(x); d, ns = size(X); U, S, p, m = _hargs(H)
+    z = Matrix{Float64}(undef, ns * m, N); ε = Matrix{Float64}(undef, ns * p, N)
+    for q in 1:N
+        z[:, q] = randn(rng, ns * m); ε[:, q] = randn(rng, ns * p)
+    end
+    out = Matrix{Float64}(undef, ns * p, N)
+    if isposterior(f) && S === nothing                         # dense-H posterior: coupled latents, reference src/ilmm.jl:78-87
+        for q in 1:N
+            zq = z[:, q]; εq = ε[:, q]; oq = Vector{Float64}(undef, ns * p)
+            GC.@preserve X zq εq oq check(ccall((:lmm_ilmm_post_rand, liblmm), Cint,
+                (Ptr{Cvoid}, Cdouble, Cint, Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{LmmJitters}, Ptr{Cdouble}),
+                f.handle, σ², 1, X, d, ns, zq, εq, C_NULL, oq))
+            out[:, q] = oq
+        end
+        return out
+    end
+    gps = isposterior(f) ? LmmGp[] : _gps(f.fs)
+    GC.@preserve X U S gps z ε out check(ccall((:lmm_lmm_rand_multi, liblmm), Cint,
+        (Ptr{Cvoid}, Ptr{LmmGp}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Cint, Cint, Cdouble, Cint, Ptr{Cdouble}, Cint, Cint, Cint,
+         Ptr{Cdouble}, Ptr{Cdouble}, Ptr{LmmJitters}, Ptr{Cdouble}),
+        f.handle, isposterior(f) ? Ptr{LmmGp}(C_NULL) : pointer(gps), U, _ptr(S), p, m, 0, m, σ², 1, X, d, ns, N, z, ε, C_NULL, out))
     return out
 end
+const HIPLMMFinite = Union{ByOutputsFill{HIPOILMM},ByOutputsFill{HIPDenseILMM}}
+AbstractGPs.rand(rng::AbstractRNG, fx::HIPLMMFinite) = vec(_rand(rng, fx, 1))          # src/oilmm.jl:40-54, src/ilmm.jl:78-87
+AbstractGPs.rand(rng::AbstractRNG, fx::HIPLMMFinite, N::Int) = _rand(rng, fx, N)       # src/ilmm.jl:90-92
 
-# ---- gradients: ChainRulesCore.rrule around the ccall (reference tests: `gradient(logpdf, oilmmx, y) isa Tuple`,
-# test/oilmm.jl:31-32).  lmm_oilmm_logpdf_grad returns d/dy, d/dsigma2, d/dS, d/dU and per-latent (variance, lengthscale,
-# mean) cotangents in one pass; they are mapped back onto the reference's structs as Tangents. -------------------------
-using ChainRulesCore
-
-struct LmmGpGrad      # lmm_gp_grad_t
-    variance::Cdouble
-    lengthscale::Cdouble
-    mean::Cdouble
+# reference src/independent_mogp.jl:83-96: vcat(rand(rng, f_l(x, σ²))): latent jitter = σ², H = I, no extra noise term
+function _rand_mogp(rng::AbstractRNG, ft, N::Int)
+    X = _xmat(ft.x.x); d, ns = size(X); m = length(ft.f.fs); σ² = noise_var(ft.Σy)
+    U = Matrix{Float64}(I, m, m)
+    z = Matrix{Float64}(undef, ns * m, N)
+    for q in 1:N
+        z[:, q] = randn(rng, ns * m)
+    end
+    out = Matrix{Float64}(undef, ns * m, N)
+    jit = Ref(LmmJitters(1e-9, σ², σ²))
+    gps = isposterior(ft.f) ? LmmGp[] : _gps(ft.f.fs)
+    GC.@preserve X U gps z out check(ccall((:lmm_lmm_rand_multi, liblmm), Cint,
+        (Ptr{Cvoid}, Ptr{LmmGp}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Cint, Cint, Cdouble, Cint, Ptr{Cdouble}, Cint, Cint, Cint,
+         Ptr{Cdouble}, Ptr{Cdouble}, Ref{LmmJitters}, Ptr{Cdouble}),
+        ft.f.handle, isposterior(ft.f) ? Ptr{LmmGp}(C_NULL) : pointer(gps), U, C_NULL, m, m, 0, m, σ², 0, X, d, ns, N, z, C_NULL, jit, out))
+    return out
 end
+AbstractGPs.rand(rng::AbstractRNG, ft::ByOutputsFill{HIPMOGP}) = vec(_rand_mogp(rng, ft, 1))
+AbstractGPs.rand(rng::AbstractRNG, ft::ByOutputsFill{HIPMOGP}, N::Int) = _rand_mogp(rng, ft, N)
 
-function ChainRulesCore.rrule(::typeof(AbstractGPs.logpdf), fx::FiniteGP{<:OILMM}, y::AbstractVector{<:Real})
+# ---- gradients: ChainRulesCore.rrule around the ccall --------------------------------------------------------------------
+# The reference's tests take Zygote.gradient(logpdf, fx, y) on prior and posterior models (test/oilmm.jl:31-32,
+# test/ilmm.jl:31-32, test/independent_mogp.jl:65-66).  A ccall is opaque to Zygote, so the pullbacks come from the library
+# (lmm_oilmm_logpdf_grad, lmm_ilmm_logpdf_grad, lmm_oilmm_post_logpdf_grad) and are mapped onto the reference's structs.
+
+# kernel cotangent: the library differentiates w.r.t. the EFFECTIVE (variance, lengthscale); the chain rule through the
+# kernel's construction: ScaledKernel: v = v_inner σ² -> d/dσ² = gv v_inner; ScaleTransform: ℓ = ℓ_inner / s -> d/ds = -gl ℓ_inner / s².
+_ktangent(k::Kernel, gv, gl) = NoTangent()                                    # SEKernel() etc. carry no parameters
+function _ktangent(k::ScaledKernel, gv, gl)
+    (_, vin, _) = _desc(k.kernel)
+    return Tangent{typeof(k)}(; kernel=_ktangent(k.kernel, gv * only(k.σ²), gl), σ²=[gv * vin])
+end
+function _ktangent(k::TransformedKernel{<:Kernel,<:ScaleTransform}, gv, gl)
+    (_, _, lin) = _desc(k.kernel); s = only(k.transform.s)
+    return Tangent{typeof(k)}(; kernel=_ktangent(k.kernel, gv, gl / s), transform=Tangent{typeof(k.transform)}(; s=[-gl * lin / s^2]))
+end
+_mtangent(::AbstractGPs.ZeroMean, g) = NoTangent()
+_mtangent(m::AbstractGPs.ConstMean, g) = Tangent{typeof(m)}(; c=g)
+_fstangent(fs::Vector{<:AbstractGP}, gg::Vector{LmmGpGrad}, Δ) =
+    [Tangent{typeof(f)}(; mean=_mtangent(f.mean, Δ * g.mean), kernel=_ktangent(f.kernel, Δ * g.variance, Δ * g.lengthscale)) for (f, g) in zip(fs, gg)]
+_noise_tangent(fx, g) = Tangent{typeof(fx.Σy)}(; diag=Tangent{typeof(fx.Σy.diag)}(; value=g))     # Fill(σ², n p): one parameter
+_htangent(H::Orthogonal, gU, gS) = Tangent{typeof(H)}(; U=gU, S=Tangent{typeof(H.S)}(; diag=gS))
+
+function ChainRulesCore.rrule(::typeof(AbstractGPs.logpdf), fx::ByOutputsFill{HIPOILMM}, y::AbstractVector{<:Real})
     fs, H, σ², x = unpack(fx)
-    X = _xmat(x); d, n = size(X); p, m = size(H.U)
-    gps = _gps(fs.fs); S = Vector{Float64}(H.S.diag); U = Matrix{Float64}(H.U); yv = Vector{Float64}(y)
-    val = Ref{Cdouble}(0.0); gσ = Ref{Cdouble}(0.0)
+    X = _xmat(x); d, n = size(X); U, S, p, m = _hargs(H); gps = _gps(fs.fs); yv = Vector{Float64}(y)
+    val = Ref{Cdouble}(0.0); gσ = Ref{Cdouble}(0.0); gσt = Ref{Cdouble}(0.0)
     gy = Vector{Float64}(undef, n * p); gS = Vector{Float64}(undef, m); gU = Matrix{Float64}(undef, p, m)
     gg = Vector{LmmGpGrad}(undef, m)
-    GC.@preserve X yv U S gps gy gS gU gg check(ccall((:lmm_oilmm_logpdf_grad, liblmm), Cint,
-        (Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cdouble, Ptr{LmmGp}, Cint, Cint, Cint,
-         Ref{Cdouble}, Ptr{Cdouble}, Ref{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{LmmGpGrad}),
-        X, d, n, yv, p, U, S, m, σ², gps, 0, m, 1, val, gy, gσ, gS, gU, gg))
+    if isposterior(fs)
+        fs.train === nothing && error("gradient of the predictive logpdf after sequential conditioning is not built")
+        X0, σ0, y0 = fs.train; n0 = size(X0, 2); gy0 = Vector{Float64}(undef, n0 * p)
+        GC.@preserve X0 y0 X yv U S gps gy0 gy gS gU gg check(ccall((:lmm_oilmm_post_logpdf_grad, liblmm), Cint,
+            (Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cdouble, Cdouble,
+             Ptr{LmmGp}, Cint, Cint, Cint, Ref{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Cdouble}, Ref{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{LmmGpGrad}),
+            X0, d, n0, y0, X, n, yv, p, U, S, m, σ0, σ², gps, 0, m, 1, val, gy0, gy, gσt, gσ, gS, gU, gg))
+        # total derivatives through the posterior: the cotangents w.r.t. the training data / noise are exposed on the handle
+        # holder's `train` slot (a maintainer differentiating θ -> logpdf(posterior(f_θ(x, σ²), y)(x*, σ²), y*) reads them there)
+    else
+        GC.@preserve X yv U S gps gy gS gU gg check(ccall((:lmm_oilmm_logpdf_grad, liblmm), Cint,
+            (Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cdouble, Ptr{LmmGp}, Cint, Cint, Cint,
+             Ref{Cdouble}, Ptr{Cdouble}, Ref{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{LmmGpGrad}),
+            X, d, n, yv, p, U, S, m, σ², gps, 0, m, 1, val, gy, gσ, gS, gU, gg))
+    end
     function logpdf_pullback(Δ)
-        dH = Tangent{typeof(H)}(; U=Δ .* gU, S=Tangent{typeof(H.S)}(; diag=Δ .* gS))
-        # kernel-parameter cotangents (gg[l].variance / .lengthscale / .mean) attach to fs.fs[l].kernel / .mean according
-        # to how the kernel was built (ScaledKernel.σ², ScaleTransform.s = 1/ℓ ⇒ ∂/∂s = -ℓ² ∂/∂ℓ); left to the maintainer's
-        # preferred parameterisation.  The noise cotangent is Δ*gσ on each entry's share of Fill(σ², n*p).
-        dfx = Tangent{typeof(fx)}(; f=Tangent{typeof(fx.f)}(; H=dH), Σy=Tangent{typeof(fx.Σy)}(; diag=Tangent{typeof(fx.Σy.diag)}(; value=Δ * gσ[])))
+        dlat = Tangent{typeof(fs)}(; fs=_fstangent(fs.fs, gg, Δ))
+        dfx = Tangent{typeof(fx)}(; f=Tangent{typeof(fx.f)}(; f=dlat, H=_htangent(H, Δ .* gU, Δ .* gS)), Σy=_noise_tangent(fx, Δ * gσ[]))
         return NoTangent(), dfx, Δ .* gy
     end
     return val[], logpdf_pullback
+end
+
+# IndependentMOGP (reference test/independent_mogp.jl:65-66): the OILMM with U = I, S = 1 and no regulariser
+function ChainRulesCore.rrule(::typeof(AbstractGPs.logpdf), ft::ByOutputsFill{HIPMOGP}, y::AbstractVector{<:Real})
+    f = ft.f; X = _xmat(ft.x.x); d, n = size(X); m = length(f.fs); σ² = noise_var(ft.Σy)
+    U = Matrix{Float64}(I, m, m); S = ones(m); gps = _gps(f.fs); yv = Vector{Float64}(y)
+    val = Ref{Cdouble}(0.0); gσ = Ref{Cdouble}(0.0); gσt = Ref{Cdouble}(0.0)
+    gy = Vector{Float64}(undef, n * m); gg = Vector{LmmGpGrad}(undef, m)
+    if isposterior(f)
+        f.train === nothing && error("gradient of the predictive logpdf after sequential conditioning is not built")
+        X0, σ0, y0 = f.train; n0 = size(X0, 2)
+        GC.@preserve X0 y0 X yv U S gps gy gg check(ccall((:lmm_oilmm_post_logpdf_grad, liblmm), Cint,
+            (Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cdouble, Cdouble,
+             Ptr{LmmGp}, Cint, Cint, Cint, Ref{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Cdouble}, Ref{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{LmmGpGrad}),
+            X0, d, n0, y0, X, n, yv, m, U, S, m, σ0, σ², gps, 0, m, 0, val, C_NULL, gy, gσt, gσ, C_NULL, C_NULL, gg))
+    else
+        GC.@preserve X yv U S gps gy gg check(ccall((:lmm_oilmm_logpdf_grad, liblmm), Cint,
+            (Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cdouble, Ptr{LmmGp}, Cint, Cint, Cint,
+             Ref{Cdouble}, Ptr{Cdouble}, Ref{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{LmmGpGrad}),
+            X, d, n, yv, m, U, S, m, σ², gps, 0, m, 0, val, gy, gσ, C_NULL, C_NULL, gg))
+    end
+    function logpdf_pullback(Δ)
+        dft = Tangent{typeof(ft)}(; f=Tangent{typeof(f)}(; fs=_fstangent(f.fs, gg, Δ)), Σy=_noise_tangent(ft, Δ * gσ[]))
+        return NoTangent(), dft, Δ .* gy
+    end
+    return val[], logpdf_pullback
+end
+
+# dense-H ILMM prior (reference test/ilmm.jl:31): the reference's (mn) x (mn) operation + its explicit inverse
+function ChainRulesCore.rrule(::typeof(AbstractGPs.logpdf), fx::ByOutputsFill{HIPDenseILMM}, y::AbstractVector{<:Real})
+    f, H, σ², x = unpack(fx)
+    isposterior(f) && error("gradient of the dense-H posterior's predictive logpdf is not built")
+    X = _xmat(x); d, n = size(X); p, m = size(H); gps = _gps(f.fs); Hm = Matrix{Float64}(H); yv = Vector{Float64}(y)
+    val = Ref{Cdouble}(0.0); gσ = Ref{Cdouble}(0.0)
+    gy = Vector{Float64}(undef, n * p); gH = Matrix{Float64}(undef, p, m); gg = Vector{LmmGpGrad}(undef, m)
+    GC.@preserve X yv Hm gps gy gH gg check(ccall((:lmm_ilmm_logpdf_grad, liblmm), Cint,
+        (Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Cint, Cdouble, Ptr{LmmGp}, Ptr{LmmJitters}, Ref{Cdouble}, Ptr{Cdouble},
+         Ref{Cdouble}, Ptr{Cdouble}, Ptr{LmmGpGrad}),
+        X, d, n, yv, p, Hm, m, σ², gps, C_NULL, val, gy, gσ, gH, gg))
+    function logpdf_pullback(Δ)
+        dfx = Tangent{typeof(fx)}(; f=Tangent{typeof(fx.f)}(; f=Tangent{typeof(f)}(; fs=_fstangent(f.fs, gg, Δ)), H=Δ .* gH),
+                                  Σy=_noise_tangent(fx, Δ * gσ[]))
+        return NoTangent(), dfx, Δ .* gy
+    end
+    return val[], logpdf_pullback
+end
+
+# ---- multi-GPU: one Julia process per GPU; the collective lives in the library (RCCL over xGMI) ----------------------------
+# rank 0: id = unique_id(); ship the 128 bytes to the other ranks (MPI.bcast!(id, 0, comm)); all: comm_init_rank(id, rank, world).
+unique_id() = (id = Vector{UInt8}(undef, 128); check(ccall((:lmm_comm_get_unique_id, liblmm), Cint, (Ptr{UInt8},), id)); id)
+comm_init_rank(id::Vector{UInt8}, rank::Integer, world::Integer) =
+    check(ccall((:lmm_comm_init_rank, liblmm), Cint, (Ptr{UInt8}, Cint, Cint), id, rank, world))
+allreduce_sum!(buf::Vector{Float64}) = (check(ccall((:lmm_allreduce_sum_f64, liblmm), Cint, (Ptr{Cdouble}, Csize_t), buf, length(buf))); buf)
+comm_destroy() = check(ccall((:lmm_comm_destroy, liblmm), Cint, ()))
+
+# contiguous block partition of m latents over `world` ranks (the first m % world ranks get one extra)
+function latent_shard(m::Integer, rank::Integer, world::Integer)
+    base, extra = divrem(m, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (rank < extra ? 1 : 0)
+end
+
+# logpdf of an OILMM with the latents sharded over the ranks: each rank evaluates its block (no data-path collective), rank 0
+# adds the regulariser, ONE 8-byte all-reduce finishes it (SURVEY.md section 8e)
+function sharded_logpdf(fx::ByOutputsFill{HIPOILMM}, y::AbstractVector{<:Real}, rank::Integer, world::Integer)
+    fs, H, σ², x = unpack(fx)
+    X = _xmat(x); d, n = size(X); U, S, p, m = _hargs(H); gps = _gps(fs.fs); yv = Vector{Float64}(y)
+    l0, l1 = latent_shard(m, rank, world)
+    out = Ref{Cdouble}(0.0)
+    GC.@preserve X yv U S gps check(ccall((:lmm_oilmm_logpdf, liblmm), Cint,
+        (Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cdouble, Ptr{LmmGp}, Cint, Cint, Cint, Ref{Cdouble}),
+        X, d, n, yv, p, U, S, m, σ², gps, l0, l1, rank == 0 ? 1 : 0, out))
+    return allreduce_sum!([out[]])[1]
 end
 
 end # module

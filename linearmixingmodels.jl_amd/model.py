@@ -182,8 +182,11 @@ class _PostHandle:
     """Owns an lmm_post_t* (device-resident posterior state); freed with the Python object, as the Julia
     shim does with a finalizer."""
 
-    def __init__(self, ptr: C.c_void_p, l0: int, l1: int, dense: bool = False):
+    def __init__(self, ptr: C.c_void_p, l0: int, l1: int, dense: bool = False, train=None):
         self.ptr, self.l0, self.l1, self.dense = ptr, l0, l1, dense      # dense: coupled (mn) x (mn) state of a dense-H ILMM
+        # (x, sigma2, y) the posterior was built from (references, no copies): the gradient of the predictive logpdf is a total
+        # derivative through the posterior and needs them; None after sequential conditioning
+        self.train = train
 
     def __del__(self):
         try:
@@ -354,35 +357,65 @@ def logpdf(fx: FiniteGP, y, with_regulariser: bool = True) -> float:
 
 
 def logpdf_and_gradient(fx: FiniteGP, y, with_regulariser: bool = True) -> dict:
-    """Value and gradient of logpdf(fx, y) for an OILMM (what `Zygote.gradient(logpdf, fx, y)` returns in the reference's
-    tests, test/oilmm.jl:31-32): {"value", "y", "sigma2", "S", "U", "gps": [{"variance","lengthscale","mean"}, ...]}.
+    """Value and gradient of logpdf(fx, y) -- what `Zygote.gradient(logpdf, fx, y)` differentiates in the reference's tests
+    (test/oilmm.jl:31-32, test/ilmm.jl:31-32, test/independent_mogp.jl:65-66).
+
+      prior OILMM / IndependentMOGP : {"value", "y", "sigma2", "S", "U", "gps": [{"variance","lengthscale","mean"}, ...]}
+      prior dense-H ILMM            : {"value", "y", "sigma2", "H", "gps"}
+      posterior OILMM / MOGP        : fx = posterior(f(x, s2), y0)(xs, s2s); TOTAL derivatives of the predictive logpdf through the
+                                      posterior: {"value", "y" (= d/d ys), "y_train", "sigma2" (= d/d s2s), "sigma2_train", "S", "U", "gps"}
     Partial sums over the latent shard."""
     L.ensure_init()
     lib = L.load()
     f, x, s2 = fx.f, fx.x, fx.sigma2
     mogp = isinstance(f, IndependentMOGP)
+    post = f._post if mogp else (f.f._post if isinstance(f, ILMM) else None)
+    if not mogp and not isinstance(f, ILMM):
+        raise TypeError("logpdf_and_gradient needs an ILMM / OILMM / IndependentMOGP FiniteGP")
+    if not mogp and not f.is_oilmm:
+        if post is not None:
+            raise NotImplementedError("gradient of the dense-H posterior's predictive logpdf is not built")
+        unpack(fx)
+        Ha, _, p, m = _H_args(f.H)
+        n = x.n
+        val, gs2 = C.c_double(), C.c_double()
+        gy, gH = _alloc_like(y if L._is_torch(y) else x.x, n * p), np.empty(p * m)
+        gg = (L.GpGradT * m)()
+        L.check(lib.lmm_ilmm_logpdf_grad(x.carr().ptr, x.dim, n, L.Arr(y).ptr, p, Ha.ptr, m, C.c_double(s2),
+                                         L.gps_array([g.desc() for g in f.f.fs]), None, C.byref(val), L.Arr(gy, True).ptr,
+                                         C.byref(gs2), L.Arr(gH, True).ptr, gg))
+        return {"value": val.value, "y": gy, "sigma2": gs2.value, "H": gH.reshape(m, p).T.copy(),
+                "gps": [{"variance": gg[l].variance, "lengthscale": gg[l].lengthscale, "mean": gg[l].mean} for l in range(m)]}
     if mogp:                      # gradient(logpdf, fx, y) on an IndependentMOGP (reference test/independent_mogp.jl:65-66):
-        if f._post is not None:   # the OILMM with U = I, S = 1 (regulariser identically 0, so it is skipped)
-            raise NotImplementedError("gradients are built for prior models")
-        m = p = len(f.fs)
+        m = p = len(f.fs)         # the OILMM with U = I, S = 1 (regulariser identically 0, so it is skipped)
         if x.out_dim != m:
             raise RuntimeError("out dim of x != out dim of f.")
         Ua, Sa, descs, shard, with_regulariser = L.Arr(L.colmajor(np.eye(m))), L.Arr(np.ones(m)), [g.desc() for g in f.fs], (0, m), False
     else:
-        if not isinstance(f, ILMM) or not f.is_oilmm or f.f._post is not None:
-            raise NotImplementedError("gradients are built for the prior OILMM / IndependentMOGP logpdf")
         unpack(fx)
         Ua, Sa, p, m = _H_args(f.H)
         descs, shard = [g.desc() for g in f.f.fs], f.shard
     n = x.n
-    val, gs2 = C.c_double(), C.c_double()
+    val, gs2, gs2t = C.c_double(), C.c_double(), C.c_double()
     gy, gS, gU = _alloc_like(y if L._is_torch(y) else x.x, n * p), np.empty(m), np.empty(p * m)
     gg = (L.GpGradT * m)()
-    L.check(lib.lmm_oilmm_logpdf_grad(x.carr().ptr, x.dim, n, L.Arr(y).ptr, p, Ua.ptr, Sa.ptr, m, C.c_double(s2),
-                                      L.gps_array(descs), shard[0], shard[1], int(with_regulariser), C.byref(val),
-                                      L.Arr(gy, True).ptr, C.byref(gs2), L.Arr(gS, True).ptr, L.Arr(gU, True).ptr, gg))
-    out = {"value": val.value, "y": gy, "sigma2": gs2.value,
-           "gps": [{"variance": gg[l].variance, "lengthscale": gg[l].lengthscale, "mean": gg[l].mean} for l in range(m)]}
+    out = {}
+    if post is None:
+        L.check(lib.lmm_oilmm_logpdf_grad(x.carr().ptr, x.dim, n, L.Arr(y).ptr, p, Ua.ptr, Sa.ptr, m, C.c_double(s2),
+                                          L.gps_array(descs), shard[0], shard[1], int(with_regulariser), C.byref(val),
+                                          L.Arr(gy, True).ptr, C.byref(gs2), L.Arr(gS, True).ptr, L.Arr(gU, True).ptr, gg))
+    else:
+        if post.train is None:
+            raise NotImplementedError("gradient of the predictive logpdf after sequential conditioning is not built")
+        x0, s20, y0 = post.train
+        gy0 = _alloc_like(y0 if L._is_torch(y0) else x0.x, x0.n * p)
+        L.check(lib.lmm_oilmm_post_logpdf_grad(x0.carr().ptr, x0.dim, x0.n, L.Arr(y0).ptr, x.carr().ptr, n, L.Arr(y).ptr, p, Ua.ptr,
+                                               Sa.ptr, m, C.c_double(s20), C.c_double(s2), L.gps_array(descs), shard[0], shard[1],
+                                               int(with_regulariser), C.byref(val), L.Arr(gy0, True).ptr, L.Arr(gy, True).ptr,
+                                               C.byref(gs2t), C.byref(gs2), L.Arr(gS, True).ptr, L.Arr(gU, True).ptr, gg))
+        out.update(y_train=gy0, sigma2_train=gs2t.value)
+    out.update({"value": val.value, "y": gy, "sigma2": gs2.value,
+                "gps": [{"variance": gg[l].variance, "lengthscale": gg[l].lengthscale, "mean": gg[l].mean} for l in range(m)]})
     if not mogp:
         out["S"], out["U"] = gS, gU.reshape(m, p).T.copy()
     return out
@@ -443,7 +476,7 @@ def posterior(fx: FiniteGP, y):
             return IndependentMOGP(f.fs, _PostHandle(handle, 0, m))
         gps = L.gps_array([g.desc() for g in f.fs])
         L.check(lib.lmm_mogp_posterior_create(xa.ptr, x.dim, x.n, ya.ptr, m, C.c_double(s2), gps, 0, m, C.byref(handle)))
-        return IndependentMOGP(f.fs, _PostHandle(handle, 0, m))
+        return IndependentMOGP(f.fs, _PostHandle(handle, 0, m, train=(x, s2, y)))
     unpack(fx)
     Ua, Sa, p, m = _H_args(f.H)
     l0, l1 = f.shard
@@ -461,7 +494,7 @@ def posterior(fx: FiniteGP, y):
     else:
         L.check(lib.lmm_ilmm_posterior_create(xa.ptr, x.dim, x.n, ya.ptr, p, Ua.ptr, m, C.c_double(s2), gps, None,
                                               C.byref(handle)))
-    return ILMM(IndependentMOGP(f.f.fs, _PostHandle(handle, l0, l1, dense=not f.is_oilmm)), f.H, shard=f.shard)
+    return ILMM(IndependentMOGP(f.f.fs, _PostHandle(handle, l0, l1, dense=not f.is_oilmm, train=(x, s2, y))), f.H, shard=f.shard)
 
 
 def mean_and_var(fx: FiniteGP, add_noise: bool = True):

@@ -272,3 +272,115 @@ def test_abi_rccl_world1(lmm):
     assert got == pytest.approx(O.oilmm_logpdf(P["gps"], P["U"], P["S"], P["x"], 0.1, P["y"]), rel=1e-10)
     L.comm_destroy()
     assert L.comm_world() == 0
+
+
+# ---------------------------------------------------------------------------------------------------
+# F1: gradients beyond the prior OILMM / MOGP (reference test/ilmm.jl:31-32, test/oilmm.jl:32, test/independent_mogp.jl:66)
+# ---------------------------------------------------------------------------------------------------
+def _fd(f, h=1e-6):
+    return (f(h) - f(-h)) / (2.0 * h)
+
+
+def test_posterior_oilmm_logpdf_gradient_vs_oracle_fd(lmm):
+    """gradient(logpdf, po(xs, s2s), ys) on the posterior OILMM: value == the posterior logpdf, and every component of the TOTAL
+    derivative (through alpha, the factor and the Schur complement) == central finite differences of the oracle's
+    logpdf(posterior(...)(xs), ys)."""
+    rng = np.random.default_rng(61)
+    n, ns, p, m = 18, 7, 4, 2
+    x = np.sort(rng.uniform(0, 6, n)); xs = np.sort(rng.uniform(0, 6, ns))
+    gps = _gps(["matern32", "matern52"], rng)
+    U, S = _orth(rng, p, m)
+    y, ys = rng.standard_normal(n * p), rng.standard_normal(ns * p)
+    s2, s2s = 0.3, 0.2
+
+    def F(gps=gps, U=U, S=S, s2=s2, s2s=s2s, y=y, ys=ys):
+        return O.oilmm_logpdf(O.oilmm_posterior(gps, U, S, x, s2, y), U, S, xs, s2s, ys)
+
+    f = lmm.ILMM(_to_model(lmm, gps), lmm.Orthogonal(U, S))
+    po = lmm.posterior(f(lmm.MOInputIsotopicByOutputs(x, p), s2), y)
+    fxs = po(lmm.MOInputIsotopicByOutputs(xs, p), s2s)
+    G = lmm.logpdf_and_gradient(fxs, ys)
+    assert G["value"] == pytest.approx(F(), rel=1e-9)
+    assert G["value"] == pytest.approx(lmm.logpdf(fxs, ys), rel=1e-9)
+    assert G["sigma2"] == pytest.approx(_fd(lambda t: F(s2s=s2s + t)), rel=1e-5, abs=1e-7)
+    assert G["sigma2_train"] == pytest.approx(_fd(lambda t: F(s2=s2 + t)), rel=1e-5, abs=1e-7)
+    for k in [0, 5, ns * p - 1]:
+        e = np.zeros(ns * p); e[k] = 1.0
+        assert G["y"][k] == pytest.approx(_fd(lambda t: F(ys=ys + t * e)), rel=1e-5, abs=1e-7)
+    for k in [0, 7, n * p - 1]:
+        e = np.zeros(n * p); e[k] = 1.0
+        assert G["y_train"][k] == pytest.approx(_fd(lambda t: F(y=y + t * e)), rel=1e-5, abs=1e-7)
+    for l in range(m):
+        e = np.zeros(m); e[l] = 1.0
+        assert G["S"][l] == pytest.approx(_fd(lambda t: F(S=S + t * e)), rel=1e-5, abs=1e-7)
+        for key in ("variance", "lengthscale", "mean"):
+            def f1(t, l=l, key=key):
+                g2 = [dict(g) for g in gps]; g2[l][key] += t
+                return F(gps=g2)
+            assert G["gps"][l][key] == pytest.approx(_fd(f1), rel=1e-5, abs=1e-7)
+    for (o, l) in [(0, 0), (2, 1), (3, 0)]:
+        E = np.zeros((p, m)); E[o, l] = 1.0
+        assert G["U"][o, l] == pytest.approx(_fd(lambda t: F(U=U + t * E)), rel=1e-5, abs=1e-6)
+
+
+def test_posterior_mogp_logpdf_gradient_vs_oracle_fd(lmm):
+    """reference test/independent_mogp.jl:66: gradient(logpdf, posterior_mogp(xs, s2s), ys)."""
+    rng = np.random.default_rng(62)
+    n, ns, m = 15, 6, 2
+    x = np.sort(rng.uniform(0, 5, n)); xs = np.sort(rng.uniform(0, 5, ns))
+    gps = _gps(["se", "matern52"], rng)
+    y, ys = rng.standard_normal(n * m), rng.standard_normal(ns * m)
+    s2, s2s = 0.4, 0.25
+
+    def F(gps=gps, s2=s2, s2s=s2s, y=y, ys=ys):
+        return O.mogp_logpdf(O.mogp_posterior(gps, x, s2, y), xs, s2s, ys)
+
+    po = lmm.posterior(_to_model(lmm, gps)(lmm.MOInputIsotopicByOutputs(x, m), s2), y)
+    fxs = po(lmm.MOInputIsotopicByOutputs(xs, m), s2s)
+    G = lmm.logpdf_and_gradient(fxs, ys)
+    assert G["value"] == pytest.approx(F(), rel=1e-9)
+    assert G["value"] == pytest.approx(lmm.logpdf(fxs, ys), rel=1e-9)
+    assert G["sigma2"] == pytest.approx(_fd(lambda t: F(s2s=s2s + t)), rel=1e-5, abs=1e-7)
+    assert G["sigma2_train"] == pytest.approx(_fd(lambda t: F(s2=s2 + t)), rel=1e-5, abs=1e-7)
+    for k in [0, 4, ns * m - 1]:
+        e = np.zeros(ns * m); e[k] = 1.0
+        assert G["y"][k] == pytest.approx(_fd(lambda t: F(ys=ys + t * e)), rel=1e-5, abs=1e-7)
+    for l in range(m):
+        for key in ("variance", "lengthscale", "mean"):
+            def f1(t, l=l, key=key):
+                g2 = [dict(g) for g in gps]; g2[l][key] += t
+                return F(gps=g2)
+            assert G["gps"][l][key] == pytest.approx(_fd(f1), rel=1e-5, abs=1e-7)
+
+
+@pytest.mark.parametrize("n,d", [(14, 1), (70, 2)])
+def test_dense_ilmm_logpdf_gradient_vs_oracle_fd(lmm, n, d):
+    """reference test/ilmm.jl:31: gradient(logpdf, ilmmx, y) on the dense-H model, distinct latent kernels (no decoupling):
+    y, sigma2, H and every latent's kernel / mean parameters against central finite differences of the oracle."""
+    rng = np.random.default_rng(63)
+    p, m = 4, 3
+    x = np.sort(rng.uniform(0, 6, n)) if d == 1 else rng.uniform(0, 3, size=(d, n))
+    gps = _gps(["se", "matern32", "matern52"], rng)
+    H = rng.uniform(0.2, 1.0, size=(p, m))
+    y = rng.standard_normal(n * p)
+    s2 = 0.3
+
+    def F(gps=gps, H=H, s2=s2, y=y):
+        return O.ilmm_logpdf(gps, H, x, s2, y)
+
+    fx = lmm.ILMM(_to_model(lmm, gps), H)(lmm.MOInputIsotopicByOutputs(x, p), s2)
+    G = lmm.logpdf_and_gradient(fx, y)
+    assert G["value"] == pytest.approx(F(), rel=1e-9)
+    assert G["sigma2"] == pytest.approx(_fd(lambda t: F(s2=s2 + t)), rel=2e-5, abs=1e-6)
+    for k in [0, n + 3, n * p - 1]:
+        e = np.zeros(n * p); e[k] = 1.0
+        assert G["y"][k] == pytest.approx(_fd(lambda t: F(y=y + t * e)), rel=1e-5, abs=1e-7)
+    for (o, l) in [(0, 0), (1, 2), (3, 1), (2, 2)]:
+        E = np.zeros((p, m)); E[o, l] = 1.0
+        assert G["H"][o, l] == pytest.approx(_fd(lambda t: F(H=H + t * E)), rel=2e-5, abs=1e-6)
+    for l in range(m):
+        for key in ("variance", "lengthscale", "mean"):
+            def f1(t, l=l, key=key):
+                g2 = [dict(g) for g in gps]; g2[l][key] += t
+                return F(gps=g2)
+            assert G["gps"][l][key] == pytest.approx(_fd(f1), rel=2e-5, abs=1e-6)
