@@ -40,8 +40,14 @@ WORKLOADS = {
                                             "(step = posterior + mean_and_var at x*)"),
     # the reference notebook's timing shape (examples/oilmm_and_ilmm.ipynb:124-129, 226-235): the only published number
     "notebook": (20, 600, 552, "matern52", True, "reference notebook: OILMM logpdf, p=600, m=20, n=552 Matern52, sigma2=1e-6, f64"),
+    # secondary metric: BASELINE configs[4] -- one step = ONE prior sample rand(rng, fx) of the whole model: a Cholesky of every
+    # latent Gram + the sampling transform L z + the H mix, latents sharded, ONE all-reduce of the n x p partial sample per step.
+    # Run with --dtype f32 for the configuration as named (latent jitter 1e-4 x variance: SURVEY.md section 7 "jitter hazards").
+    "c4": (128, 256, 32768, "matern52", True, "configs[4]: OILMM rand, 256 outputs, 128 Matern52 latents, n=32768 "
+                                              "(step = one prior sample: per-latent Cholesky + L z + mix)"),
 }
 NOTEBOOK_PUBLISHED_EVALS_PER_S = 1.0 / 0.172541   # median 172.541 ms, unstated CPU, Julia 1.6.1
+FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD (155 measured)
 FP64_MFMA_PEAK_TFLOPS = 78.6      # AMD MI355X datasheet FP64 matrix (= vector) peak; the local guide lists no FP64 MFMA
                                   # rate.  Measured here: v_mfma_f64_4x4x4_4b_f64 issues at 76.8 TFLOP/s (tools/mfma_probe3,
                                   # profiles/r01_probes/probe3.log) = 97.7 % of it, so 78.6 is the denominator.
@@ -106,12 +112,27 @@ def cpu_baseline_predictive(P):
             "sample": f"oracle posterior + marginals of 1 of {m} latents at n = n* = {n}: {dt:.2f} s, extrapolated x{m}"}
 
 
+def cpu_baseline_sampling(P):
+    """Oracle prior sample of ONE latent at full n (NumPy Gram + LAPACK potrf + L z), extrapolated to the m independent latents."""
+    from oracle import lmm_oracle as O
+    m, n = P["m"], P["n"]
+    z = np.random.default_rng(0).standard_normal(n)
+    np.linalg.cholesky(np.eye(256) * 2.0)
+    t0 = time.perf_counter()
+    O.gp_rand(P["gps"][0], P["x"], 1e-4, z)
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / (dt * m), "unit": "samples/s", "cores": os.cpu_count() or 1, "kind": "port",
+            "sample": f"oracle gp_rand (Gram + LAPACK potrf + L z, Float64) of 1 of {m} latents at n = {n}: {dt:.2f} s, extrapolated x{m}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"],
+                    help="compute dtype of the per-latent matrices (lmm_set_compute_dtype); f64 is the parity mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -155,6 +176,7 @@ def main():
     from lmm_amd import _lib as L
     from lmm_amd.workloads import synthetic_problem      # input generation only; the oracle is imported by the cpu_baseline leg alone
     lmm_amd.init(local_rank)
+    lmm_amd.set_compute_dtype(args.dtype)
     dev = torch.device("cuda", local_rank)
     # The data-path collective is the C ABI's own RCCL communicator (lmm_allreduce_sum_f64: what a Julia / C caller binds);
     # torch.distributed is kept for the rendezvous (it ships the RCCL unique id), the fence barrier and the max-over-ranks clock.
@@ -191,6 +213,20 @@ def main():
     red_host = np.zeros(1)
 
     predictive = (args.workload == "c3")
+    sampling = (args.workload == "c4")
+    if sampling:
+        normals = lmm_amd.DeviceNormals(1234 + 0)            # every rank draws the SAME normals (same seed, same stream order)
+        jit_rand = (1e-9, 1e-4, 1e-4)
+
+    def step_sampling():
+        part = lmm_amd.rand(normals, fx, jitters=jit_rand, add_noise=(rank == 0))     # this rank's latents mixed through its H columns
+        if world > 1:
+            if abi_comm:
+                L.allreduce_sum(part)                        # ONE all-reduce of the n x p partial sample
+            else:
+                pc = part.cpu(); dist.all_reduce(pc); part = pc
+        return float(part[0])
+
     if predictive:
         xs_in = lmm_amd.MOInputIsotopicByOutputs(xd + 0.5 * 20.0 / 575.0, p)      # test points between the training points
 
@@ -202,6 +238,8 @@ def main():
     def step():
         if predictive:
             return step_predictive()
+        if sampling:
+            return step_sampling()
         part = lmm_amd.logpdf(fx, yd, rank == 0)
         if world > 1 and orth:
             if abi_comm:
@@ -238,6 +276,7 @@ def main():
 
     roof = None
     extra = {}
+    peak_tf = FP32_MFMA_PEAK_TFLOPS if args.dtype == "f32" else FP64_MFMA_PEAK_TFLOPS
     if rank == 0 and not args.no_roofline and not predictive:
         # Roofline leg: one more evaluation of one batch of latents of the same workload with every launch of the hot
         # kernels bracketed by HIP events on its stream; the batch runs on ONE stream so that an event pair times its
@@ -246,7 +285,10 @@ def main():
         nprof = min(8, shard[1] - shard[0]) if orth else m      # one production-sized batch of latents
         fprof = lmm_amd.ILMM(fs, H, shard=(shard[0], shard[0] + nprof))(xin, s2) if orth else fx
         L.check(lib.lmm_profile_begin(1))
-        lmm_amd.logpdf(fprof, yd, False)
+        if sampling:
+            lmm_amd.rand(lmm_amd.DeviceNormals(99), fprof, jitters=jit_rand, add_noise=False)
+        else:
+            lmm_amd.logpdf(fprof, yd, False)
         ent = (L.ProfEntryT * len(L.PROF_CLASSES))()
         L.check(lib.lmm_profile_end(ent))
         prof = {c: {"launches": int(ent[i].launches), "ms": float(ent[i].ms), "work": float(ent[i].work),
@@ -260,9 +302,10 @@ def main():
                 tj = json.load(open(tpath))
                 if tj.get("workload") == args.workload:
                     traffic = tj.get("gemm44_kernel<128, false>", {}).get("bytes_per_launch")
-            roof = {"bound": "mfma", "kernel": "gemm44_kernel<128,false> (v_mfma_f64_4x4x4_4b_f64 SYRK/GEMM trailing update)",
-                    "achieved": round(ach, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+            roof = {"bound": "mfma", "kernel": ("gemm32_kernel<128,false> (v_mfma_f32_32x32x2_f32 SYRK/GEMM trailing update)" if args.dtype == "f32"
+                                                else "gemm44_kernel<128,false> (v_mfma_f64_4x4x4_4b_f64 SYRK/GEMM trailing update)"),
+                    "achieved": round(ach, 3), "peak": peak_tf, "unit": "TFLOP/s",
+                    "frac": round(ach / peak_tf, 4), "traffic": traffic if args.dtype == "f64" else None,
                     "launches": up["launches"], "avg_launch_ms": round(up["ms"] / up["launches"], 4),
                     "flops_per_launch": up["work"] / up["launches"],
                     "algorithmic_bytes_per_launch": up["bytes"] / up["launches"],
@@ -285,23 +328,23 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline_predictive(P) if predictive else cpu_baseline(P, orth)
+        cpu = cpu_baseline_predictive(P) if predictive else (cpu_baseline_sampling(P) if sampling else cpu_baseline(P, orth))
 
     if rank == 0:
         line = {
-            "metric": ("posterior + marginals evals/sec" if predictive else "logpdf evals/sec") +
+            "metric": ("posterior + marginals evals/sec" if predictive else ("prior samples/sec" if sampling else "logpdf evals/sec")) +
                       ("" if orth or world == 1 else " (independent replicas: the dense-H path does not shard)"),
             "value": evals_per_s, "unit": "evals/s",
             "obs_per_s": evals_per_s * n * p if evals_per_s else None,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if orth else "replicas",
             "vs_baseline": (evals_per_s / NOTEBOOK_PUBLISHED_EVALS_PER_S) if (args.workload == "notebook" and evals_per_s) else None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": desc, "m": m, "p": p, "n": n, "kernel": kind, "sigma2": s2,
                        "latents_per_gpu": (shard[1] - shard[0]), "parallelism": f"latent-shard x{world}" if orth else "replicas",
                        "collective": ("lmm_allreduce_sum_f64 (RCCL inside liblmm_hip.so)" if abi_comm else
                                       ("torch.distributed/" + backend if world > 1 else None))},
-            ("first_predictive_mean" if predictive else "logpdf"): val,
+            ("first_predictive_mean" if predictive else ("first_sample_value" if sampling else "logpdf")): val,
             "roofline": roof, "cpu_baseline": cpu,
         }
         line.update(extra)

@@ -74,6 +74,19 @@ const char* lmm_last_error_string(void);
 int lmm_last_error_detail(int* latent, int* info);
 int lmm_device_synchronize(void);
 int lmm_release_cached_memory(void);      /* return the caching device-memory pool (factor-matrix slots) to HIP */
+/* Compute dtype of the per-latent hot path (SURVEY.md section 8b "dtype selected by symbol suffix or enum"; BASELINE configs[4]).
+ * LMM_F64 (default): everything Float64 -- the parity mode (rtol 1e-6 against the reference's CPU path).
+ * LMM_F32: the MATRICES -- latent Grams, Cholesky factors, inverse diagonal blocks, cross-solve blocks -- are Float32 and the
+ *   trailing updates / TRSMs run on v_mfma_f32_32x32x2_f32 (2x the FP64 matrix rate, half the factor memory); vectors at the
+ *   boundary (x, y, normals, outputs), the kernel evaluation, the 64x64 diagonal-block factorisation and all reductions stay
+ *   Float64.  Served: OILMM / IndependentMOGP logpdf, posterior, marginals, rand, posterior logpdf, sequential conditioning and
+ *   the decoupled dense-H logpdf; the dense (mn)x(mn) ILMM paths, gradients and full covariances return LMM_ERR_UNSUPPORTED.
+ *   Jitters stay explicit arguments: the reference's 1e-18 / 1e-12 defaults are below Float32 resolution, so prior sampling
+ *   needs a caller-chosen jitter (>= ~1e-5 x kernel variance).  A posterior handle remembers the dtype it was built in. */
+typedef enum { LMM_F64 = 0, LMM_F32 = 1 } lmm_dtype;
+int lmm_set_compute_dtype(int dtype);
+int lmm_get_compute_dtype(void);
+
 /* Order the library's streams behind everything queued so far on `hip_stream` (a hipStream_t; NULL = the legacy default
  * stream): the NEXT entry point may then be handed device pointers that stream is still producing, or output buffers it is
  * still reading.  Entry points are blocking, so no ordering is needed in the other direction. */

@@ -18,7 +18,7 @@ KERNEL_KINDS = {"se": 0, "matern32": 1, "matern52": 2}
 # Every symbol include/lmm_hip.h declares (tests/test_abi.py checks the library exports each one).
 SYMBOLS = [
     "lmm_init", "lmm_shutdown", "lmm_last_error_string", "lmm_last_error_detail", "lmm_device_synchronize", "lmm_release_cached_memory",
-    "lmm_stream_wait_caller", "lmm_comm_get_unique_id", "lmm_comm_init_rank", "lmm_comm_info", "lmm_allreduce_sum_f64", "lmm_allreduce_max_f64",
+    "lmm_stream_wait_caller", "lmm_set_compute_dtype", "lmm_get_compute_dtype", "lmm_comm_get_unique_id", "lmm_comm_init_rank", "lmm_comm_info", "lmm_allreduce_sum_f64", "lmm_allreduce_max_f64",
     "lmm_comm_destroy",
     "lmm_orthogonal_validate", "lmm_oilmm_logpdf", "lmm_oilmm_logpdf_grad", "lmm_oilmm_post_logpdf_grad", "lmm_ilmm_logpdf_grad", "lmm_oilmm_logpdf_multi", "lmm_reorder", "lmm_ilmm_logpdf", "lmm_ilmm_logpdf_ex", "lmm_mogp_logpdf", "lmm_mogp_logpdf_diag",
     "lmm_oilmm_posterior_create", "lmm_mogp_posterior_create", "lmm_post_condition", "lmm_ilmm_posterior_create", "lmm_post_destroy", "lmm_ilmm_post_mean_and_var", "lmm_ilmm_post_mean_and_cov", "lmm_ilmm_post_condition", "lmm_ilmm_post_logpdf", "lmm_ilmm_post_rand",
@@ -149,6 +149,15 @@ class Arr:
             self.owner = a
             self.ptr = a.ctypes.data_as(C.c_void_p)
             self.size = a.size
+
+
+def set_compute_dtype(dtype: str) -> None:
+    """"f64" (default, parity mode) or "f32": Float32 matrices on v_mfma_f32 for the per-latent paths (include/lmm_hip.h)."""
+    check(load().lmm_set_compute_dtype(C.c_int({"f64": 0, "f32": 1}[dtype])))
+
+
+def get_compute_dtype() -> str:
+    return "f32" if load().lmm_get_compute_dtype() == 1 else "f64"
 
 
 def order_after_torch() -> None:

@@ -163,6 +163,13 @@ struct DevOut {
 
 inline int rup(int v, int m) { return (v + m - 1) / m * m; }
 
+// fp32 compute mode (lmm_set_compute_dtype): MATRICES (factor matrices, inverse diagonal blocks, cross-solve blocks) are float
+// buffers; they are still carried as Buf<double> / double* (opaque to the host, which never dereferences them), sized by
+// mat_count(elements) doubles.  Vectors stay double.
+inline size_t mat_count(size_t elems) { return g_f32 ? (elems + 1) / 2 : elems; }
+inline double mat_bytes(double elems) { return elems * (g_f32 ? 4.0 : 8.0); }
+#define REQUIRE_F64(what) if (g_f32) return fail(LMM_ERR_UNSUPPORTED, what " is not built for the fp32 compute mode (lmm_set_compute_dtype)")
+
 // Brackets one launch with events when profiling is on (lmm_profile_begin); otherwise just launches.
 struct ProfScope {
   bool on; hipStream_t st; size_t idx;
@@ -319,8 +326,13 @@ void batch_plan(int ms, int* nb_per, int* nstreams_used, double bytes_per_latent
   static int minb_env = -2;
   if (minb_env == -2) { const char* e = getenv("LMM_MIN_BATCHES"); minb_env = e ? std::max(1, atoi(e)) : -1; }
   const int minb = minb_env > 0 ? minb_env : ((bytes_per_latent > 0.0 && bytes_per_latent <= 6e8) ? 1 : 2);
-  int b = std::min(bmax, std::max(1, ms / minb));
-  if (g.prof && g.prof_serial) b = std::min(bmax, ms);  // instrumented pass: production-sized batches on ONE stream
+  // small factor matrices (n <= ~2000) are latency-bound end to end: one lock-step batch of up to LMM_MAX_BATCH latents costs the
+  // same leaf chain as a batch of 8 (reference notebook shape, 20 latents: 3 batches of 8/8/4 -> one of 20)
+  static int bsmall = -1;
+  if (bsmall < 0) { const char* e = getenv("LMM_BATCH_SMALL"); bsmall = e ? std::max(1, std::min(LMM_MAX_BATCH, atoi(e))) : LMM_MAX_BATCH; }
+  const int bcap = (bytes_per_latent > 0.0 && bytes_per_latent <= 4e7) ? std::max(bmax, bsmall) : bmax;
+  int b = std::min(bcap, std::max(1, ms / minb));
+  if (g.prof && g.prof_serial) b = std::min(bcap, ms);  // instrumented pass: production-sized batches on ONE stream
   int nbatches = (ms + b - 1) / b;
   int ns = std::max(1, std::min(nbatches, eff_streams()));
   if ((double)b * ns * bytes_per_latent > 8e9) {      // small working sets never need the (slow) driver query
@@ -349,8 +361,8 @@ void make_slots(std::vector<Slot>& slots, int count, int nb_per, size_t a_elems,
   slots.resize(count);
   for (int s = 0; s < count; ++s) {
     for (int j = 0; j < nb_per; ++j) {
-      slots[s].A.emplace_back(a_elems);
-      slots[s].W.emplace_back((size_t)(NC / 64) * 4096);
+      slots[s].A.emplace_back(mat_count(a_elems));
+      slots[s].W.emplace_back(mat_count((size_t)(NC / 64) * 4096));
     }
     slots[s].st = g.streams[s];
   }
@@ -536,7 +548,7 @@ int latent_lmls(const double* xd, int d, int n, const lmm_gp_t* gps, const doubl
   }
   Dims D(n, nrhs);
   int nb_per = 1, nslots = 1;
-  batch_plan(ms, &nb_per, &nslots, (double)D.elems() * sizeof(double));
+  batch_plan(ms, &nb_per, &nslots, mat_bytes((double)D.elems()));
   std::vector<Slot> slots;
   make_slots(slots, nslots, nb_per, D.elems(), D.NC);
   Buf<double> out((size_t)ms * nrhs);
@@ -595,6 +607,7 @@ void drain_after_error() {
 // posterior handle
 // ------------------------------------------------------------------------------------------------
 struct lmm_post {
+  int f32 = 0;                // compute dtype the state was built in (its matrices are float buffers when 1)
   int kind = 0;               // 0: per-latent (OILMM / MOGP), 1: dense ILMM
   int n = 0, d = 0, l0 = 0, l1 = 0, m = 0;
   int NC = 0, NR = 0, ld = 0;
@@ -781,6 +794,14 @@ int lmm_comm_destroy(void) {
   return LMM_OK;
   LMM_CATCH
 }
+
+int lmm_set_compute_dtype(int dtype) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (dtype != LMM_F64 && dtype != LMM_F32) return fail(LMM_ERR_ARG, "dtype must be LMM_F64 or LMM_F32");
+  g_f32 = (dtype == LMM_F32) ? 1 : 0;
+  return LMM_OK;
+}
+int lmm_get_compute_dtype(void) { return g_f32 ? LMM_F32 : LMM_F64; }
 
 int lmm_device_synchronize(void) {
   std::lock_guard<std::mutex> lk(g_mu);
@@ -1087,6 +1108,7 @@ int lmm_oilmm_logpdf_grad(const double* x, int d, int n, const double* y, int p,
   std::lock_guard<std::mutex> lk(g_mu);
   REQUIRE_INIT();
   LMM_TRY
+  REQUIRE_F64("the OILMM gradient");
   if (!x || !y || !U || !S || !out_logpdf || d <= 0 || n <= 0 || p <= 0 || m <= 0) return fail(LMM_ERR_ARG, "bad arguments");
   if (m > p) return fail(LMM_ERR_DIM, "out dim of x != out dim of f.");
   if (latent_begin < 0 || latent_end > m || latent_begin > latent_end) return fail(LMM_ERR_ARG, "bad latent shard");
@@ -1118,6 +1140,7 @@ int lmm_oilmm_post_logpdf_grad(const double* x, int d, int n, const double* y, c
   std::lock_guard<std::mutex> lk(g_mu);
   REQUIRE_INIT();
   LMM_TRY
+  REQUIRE_F64("the predictive-logpdf gradient");
   if (!x || !y || !xs || !ys || !U || !S || !out_logpdf || d <= 0 || n <= 0 || ns <= 0 || p <= 0 || m <= 0)
     return fail(LMM_ERR_ARG, "bad arguments");
   if (m > p) return fail(LMM_ERR_DIM, "out dim of x != out dim of f.");
@@ -1345,6 +1368,7 @@ int lmm_ilmm_logpdf_ex(const double* x, int d, int n, const double* y, int p, co
     *out = total + regulariser(resid);
     return LMM_OK;
   }
+  REQUIRE_F64("the dense (mn) x (mn) ILMM factorisation");
   project_on_device(yd.p, n, p, Td.buf, m, 0, m, meansd.buf.p, delta.p, st0);
   // one dense (mn) x (mn) factorisation: reference src/ilmm.jl:160-162
   const int N = m * n;
@@ -1387,6 +1411,7 @@ int lmm_ilmm_logpdf_grad(const double* x, int d, int n, const double* y, int p, 
   std::lock_guard<std::mutex> lk(g_mu);
   REQUIRE_INIT();
   LMM_TRY
+  REQUIRE_F64("the dense-H ILMM gradient");
   if (!x || !y || !H || !out_logpdf || d <= 0 || n <= 0 || p <= 0 || m <= 0) return fail(LMM_ERR_ARG, "bad arguments");
   if (int rc = check_gps(gps, m)) return rc;
   if (!(sigma2 > 0.0)) return fail(LMM_ERR_ARG, "sigma2 must be > 0");
@@ -1566,7 +1591,7 @@ static int posterior_create_common(const double* xd, int d, int n, const lmm_gp_
   lmm_post* P = new lmm_post();
   try {
     Dims D(n, 1);
-    P->kind = 0; P->n = n; P->d = d; P->l0 = l0; P->l1 = l1; P->m = m;
+    P->kind = 0; P->f32 = g_f32; P->n = n; P->d = d; P->l0 = l0; P->l1 = l1; P->m = m;
     P->NC = D.NC; P->NR = D.NR; P->ld = D.ld;
     P->gps.assign(gps, gps + m);
     P->x = Buf<double>((size_t)d * n);
@@ -1574,10 +1599,10 @@ static int posterior_create_common(const double* xd, int d, int n, const lmm_gp_
     Buf<int> info(std::max(ms, 1));
     HIPCHK(hipMemsetAsync(info.p, 0, std::max(ms, 1) * sizeof(int), g.streams[0]));
     int nb_per = 1, nslots = 1;
-    batch_plan(std::max(ms, 1), &nb_per, &nslots, (double)D.elems() * sizeof(double));
+    batch_plan(std::max(ms, 1), &nb_per, &nslots, mat_bytes((double)D.elems()));
     for (int k = 0; k < ms; ++k) {
-      P->L.emplace_back((size_t)D.elems());
-      P->W.emplace_back((size_t)(D.NC / 64) * 4096);
+      P->L.emplace_back(mat_count((size_t)D.elems()));
+      P->W.emplace_back(mat_count((size_t)(D.NC / 64) * 4096));
       P->alpha.emplace_back((size_t)D.NC);
       P->z.emplace_back((size_t)D.NC);
     }
@@ -1661,6 +1686,7 @@ int lmm_post_condition(const lmm_post_t* post, const double* U, const double* S,
   std::lock_guard<std::mutex> lk(g_mu);
   REQUIRE_INIT();
   LMM_TRY
+  if (post && post->f32 != g_f32) return fail(LMM_ERR_ARG, "posterior handle was built in the other compute dtype (lmm_set_compute_dtype)");
   if (!post || !U || !S || !x2 || !y2 || !out || d <= 0 || n2 <= 0) return fail(LMM_ERR_ARG, "bad arguments");
   const lmm_post* P = post;
   if (P->kind != 0) return fail(LMM_ERR_UNSUPPORTED, "sequential conditioning of the dense-H posterior is not built");
@@ -1768,6 +1794,7 @@ int lmm_ilmm_posterior_create(const double* x, int d, int n, const double* y, in
   std::lock_guard<std::mutex> lk(g_mu);
   REQUIRE_INIT();
   LMM_TRY
+  REQUIRE_F64("the dense-H ILMM posterior");
   if (!x || !y || !H || !out || d <= 0 || n <= 0 || p <= 0 || m <= 0) return fail(LMM_ERR_ARG, "bad arguments");
   if (int rc = check_gps(gps, m)) return rc;
   if (!jit) jit = &kDefaultJit;
@@ -1793,6 +1820,7 @@ int lmm_ilmm_post_condition(const lmm_post_t* post, double sigma2, const double*
   std::lock_guard<std::mutex> lk(g_mu);
   REQUIRE_INIT();
   LMM_TRY
+  REQUIRE_F64("the dense-H ILMM posterior");
   if (!post || !x2 || !y2 || !out || d <= 0 || n2 <= 0) return fail(LMM_ERR_ARG, "bad arguments");
   const lmm_post* P = post;
   if (P->kind != 1) return fail(LMM_ERR_ARG, "not a dense-H ILMM posterior");
@@ -1828,6 +1856,7 @@ int lmm_ilmm_post_mean_and_var(const lmm_post_t* post, double sigma2, const doub
   std::lock_guard<std::mutex> lk(g_mu);
   REQUIRE_INIT();
   LMM_TRY
+  REQUIRE_F64("the dense-H ILMM posterior");
   if (!post || !xs || !mean_out || !var_out || d <= 0 || ns <= 0) return fail(LMM_ERR_ARG, "bad arguments");
   const lmm_post* P = post;
   if (P->kind != 1) return fail(LMM_ERR_ARG, "not a dense-H ILMM posterior");
@@ -1880,6 +1909,7 @@ int lmm_ilmm_post_mean_and_cov(const lmm_post_t* post, double sigma2, const doub
   std::lock_guard<std::mutex> lk(g_mu);
   REQUIRE_INIT();
   LMM_TRY
+  REQUIRE_F64("the dense-H ILMM posterior");
   if (!post || !xs || !mean_out || !cov_out || d <= 0 || ns <= 0) return fail(LMM_ERR_ARG, "bad arguments");
   const lmm_post* P = post;
   if (P->kind != 1) return fail(LMM_ERR_ARG, "not a dense-H ILMM posterior");
@@ -1913,6 +1943,7 @@ int lmm_ilmm_post_logpdf(const lmm_post_t* post, double sigma2, const double* xs
   std::lock_guard<std::mutex> lk(g_mu);
   REQUIRE_INIT();
   LMM_TRY
+  REQUIRE_F64("the dense-H ILMM posterior");
   if (!post || !xs || !ys || !out || d <= 0 || ns <= 0) return fail(LMM_ERR_ARG, "bad arguments");
   const lmm_post* P = post;
   if (P->kind != 1) return fail(LMM_ERR_ARG, "not a dense-H ILMM posterior");
@@ -1958,6 +1989,7 @@ int lmm_ilmm_post_rand(const lmm_post_t* post, double sigma2, int add_noise, con
   std::lock_guard<std::mutex> lk(g_mu);
   REQUIRE_INIT();
   LMM_TRY
+  REQUIRE_F64("the dense-H ILMM posterior");
   if (!post || !xs || !z_lat || !out || d <= 0 || ns <= 0 || (add_noise && !eps)) return fail(LMM_ERR_ARG, "bad arguments");
   const lmm_post* P = post;
   if (P->kind != 1) return fail(LMM_ERR_ARG, "not a dense-H ILMM posterior");
@@ -2033,11 +2065,11 @@ static int latent_marginals_dev(const lmm_post* P, const lmm_gp_t* gps_shard, in
   const int nsr = rup(ns, 64);
   int ldr = nsr; if ((ldr % 512) == 0) ldr += 16;
   int nb_per = 1, nslots = 1;
-  batch_plan(ms, &nb_per, &nslots, (double)ldr * P->NC * sizeof(double));
+  batch_plan(ms, &nb_per, &nslots, mat_bytes((double)ldr * P->NC));
   std::vector<std::vector<Buf<double>>> R(nslots);
   std::vector<Buf<double>> part;
   for (int s = 0; s < nslots; ++s) {
-    for (int j = 0; j < nb_per; ++j) R[s].emplace_back((size_t)ldr * P->NC);
+    for (int j = 0; j < nb_per; ++j) R[s].emplace_back(mat_count((size_t)ldr * P->NC));
     part.emplace_back(strip_partial_elems(nsr, P->NC, 2));
   }
   fork_slots(nslots);
@@ -2072,6 +2104,7 @@ int lmm_latent_marginals(const lmm_post_t* post, const lmm_gp_t* gps, int m_shar
   std::lock_guard<std::mutex> lk(g_mu);
   REQUIRE_INIT();
   LMM_TRY
+  if (post && post->f32 != g_f32) return fail(LMM_ERR_ARG, "posterior handle was built in the other compute dtype (lmm_set_compute_dtype)");
   if (!xs || !mean_lat || !var_lat || d <= 0 || ns <= 0) return fail(LMM_ERR_ARG, "bad arguments");
   if (post && post->kind != 0) return fail(LMM_ERR_UNSUPPORTED, "per-latent marginals of the dense-H posterior (coupled latents): use lmm_ilmm_post_mean_and_var");
   const int ms = post ? (post->l1 - post->l0) : m_shard;
@@ -2092,6 +2125,7 @@ int lmm_oilmm_mean_and_var(const lmm_post_t* post, const lmm_gp_t* gps, const do
   std::lock_guard<std::mutex> lk(g_mu);
   REQUIRE_INIT();
   LMM_TRY
+  if (post && post->f32 != g_f32) return fail(LMM_ERR_ARG, "posterior handle was built in the other compute dtype (lmm_set_compute_dtype)");
   if (!U || !xs || !mean_out || d <= 0 || ns <= 0 || p <= 0 || m <= 0) return fail(LMM_ERR_ARG, "bad arguments");
   if (post && post->kind != 0) return fail(LMM_ERR_UNSUPPORTED, "dense-H posterior handle: use lmm_ilmm_post_mean_and_var");
   if (!jit) jit = &kDefaultJit;
@@ -2108,7 +2142,10 @@ int lmm_oilmm_mean_and_var(const lmm_post_t* post, const lmm_gp_t* gps, const do
   Uploaded Hd(Hs, st0);
   DevIn xsd(xs, (size_t)d * ns, st0);
   Buf<double> ml((size_t)ns * std::max(ms, 1)), vl((size_t)ns * std::max(ms, 1));
-  if (var_out == nullptr) {
+  // fp32 mode: mu + K(x*, x) alpha is a cancelling sum over weights alpha = Kt^-1 delta whose Float32-factor error is amplified
+  // (cond x eps x |alpha|); the rider form mu + R' (L^-1 delta) of the full path is stable, so posterior means take that path
+  const bool mean_only = var_out == nullptr && !(g_f32 && post);
+  if (mean_only) {
     // mean only (AbstractGPs.mean(fx), reference src/ilmm.jl:142 -> mean_and_var(fx)[1]): the posterior latent means are
     // mu + K(x*, x) alpha -- n n* kernel evaluations, no triangular solve (the reference pays for the variances it discards)
     if (post && post->d != d) return fail(LMM_ERR_DIM, "input dimension mismatch: posterior has d=%d, xs has d=%d", post->d, d);
@@ -2128,7 +2165,7 @@ int lmm_oilmm_mean_and_var(const lmm_post_t* post, const lmm_gp_t* gps, const do
   DevOut mo(mean_out, (size_t)ns * p), vo(var_out, (size_t)ns * p);
   // reference src/oilmm.jl:69,72: M = H M_latent;  V = abs2.(H) V_latent .+ sigma2   (V_latent carries the 1e-18 jitter)
   launch_mix(ml.p, ns, ms, Hd.buf.p, p, 1, 0.0, 0.0, nullptr, 0.0, mo.p, st0);
-  launch_mix(vl.p, ns, ms, Hd.buf.p, p, 2, jit->default_jitter, add_noise ? sigma2 : 0.0, nullptr, 0.0, vo.p, st0);
+  if (var_out) launch_mix(vl.p, ns, ms, Hd.buf.p, p, 2, jit->default_jitter, add_noise ? sigma2 : 0.0, nullptr, 0.0, vo.p, st0);
   mo.finish(st0); vo.finish(st0);
   HIPCHK(hipStreamSynchronize(st0));
   return LMM_OK;
@@ -2175,13 +2212,13 @@ struct XsSlots {
   XsSlots(const lmm_post* P, int ms, int ns, const Dims& Ds) {
     nsr = rup(ns, 64);
     ldr = nsr; if ((ldr % 512) == 0) ldr += 16;
-    batch_plan(std::max(ms, 1), &nb_per, &nslots, ((double)Ds.elems() + (P ? (double)ldr * P->NC : 0.0)) * sizeof(double));
+    batch_plan(std::max(ms, 1), &nb_per, &nslots, mat_bytes((double)Ds.elems() + (P ? (double)ldr * P->NC : 0.0)));
     B.resize(nslots); WB.resize(nslots); mu.resize(nslots); rid.resize(nslots); R.resize(nslots);
     for (int s = 0; s < nslots; ++s) {
       for (int j = 0; j < nb_per; ++j) {
-        B[s].emplace_back(Ds.elems()); WB[s].emplace_back((size_t)(Ds.NC / 64) * 4096);
+        B[s].emplace_back(mat_count(Ds.elems())); WB[s].emplace_back(mat_count((size_t)(Ds.NC / 64) * 4096));
         mu[s].emplace_back((size_t)ns); rid[s].emplace_back((size_t)ns);
-        R[s].emplace_back(P ? (size_t)ldr * P->NC : 1);
+        R[s].emplace_back(P ? mat_count((size_t)ldr * P->NC) : 1);
       }
       part.emplace_back(std::max(strip_partial_elems(nsr, P ? P->NC : 1, 1), strip_partial_elems(ns, ns, 1)));
     }
@@ -2207,6 +2244,7 @@ extern "C" int lmm_lmm_mean_and_cov(const lmm_post_t* post, const lmm_gp_t* gps,
   std::lock_guard<std::mutex> lk(g_mu);
   REQUIRE_INIT();
   LMM_TRY
+  REQUIRE_F64("the full covariance");
   if (!U || !xs || !mean_out || !cov_out || d <= 0 || ns <= 0 || p <= 0 || m <= 0) return fail(LMM_ERR_ARG, "bad arguments");
   if ((double)p * ns * (double)p * ns > 4e8) return fail(LMM_ERR_UNSUPPORTED, "full covariance (p*ns)^2 too large");
   if (!jit) jit = &kDefaultJit;
@@ -2267,6 +2305,7 @@ int lmm_oilmm_post_logpdf(const lmm_post_t* post, const double* U, const double*
   std::lock_guard<std::mutex> lk(g_mu);
   REQUIRE_INIT();
   LMM_TRY
+  if (post && post->f32 != g_f32) return fail(LMM_ERR_ARG, "posterior handle was built in the other compute dtype (lmm_set_compute_dtype)");
   if (!post || !U || !S || !xs || !ys || !out || d <= 0 || ns <= 0) return fail(LMM_ERR_ARG, "bad arguments");
   const lmm_post* P = post;
   if (P->kind != 0) return fail(LMM_ERR_UNSUPPORTED, "dense-H posterior handle: use lmm_ilmm_post_logpdf");
@@ -2344,6 +2383,7 @@ int lmm_lmm_rand_multi(const lmm_post_t* post, const lmm_gp_t* gps, const double
   std::lock_guard<std::mutex> lk(g_mu);
   REQUIRE_INIT();
   LMM_TRY
+  if (post && post->f32 != g_f32) return fail(LMM_ERR_ARG, "posterior handle was built in the other compute dtype (lmm_set_compute_dtype)");
   if (!U || !xs || !z_lat || !out || d <= 0 || ns <= 0 || p <= 0 || m <= 0 || nsamples <= 0) return fail(LMM_ERR_ARG, "bad arguments");
   if (add_noise && !eps) return fail(LMM_ERR_ARG, "eps is NULL");
   if (!jit) jit = &kDefaultJit;

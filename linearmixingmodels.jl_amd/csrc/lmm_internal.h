@@ -3,7 +3,8 @@
 #include <hip/hip_runtime.h>
 #include "../../include/lmm_hip.h"
 
-#define LMM_MAX_BATCH 8
+extern int g_f32;              // compute dtype of the matrices: 0 = Float64, 1 = Float32 (lmm_kernels.hip)
+#define LMM_MAX_BATCH 32
 struct BatchPtr { double* p[LMM_MAX_BATCH]; };   // base pointers of the matrices of one batch (kernel argument, by value)
 struct BatchInfo { int* p[LMM_MAX_BATCH]; };
 

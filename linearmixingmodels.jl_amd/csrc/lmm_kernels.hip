@@ -25,6 +25,41 @@ __device__ __forceinline__ d2 mk2(double x, double y) { d2 v; v.x = x; v.y = y; 
 #define LOG2PI 1.8378770664093453
 
 // ---------------------------------------------------------------------------------------------------
+// Storage type of MATRICES (factor matrices, inverse diagonal blocks, cross-solve blocks): double, or float for the fp32
+// compute mode (BASELINE configs[4]; lmm_set_compute_dtype).  Vectors (inputs, observations, normals, alpha, outputs) and all
+// scalar arithmetic outside the MFMA update stay double in both modes.  Element indices are in elements of TS.
+// ---------------------------------------------------------------------------------------------------
+template <typename TS> struct MatIO;
+template <> struct MatIO<double> {
+  static __device__ __forceinline__ double ld1(const void* b, size_t i) { return reinterpret_cast<const double*>(b)[i]; }
+  static __device__ __forceinline__ void st1(void* b, size_t i, double v) { reinterpret_cast<double*>(b)[i] = v; }
+  static __device__ __forceinline__ void st2(void* b, size_t i, d2 v) { *reinterpret_cast<d2*>(reinterpret_cast<double*>(b) + i) = v; }
+  static __device__ __forceinline__ void ld4(const void* b, size_t i, double* o) {
+    const d2* q = reinterpret_cast<const d2*>(reinterpret_cast<const double*>(b) + i);
+    const d2 u = q[0], v = q[1];
+    o[0] = u.x; o[1] = u.y; o[2] = v.x; o[3] = v.y;
+  }
+  static __device__ __forceinline__ void st4(void* b, size_t i, const double* v) {
+    d2* q = reinterpret_cast<d2*>(reinterpret_cast<double*>(b) + i);
+    q[0] = mk2(v[0], v[1]); q[1] = mk2(v[2], v[3]);
+  }
+};
+template <> struct MatIO<float> {
+  static __device__ __forceinline__ double ld1(const void* b, size_t i) { return (double)reinterpret_cast<const float*>(b)[i]; }
+  static __device__ __forceinline__ void st1(void* b, size_t i, double v) { reinterpret_cast<float*>(b)[i] = (float)v; }
+  static __device__ __forceinline__ void st2(void* b, size_t i, d2 v) {
+    *reinterpret_cast<float2*>(reinterpret_cast<float*>(b) + i) = make_float2((float)v.x, (float)v.y);
+  }
+  static __device__ __forceinline__ void ld4(const void* b, size_t i, double* o) {
+    const float4 u = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(b) + i);
+    o[0] = u.x; o[1] = u.y; o[2] = u.z; o[3] = u.w;
+  }
+  static __device__ __forceinline__ void st4(void* b, size_t i, const double* v) {
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(b) + i) = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------
 // math helpers
 // ---------------------------------------------------------------------------------------------------
 // exp(x) for x <= 0, Float64, < 1 ulp-ish: Cody-Waite reduction + degree-13 Taylor on |r| <= ln2/2
@@ -108,6 +143,17 @@ __device__ __forceinline__ double sqrt_dist(double x) {
   return (x > 1e-300) ? r : 0.0;
 }
 
+// 16-byte store of two consecutive rows of a Gram column.  LMM_GRAM_NT: non-temporal (streaming) store -- the factor matrix is
+// next touched by the factorisation's first update, long after it left L2.
+template <typename TS>
+__device__ __forceinline__ void gram_store(void* base, size_t idx, d2 v) {
+#ifdef LMM_GRAM_NT
+  __builtin_nontemporal_store(v, reinterpret_cast<d2*>(reinterpret_cast<double*>(base) + idx));
+#else
+  MatIO<TS>::st2(base, idx, v);
+#endif
+}
+
 template <int KIND>
 __device__ __forceinline__ double kappa_t(double var, double r, double r2) {
 #ifdef LMM_ABLATE_NOMATH
@@ -122,6 +168,7 @@ __device__ __forceinline__ double kappa_t(double var, double r, double r2) {
   return var * __builtin_fma(5.0 / 3.0, r2, 1.0 + s) * exp_nonpos(-s);
 }
 
+template <typename TS>
 __device__ __forceinline__ void gram_tile_generic(const GramArgs& a, int ti, int tj) {
   const int t = threadIdx.x;
   const int i0 = ti * 64 + 2 * (t & 31);
@@ -170,7 +217,7 @@ __device__ __forceinline__ void gram_tile_generic(const GramArgs& a, int ti, int
       }
       v.x = out[0]; v.y = out[1];
     }
-    *reinterpret_cast<d2*>(a.A + (size_t)j * a.ld + (i0 - a.row_shift)) = v;
+    MatIO<TS>::st2(a.A, (size_t)j * a.ld + (i0 - a.row_shift), v);
   }
 }
 
@@ -204,7 +251,7 @@ __device__ __forceinline__ double exp_any(double x) {
 // column factors), so the per-element cost drops from a full exp (~20 f64 ops) to 2 multiplies and a min; the 4 row and
 // 2 x 64 column exponentials are amortised over 64 elements per thread.  Guard: |a (x - c)| <= 40 inside the strip (else
 // the direct per-element exp is used, e.g. for unsorted inputs).  Relative error of the product form <= ~1e-14.
-template <int KIND, bool ND>      // ND: the 1 < d <= 8 fast path is compiled in (kept out of the d == 1 kernel's register budget)
+template <int KIND, bool ND, typename TS>      // ND: the 1 < d <= 8 fast path is compiled in (kept out of the d == 1 kernel's register budget)
 __device__ __forceinline__ void gram_body(const GramArgs& a) {
   constexpr int DMAX = 8;                                     // input dimensions with a fast path (d > DMAX: generic tiles)
   __shared__ double colE[64], colF[64], colX[64];
@@ -246,7 +293,7 @@ __device__ __forceinline__ void gram_body(const GramArgs& a) {
     if (tj * 64 >= a.ncols) break;
     if (!a.full && ti < tj) break;                          // lower tiles only
     const bool cols_in = (tj * 64 + 63 < a.n);
-    double* out = a.A + (size_t)(tj * 64 + cg) * a.ld + (i0 - a.row_shift);
+    const size_t out = (size_t)(tj * 64 + cg) * a.ld + (i0 - a.row_shift);      // element index of this thread's first store
     if (ND && rows_nd && cols_in) {                         // d > 1 interior tile: column points staged (pre-scaled) in LDS
       __syncthreads();
       for (int e = t; e < 64 * a.d; e += 256) colP[e] = a.x[(size_t)tj * 64 * a.d + e] * a.inv_ls;
@@ -273,12 +320,12 @@ __device__ __forceinline__ void gram_body(const GramArgs& a) {
           if (i0 == j) v.x += da;
           if (i0 + 1 == j) v.y += da;
         }
-        *reinterpret_cast<d2*>(out + (size_t)(8 * q) * a.ld) = v;
+        gram_store<TS>(a.A, out + (size_t)(8 * q) * a.ld, v);
       }
       continue;
     }
     const bool interior = rows_interior && cols_in;
-    if (!interior) { gram_tile_generic(a, ti, tj); continue; }
+    if (!interior) { gram_tile_generic<TS>(a, ti, tj); continue; }
     bool sep = false;
     if (SEP) {
       __syncthreads();                                      // previous tile's readers are done with colE/colF/colX
@@ -316,7 +363,7 @@ __device__ __forceinline__ void gram_body(const GramArgs& a) {
           if (i0 == j) v.x += da;
           if (i0 + 1 == j) v.y += da;
         }
-        *reinterpret_cast<d2*>(out + (size_t)(8 * q) * a.ld) = v;
+        gram_store<TS>(a.A, out + (size_t)(8 * q) * a.ld, v);
       }
     } else {
       const double* xc = a.x + tj * 64 + cg;
@@ -333,21 +380,21 @@ __device__ __forceinline__ void gram_body(const GramArgs& a) {
           if (i0 == j) v.x += da;
           if (i0 + 1 == j) v.y += da;
         }
-        *reinterpret_cast<d2*>(out + (size_t)(8 * q) * a.ld) = v;
+        gram_store<TS>(a.A, out + (size_t)(8 * q) * a.ld, v);
       }
     }
   }
 }
 
-template <int KIND, bool ND>
-__global__ __launch_bounds__(256) void gram_kernel(GramArgs a) { gram_body<KIND, ND>(a); }
+template <int KIND, bool ND, typename TS>
+__global__ __launch_bounds__(256) void gram_kernel(GramArgs a) { gram_body<KIND, ND, TS>(a); }
 
-template <int KIND, bool ND>
+template <int KIND, bool ND, typename TS>
 __global__ __launch_bounds__(256) void gram_batch_kernel(GramBatchArgs b) {
   GramArgs a = b.base;
   const int z = blockIdx.z;
   a.A = b.A[z]; a.var = b.var[z]; a.inv_ls = b.inv_ls[z]; a.diag_add = b.diag_add[z]; a.diag_vec = b.diag_vec[z]; a.rider = b.rider[z]; a.rider_sub = b.rider_sub[z];
-  gram_body<KIND, ND>(a);
+  gram_body<KIND, ND, TS>(a);
 }
 
 // K8: dense ILMM latent covariance  blockdiag(K_1..K_m) + SigmaT (x) I_n  (+ mean-free rider row):
@@ -468,10 +515,11 @@ __global__ void dense_var_finish_kernel(const double* __restrict__ partial, int 
 // W part; every thread factors the 4x4 pivot block P = Lp Lp' redundantly, forms y = B Lp^-T for its four rows (the final L
 // entries in these columns) and the multipliers m = y Lp^-1, and applies one rank-4 update to its 16 + 16 register values.
 // Rows inside the block finish their W rows as Lp^-1 Wtop.  s holds L sqrt(d), w holds sqrt(d) L^-1, dd the pivots.
+template <typename TS>
 __global__ __launch_bounds__(256) void diag64_kernel(BatchPtr Ab, size_t offA, int ld, BatchPtr Wb, size_t offW,
                                                      int gcol0, int n_real, BatchInfo infob) {
-  double* __restrict__ A = Ab.p[blockIdx.x] + offA;
-  double* __restrict__ W = Wb.p[blockIdx.x] + offW;
+  void* __restrict__ A = Ab.p[blockIdx.x];        // element offsets offA / offW are applied in units of TS
+  void* __restrict__ W = Wb.p[blockIdx.x];
   int* __restrict__ info = infob.p[blockIdx.x];
   __shared__ __attribute__((aligned(16))) double cb[2][4][64];     // raw columns J..J+3 (all rows)
   __shared__ __attribute__((aligned(16))) double cm[2][4][64];     // the same, zero for rows <= J+3
@@ -482,10 +530,8 @@ __global__ __launch_bounds__(256) void diag64_kernel(BatchPtr Ab, size_t offA, i
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const int k = 4 * b + c;
-    const d2* src = reinterpret_cast<const d2*>(A + (size_t)k * ld + 4 * a);
-    d2 v0 = mk2(0.0, 0.0), v1 = v0;
-    if (a >= b) { v0 = src[0]; v1 = src[1]; }
-    const double col[4] = {v0.x, v0.y, v1.x, v1.y};
+    double col[4] = {0.0, 0.0, 0.0, 0.0};
+    if (a >= b) MatIO<TS>::ld4(A, offA + (size_t)k * ld + 4 * a, col);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       s[r][c] = (4 * a + r >= k) ? col[r] : 0.0;
@@ -610,14 +656,12 @@ __global__ __launch_bounds__(256) void diag64_kernel(BatchPtr Ab, size_t offA, i
       wo[r] = (i >= k) ? w[r][c] * rsr[r] : 0.0;
     }
     if (a > b) {
-      d2* o = reinterpret_cast<d2*>(A + (size_t)k * ld + 4 * a);
-      o[0] = mk2(ao[0], ao[1]); o[1] = mk2(ao[2], ao[3]);
+      MatIO<TS>::st4(A, offA + (size_t)k * ld + 4 * a, ao);
     } else if (a == b) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) if (r >= c) A[(size_t)k * ld + 4 * a + r] = ao[r];
+      for (int r = 0; r < 4; ++r) if (r >= c) MatIO<TS>::st1(A, offA + (size_t)k * ld + 4 * a + r, ao[r]);
     }
-    d2* ow = reinterpret_cast<d2*>(W + k * 64 + 4 * a);
-    ow[0] = mk2(wo[0], wo[1]); ow[1] = mk2(wo[2], wo[3]);
+    MatIO<TS>::st4(W, offW + (size_t)k * 64 + 4 * a, wo);
   }
 }
 
@@ -640,6 +684,52 @@ __global__ __launch_bounds__(256) void diag64_kernel(BatchPtr Ab, size_t offA, i
 #ifdef LMM_CLOCK_PROBE
 __device__ unsigned long long g_clk_probe[4];     // tools/gemm_ablate: shader-clock vs 100 MHz real-time ticks of one tile
 #endif
+
+// Work item -> (tile, k-part) of the update kernels (shared by the f64 and f32 variants).
+__device__ __forceinline__ void gemm_work_item(int BM, int BN, int N, int lower, int MT, int full_items, int splitk, int& part,
+                                               int& nparts, int& ti, int& tj) {
+  // Work item -> (tile, k-part).  Tiles on/below the diagonal are enumerated column by column; the first
+  // `full_items` tiles run their whole K range, the remaining ones (the last, partial round of workgroups over the
+  // chip) are split `splitk`-ways along K and combined with f64 atomics, so the launch ends without a long tail.
+  int tile = blockIdx.x;
+  part = 0; nparts = 1;
+  {
+    // XCD-aware order (speed only): workgroups are dealt round-robin over the 8 XCDs, so workgroup 8q + g runs on the XCD
+    // of group g.  Give group g the contiguous logical tiles [32g, 32g + 32) of every round of 256: with bands of 8 row
+    // tiles that is an 8-row x 4-column patch of C per XCD (12 operand panels through that XCD's L2 instead of 18+;
+    // measured FETCH_SIZE of the K = 8192 SYRK: 11.9 -> 7.3 GB; 64-tile patches measured no better).
+    const int nfull = (full_items / 256) * 256;
+    if (tile < nfull) {
+      const int g8 = tile & 7, q = tile >> 3;
+      tile = (q >> 5) * 256 + g8 * 32 + (q & 31);
+    }
+  }
+  if (tile >= full_items) {
+    const int r = tile - full_items;
+    tile = full_items + r / splitk; part = r - (r / splitk) * splitk; nparts = splitk;
+  }
+  // Tile order: bands of 8 row tiles, column-major inside a band, so that the ~256 tiles in flight form a compact
+  // 8 x 32 patch of C (40 operand panels instead of ~68 for plain column-major order) and 32 consecutive logical
+  // tiles are an 8 x 4 patch (see the XCD remap above): fewer re-reads of A/B.
+  tj = 0; ti = 0;
+  {
+    const int NTc = (N + BN - 1) / BN;
+    int rem = tile;
+    for (int r0 = 0; r0 < MT; r0 += 8) {
+      const int r1 = (r0 + 8 < MT) ? r0 + 8 : MT;             // band rows [r0, r1)
+      bool found = false;
+      for (int c = 0; c < NTc; ++c) {
+        int first = lower ? (c * BN) / BM : 0;                 // first active row tile of column c
+        if (first < r0) first = r0;
+        const int cnt = r1 - first;
+        if (cnt <= 0) break;                                   // columns further right are above the diagonal for this band
+        if (rem < cnt) { tj = c; ti = first + rem; found = true; break; }
+        rem -= cnt;
+      }
+      if (found) break;
+    }
+  }
+}
 
 // ---- LDS-flag synchronisation (FLAGS variant of gemm44_kernel) ----------------------------------------------------------
 // s_barrier makes the four waves of a workgroup meet once per k-stage, so every stage pays the arrival skew of waves whose
@@ -688,46 +778,8 @@ __global__ __launch_bounds__(256, 2) void gemm44_kernel(BatchPtr Cb, size_t goff
   __shared__ unsigned sync_cnt[FLAGS ? 2 : 1];          // FLAGS: [0] stages published, [1] stages retired (x 4 waves)
   if (FLAGS && threadIdx.x == 0) { sync_cnt[0] = 0; sync_cnt[1] = 0; }        // visible after the prologue barrier
 
-  // Work item -> (tile, k-part).  Tiles on/below the diagonal are enumerated column by column; the first
-  // `full_items` tiles run their whole K range, the remaining ones (the last, partial round of workgroups over the
-  // chip) are split `splitk`-ways along K and combined with f64 atomics, so the launch ends without a long tail.
-  int tile = blockIdx.x, part = 0, nparts = 1;
-  {
-    // XCD-aware order (speed only): workgroups are dealt round-robin over the 8 XCDs, so workgroup 8q + g runs on the XCD
-    // of group g.  Give group g the contiguous logical tiles [32g, 32g + 32) of every round of 256: with bands of 8 row
-    // tiles that is an 8-row x 4-column patch of C per XCD (12 operand panels through that XCD's L2 instead of 18+;
-    // measured FETCH_SIZE of the K = 8192 SYRK: 11.9 -> 7.3 GB; 64-tile patches measured no better).
-    const int nfull = (full_items / 256) * 256;
-    if (tile < nfull) {
-      const int g8 = tile & 7, q = tile >> 3;
-      tile = (q >> 5) * 256 + g8 * 32 + (q & 31);
-    }
-  }
-  if (tile >= full_items) {
-    const int r = tile - full_items;
-    tile = full_items + r / splitk; part = r - (r / splitk) * splitk; nparts = splitk;
-  }
-  // Tile order: bands of 8 row tiles, column-major inside a band, so that the ~256 tiles in flight form a compact
-  // 8 x 32 patch of C (40 operand panels instead of ~68 for plain column-major order) and 32 consecutive logical
-  // tiles are an 8 x 4 patch (see the XCD remap above): fewer re-reads of A/B.
-  int tj = 0, ti = 0;
-  {
-    const int NTc = (N + BN - 1) / BN;
-    int rem = tile;
-    for (int r0 = 0; r0 < MT; r0 += 8) {
-      const int r1 = (r0 + 8 < MT) ? r0 + 8 : MT;             // band rows [r0, r1)
-      bool found = false;
-      for (int c = 0; c < NTc; ++c) {
-        int first = lower ? (c * BN) / BM : 0;                 // first active row tile of column c
-        if (first < r0) first = r0;
-        const int cnt = r1 - first;
-        if (cnt <= 0) break;                                   // columns further right are above the diagonal for this band
-        if (rem < cnt) { tj = c; ti = first + rem; found = true; break; }
-        rem -= cnt;
-      }
-      if (found) break;
-    }
-  }
+  int part = 0, nparts = 1, tj = 0, ti = 0;
+  gemm_work_item(BM, BN, N, lower, MT, full_items, splitk, part, nparts, ti, tj);
   const int bm = ti * BM, bn = tj * BN;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int wr = (w & 1) * 64, wc = (w >> 1) * WN;
@@ -940,18 +992,145 @@ __global__ __launch_bounds__(256, 2) void gemm44_kernel(BatchPtr Cb, size_t goff
 }
 
 // ---------------------------------------------------------------------------------------------------
+// K2b (fp32 compute mode): the same C {-=, =} A B' on v_mfma_f32_32x32x2_f32 (exact f32, 64 FLOP/clk/SIMD = 157 TFLOP/s peak:
+// twice the FP64 matrix rate; MI355X_MICROARCH.md "Matrix cores").  128 x BN block tile, 4 waves (2 x 2), wave tile
+// 64 x BN/2 as 32x32 MFMA blocks, BK = 16, two LDS stages, one barrier per stage, k-major LDS image (a k-column of the
+// tile is one contiguous 512-byte global segment; a fragment read is one conflict-free ds_read_b32: 32 consecutive floats
+// per half-wave).  The MFMA's A operand is fed from the B matrix and its B operand from the A matrix, so the result comes
+// out transposed: the lane index of D runs along the ROWS of C (contiguous in memory) and the read-modify-write epilogue is
+// coalesced 128-byte segments without an LDS transpose:
+//     acc[tv][tu][r] (lane l)  <->  C[bm + wr + 32 tu + (l & 31),  bn + wc + 32 tv + (r & 3) + 8 (r >> 2) + 4 (l >> 5)].
+// ---------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int BN, bool SET>
+__global__ __launch_bounds__(256, 2) void gemm32_kernel(BatchPtr Cb, size_t goffC, int ldc, BatchPtr Ab, size_t goffA, int lda,
+                                                         BatchPtr Bb, size_t goffB, int ldb,
+                                                         int M, int N, int K, int lower, int MT, int full_items,
+                                                         int splitk, int kfrom_row) {
+  float* C = reinterpret_cast<float*>(Cb.p[blockIdx.y]) + goffC;
+  const float* A = reinterpret_cast<const float*>(Ab.p[blockIdx.y]) + goffA;
+  const float* B = reinterpret_cast<const float*>(Bb.p[blockIdx.y]) + goffB;
+  constexpr int BM = 128, BK = 16;
+  constexpr int WN = BN / 2;
+  constexpr int TU = 2, TV = WN / 32;
+  constexpr int SA = BM + 4, SB = BN + 4;      // +4 floats: k-columns start 16 B apart modulo the bank row (ds_write_b128 of 4 rows)
+  constexpr int NLA = (BM * BK / 4) / 256;     // 2: thread t stages rows 4(t%32).. of k-columns t/32 + 8q
+  constexpr int NLB = (BN * BK / 4) / 256;     // 2 (BN=128) or 1 (BN=64)
+  constexpr int KSB = 256 / (BN / 4);          // k-columns covered per pass of the B staging (8 or 16)
+  __shared__ __attribute__((aligned(16))) float As[2][BK * SA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * SB];
+
+  int part = 0, nparts = 1, tj = 0, ti = 0;
+  gemm_work_item(BM, BN, N, lower, MT, full_items, splitk, part, nparts, ti, tj);
+  const int bm = ti * BM, bn = tj * BN;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int wr = (w & 1) * 64, wc = (w >> 1) * WN;
+  const bool active = (bm + wr < M) && (bn + wc < N) && !(lower && bm + wr + 63 < bn + wc);
+  const int nk_all = K / BK;
+  int kc0 = (int)((long long)nk_all * part / nparts);
+  const int kc1 = (int)((long long)nk_all * (part + 1) / nparts);
+  if (kfrom_row && kc0 < bm / BK) kc0 = bm / BK;
+  A += (size_t)kc0 * BK * lda;
+  B += (size_t)kc0 * BK * ldb;
+
+  int rowa = bm + 4 * (t % (BM / 4)); if (rowa > M - 4) rowa = M - 4;
+  int rowb = bn + 4 * (t % (BN / 4)); if (rowb > N - 4) rowb = N - 4;
+  const float* ga0 = A + (size_t)(t / (BM / 4)) * lda + rowa;
+  const float* gb0 = B + (size_t)(t / (BN / 4)) * ldb + rowb;
+  const int sa0 = (t / (BM / 4)) * SA + 4 * (t % (BM / 4));
+  const int sb0 = (t / (BN / 4)) * SB + 4 * (t % (BN / 4));
+  float4 ra[NLA], rb[NLB];
+#pragma unroll
+  for (int q = 0; q < NLA; ++q) ra[q] = *reinterpret_cast<const float4*>(ga0 + (size_t)(8 * q) * lda);
+#pragma unroll
+  for (int q = 0; q < NLB; ++q) rb[q] = *reinterpret_cast<const float4*>(gb0 + (size_t)(KSB * q) * ldb);
+#pragma unroll
+  for (int q = 0; q < NLA; ++q) *reinterpret_cast<float4*>(&As[0][sa0 + 8 * q * SA]) = ra[q];
+#pragma unroll
+  for (int q = 0; q < NLB; ++q) *reinterpret_cast<float4*>(&Bs[0][sb0 + KSB * q * SB]) = rb[q];
+  __syncthreads();
+
+  f32x16 acc[TV][TU];
+#pragma unroll
+  for (int v = 0; v < TV; ++v)
+#pragma unroll
+    for (int u = 0; u < TU; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[v][u][r] = 0.f;
+
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int offA = lh * SA + wr + l31, offB = lh * SB + wc + l31;
+  const int nk = kc1 - kc0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) {
+      const float* pa = ga0 + (size_t)(kt + 1) * BK * lda;
+      const float* pb = gb0 + (size_t)(kt + 1) * BK * ldb;
+#pragma unroll
+      for (int q = 0; q < NLA; ++q) ra[q] = *reinterpret_cast<const float4*>(pa + (size_t)(8 * q) * lda);
+#pragma unroll
+      for (int q = 0; q < NLB; ++q) rb[q] = *reinterpret_cast<const float4*>(pb + (size_t)(KSB * q) * ldb);
+    }
+    if (active) {
+      const float* as = &As[buf][0];
+      const float* bs = &Bs[buf][0];
+#pragma unroll
+      for (int s2 = 0; s2 < BK / 2; ++s2) {
+        float fu[TU], fv[TV];
+#pragma unroll
+        for (int u = 0; u < TU; ++u) fu[u] = as[offA + 2 * s2 * SA + 32 * u];      // rows of C: the MFMA's B operand
+#pragma unroll
+        for (int v = 0; v < TV; ++v) fv[v] = bs[offB + 2 * s2 * SB + 32 * v];      // columns of C: the MFMA's A operand
+#pragma unroll
+        for (int v = 0; v < TV; ++v)
+#pragma unroll
+          for (int u = 0; u < TU; ++u) acc[v][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[v], fu[u], acc[v][u], 0, 0, 0);
+      }
+    }
+    if (kt + 1 < nk) {
+#pragma unroll
+      for (int q = 0; q < NLA; ++q) *reinterpret_cast<float4*>(&As[buf ^ 1][sa0 + 8 * q * SA]) = ra[q];
+#pragma unroll
+      for (int q = 0; q < NLB; ++q) *reinterpret_cast<float4*>(&Bs[buf ^ 1][sb0 + KSB * q * SB]) = rb[q];
+    }
+    __syncthreads();
+  }
+  if (!active) return;
+#pragma unroll
+  for (int v = 0; v < TV; ++v)
+#pragma unroll
+    for (int u = 0; u < TU; ++u) {
+      float* cp = C + (size_t)(bn + wc + 32 * v + 4 * lh) * ldc + bm + wr + 32 * u + l31;
+      if (SET) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cp[(size_t)((r & 3) + 8 * (r >> 2)) * ldc] = acc[v][u][r];
+      } else if (nparts == 1) {
+        float cv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cv[r] = cp[(size_t)((r & 3) + 8 * (r >> 2)) * ldc];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cp[(size_t)((r & 3) + 8 * (r >> 2)) * ldc] = cv[r] - acc[v][u][r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) unsafeAtomicAdd(cp + (size_t)((r & 3) + 8 * (r >> 2)) * ldc, -acc[v][u][r]);
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // K3/K6: per-latent log marginal likelihood from the factor:  -(n log 2pi + 2 sum log L_kk + |z|^2)/2,
 // z = rider row `rider_row` (= (L^-1 delta)').  One workgroup; wavefront shuffle reductions.
 // Also used with nrhs > 1 riders (matrix-Y): out[r].
 // ---------------------------------------------------------------------------------------------------
 // One workgroup per matrix of the batch (blockIdx.x); matrix b writes out[b * nrhs + r].
+template <typename TS>
 __global__ __launch_bounds__(256) void lml_reduce_kernel(BatchPtr Ab, int ld, int n,
                                                          int rider_row0, int nrhs, double* __restrict__ out) {
-  const double* __restrict__ A = Ab.p[blockIdx.x];
+  const void* __restrict__ A = Ab.p[blockIdx.x];
   out += (size_t)blockIdx.x * nrhs;
   __shared__ double sh[4];
   double sl = 0.0;
-  for (int k = threadIdx.x; k < n; k += 256) sl += log(A[(size_t)k * ld + k]);
+  for (int k = threadIdx.x; k < n; k += 256) sl += log(MatIO<TS>::ld1(A, (size_t)k * ld + k));
   const double sumlog = block_sum_256(sl, sh);
   __shared__ double bc;
   if (threadIdx.x == 0) bc = sumlog;
@@ -959,7 +1138,7 @@ __global__ __launch_bounds__(256) void lml_reduce_kernel(BatchPtr Ab, int ld, in
   for (int r = 0; r < nrhs; ++r) {
     double q = 0.0;
     for (int k = threadIdx.x; k < n; k += 256) {
-      const double v = A[(size_t)k * ld + rider_row0 + r];
+      const double v = MatIO<TS>::ld1(A, (size_t)k * ld + rider_row0 + r);
       q = __builtin_fma(v, v, q);
     }
     const double quad = block_sum_256(q, sh);
@@ -968,17 +1147,19 @@ __global__ __launch_bounds__(256) void lml_reduce_kernel(BatchPtr Ab, int ld, in
 }
 
 // Extract rider row r (length n) of a factor matrix into a contiguous vector.
-__global__ void extract_row_kernel(const double* __restrict__ A, int ld, int row, int n, double* __restrict__ out) {
+template <typename TS>
+__global__ void extract_row_kernel(const void* __restrict__ A, int ld, int row, int n, double* __restrict__ out) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < n) out[k] = A[(size_t)k * ld + row];
+  if (k < n) out[k] = MatIO<TS>::ld1(A, (size_t)k * ld + row);
 }
 
 // The same for the matrices of a batch (blockIdx.y), zero-filled up to nfill, into two destinations per matrix (alpha, which
 // the back substitution then overwrites, and the kept copy z = L^-1 delta).
+template <typename TS>
 __global__ void extract_rows_kernel(BatchPtr Ab, int ld, int row, int n, int nfill, BatchPtr o1, BatchPtr o2) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= nfill) return;
-  const double v = (k < n) ? Ab.p[blockIdx.y][(size_t)k * ld + row] : 0.0;
+  const double v = (k < n) ? MatIO<TS>::ld1(Ab.p[blockIdx.y], (size_t)k * ld + row) : 0.0;
   o1.p[blockIdx.y][k] = v;
   o2.p[blockIdx.y][k] = v;
 }
@@ -990,8 +1171,8 @@ __global__ void extract_rows_kernel(BatchPtr Ab, int ld, int row, int n, int nfi
 // in a fixed order.  Serves the posterior marginals (mean = mu + R' z, var = k(x*,x*) - colsumsq(R) with R = L^-1 K(x,x*)
 // -- AbstractGPs PosteriorGP mean/var) and the sample transform L z.  The four waves take
 // interleaved 16-column slabs so that 16 independent coalesced 512-byte loads per wave are in flight.
-template <bool SQ, bool TRI>
-__global__ __launch_bounds__(256) void strip_reduce_kernel(const double* __restrict__ M, int ld, int nk, int kc,
+template <bool SQ, bool TRI, typename TS>
+__global__ __launch_bounds__(256) void strip_reduce_kernel(const void* __restrict__ M, int ld, int nk, int kc,
                                                            const double* __restrict__ v, double* __restrict__ partial) {
   __shared__ double red[2][3][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1000,12 +1181,11 @@ __global__ __launch_bounds__(256) void strip_reduce_kernel(const double* __restr
   int kend = kbeg + kc; if (kend > nk) kend = nk;
   if (TRI) { const int rowmax = blockIdx.x * 64 + 63; if (kend > rowmax + 1) kend = rowmax + 1; if (kbeg > rowmax) return; }
   double dot = 0.0, sq = 0.0;
-  const double* Mr = M + r;
   for (int k0 = kbeg + w * 16; k0 < kend; k0 += 64) {
     if (k0 + 16 <= kend) {
       double a[16];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) a[u] = Mr[(size_t)(k0 + u) * ld];
+      for (int u = 0; u < 16; ++u) a[u] = MatIO<TS>::ld1(M, (size_t)(k0 + u) * ld + r);
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
         const double av = (TRI && (k0 + u > r)) ? 0.0 : a[u];
@@ -1014,7 +1194,7 @@ __global__ __launch_bounds__(256) void strip_reduce_kernel(const double* __restr
       }
     } else {
       for (int k = k0; k < kend; ++k) {
-        double av = Mr[(size_t)k * ld];
+        double av = MatIO<TS>::ld1(M, (size_t)k * ld + r);
         if (TRI && k > r) av = 0.0;
         dot = __builtin_fma(av, v[k], dot);
         if (SQ) sq = __builtin_fma(av, av, sq);
@@ -1058,13 +1238,15 @@ __global__ void strip_finish_kernel(const double* __restrict__ partial, int nrp,
 // LDS copy of the 64x64 inverse block), then z_i -= sum_{j in b} L[j, i] alpha_j for the 256 columns i < 64 b of this
 // workgroup: 16 lanes share a column (4 consecutive rows each, so a wave load covers 4 whole 512-byte column segments).
 // ---------------------------------------------------------------------------------------------------
+template <typename TS>
 __global__ __launch_bounds__(256) void backsolve_step_kernel(BatchPtr Lb, int ld, BatchPtr Wb_, int b, BatchPtr zb_) {
   __shared__ double Ws[64 * 65];
   __shared__ double zb[64];
   __shared__ double ps[4][64];
   __shared__ double ab[64];
-  const double* __restrict__ L = Lb.p[blockIdx.y];
-  const double* __restrict__ Wb = Wb_.p[blockIdx.y] + (size_t)b * 4096;
+  const void* __restrict__ L = Lb.p[blockIdx.y];
+  const void* __restrict__ Wb = Wb_.p[blockIdx.y];
+  const size_t woff = (size_t)b * 4096;
   double* __restrict__ z = zb_.p[blockIdx.y];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   // issue this workgroup's 32 panel loads first: they do not depend on alpha_b
@@ -1075,11 +1257,12 @@ __global__ __launch_bounds__(256) void backsolve_step_kernel(BatchPtr Lb, int ld
   for (int gI = 0; gI < 16; ++gI) {
     const int col = c0 + gI * 4 + cq;
     if (col < b * 64) {
-      const double2* src = reinterpret_cast<const double2*>(L + (size_t)col * ld + b * 64 + jq * 4);
-      pa[gI] = src[0]; pb[gI] = src[1];
+      double q4[4];
+      MatIO<TS>::ld4(L, (size_t)col * ld + b * 64 + jq * 4, q4);
+      pa[gI] = make_double2(q4[0], q4[1]); pb[gI] = make_double2(q4[2], q4[3]);
     } else { pa[gI] = make_double2(0.0, 0.0); pb[gI] = pa[gI]; }
   }
-  for (int e = t; e < 4096; e += 256) Ws[(e >> 6) * 65 + (e & 63)] = Wb[e];     // Wb[c*64 + j] = W[j, c]
+  for (int e = t; e < 4096; e += 256) Ws[(e >> 6) * 65 + (e & 63)] = MatIO<TS>::ld1(Wb, woff + e);     // Wb[c*64 + j] = W[j, c]
   if (t < 64) zb[t] = z[b * 64 + t];
   __syncthreads();
   {
@@ -1485,13 +1668,23 @@ __global__ __launch_bounds__(256) void mfma_f64_peak_kernel(double* out, int ite
 // ---------------------------------------------------------------------------------------------------
 // launch wrappers (host)
 // ---------------------------------------------------------------------------------------------------
+// Compute dtype of the matrices the launches below touch: 0 = Float64, 1 = Float32 (lmm_set_compute_dtype; set by the API
+// layer under its context lock).  Every matrix pointer (BatchPtr entries, GramArgs.A, ...) is then a float buffer; offsets and
+// leading dimensions stay in elements.
+int g_f32 = 0;
+#define LMM_TS_LAUNCH(KERNEL_T, ...)                                                   \
+  do {                                                                                 \
+    if (g_f32) { using TS = float; hipLaunchKernelGGL(KERNEL_T, __VA_ARGS__); }        \
+    else { using TS = double; hipLaunchKernelGGL(KERNEL_T, __VA_ARGS__); }             \
+  } while (0)
+
 void launch_gram(const GramArgs& a, hipStream_t st) {
   dim3 grid(a.nrows / 64 - a.row_tile0, (a.ncols / 64 + 3) / 4);
   const bool nd = (a.d > 1 && a.d <= 8);
 #define LMM_GRAM_LAUNCH(K)                                                                          \
   do {                                                                                              \
-    if (nd) hipLaunchKernelGGL((gram_kernel<K, true>), grid, dim3(256), 0, st, a);                  \
-    else hipLaunchKernelGGL((gram_kernel<K, false>), grid, dim3(256), 0, st, a);                    \
+    if (nd) LMM_TS_LAUNCH((gram_kernel<K, true, TS>), grid, dim3(256), 0, st, a);                   \
+    else LMM_TS_LAUNCH((gram_kernel<K, false, TS>), grid, dim3(256), 0, st, a);                     \
   } while (0)
   if (a.kind == LMM_KERNEL_SE) LMM_GRAM_LAUNCH(LMM_KERNEL_SE);
   else if (a.kind == LMM_KERNEL_MATERN32) LMM_GRAM_LAUNCH(LMM_KERNEL_MATERN32);
@@ -1517,8 +1710,8 @@ void launch_gram_batch(const GramArgs* args, int nb, hipStream_t st) {
     const bool nd = (a.d > 1 && a.d <= 8);
 #define LMM_GRAM_LAUNCH(K)                                                                          \
     do {                                                                                            \
-      if (nd) hipLaunchKernelGGL((gram_batch_kernel<K, true>), grid, dim3(256), 0, st, b);          \
-      else hipLaunchKernelGGL((gram_batch_kernel<K, false>), grid, dim3(256), 0, st, b);            \
+      if (nd) LMM_TS_LAUNCH((gram_batch_kernel<K, true, TS>), grid, dim3(256), 0, st, b);           \
+      else LMM_TS_LAUNCH((gram_batch_kernel<K, false, TS>), grid, dim3(256), 0, st, b);             \
     } while (0)
     if (a.kind == LMM_KERNEL_SE) LMM_GRAM_LAUNCH(LMM_KERNEL_SE);
     else if (a.kind == LMM_KERNEL_MATERN32) LMM_GRAM_LAUNCH(LMM_KERNEL_MATERN32);
@@ -1563,7 +1756,7 @@ void launch_dense_assemble(const DenseArgs& a, hipStream_t st) {
 
 void launch_diag64(const BatchPtr& A, size_t offA, int ld, const BatchPtr& W, size_t offW, int gcol0, int n_real,
                    const BatchInfo& info, int nb, hipStream_t st) {
-  hipLaunchKernelGGL(diag64_kernel, dim3(nb), dim3(256), 0, st, A, offA, ld, W, offW, gcol0, n_real, info);
+  LMM_TS_LAUNCH((diag64_kernel<TS>), dim3(nb), dim3(256), 0, st, A, offA, ld, W, offW, gcol0, n_real, info);
 }
 
 // Update-kernel variant: 0 = one s_barrier per k-stage (default), 1 = LDS-flag synchronised main loop (correct, but measured
@@ -1577,8 +1770,10 @@ void launch_gemm_nt(const BatchPtr& C, size_t offC, int ldc, const BatchPtr& A, 
   const bool narrow = (N <= 64);
   const int MT = (M + 127) / 128;
   if (set) {   // in-place TRSM by inverse: one block column, no K split
-    hipLaunchKernelGGL((gemm44_kernel<64, true>), dim3(MT, nb), dim3(256), 0, st, C, offC, ldc, A, offA, lda, B, offB, ldb, M, N,
-                       K, 0, MT, MT, 1, 0);
+    if (g_f32) hipLaunchKernelGGL((gemm32_kernel<64, true>), dim3(MT, nb), dim3(256), 0, st, C, offC, ldc, A, offA, lda, B, offB, ldb, M, N,
+                                  K, 0, MT, MT, 1, 0);
+    else hipLaunchKernelGGL((gemm44_kernel<64, true>), dim3(MT, nb), dim3(256), 0, st, C, offC, ldc, A, offA, lda, B, offB, ldb, M, N,
+                            K, 0, MT, MT, 1, 0);
     return;
   }
   const int BNsel = narrow ? 64 : 128;
@@ -1604,6 +1799,13 @@ void launch_gemm_nt(const BatchPtr& C, size_t offC, int ldc, const BatchPtr& A, 
   }
   if (splitk == 1) full_items = (int)T;
   const int items = full_items + (int)(T - full_items) * splitk;
+  if (g_f32) {
+    if (narrow) hipLaunchKernelGGL((gemm32_kernel<64, false>), dim3(items, nb), dim3(256), 0, st, C, offC, ldc, A, offA, lda, B, offB,
+                                   ldb, M, N, K, lower, MT, full_items, splitk, 0);
+    else hipLaunchKernelGGL((gemm32_kernel<128, false>), dim3(items, nb), dim3(256), 0, st, C, offC, ldc, A, offA, lda, B, offB,
+                            ldb, M, N, K, lower, MT, full_items, splitk, 0);
+    return;
+  }
   if (narrow) hipLaunchKernelGGL((gemm44_kernel<64, false>), dim3(items, nb), dim3(256), 0, st, C, offC, ldc, A, offA, lda, B, offB,
                                  ldb, M, N, K, lower, MT, full_items, splitk, 0);
   else if (g_gemm_flags) hipLaunchKernelGGL((gemm44_kernel<128, false, true>), dim3(items, nb), dim3(256), 0, st, C, offC, ldc, A, offA, lda,
@@ -1635,7 +1837,7 @@ void launch_gemm_nt(double* C, int ldc, const double* A, int lda, const double* 
 }
 
 void launch_lml_reduce(const BatchPtr& A, int nb, int ld, int n, int rider_row0, int nrhs, double* out, hipStream_t st) {
-  hipLaunchKernelGGL(lml_reduce_kernel, dim3(nb), dim3(256), 0, st, A, ld, n, rider_row0, nrhs, out);
+  LMM_TS_LAUNCH((lml_reduce_kernel<TS>), dim3(nb), dim3(256), 0, st, A, ld, n, rider_row0, nrhs, out);
 }
 void launch_lml_reduce(const double* A, int ld, int n, int rider_row0, int nrhs, double* out, hipStream_t st) {
   BatchPtr b{};
@@ -1644,12 +1846,12 @@ void launch_lml_reduce(const double* A, int ld, int n, int rider_row0, int nrhs,
 }
 
 void launch_extract_row(const double* A, int ld, int row, int n, double* out, hipStream_t st) {
-  hipLaunchKernelGGL(extract_row_kernel, dim3((n + 255) / 256), dim3(256), 0, st, A, ld, row, n, out);
+  LMM_TS_LAUNCH((extract_row_kernel<TS>), dim3((n + 255) / 256), dim3(256), 0, st, (const void*)A, ld, row, n, out);
 }
 
 void launch_extract_rows(const BatchPtr& A, int nb, int ld, int row, int n, int nfill, const BatchPtr& o1, const BatchPtr& o2,
                          hipStream_t st) {
-  hipLaunchKernelGGL(extract_rows_kernel, dim3((nfill + 255) / 256, nb), dim3(256), 0, st, A, ld, row, n, nfill, o1, o2);
+  LMM_TS_LAUNCH((extract_rows_kernel<TS>), dim3((nfill + 255) / 256, nb), dim3(256), 0, st, A, ld, row, n, nfill, o1, o2);
 }
 
 // k-chunk width of the strip reductions: at most 64 chunks, a multiple of 256 columns
@@ -1670,8 +1872,8 @@ void launch_rider_stats(const double* R, int ld, int nr, int nk, const double* z
   }
   const int kc = strip_kc(nk), nch = (nk + kc - 1) / kc, nrp = (nr + 63) / 64 * 64;
   dim3 grid(nrp / 64, nch);
-  if (var_out) hipLaunchKernelGGL((strip_reduce_kernel<true, false>), grid, dim3(256), 0, st, R, ld, nk, kc, z, partial);
-  else hipLaunchKernelGGL((strip_reduce_kernel<false, false>), grid, dim3(256), 0, st, R, ld, nk, kc, z, partial);
+  if (var_out) LMM_TS_LAUNCH((strip_reduce_kernel<true, false, TS>), grid, dim3(256), 0, st, (const void*)R, ld, nk, kc, z, partial);
+  else LMM_TS_LAUNCH((strip_reduce_kernel<false, false, TS>), grid, dim3(256), 0, st, (const void*)R, ld, nk, kc, z, partial);
   hipLaunchKernelGGL(strip_finish_kernel, dim3((nr + 255) / 256), dim3(256), 0, st, partial, nrp, nch, var_out ? 2 : 1, nr, 0,
                      mu, base, mean_out, var_out);
 }
@@ -1679,7 +1881,7 @@ void launch_rider_stats(const double* R, int ld, int nr, int nk, const double* z
 void launch_backsolve(const BatchPtr& L, int ld, const BatchPtr& W, int nblk, const BatchPtr& z, int nb, hipStream_t st) {
   for (int b = nblk - 1; b >= 0; --b) {
     int grid = (b * 64 + 255) / 256; if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(backsolve_step_kernel, dim3(grid, nb), dim3(256), 0, st, L, ld, W, b, z);
+    LMM_TS_LAUNCH((backsolve_step_kernel<TS>), dim3(grid, nb), dim3(256), 0, st, L, ld, W, b, z);
   }
 }
 
@@ -1731,7 +1933,7 @@ void launch_cov_mix(const BatchPtr& Cl, int ldcl, int nl, const double* Hs, int 
 void launch_trmv_lower(const double* L, int ld, int n, const double* z, double mu, double* partial, double* out,
                        hipStream_t st) {
   const int kc = strip_kc(n), nch = (n + kc - 1) / kc, nrp = (n + 63) / 64 * 64;
-  hipLaunchKernelGGL((strip_reduce_kernel<false, true>), dim3(nrp / 64, nch), dim3(256), 0, st, L, ld, n, kc, z, partial);
+  LMM_TS_LAUNCH((strip_reduce_kernel<false, true, TS>), dim3(nrp / 64, nch), dim3(256), 0, st, (const void*)L, ld, n, kc, z, partial);
   hipLaunchKernelGGL(strip_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, st, partial, nrp, nch, 1, n, kc, mu, 0.0, out,
                      (double*)nullptr);
 }

@@ -1,0 +1,178 @@
+"""-m gpu: the fp32 compute mode (lmm_set_compute_dtype(LMM_F32); BASELINE configs[4] names an fp32 rand / marginals workload).
+Matrices (Grams, factors, cross-solve blocks) are Float32 and the updates run on v_mfma_f32_32x32x2_f32; the oracle stays
+Float64.  Stated tolerance: rtol 2e-4 on logpdf / marginals / samples at sigma2 = 0.1 and unit-scale kernels (cond(K + s I) ~ 1e3;
+Float32 eps 6e-8 x condition x a sqrt(n) accumulation factor), against rtol 1e-6 in the Float64 parity mode."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+from oracle import lmm_oracle as O
+
+pytestmark = pytest.mark.gpu
+RTOL32 = 2e-4
+
+
+@pytest.fixture()
+def lmm32():
+    import lmm_amd
+    lmm_amd.init(0)
+    lmm_amd.set_compute_dtype("f32")
+    yield lmm_amd
+    lmm_amd.set_compute_dtype("f64")
+
+
+def _model(lmm, gps):
+    K = {"se": lmm.SEKernel, "matern32": lmm.Matern32Kernel, "matern52": lmm.Matern52Kernel}
+    return lmm.independent_mogp([lmm.GP(g["mean"], K[g["kind"]](g["variance"], g["lengthscale"])) for g in gps])
+
+
+def test_f32_gemm_and_potrf_building_blocks(lmm32):
+    """The f32 MFMA tile kernel against torch (asymmetric operands: catches a swapped C/D map) and the blocked f32 Cholesky
+    (diag64 in f64 registers, TRSM and updates on v_mfma_f32) against LAPACK."""
+    import torch
+    lib = lmm32.load()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for (M, N, K, lower) in [(128, 128, 64, 0), (192, 64, 16, 0), (320, 192, 208, 0), (256, 256, 128, 1), (448, 320, 64, 1), (1024, 512, 1024, 1)]:
+        ldc, lda, ldb = M + 16, M + 4, N + 8
+        Ct = torch.randn(N, ldc, generator=g, device="cuda", dtype=torch.float32)     # column-major: [col][row]
+        At = torch.randn(K, lda, generator=g, device="cuda", dtype=torch.float32)
+        Bt = torch.randn(K, ldb, generator=g, device="cuda", dtype=torch.float32)
+        C0 = Ct.clone()
+        rc = lib.lmm_dev_gemm_nt_sub(C.c_void_p(Ct.data_ptr()), ldc, C.c_void_p(At.data_ptr()), lda, C.c_void_p(Bt.data_ptr()), ldb, M, N, K, lower)
+        assert rc == 0, lib.lmm_last_error_string()
+        ref = C0[:, :M].double() - (Bt[:, :N].double().T @ At[:, :M].double())          # [col][row]
+        got = Ct[:, :M].double()
+        if lower:
+            # tiles on/below the diagonal of the 128-blocked lower trapezoid are updated; compare where row >= col
+            r = torch.arange(M, device="cuda")[None, :]; c = torch.arange(N, device="cuda")[:, None]
+            mask = r >= c
+            assert torch.allclose(got[mask], ref[mask], rtol=1e-4, atol=1e-4 * math.sqrt(K))
+        else:
+            assert torch.allclose(got, ref, rtol=1e-4, atol=1e-4 * math.sqrt(K))
+        assert torch.equal(Ct[:, M:], C0[:, M:])                                       # padding rows untouched
+    rng = np.random.default_rng(3)
+    for n, riders in [(64, 64), (192, 64), (448, 128), (1024, 64)]:
+        X = rng.standard_normal((n, n))
+        A = X @ X.T / n + 2.0 * np.eye(n)
+        R = rng.standard_normal((riders, n))
+        ld = n + riders
+        buf = np.zeros((n, ld), dtype=np.float32)                                      # [col][row]
+        buf[:, :n] = np.tril(A).T
+        buf[:, n:] = R.T
+        Ad = torch.from_numpy(buf).cuda()
+        W = torch.zeros((n // 64) * 4096, dtype=torch.float32, device="cuda")
+        info = torch.zeros(1, dtype=torch.int32, device="cuda")
+        assert lib.lmm_dev_potrf(C.c_void_p(Ad.data_ptr()), ld, n, ld, C.c_void_p(W.data_ptr()), n, C.c_void_p(info.data_ptr())) == 0
+        assert int(info.item()) == 0
+        out = Ad.cpu().numpy().astype(np.float64)
+        L = np.linalg.cholesky(A)
+        np.testing.assert_allclose(np.tril(out[:, :n].T), L, rtol=2e-5, atol=2e-5)
+        import scipy.linalg as sla
+        np.testing.assert_allclose(out[:, n:].T, sla.solve_triangular(L, R.T, lower=True).T, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("kind,n,m,p,d", [("matern52", 700, 3, 5, 1), ("se", 1100, 2, 4, 2), ("matern32", 2100, 4, 6, 1)])
+def test_f32_oilmm_logpdf_posterior_marginals_rand_vs_f64_oracle(lmm32, kind, n, m, p, d):
+    lmm = lmm32
+    rng = np.random.default_rng(n)
+    x = np.sort(rng.uniform(0, n * 20.0 / 575.0, n)) if d == 1 else rng.uniform(0, 12.0, size=(d, n))
+    gps = [{"kind": kind, "variance": float(rng.uniform(0.7, 1.5)), "lengthscale": float(rng.uniform(0.8, 1.5)), "mean": float(rng.normal())}
+           for _ in range(m)]
+    U, S, _ = np.linalg.svd(rng.uniform(size=(p, m)), full_matrices=False)
+    S = np.linspace(2.0, 1.0, m)
+    y = rng.standard_normal(n * p)
+    f = lmm.ILMM(_model(lmm, gps), lmm.Orthogonal(U, S))
+    xin = lmm.MOInputIsotopicByOutputs(x, p)
+    assert lmm.get_compute_dtype() == "f32"
+    got = lmm.logpdf(f(xin, 0.1), y)
+    assert got == pytest.approx(O.oilmm_logpdf(gps, U, S, x, 0.1, y), rel=RTOL32)
+    post = lmm.posterior(f(xin, 0.1), y)
+    xs = (x[:96] + 0.013) if d == 1 else (x[:, :96] + 0.013)
+    xsin = lmm.MOInputIsotopicByOutputs(xs, p)
+    mu, v = lmm.mean_and_var(post(xsin, 0.1))
+    po = O.oilmm_posterior(gps, U, S, x, 0.1, y)
+    mo, vo = O.oilmm_mean_var(po, U, S, xs, 0.1)
+    np.testing.assert_allclose(mu, mo, rtol=RTOL32, atol=RTOL32)
+    np.testing.assert_allclose(v, vo, rtol=RTOL32)
+    np.testing.assert_allclose(lmm.mean(post(xsin, 0.1)), mo, rtol=RTOL32, atol=RTOL32)
+    assert lmm.logpdf(post(xsin, 0.1), y[:96 * p]) == pytest.approx(O.oilmm_logpdf(po, U, S, xs, 0.1, y[:96 * p]), rel=5 * RTOL32)
+    # posterior sample on the same normals (latent jitter 1e-3: Float32 needs a real jitter)
+    jit = (1e-9, 1e-3, 1e-3)
+    s = lmm.rand(np.random.default_rng(5), post(xsin, 0.1), jitters=jit)
+    g2 = np.random.default_rng(5); z = g2.standard_normal(m * 96); eps = g2.standard_normal(96 * p)
+    X = np.stack([O.gp_rand(g, xs, 1e-3, z[l * 96:(l + 1) * 96]) for l, g in enumerate(po)])
+    np.testing.assert_allclose(s, (O.orthogonal_dense(U, S) @ X).reshape(-1) + math.sqrt(0.1) * eps, rtol=20 * RTOL32, atol=20 * RTOL32)
+    # prior sample
+    s0 = lmm.rand(np.random.default_rng(6), f(xsin, 0.1), jitters=jit)
+    g2 = np.random.default_rng(6); z = g2.standard_normal(m * 96); eps = g2.standard_normal(96 * p)
+    X = np.stack([O.gp_rand(g, xs, 1e-3, z[l * 96:(l + 1) * 96]) for l, g in enumerate(gps)])
+    np.testing.assert_allclose(s0, (O.orthogonal_dense(U, S) @ X).reshape(-1) + math.sqrt(0.1) * eps, rtol=20 * RTOL32, atol=20 * RTOL32)
+
+
+def test_f32_mode_boundaries(lmm32):
+    """Handles remember their dtype; unsupported paths say so instead of computing in the wrong precision; switching back to
+    Float64 restores the parity mode bit for bit."""
+    lmm = lmm32
+    from lmm_amd import _lib as L
+    P = O.synthetic_problem(3, 5, 200, "se", True, s2=0.1, seed=0)
+    f = lmm.ILMM(_model(lmm, P["gps"]), lmm.Orthogonal(P["U"], P["S"]))
+    xin = lmm.MOInputIsotopicByOutputs(P["x"], 5)
+    post32 = lmm.posterior(f(xin, 0.1), P["y"])
+    v32 = lmm.logpdf(f(xin, 0.1), P["y"])
+    with pytest.raises(NotImplementedError):
+        lmm.logpdf_and_gradient(f(xin, 0.1), P["y"])
+    with pytest.raises(NotImplementedError):
+        lmm.mean_and_cov(f(lmm.MOInputIsotopicByOutputs(P["x"][:8], 5), 0.1))
+    lmm.set_compute_dtype("f64")
+    v64 = lmm.logpdf(f(xin, 0.1), P["y"])
+    ref = O.oilmm_logpdf(P["gps"], P["U"], P["S"], P["x"], 0.1, P["y"])
+    assert v64 == pytest.approx(ref, rel=1e-12)
+    assert v32 == pytest.approx(ref, rel=RTOL32) and v32 != v64
+    with pytest.raises(ValueError, match="other compute dtype"):
+        lmm.mean_and_var(post32(lmm.MOInputIsotopicByOutputs(P["x"][:8], 5), 0.1))
+    lmm.set_compute_dtype("f32")
+    mu, _ = lmm.mean_and_var(post32(lmm.MOInputIsotopicByOutputs(P["x"][:8], 5), 0.1))
+    assert np.all(np.isfinite(mu))
+
+
+def test_f32_c4_share_full_size(lmm32):
+    """configs[4] AS NAMED: OILMM rand / marginals, p = 256 outputs, 128 latents, n = 32768, fp32 -- one lock-step batch (8 of one
+    GPU's 16 latents).  Checked against the Float64 HIP path on latent 0 (itself checked against host LAPACK in
+    test_gpu_full_size.py::test_c4_shape_rand_marginals) at the stated fp32 tolerance, plus the size-independent properties."""
+    import torch
+    lmm = lmm32
+    from lmm_amd import _lib as L
+    n, p, m, nl, ns = 32768, 256, 128, 8, 1024
+    P = O.synthetic_problem(m, p, n, "matern52", True, s2=0.1, seed=0)
+    fs, H = _model(lmm, P["gps"]), lmm.Orthogonal(P["U"], P["S"])
+    xd = torch.from_numpy(P["x"]).cuda(); yd = torch.from_numpy(P["y"]).cuda()
+    xin = lmm.MOInputIsotopicByOutputs(xd, p)
+    xs = P["x"][:ns] + 0.01
+    xsin = lmm.MOInputIsotopicByOutputs(xs, p)
+    Hs = O.orthogonal_dense(P["U"], P["S"])[:, :nl]
+    post = lmm.posterior(lmm.ILMM(fs, H, shard=(0, nl))(xin, 0.1), yd)
+    ml, vl = np.empty(nl * ns), np.empty(nl * ns)
+    L.check(lmm.load().lmm_latent_marginals(post.f._post.ptr, None, nl, L.Arr(xs).ptr, 1, ns, L.Arr(ml, True).ptr, L.Arr(vl, True).ptr))
+    mup, vp = lmm.mean_and_var(post(xsin, 0.1))
+    # two calls = two Float32 cross-solves whose split-K tails add with f32 atomics: equal to rounding, not bitwise
+    np.testing.assert_allclose(mup, (Hs @ ml.reshape(nl, ns)).reshape(-1), rtol=RTOL32, atol=RTOL32)
+    assert np.all(vl > 0) and np.all(vl < 1.0 + 1e-6)
+    jit = (1e-9, 1e-3, 1e-3)
+    s = lmm.rand(np.random.default_rng(0), post(xsin, 0.1), jitters=jit, add_noise=False)
+    R = (s - mup).reshape(p, ns)
+    resid = R - Hs @ np.linalg.lstsq(Hs, R, rcond=None)[0]
+    assert np.abs(resid).max() < 1e-9 * max(1.0, np.abs(R).max())
+    lp32 = lmm.logpdf(lmm.ILMM(fs, H, shard=(0, 1))(xin, 0.1), yd, False)
+    del post
+    # the same latent 0 in Float64
+    lmm.set_compute_dtype("f64")
+    post64 = lmm.posterior(lmm.ILMM(fs, H, shard=(0, 1))(xin, 0.1), yd)
+    m64, v64 = np.empty(ns), np.empty(ns)
+    L.check(lmm.load().lmm_latent_marginals(post64.f._post.ptr, None, 1, L.Arr(xs).ptr, 1, ns, L.Arr(m64, True).ptr, L.Arr(v64, True).ptr))
+    lp64 = lmm.logpdf(lmm.ILMM(fs, H, shard=(0, 1))(xin, 0.1), yd, False)
+    lmm.set_compute_dtype("f32")
+    np.testing.assert_allclose(ml[:ns], m64, rtol=RTOL32, atol=RTOL32)
+    np.testing.assert_allclose(vl[:ns], v64, rtol=10 * RTOL32)
+    assert lp32 == pytest.approx(lp64, rel=RTOL32)
