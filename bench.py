@@ -301,9 +301,9 @@ def main():
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))
                 if tj.get("workload") == args.workload:
-                    traffic = tj.get("gemm44_kernel<128, false>", {}).get("bytes_per_launch")
+                    traffic = tj.get("update_kernel", {}).get("bytes_per_launch")
             roof = {"bound": "mfma", "kernel": ("gemm32_kernel<128,false> (v_mfma_f32_32x32x2_f32 SYRK/GEMM trailing update)" if args.dtype == "f32"
-                                                else "gemm44_kernel<128,false> (v_mfma_f64_4x4x4_4b_f64 SYRK/GEMM trailing update)"),
+                                                else "gemm16p_kernel<128,false> (v_mfma_f64_16x16x4_f64, VGPR accumulators, software-pipelined SYRK/GEMM trailing update)"),
                     "achieved": round(ach, 3), "peak": peak_tf, "unit": "TFLOP/s",
                     "frac": round(ach / peak_tf, 4), "traffic": traffic if args.dtype == "f64" else None,
                     "launches": up["launches"], "avg_launch_ms": round(up["ms"] / up["launches"], 4),

@@ -666,6 +666,181 @@ __global__ __launch_bounds__(256) void diag64_kernel(BatchPtr Ab, size_t offA, i
 }
 
 // ---------------------------------------------------------------------------------------------------
+// K2a, second form (round 2): the same rank-4 / 4x4-register-block elimination, but the pivot-block work is done ONCE per step by
+// the 16 threads that own the current block column instead of redundantly by all 256:
+//   phase A (owners of block column st: one quarter-wave): pivot block through wave shuffles, 4x4 Cholesky Lp and Lp^-1, then for
+//           the thread's four rows y = B Lp^-T and the multipliers m = y Lp^-1 as short dot products (no substitution chains);
+//           publish m (rows below the block), the raw pivot columns (= pivot rows by symmetry), Lp^-1 scaled for the W rows, pivots;
+//   barrier;
+//   phase B (all threads): 3 x 4 sixteen-byte LDS rows, one rank-4 update of the 16 + 16 registers.
+// A step costs ~1.8k clocks instead of ~3.5k (every thread used to run the ~600-clock 4x4 Cholesky chain and ~470 clocks of
+// forward/backward substitution for its rows, and to read 512 instead of 384 bytes of pivot data).
+// ---------------------------------------------------------------------------------------------------
+template <typename TS>
+__global__ __launch_bounds__(256) void diag64v2_kernel(BatchPtr Ab, size_t offA, int ld, BatchPtr Wb, size_t offW,
+                                                       int gcol0, int n_real, BatchInfo infob) {
+  void* __restrict__ A = Ab.p[blockIdx.x];
+  void* __restrict__ W = Wb.p[blockIdx.x];
+  int* __restrict__ info = infob.p[blockIdx.x];
+  __shared__ __attribute__((aligned(16))) double mm[2][4][64];     // multipliers m[k][row] (0 for rows not below the block)
+  __shared__ __attribute__((aligned(16))) double cm[2][4][64];     // raw pivot columns k, rows below the block (0 elsewhere)
+  __shared__ __attribute__((aligned(16))) double rw[2][4][64];     // rows J..J+3 of the W part
+  __shared__ __attribute__((aligned(16))) double li[2][16];        // l_rr (Lp^-1)[r][k]: the W rows inside the block
+  __shared__ double dd[64];
+  const int t = threadIdx.x, a = t & 15, b = t >> 4, wv = t >> 6;
+  double s[4][4], w[4][4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int k = 4 * b + c;
+    double col[4] = {0.0, 0.0, 0.0, 0.0};
+    if (a >= b) MatIO<TS>::ld4(A, offA + (size_t)k * ld + 4 * a, col);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      s[r][c] = (4 * a + r >= k) ? col[r] : 0.0;
+      w[r][c] = (4 * a + r == k) ? 1.0 : 0.0;
+    }
+  }
+  auto rsq = [](double x) {          // 1/sqrt(x): v_rsq_f64 + two Newton steps
+    double y = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    y = y * __builtin_fma(-h * y, y, 1.5);
+    y = y * __builtin_fma(-h * y, y, 1.5);
+    return y;
+  };
+  for (int st = 0; st < 16; ++st) {
+    const int J = 4 * st, bf = st & 1;
+    if (wv == (st >> 2)) {               // the wave holding block column st (wave-uniform branch: shuffles are safe)
+      const int src = (st & 3) * 16 + st;            // lane of thread (a = st, b = st) inside this wave
+      // pivot block P (lower part), broadcast from its owner
+      const double p00 = __shfl(s[0][0], src), p10 = __shfl(s[1][0], src), p20 = __shfl(s[2][0], src), p30 = __shfl(s[3][0], src);
+      const double p11 = __shfl(s[1][1], src), p21 = __shfl(s[2][1], src), p31 = __shfl(s[3][1], src);
+      const double p22 = __shfl(s[2][2], src), p32 = __shfl(s[3][2], src), p33 = __shfl(s[3][3], src);
+      if (b == st) {
+        // 4x4 Cholesky P = Lp Lp'
+        const double d0 = p00, r0 = rsq(d0);
+        const double l10 = p10 * r0, l20 = p20 * r0, l30 = p30 * r0;
+        const double d1 = __builtin_fma(-l10, l10, p11), r1 = rsq(d1);
+        const double l21 = __builtin_fma(-l20, l10, p21) * r1, l31 = __builtin_fma(-l30, l10, p31) * r1;
+        const double d2v = __builtin_fma(-l21, l21, __builtin_fma(-l20, l20, p22)), r2 = rsq(d2v);
+        const double l32 = __builtin_fma(-l31, l21, __builtin_fma(-l30, l20, p32)) * r2;
+        const double d3 = __builtin_fma(-l32, l32, __builtin_fma(-l31, l31, __builtin_fma(-l30, l30, p33))), r3 = rsq(d3);
+        const double l00 = d0 * r0, l11 = d1 * r1, l22 = d2v * r2, l33 = d3 * r3;
+        // Lp^-1 (lower): diagonal r0..r3
+        const double i10 = -l10 * r0 * r1;
+        const double i20 = -(l20 * r0 + l21 * i10) * r2, i21 = -l21 * r1 * r2;
+        const double i30 = -(l30 * r0 + l31 * i10 + l32 * i20) * r3, i31 = -(l31 * r1 + l32 * i21) * r3, i32 = -l32 * r2 * r3;
+        const bool below = (a > st);
+        double mk[4][4], ck[4][4];       // [k][row]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double b0 = s[r][0], b1 = s[r][1], b2 = s[r][2], b3 = s[r][3];
+          // y = B Lp^-T: y_k = sum_{j <= k} B_j (Lp^-1)[k][j]
+          const double y0 = b0 * r0;
+          const double y1 = __builtin_fma(b1, r1, b0 * i10);
+          const double y2 = __builtin_fma(b2, r2, __builtin_fma(b1, i21, b0 * i20));
+          const double y3 = __builtin_fma(b3, r3, __builtin_fma(b2, i32, __builtin_fma(b1, i31, b0 * i30)));
+          // m = y Lp^-1: m_k = sum_{j >= k} y_j (Lp^-1)[j][k]
+          const double m3 = y3 * r3;
+          const double m2 = __builtin_fma(y2, r2, y3 * i32);
+          const double m1 = __builtin_fma(y1, r1, __builtin_fma(y2, i21, y3 * i31));
+          const double m0 = __builtin_fma(y0, r0, __builtin_fma(y1, i10, __builtin_fma(y2, i20, y3 * i30)));
+          mk[0][r] = below ? m0 : 0.0; mk[1][r] = below ? m1 : 0.0; mk[2][r] = below ? m2 : 0.0; mk[3][r] = below ? m3 : 0.0;
+          ck[0][r] = below ? b0 : 0.0; ck[1][r] = below ? b1 : 0.0; ck[2][r] = below ? b2 : 0.0; ck[3][r] = below ? b3 : 0.0;
+          // my rows' final entries in columns J..J+3, in the s = L sqrt(d) convention (rows inside the block: Lp itself)
+          if (a >= st) { s[r][0] = y0 * l00; s[r][1] = y1 * l11; s[r][2] = y2 * l22; s[r][3] = y3 * l33; }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          d2* om = reinterpret_cast<d2*>(&mm[bf][k][4 * a]);
+          d2* oc = reinterpret_cast<d2*>(&cm[bf][k][4 * a]);
+          om[0] = mk2(mk[k][0], mk[k][1]); om[1] = mk2(mk[k][2], mk[k][3]);
+          oc[0] = mk2(ck[k][0], ck[k][1]); oc[1] = mk2(ck[k][2], ck[k][3]);
+        }
+        if (a == st) {
+          dd[J] = d0; dd[J + 1] = d1; dd[J + 2] = d2v; dd[J + 3] = d3;
+          double* q = &li[bf][0];          // row r of l_rr Lp^-1
+          q[0] = l00 * r0;  q[1] = 0.0;        q[2] = 0.0;        q[3] = 0.0;
+          q[4] = l11 * i10; q[5] = l11 * r1;   q[6] = 0.0;        q[7] = 0.0;
+          q[8] = l22 * i20; q[9] = l22 * i21;  q[10] = l22 * r2;  q[11] = 0.0;
+          q[12] = l33 * i30; q[13] = l33 * i31; q[14] = l33 * i32; q[15] = l33 * r3;
+        }
+      }
+    }
+    if (a == st) {                       // owners of rows J..J+3 of the W part
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        d2* o = reinterpret_cast<d2*>(&rw[bf][r][4 * b]);
+        o[0] = mk2(w[r][0], w[r][1]); o[1] = mk2(w[r][2], w[r][3]);
+      }
+    }
+    __syncthreads();
+    double Mv[4][4], Rv[4][4], Wv[4][4];     // [pivot k][row r of mine] / [pivot k][col c of mine]
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const d2* pm = reinterpret_cast<const d2*>(&mm[bf][k][4 * a]);
+      const d2* pr = reinterpret_cast<const d2*>(&cm[bf][k][4 * b]);
+      const d2* pw = reinterpret_cast<const d2*>(&rw[bf][k][4 * b]);
+      const d2 m0 = pm[0], m1 = pm[1], r0 = pr[0], r1 = pr[1], w0 = pw[0], w1 = pw[1];
+      Mv[k][0] = m0.x; Mv[k][1] = m0.y; Mv[k][2] = m1.x; Mv[k][3] = m1.y;
+      Rv[k][0] = r0.x; Rv[k][1] = r0.y; Rv[k][2] = r1.x; Rv[k][3] = r1.y;
+      Wv[k][0] = w0.x; Wv[k][1] = w0.y; Wv[k][2] = w1.x; Wv[k][3] = w1.y;
+    }
+    // S part: rows below the block, columns right of it (Mv / Rv are zero elsewhere)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        s[r][c] = __builtin_fma(-Mv[3][r], Rv[3][c], __builtin_fma(-Mv[2][r], Rv[2][c], __builtin_fma(-Mv[1][r], Rv[1][c],
+                  __builtin_fma(-Mv[0][r], Rv[0][c], s[r][c]))));
+    if (a == st) {                       // rows J..J+3: w <- l_rr (Lp^-1 Wtop)[r]
+      const double* q = &li[bf][0];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          w[r][c] = __builtin_fma(q[4 * r + 3], Wv[3][c], __builtin_fma(q[4 * r + 2], Wv[2][c], __builtin_fma(q[4 * r + 1], Wv[1][c],
+                    q[4 * r] * Wv[0][c])));
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          w[r][c] = __builtin_fma(-Mv[3][r], Wv[3][c], __builtin_fma(-Mv[2][r], Wv[2][c], __builtin_fma(-Mv[1][r], Wv[1][c],
+                    __builtin_fma(-Mv[0][r], Wv[0][c], w[r][c]))));
+    }
+  }
+  __syncthreads();
+  if (t < 64) {                                    // LAPACK-style info: first non-positive (or NaN) pivot, 1-based
+    const bool bad = !(dd[t] > 0.0) && (gcol0 + t < n_real);
+    const unsigned long long mask = __ballot(bad);
+    if (t == 0 && mask != 0ull) atomicCAS(info, 0, gcol0 + __builtin_ctzll(mask) + 1);
+  }
+  __syncthreads();
+  double rsr[4];                                   // row scales of W = D^-1/2 L1^-1
+#pragma unroll
+  for (int r = 0; r < 4; ++r) rsr[r] = rsq(dd[4 * a + r]);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int k = 4 * b + c;
+    const double dk = dd[k], lki = rsq(dk);
+    double ao[4], wo[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 4 * a + r;
+      ao[r] = (i == k) ? dk * lki : s[r][c] * lki;
+      wo[r] = (i >= k) ? w[r][c] * rsr[r] : 0.0;
+    }
+    if (a > b) {
+      MatIO<TS>::st4(A, offA + (size_t)k * ld + 4 * a, ao);
+    } else if (a == b) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) if (r >= c) MatIO<TS>::st1(A, offA + (size_t)k * ld + 4 * a + r, ao[r]);
+    }
+    MatIO<TS>::st4(W, offW + (size_t)k * 64 + 4 * a, wo);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // K2b: C (M x N) {-=, =} A (M x K) * B (N x K)^T  (column-major; M, N multiples of 64, K of 16), batched over up to
 // LMM_MAX_BATCH independent matrices (blockIdx.y), on v_mfma_f64_4x4x4_4b_f64 -- the FP64 MFMA form that issues at the
 // full FP64 rate on gfx950 (tools/mfma_probe3: 76.8 TFLOP/s; the 16x16x4 form issues at 36-59 depending on the
@@ -989,6 +1164,307 @@ __global__ __launch_bounds__(256, 2) void gemm44_kernel(BatchPtr Cb, size_t goff
     g_clk_probe[0] = __builtin_readcyclecounter() - clk0; g_clk_probe[1] = __builtin_amdgcn_s_memrealtime() - rt0;
   }
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K2b, second form (round 2): the same update on v_mfma_f64_16x16x4_f64 with the accumulators in ARCHITECTURAL VGPRs.
+// Round 1 measured this instruction at 36-59 TFLOP/s and chose the 4x4x4 form; tools/mfma_probe4 shows why: with AccVGPR
+// accumulators (what hipcc allocates by default once a kernel holds many of them) v_mfma_f64_16x16x4 issues at 36 TFLOP/s,
+// with VGPR accumulators (-mllvm -amdgpu-mfma-vgpr-form=1, the form rocBLAS' gfx950 dgemm kernels use) at 77.7 TFLOP/s
+// = 98.9 % of the FP64 peak, whatever the operand order.  Per k-step of 4 a wave's 64 x 64 tile then needs 4 + 4 ds_read_b64
+// feeding 16 MFMAs of 64 cycles (the 4x4x4 form: 4 + 16 reads feeding 64 MFMAs of 16 cycles) -- a fifth of the instruction
+// stream.  Same block tile, staging and LDS image as gemm44_kernel (the A fragment of the 4x4x4 form IS the 16x16x4 operand
+// read; B needs no rotations).  As in the fp32 kernel the MFMA's A operand is fed from the B matrix and its B operand from
+// the A matrix, so D's lane index runs along the rows of C:
+//     acc[v][u][r] (lane l)  <->  C[bm + wr + 16 u + (l & 15),  bn + wc + 16 v + (l >> 4) + 4 r]
+// and every global access of the epilogue is four contiguous 128-byte row segments.
+// ---------------------------------------------------------------------------------------------------
+template <int BN, bool SET>
+__global__ __launch_bounds__(256, 2) void gemm16_kernel(BatchPtr Cb, size_t goffC, int ldc, BatchPtr Ab, size_t goffA, int lda,
+                                                         BatchPtr Bb, size_t goffB, int ldb,
+                                                         int M, int N, int K, int lower, int MT, int full_items,
+                                                         int splitk, int kfrom_row) {
+  double* C = Cb.p[blockIdx.y] + goffC;
+  const double* A = Ab.p[blockIdx.y] + goffA;
+  const double* B = Bb.p[blockIdx.y] + goffB;
+  constexpr int BM = 128, BK = 16;
+  constexpr int WN = BN / 2;
+  constexpr int TM = 4, TN = WN / 16;
+  constexpr int SA = BM + 16, SB = BN + 16;
+  constexpr int NLA = (BM * BK / 2) / 256;
+  constexpr int NLB = (BN * BK / 2) / 256;
+  constexpr int KSB = 256 / (BN / 2);
+  __shared__ __attribute__((aligned(16))) double As[2][BK * SA];
+  __shared__ __attribute__((aligned(16))) double Bs[2][BK * SB];
+
+  int part = 0, nparts = 1, tj = 0, ti = 0;
+  gemm_work_item(BM, BN, N, lower, MT, full_items, splitk, part, nparts, ti, tj);
+  const int bm = ti * BM, bn = tj * BN;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int wr = (w & 1) * 64, wc = (w >> 1) * WN;
+  const bool active = (bm + wr < M) && (bn + wc < N) && !(lower && bm + wr + 63 < bn + wc);
+  const int nk_all = K / BK;
+  int kc0 = (int)((long long)nk_all * part / nparts);
+  const int kc1 = (int)((long long)nk_all * (part + 1) / nparts);
+  if (kfrom_row && kc0 < bm / BK) kc0 = bm / BK;
+  A += (size_t)kc0 * BK * lda;
+  B += (size_t)kc0 * BK * ldb;
+
+  int rowa = bm + 2 * (t % (BM / 2)); if (rowa > M - 2) rowa = M - 2;
+  int rowb = bn + 2 * (t % (BN / 2)); if (rowb > N - 2) rowb = N - 2;
+  const double* ga0 = A + (size_t)(t / (BM / 2)) * lda + rowa;
+  const double* gb0 = B + (size_t)(t / (BN / 2)) * ldb + rowb;
+  const int sa0 = (t / (BM / 2)) * SA + 2 * (t % (BM / 2));
+  const int sb0 = (t / (BN / 2)) * SB + 2 * (t % (BN / 2));
+  d2 ra[NLA], rb[NLB];
+#pragma unroll
+  for (int q = 0; q < NLA; ++q) ra[q] = *reinterpret_cast<const d2*>(ga0 + (size_t)(4 * q) * lda);
+#pragma unroll
+  for (int q = 0; q < NLB; ++q) rb[q] = *reinterpret_cast<const d2*>(gb0 + (size_t)(KSB * q) * ldb);
+#pragma unroll
+  for (int q = 0; q < NLA; ++q) *reinterpret_cast<d2*>(&As[0][sa0 + 4 * q * SA]) = ra[q];
+#pragma unroll
+  for (int q = 0; q < NLB; ++q) *reinterpret_cast<d2*>(&Bs[0][sb0 + KSB * q * SB]) = rb[q];
+  __syncthreads();
+
+  d4 acc[TN][TM];
+#pragma unroll
+  for (int v = 0; v < TN; ++v)
+#pragma unroll
+    for (int u = 0; u < TM; ++u) acc[v][u] = (d4){0.0, 0.0, 0.0, 0.0};
+
+  const int l15 = lane & 15, lk = lane >> 4;
+  const int offA = lk * SA + wr + l15, offB = lk * SB + wc + l15;
+  const int nk = kc1 - kc0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) {
+      const double* pa = ga0 + (size_t)(kt + 1) * BK * lda;
+      const double* pb = gb0 + (size_t)(kt + 1) * BK * ldb;
+#pragma unroll
+      for (int q = 0; q < NLA; ++q) ra[q] = *reinterpret_cast<const d2*>(pa + (size_t)(4 * q) * lda);
+#pragma unroll
+      for (int q = 0; q < NLB; ++q) rb[q] = *reinterpret_cast<const d2*>(pb + (size_t)(KSB * q) * ldb);
+    }
+    if (active) {
+      if (blockIdx.x & 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
+      const double* as = &As[buf][0];
+      const double* bs = &Bs[buf][0];
+#pragma unroll
+      for (int s4 = 0; s4 < BK / 4; ++s4) {
+        double fa[TM], fb[TN];
+#pragma unroll
+        for (int u = 0; u < TM; ++u) fa[u] = as[offA + 4 * s4 * SA + 16 * u];      // rows of C: the MFMA's B operand
+#pragma unroll
+        for (int v = 0; v < TN; ++v) fb[v] = bs[offB + 4 * s4 * SB + 16 * v];      // columns of C: the MFMA's A operand
+#pragma unroll
+        for (int v = 0; v < TN; ++v)
+#pragma unroll
+          for (int uu = 0; uu < TM; ++uu) {
+            const int u = (v & 1) ? TM - 1 - uu : uu;                              // serpentine: one operand is reused each time
+            acc[v][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[v], fa[u], acc[v][u], 0, 0, 0);
+          }
+      }
+      __builtin_amdgcn_s_setprio(0);
+    }
+    if (kt + 1 < nk) {
+#pragma unroll
+      for (int q = 0; q < NLA; ++q) *reinterpret_cast<d2*>(&As[buf ^ 1][sa0 + 4 * q * SA]) = ra[q];
+#pragma unroll
+      for (int q = 0; q < NLB; ++q) *reinterpret_cast<d2*>(&Bs[buf ^ 1][sb0 + KSB * q * SB]) = rb[q];
+    }
+    __syncthreads();
+  }
+  if (!active) return;
+#pragma unroll
+  for (int v = 0; v < TN; ++v) {
+    double* cpv = C + (size_t)(bn + wc + 16 * v + lk) * ldc + bm + wr + l15;
+    if (SET) {
+#pragma unroll
+      for (int u = 0; u < TM; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cpv[(size_t)(4 * r) * ldc + 16 * u] = acc[v][u][r];
+    } else if (nparts == 1) {
+      double cv[TM][4];
+#pragma unroll
+      for (int u = 0; u < TM; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cv[u][r] = cpv[(size_t)(4 * r) * ldc + 16 * u];
+#pragma unroll
+      for (int u = 0; u < TM; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cpv[(size_t)(4 * r) * ldc + 16 * u] = cv[u][r] - acc[v][u][r];
+    } else {
+#pragma unroll
+      for (int u = 0; u < TM; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) unsafeAtomicAdd(cpv + (size_t)(4 * r) * ldc + 16 * u, -acc[v][u][r]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K2b, third form (round 2): ONE workgroup per CU (one wave per SIMD, up to 256 VGPRs), software-pipelined by hand the way the
+// vendor's gfx950 dgemm kernels are (rocBLAS reaches 76.8 TFLOP/s on this box, tools/yardstick): v_mfma_f64_16x16x4 lasts 64
+// cycles, so a wave that keeps one MFMA in flight can spend the next ~60 cycles on LDS reads, LDS writes, global loads,
+// waits and even the workgroup barrier without starving the matrix pipe -- no second workgroup is needed to cover them.
+//   per k-tile (BK = 16 = four k-steps of 16 MFMAs):
+//     k-step 0..2 : 16 MFMAs each, interleaved one-for-one with the 8 fragment reads of the NEXT k-step, the 8 ds_write_b128 of
+//                   tile t+1 (its global loads were issued a whole tile earlier) and the 8 global loads of tile t+2
+//     k-step 3    : 10 MFMAs, s_barrier (tile t+1 is complete in the other LDS buffer, everybody is done reading this one),
+//                   6 MFMAs interleaved with the 8 fragment reads of tile t+1's k-step 0
+//   __builtin_amdgcn_sched_group_barrier pins the interleave (hipcc otherwise clusters the loads ahead of the MFMAs).
+// ---------------------------------------------------------------------------------------------------
+#define LMM_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+template <int BN_, bool SET_>
+__global__ __launch_bounds__(256, 1) void gemm16p_kernel(BatchPtr Cb, size_t goffC, int ldc, BatchPtr Ab, size_t goffA, int lda,
+                                                          BatchPtr Bb, size_t goffB, int ldb,
+                                                          int M, int N, int K, int lower, int MT, int full_items,
+                                                          int splitk, int kfrom_row) {
+  double* C = Cb.p[blockIdx.y] + goffC;
+  const double* A = Ab.p[blockIdx.y] + goffA;
+  const double* B = Bb.p[blockIdx.y] + goffB;
+  constexpr int BM = 128, BN = 128, BK = 16;
+  constexpr int SA = BM + 16, SB = BN + 16;
+  __shared__ __attribute__((aligned(16))) double As[2][BK * SA];
+  __shared__ __attribute__((aligned(16))) double Bs[2][BK * SB];
+
+  int part = 0, nparts = 1, tj = 0, ti = 0;
+  gemm_work_item(BM, BN, N, lower, MT, full_items, splitk, part, nparts, ti, tj);
+  const int bm = ti * BM, bn = tj * BN;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int wr = (w & 1) * 64, wc = (w >> 1) * 64;
+  const bool active = (bm + wr < M) && (bn + wc < N) && !(lower && bm + wr + 63 < bn + wc);
+  const int nk_all = K / BK;
+  int kc0 = (int)((long long)nk_all * part / nparts);
+  const int kc1 = (int)((long long)nk_all * (part + 1) / nparts);
+  if (kfrom_row && kc0 < bm / BK) kc0 = bm / BK;
+  A += (size_t)kc0 * BK * lda;
+  B += (size_t)kc0 * BK * ldb;
+  const int nk = kc1 - kc0;
+
+  int rowa = bm + 2 * (t & 63); if (rowa > M - 2) rowa = M - 2;
+  int rowb = bn + 2 * (t & 63); if (rowb > N - 2) rowb = N - 2;
+  const double* ga0 = A + (size_t)(t >> 6) * lda + rowa;       // thread t stages rows 2(t%64).. of k-columns t/64 + 4q
+  const double* gb0 = B + (size_t)(t >> 6) * ldb + rowb;
+  const int sa0 = (t >> 6) * SA + 2 * (t & 63);
+  const int sb0 = (t >> 6) * SB + 2 * (t & 63);
+  d2 ra[4], rb[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { ra[q] = *reinterpret_cast<const d2*>(ga0 + (size_t)(4 * q) * lda); rb[q] = *reinterpret_cast<const d2*>(gb0 + (size_t)(4 * q) * ldb); }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { *reinterpret_cast<d2*>(&As[0][sa0 + 4 * q * SA]) = ra[q]; *reinterpret_cast<d2*>(&Bs[0][sb0 + 4 * q * SB]) = rb[q]; }
+  {                                                  // tile 1 into registers (clamped: a one-tile product just reloads tile 0)
+    const int k1 = nk > 1 ? 1 : 0;
+    const double* pa = ga0 + (size_t)k1 * BK * lda;
+    const double* pb = gb0 + (size_t)k1 * BK * ldb;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { ra[q] = *reinterpret_cast<const d2*>(pa + (size_t)(4 * q) * lda); rb[q] = *reinterpret_cast<const d2*>(pb + (size_t)(4 * q) * ldb); }
+  }
+  __syncthreads();
+
+  d4 acc[4][4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[v][u] = (d4){0.0, 0.0, 0.0, 0.0};
+  const int l15 = lane & 15, lk = lane >> 4;
+  const int offA = lk * SA + wr + l15, offB = lk * SB + wc + l15;
+  double fa[2][4], fb[2][4];                          // two fragment sets: the k-step being multiplied and the next one
+#pragma unroll
+  for (int u = 0; u < 4; ++u) { fa[0][u] = As[0][offA + 16 * u]; fb[0][u] = Bs[0][offB + 16 * u]; }
+
+#define LMM_MFMA16(SET, V, U) acc[V][U] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[SET][V], fa[SET][U], acc[V][U], 0, 0, 0)
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    const double* as = &As[buf][0];
+    const double* bs = &Bs[buf][0];
+    double* asn = &As[buf ^ 1][0];
+    double* bsn = &Bs[buf ^ 1][0];
+    const int kn2 = (kt + 2 < nk) ? kt + 2 : nk - 1;                  // clamped: the surplus loads / writes of the last tiles are unused
+    const double* pa = ga0 + (size_t)kn2 * BK * lda;
+    const double* pb = gb0 + (size_t)kn2 * BK * ldb;
+    // ---- k-step 0: MFMAs on set 0; reads of k-step 1 into set 1; ds_write of the A half of tile t+1
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { fa[1][u] = as[offA + 4 * SA + 16 * u]; fb[1][u] = bs[offB + 4 * SB + 16 * u]; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<d2*>(&asn[sa0 + 4 * q * SA]) = ra[q];
+    LMM_MFMA16(0, 0, 0); LMM_MFMA16(0, 0, 1); LMM_MFMA16(0, 0, 2); LMM_MFMA16(0, 0, 3);
+    LMM_MFMA16(0, 1, 3); LMM_MFMA16(0, 1, 2); LMM_MFMA16(0, 1, 1); LMM_MFMA16(0, 1, 0);
+    LMM_MFMA16(0, 2, 0); LMM_MFMA16(0, 2, 1); LMM_MFMA16(0, 2, 2); LMM_MFMA16(0, 2, 3);
+    LMM_MFMA16(0, 3, 3); LMM_MFMA16(0, 3, 2); LMM_MFMA16(0, 3, 1); LMM_MFMA16(0, 3, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x100, 1); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x200, 1); }
+    LMM_SGB(0x008, 4);
+    // ---- k-step 1: MFMAs on set 1; reads of k-step 2 into set 0; ds_write of the B half; global loads of tile t+2 (A half)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { fa[0][u] = as[offA + 8 * SA + 16 * u]; fb[0][u] = bs[offB + 8 * SB + 16 * u]; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<d2*>(&bsn[sb0 + 4 * q * SB]) = rb[q];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ra[q] = *reinterpret_cast<const d2*>(pa + (size_t)(4 * q) * lda);
+    LMM_MFMA16(1, 0, 0); LMM_MFMA16(1, 0, 1); LMM_MFMA16(1, 0, 2); LMM_MFMA16(1, 0, 3);
+    LMM_MFMA16(1, 1, 3); LMM_MFMA16(1, 1, 2); LMM_MFMA16(1, 1, 1); LMM_MFMA16(1, 1, 0);
+    LMM_MFMA16(1, 2, 0); LMM_MFMA16(1, 2, 1); LMM_MFMA16(1, 2, 2); LMM_MFMA16(1, 2, 3);
+    LMM_MFMA16(1, 3, 3); LMM_MFMA16(1, 3, 2); LMM_MFMA16(1, 3, 1); LMM_MFMA16(1, 3, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x100, 1); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x200, 1); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x020, 1); }
+    // ---- k-step 2: MFMAs on set 0; reads of k-step 3 into set 1; global loads of tile t+2 (B half)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { fa[1][u] = as[offA + 12 * SA + 16 * u]; fb[1][u] = bs[offB + 12 * SB + 16 * u]; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) rb[q] = *reinterpret_cast<const d2*>(pb + (size_t)(4 * q) * ldb);
+    LMM_MFMA16(0, 0, 0); LMM_MFMA16(0, 0, 1); LMM_MFMA16(0, 0, 2); LMM_MFMA16(0, 0, 3);
+    LMM_MFMA16(0, 1, 3); LMM_MFMA16(0, 1, 2); LMM_MFMA16(0, 1, 1); LMM_MFMA16(0, 1, 0);
+    LMM_MFMA16(0, 2, 0); LMM_MFMA16(0, 2, 1); LMM_MFMA16(0, 2, 2); LMM_MFMA16(0, 2, 3);
+    LMM_MFMA16(0, 3, 3); LMM_MFMA16(0, 3, 2); LMM_MFMA16(0, 3, 1); LMM_MFMA16(0, 3, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x100, 1); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x020, 1); }
+    LMM_SGB(0x008, 4);
+    // ---- k-step 3, first part: 10 MFMAs on set 1, then the barrier
+    LMM_MFMA16(1, 0, 0); LMM_MFMA16(1, 0, 1); LMM_MFMA16(1, 0, 2); LMM_MFMA16(1, 0, 3);
+    LMM_MFMA16(1, 1, 3); LMM_MFMA16(1, 1, 2); LMM_MFMA16(1, 1, 1); LMM_MFMA16(1, 1, 0);
+    LMM_MFMA16(1, 2, 0); LMM_MFMA16(1, 2, 1);
+    __syncthreads();
+    // ---- k-step 3, second part: 6 MFMAs on set 1, interleaved with the reads of tile t+1's k-step 0 into set 0
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { fa[0][u] = asn[offA + 16 * u]; fb[0][u] = bsn[offB + 16 * u]; }
+    LMM_MFMA16(1, 2, 2); LMM_MFMA16(1, 2, 3);
+    LMM_MFMA16(1, 3, 3); LMM_MFMA16(1, 3, 2); LMM_MFMA16(1, 3, 1); LMM_MFMA16(1, 3, 0);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x100, 1); }
+    LMM_SGB(0x100, 2);
+  }
+#undef LMM_MFMA16
+  if (!active) return;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    double* cpv = C + (size_t)(bn + wc + 16 * v + lk) * ldc + bm + wr + l15;
+    if (nparts == 1) {
+      double cv[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cv[u][r] = cpv[(size_t)(4 * r) * ldc + 16 * u];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cpv[(size_t)(4 * r) * ldc + 16 * u] = cv[u][r] - acc[v][u][r];
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) unsafeAtomicAdd(cpv + (size_t)(4 * r) * ldc + 16 * u, -acc[v][u][r]);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1756,17 +2232,26 @@ void launch_dense_assemble(const DenseArgs& a, hipStream_t st) {
 
 void launch_diag64(const BatchPtr& A, size_t offA, int ld, const BatchPtr& W, size_t offW, int gcol0, int n_real,
                    const BatchInfo& info, int nb, hipStream_t st) {
-  LMM_TS_LAUNCH((diag64_kernel<TS>), dim3(nb), dim3(256), 0, st, A, offA, ld, W, offW, gcol0, n_real, info);
+  // LMM_DIAG_V2=1 selects the owner-only pivot-block form (correct, but measured SLOWER: 42 vs 29 us per 64x64 block -- the
+  // f64 dependency chain of the 4x4 pivot factorisation is the cost, not the redundant copies of it; profiles/r02/README)
+  static int v2 = -1;
+  if (v2 < 0) { const char* e = getenv("LMM_DIAG_V2"); v2 = (e && atoi(e) != 0) ? 1 : 0; }
+  if (v2) LMM_TS_LAUNCH((diag64v2_kernel<TS>), dim3(nb), dim3(256), 0, st, A, offA, ld, W, offW, gcol0, n_real, info);
+  else LMM_TS_LAUNCH((diag64_kernel<TS>), dim3(nb), dim3(256), 0, st, A, offA, ld, W, offW, gcol0, n_real, info);
 }
 
 // Update-kernel variant: 0 = one s_barrier per k-stage (default), 1 = LDS-flag synchronised main loop (correct, but measured
 // 3-6 % SLOWER: tools/gemm_ab, profiles/r02/gemm_ab_flags_vs_barrier.log -- the s_barrier is not what limits this kernel).
 // LMM_GEMM_FLAGS overrides; tools/gemm_ab flips it between timed rounds of one process.
 int g_gemm_flags = -1;
+// Wide-update kernel: 2 (default) = gemm16p_kernel (v_mfma_f64_16x16x4, VGPR accumulators, hand-pipelined), 1 = gemm16_kernel (same
+// MFMA in the round-1 loop structure), 0 = gemm44_kernel (round 1: v_mfma_f64_4x4x4_4b).  LMM_GEMM_M16 overrides; tools/gemm_ab A/Bs.
+int g_gemm_m16 = -1;
 void launch_gemm_nt(const BatchPtr& C, size_t offC, int ldc, const BatchPtr& A, size_t offA, int lda, const BatchPtr& B,
                     size_t offB, int ldb, int M, int N, int K, int lower, bool set, int nb, hipStream_t st) {
   if (M <= 0 || N <= 0 || K <= 0 || nb <= 0) return;
   if (g_gemm_flags < 0) { const char* e = getenv("LMM_GEMM_FLAGS"); g_gemm_flags = e ? (atoi(e) != 0) : 0; }
+  if (g_gemm_m16 < 0) { const char* e = getenv("LMM_GEMM_M16"); g_gemm_m16 = e ? atoi(e) : 2; }
   const bool narrow = (N <= 64);
   const int MT = (M + 127) / 128;
   if (set) {   // in-place TRSM by inverse: one block column, no K split
@@ -1808,6 +2293,10 @@ void launch_gemm_nt(const BatchPtr& C, size_t offC, int ldc, const BatchPtr& A, 
   }
   if (narrow) hipLaunchKernelGGL((gemm44_kernel<64, false>), dim3(items, nb), dim3(256), 0, st, C, offC, ldc, A, offA, lda, B, offB,
                                  ldb, M, N, K, lower, MT, full_items, splitk, 0);
+  else if (g_gemm_m16 == 2) hipLaunchKernelGGL((gemm16p_kernel<128, false>), dim3(items, nb), dim3(256), 0, st, C, offC, ldc, A, offA, lda, B, offB,
+                                               ldb, M, N, K, lower, MT, full_items, splitk, 0);
+  else if (g_gemm_m16) hipLaunchKernelGGL((gemm16_kernel<128, false>), dim3(items, nb), dim3(256), 0, st, C, offC, ldc, A, offA, lda, B, offB,
+                                          ldb, M, N, K, lower, MT, full_items, splitk, 0);
   else if (g_gemm_flags) hipLaunchKernelGGL((gemm44_kernel<128, false, true>), dim3(items, nb), dim3(256), 0, st, C, offC, ldc, A, offA, lda,
                                             B, offB, ldb, M, N, K, lower, MT, full_items, splitk, 0);
   else hipLaunchKernelGGL((gemm44_kernel<128, false>), dim3(items, nb), dim3(256), 0, st, C, offC, ldc, A, offA, lda, B, offB,

@@ -1,7 +1,8 @@
 // A/B of the trailing-update kernel variants in ONE process (interleaved rounds; cdna_hip_programming.md 5.4 rule 24):
-//   g_gemm_flags = 0: one s_barrier per k-stage        1: LDS-flag synchronised main loop
+//   variant 0: gemm44_kernel (v_mfma_f64_4x4x4_4b)        variant 1: gemm16_kernel (v_mfma_f64_16x16x4, VGPR accumulators)
+//   (the LDS-flag vs s_barrier comparison of the 4x4x4 kernel is in git history: profiles/r02/gemm_ab_flags_vs_barrier_*.log)
 // Also checks the two variants against each other on random data (same inputs -> same C up to split-K atomics order).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_ab.hip -o tools/gemm_ab && tools/gemm_ab [nb]
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form=1 tools/gemm_ab.hip -o tools/gemm_ab && tools/gemm_ab [nb]
 #include "../linearmixingmodels.jl_amd/csrc/lmm_kernels.hip"
 #include <cstdio>
 #include <vector>
@@ -20,7 +21,7 @@ __global__ void max_abs_diff(const double* a, const double* b, size_t n, double*
   for (int o = 32; o > 0; o >>= 1) { double x = __shfl_down(m, o, 64); if (!(x <= m)) m = x; }
   if ((threadIdx.x & 63) == 0) { unsigned long long* p = (unsigned long long*)out; atomicMax(p, (unsigned long long)__double_as_longlong(m)); }
 }
-extern int g_gemm_flags;
+extern int g_gemm_flags, g_gemm_m16;
 int main(int argc, char** argv) {
   const int nb = argc > 1 ? atoi(argv[1]) : 8;
   const int only_shape = argc > 2 ? atoi(argv[2]) : -1;      // profile runs: one shape ...
@@ -46,22 +47,26 @@ int main(int argc, char** argv) {
     for (int b = 0; b < nb; ++b) { C.p[b] = Cs[b]; A.p[b] = As[b]; }
     const double outs = s.lower ? ((double)s.N * (s.N + 1) / 2 + (double)(s.M - s.N) * s.N) : (double)s.M * s.N;
     const double fl = 2.0 * s.K * outs * nb;
-    // correctness: variant 1 vs variant 0 on matrix 0
+    // correctness: variants 1, 2 vs variant 0 on matrix 0
+    double hmaxv[3] = {0, 0, 0};
     if (only_variant < 0)
-    for (int v = 0; v < 2; ++v) {
-      g_gemm_flags = v;
+    for (int v = 0; v < 3; ++v) {
+      g_gemm_flags = 0; g_gemm_m16 = v;
       double* Cv = v ? C2[0] : Cs[0];
       fill_rand<<<2048, 256>>>(Cv, (size_t)ld * s.N, 77u);
       launch_gemm_nt(Cv, ld, As[0], ld, As[0], ld, s.M, s.N, s.K, s.lower, false, 0);
+      if (v) {
+        hipMemset(dmax, 0, 8);
+        max_abs_diff<<<1024, 256>>>(Cs[0], C2[0], (size_t)ld * s.N, dmax);
+        hipMemcpy(&hmaxv[v], dmax, 8, hipMemcpyDeviceToHost);
+      }
     }
-    hipMemset(dmax, 0, 8);
-    max_abs_diff<<<1024, 256>>>(Cs[0], C2[0], (size_t)ld * s.N, dmax);
-    double hmax = 0; hipMemcpy(&hmax, dmax, 8, hipMemcpyDeviceToHost);
-    double best[2] = {1e30, 1e30}, med[2][5];
+    const double hmax = hmaxv[1] > hmaxv[2] ? hmaxv[1] : hmaxv[2];
+    double best[3] = {1e30, 1e30, 1e30}, med[3][5];
     for (int round = 0; round < 5; ++round)
-      for (int v = 0; v < 2; ++v) {
+      for (int v = 0; v < 3; ++v) {
         if (only_variant >= 0 && v != only_variant) continue;
-        g_gemm_flags = v;
+        g_gemm_flags = 0; g_gemm_m16 = v;
         launch_gemm_nt(C, 0, ld, A, 0, ld, A, 0, ld, s.M, s.N, s.K, s.lower, false, nb, 0);   // warm
         hipEventRecord(e0);
         const int reps = s.K >= 4096 ? 2 : 6;
@@ -70,8 +75,8 @@ int main(int argc, char** argv) {
         float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
         med[v][round] = ms; if (ms < best[v]) best[v] = ms;
       }
-    printf("M=%5d N=%5d K=%5d lower=%d nb=%d | barrier: %.3f ms %.2f TF | flags: %.3f ms %.2f TF | flags/barrier time %.3f | maxdiff %.3e\n",
-           s.M, s.N, s.K, s.lower, nb, best[0], fl / best[0] / 1e9, best[1], fl / best[1] / 1e9, best[1] / best[0], hmax);
+    printf("M=%5d N=%5d K=%5d lower=%d nb=%d | 4x4x4: %.3f ms %.2f TF | 16x16x4: %.3f ms %.2f TF | 16x16x4 pipelined: %.3f ms %.2f TF (x%.3f) | maxdiff %.3e\n",
+           s.M, s.N, s.K, s.lower, nb, best[0], fl / best[0] / 1e9, best[1], fl / best[1] / 1e9, best[2], fl / best[2] / 1e9, best[0] / best[2], hmax);
     fflush(stdout);
   }
   return 0;
