@@ -1478,6 +1478,10 @@ __global__ __launch_bounds__(256, 1) void gemm16p_kernel(BatchPtr Cb, size_t gof
 //     acc[tv][tu][r] (lane l)  <->  C[bm + wr + 32 tu + (l & 31),  bn + wc + 32 tv + (r & 3) + 8 (r >> 2) + 4 (l >> 5)].
 // ---------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// Software-pipelined like gemm16p_kernel (one MFMA of 64 cycles in flight covers the LDS reads, LDS writes, global loads and the
+// barrier issued behind it): BK = 32 per LDS stage = 16 k-pairs of TU x TV MFMAs; per k-pair the fragments of the NEXT pair are
+// read, and one staging instruction (ds_write_b128 of tile t+1 in the first half, global_load_dwordx4 of tile t+2 in the second)
+// rides along; the barrier sits before the last k-pair, whose MFMAs cover the first fragment reads of tile t+1.
 template <int BN, bool SET>
 __global__ __launch_bounds__(256, 2) void gemm32_kernel(BatchPtr Cb, size_t goffC, int ldc, BatchPtr Ab, size_t goffA, int lda,
                                                          BatchPtr Bb, size_t goffB, int ldb,
@@ -1486,12 +1490,12 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(BatchPtr Cb, size_t goff
   float* C = reinterpret_cast<float*>(Cb.p[blockIdx.y]) + goffC;
   const float* A = reinterpret_cast<const float*>(Ab.p[blockIdx.y]) + goffA;
   const float* B = reinterpret_cast<const float*>(Bb.p[blockIdx.y]) + goffB;
-  constexpr int BM = 128, BK = 16;
+  constexpr int BM = 128, BK = 32;
   constexpr int WN = BN / 2;
   constexpr int TU = 2, TV = WN / 32;
-  constexpr int SA = BM + 4, SB = BN + 4;      // +4 floats: k-columns start 16 B apart modulo the bank row (ds_write_b128 of 4 rows)
-  constexpr int NLA = (BM * BK / 4) / 256;     // 2: thread t stages rows 4(t%32).. of k-columns t/32 + 8q
-  constexpr int NLB = (BN * BK / 4) / 256;     // 2 (BN=128) or 1 (BN=64)
+  constexpr int SA = BM + 4, SB = BN + 4;
+  constexpr int NLA = (BM * BK / 4) / 256;     // 4: thread t stages rows 4(t%32).. of k-columns t/32 + 8q
+  constexpr int NLB = (BN * BK / 4) / 256;     // 4 (BN=128) or 2 (BN=64)
   constexpr int KSB = 256 / (BN / 4);          // k-columns covered per pass of the B staging (8 or 16)
   __shared__ __attribute__((aligned(16))) float As[2][BK * SA];
   __shared__ __attribute__((aligned(16))) float Bs[2][BK * SB];
@@ -1502,28 +1506,44 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(BatchPtr Cb, size_t goff
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int wr = (w & 1) * 64, wc = (w >> 1) * WN;
   const bool active = (bm + wr < M) && (bn + wc < N) && !(lower && bm + wr + 63 < bn + wc);
-  const int nk_all = K / BK;
+  // K is a multiple of 16 (callers: multiples of 64); a trailing half stage (K % 32 == 16) is handled by zero-weighting: the
+  // k range of a part is cut on 32-column boundaries and K % 32 != 0 falls back to one extra half-filled stage
+  const int nk_all = (K + BK - 1) / BK;
   int kc0 = (int)((long long)nk_all * part / nparts);
   const int kc1 = (int)((long long)nk_all * (part + 1) / nparts);
   if (kfrom_row && kc0 < bm / BK) kc0 = bm / BK;
-  A += (size_t)kc0 * BK * lda;
-  B += (size_t)kc0 * BK * ldb;
+  const int nk = kc1 - kc0;
+  const int kmax = K - 1;                      // last valid k-column (loads are clamped to it; clamped duplicates are zeroed below)
 
   int rowa = bm + 4 * (t % (BM / 4)); if (rowa > M - 4) rowa = M - 4;
   int rowb = bn + 4 * (t % (BN / 4)); if (rowb > N - 4) rowb = N - 4;
-  const float* ga0 = A + (size_t)(t / (BM / 4)) * lda + rowa;
-  const float* gb0 = B + (size_t)(t / (BN / 4)) * ldb + rowb;
-  const int sa0 = (t / (BM / 4)) * SA + 4 * (t % (BM / 4));
-  const int sb0 = (t / (BN / 4)) * SB + 4 * (t % (BN / 4));
+  const int ka = t / (BM / 4), kb = t / (BN / 4);          // this thread's k-column inside a pass
+  const float* gA = A + rowa;
+  const float* gB = B + rowb;
+  const int sa0 = ka * SA + 4 * (t % (BM / 4));
+  const int sb0 = kb * SB + 4 * (t % (BN / 4));
   float4 ra[NLA], rb[NLB];
+  auto load_tile = [&](int kt) {                // global -> registers for k-stage kt (absolute stage index), zero beyond K
+    const int k0 = kt * BK;
 #pragma unroll
-  for (int q = 0; q < NLA; ++q) ra[q] = *reinterpret_cast<const float4*>(ga0 + (size_t)(8 * q) * lda);
+    for (int q = 0; q < NLA; ++q) {
+      const int k = k0 + ka + 8 * q;
+      ra[q] = *reinterpret_cast<const float4*>(gA + (size_t)(k <= kmax ? k : kmax) * lda);
+      if (k > kmax) ra[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 #pragma unroll
-  for (int q = 0; q < NLB; ++q) rb[q] = *reinterpret_cast<const float4*>(gb0 + (size_t)(KSB * q) * ldb);
+    for (int q = 0; q < NLB; ++q) {
+      const int k = k0 + kb + KSB * q;
+      rb[q] = *reinterpret_cast<const float4*>(gB + (size_t)(k <= kmax ? k : kmax) * ldb);
+      if (k > kmax) rb[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  load_tile(kc0);
 #pragma unroll
   for (int q = 0; q < NLA; ++q) *reinterpret_cast<float4*>(&As[0][sa0 + 8 * q * SA]) = ra[q];
 #pragma unroll
   for (int q = 0; q < NLB; ++q) *reinterpret_cast<float4*>(&Bs[0][sb0 + KSB * q * SB]) = rb[q];
+  load_tile(kc0 + (nk > 1 ? 1 : 0));
   __syncthreads();
 
   f32x16 acc[TV][TU];
@@ -1536,40 +1556,59 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(BatchPtr Cb, size_t goff
 
   const int l31 = lane & 31, lh = lane >> 5;
   const int offA = lh * SA + wr + l31, offB = lh * SB + wc + l31;
-  const int nk = kc1 - kc0;
+  float fu[2][TU], fv[2][TV];
+#pragma unroll
+  for (int u = 0; u < TU; ++u) fu[0][u] = As[0][offA + 32 * u];
+#pragma unroll
+  for (int v = 0; v < TV; ++v) fv[0][v] = Bs[0][offB + 32 * v];
+
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) {
-      const float* pa = ga0 + (size_t)(kt + 1) * BK * lda;
-      const float* pb = gb0 + (size_t)(kt + 1) * BK * ldb;
+    const float* as = &As[buf][0];
+    const float* bs = &Bs[buf][0];
+    float* asn = &As[buf ^ 1][0];
+    float* bsn = &Bs[buf ^ 1][0];
+    const int kn2 = kc0 + ((kt + 2 < nk) ? kt + 2 : nk - 1);
 #pragma unroll
-      for (int q = 0; q < NLA; ++q) ra[q] = *reinterpret_cast<const float4*>(pa + (size_t)(8 * q) * lda);
+    for (int kp = 0; kp < BK / 2; ++kp) {
+      const int cur = kp & 1, nxt = cur ^ 1;
+      // before the LAST pair: every fragment of this buffer has been read (pair 15's were issued during pair 14) and tile t+1 is
+      // complete in the other buffer
+      if (kp == BK / 2 - 1) __syncthreads();
+      // fragments of the next k-pair (the last pair reads the first pair of tile t+1 from the other buffer)
+      if (kp + 1 < BK / 2) {
 #pragma unroll
-      for (int q = 0; q < NLB; ++q) rb[q] = *reinterpret_cast<const float4*>(pb + (size_t)(KSB * q) * ldb);
-    }
-    if (active) {
-      const float* as = &As[buf][0];
-      const float* bs = &Bs[buf][0];
+        for (int u = 0; u < TU; ++u) fu[nxt][u] = as[offA + 2 * (kp + 1) * SA + 32 * u];
 #pragma unroll
-      for (int s2 = 0; s2 < BK / 2; ++s2) {
-        float fu[TU], fv[TV];
+        for (int v = 0; v < TV; ++v) fv[nxt][v] = bs[offB + 2 * (kp + 1) * SB + 32 * v];
+      } else {
 #pragma unroll
-        for (int u = 0; u < TU; ++u) fu[u] = as[offA + 2 * s2 * SA + 32 * u];      // rows of C: the MFMA's B operand
+        for (int u = 0; u < TU; ++u) fu[nxt][u] = asn[offA + 32 * u];
 #pragma unroll
-        for (int v = 0; v < TV; ++v) fv[v] = bs[offB + 2 * s2 * SB + 32 * v];      // columns of C: the MFMA's A operand
+        for (int v = 0; v < TV; ++v) fv[nxt][v] = bsn[offB + 32 * v];
+      }
+      // one staging instruction per k-pair: ds_write of tile t+1 (pairs 0 .. NLA+NLB-1), then the global loads of tile t+2
+      if (kp < NLA) *reinterpret_cast<float4*>(&asn[sa0 + 8 * kp * SA]) = ra[kp];
+      else if (kp < NLA + NLB) *reinterpret_cast<float4*>(&bsn[sb0 + KSB * (kp - NLA) * SB]) = rb[kp - NLA];
+      else if (kp < 2 * NLA + NLB) {
+        const int q = kp - NLA - NLB, k = kn2 * BK + ka + 8 * q;
+        ra[q] = *reinterpret_cast<const float4*>(gA + (size_t)(k <= kmax ? k : kmax) * lda);
+        if (k > kmax) ra[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else if (kp < 2 * NLA + 2 * NLB) {
+        const int q = kp - 2 * NLA - NLB, k = kn2 * BK + kb + KSB * q;
+        rb[q] = *reinterpret_cast<const float4*>(gB + (size_t)(k <= kmax ? k : kmax) * ldb);
+        if (k > kmax) rb[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      if (active) {
 #pragma unroll
         for (int v = 0; v < TV; ++v)
 #pragma unroll
-          for (int u = 0; u < TU; ++u) acc[v][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[v], fu[u], acc[v][u], 0, 0, 0);
+          for (int uu = 0; uu < TU; ++uu) {
+            const int u = (v & 1) ? TU - 1 - uu : uu;
+            acc[v][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[cur][v], fu[cur][u], acc[v][u], 0, 0, 0);
+          }
       }
     }
-    if (kt + 1 < nk) {
-#pragma unroll
-      for (int q = 0; q < NLA; ++q) *reinterpret_cast<float4*>(&As[buf ^ 1][sa0 + 8 * q * SA]) = ra[q];
-#pragma unroll
-      for (int q = 0; q < NLB; ++q) *reinterpret_cast<float4*>(&Bs[buf ^ 1][sb0 + KSB * q * SB]) = rb[q];
-    }
-    __syncthreads();
   }
   if (!active) return;
 #pragma unroll
