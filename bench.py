@@ -306,6 +306,8 @@ def main():
                                                 else "gemm16p_kernel<128,false> (v_mfma_f64_16x16x4_f64, VGPR accumulators, software-pipelined SYRK/GEMM trailing update)"),
                     "achieved": round(ach, 3), "peak": peak_tf, "unit": "TFLOP/s",
                     "frac": round(ach / peak_tf, 4), "traffic": traffic if args.dtype == "f64" else None,
+                    "traffic_source": ("profiles/pmc_traffic.json: fabric bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                       "passes of this command (FETCH_SIZE x2, gfx950); NOT measured in this run") if traffic else None,
                     "launches": up["launches"], "avg_launch_ms": round(up["ms"] / up["launches"], 4),
                     "flops_per_launch": up["work"] / up["launches"],
                     "algorithmic_bytes_per_launch": up["bytes"] / up["launches"],
@@ -325,6 +327,19 @@ def main():
         fl = m * n ** 3 / 3.0 if orth else (m * n) ** 3 / 3.0
         if evals_per_s:
             extra["end_to_end_cholesky_tflops"] = round(fl * evals_per_s / 1e12 / (1 if orth else world), 3)
+        if args.workload == "c2" and world == 1 and orth and args.steps > 0:
+            # what ONE rank of the 8-GPU job does per evaluation: its 4-latent share (with the regulariser, as rank 0), timed here
+            # on one GPU -- the per-rank time the driver's N = 8 run should show, before the 8-byte all-reduce
+            fsh = lmm_amd.ILMM(fs, H, shard=lmm_amd.latent_shard(m, 0, 8))(xin, s2)
+            lmm_amd.logpdf(fsh, yd, True)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            for _ in range(3):
+                lmm_amd.logpdf(fsh, yd, True)
+            torch.cuda.synchronize(); dts = (time.perf_counter() - t1) / 3
+            tfs = (m // 8) * n ** 3 / 3.0 / dts / 1e12
+            extra["share_of_8gpu_job"] = {"latents": m // 8, "ms_per_eval": round(dts * 1e3, 2), "cholesky_tflops": round(tfs, 2),
+                                          "frac_of_fp64_peak": round(tfs / FP64_MFMA_PEAK_TFLOPS, 4),
+                                          "implied_speedup_at_8_gpus": round((dt / steps) / dts, 2)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -176,6 +176,11 @@ int lmm_ilmm_logpdf_ex(const double* x, int d, int n, const double* y, int p,
                        const double* H, int m, double sigma2, const lmm_gp_t* gps,
                        const lmm_jitters_t* jit, int allow_decoupled, int* path_used, double* out);
 
+/* logpdf(fx::FiniteGP{<:ILMM}, Y::AbstractMatrix), dense H: one value per column of Y ((n p) x ncol, column-major) from ONE
+ * (mn) x (mn) factorisation (TestUtils on ilmmx, reference test/ilmm.jl:34-37).  out: ncol values. */
+int lmm_ilmm_logpdf_multi(const double* x, int d, int n, const double* Y, int p, int ncol, const double* H, int m, double sigma2,
+                          const lmm_gp_t* gps, const lmm_jitters_t* jit, double* out);
+
 /* logpdf(ft::FiniteGP{<:IndependentMOGP,<:MOInputIsotopicByOutputs,<:Diagonal{<:Real,<:Fill}}, y):
  * reference src/independent_mogp.jl:74-80.  y is n x m. */
 int lmm_mogp_logpdf(const double* x, int d, int n, const double* y, int m, double sigma2,

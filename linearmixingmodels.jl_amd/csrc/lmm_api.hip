@@ -1399,6 +1399,63 @@ int lmm_ilmm_logpdf(const double* x, int d, int n, const double* y, int p, const
   return lmm_ilmm_logpdf_ex(x, d, n, y, p, H, m, sigma2, gps, jit, 1, nullptr, out);
 }
 
+// logpdf(fx::FiniteGP{<:ILMM}, Y::AbstractMatrix), dense H: one value per column of Y ((n p) x ncol) from ONE (mn) x (mn)
+// factorisation -- the columns ride it as rider rows (AbstractGPs.TestUtils calls logpdf(fx, Y) on ilmmx, reference
+// test/ilmm.jl:34-37; the reference answers through the generic dense fallback, one factorisation per call all the same).
+int lmm_ilmm_logpdf_multi(const double* x, int d, int n, const double* Y, int p, int ncol, const double* H, int m, double sigma2,
+                          const lmm_gp_t* gps, const lmm_jitters_t* jit, double* out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  REQUIRE_INIT();
+  LMM_TRY
+  REQUIRE_F64("the dense (mn) x (mn) ILMM factorisation");
+  if (!x || !Y || !H || !out || d <= 0 || n <= 0 || p <= 0 || m <= 0 || ncol <= 0) return fail(LMM_ERR_ARG, "bad arguments");
+  if (int rc = check_gps(gps, m)) return rc;
+  if (!(sigma2 > 0.0)) return fail(LMM_ERR_ARG, "sigma2 must be > 0");
+  if (!jit) jit = &kDefaultJit;
+  if ((long long)m * n > 2000000000LL / 64) return fail(LMM_ERR_UNSUPPORTED, "m*n too large for the dense path");
+  hipStream_t st0 = g.streams[0];
+  std::vector<double> T, ST;
+  double logdetST = 0.0;
+  if (int rc = project_dense(H, p, m, sigma2, jit->project_jitter, T, ST, &logdetST)) return rc;
+  DevIn xd(x, (size_t)d * n, st0), yd(Y, (size_t)n * p * ncol, st0);
+  Uploaded Td(T, st0), STd(ST, st0);
+  std::vector<double> Hv(H, H + (size_t)p * m), means(m);
+  std::vector<LatentDev> lat(m);
+  for (int l = 0; l < m; ++l) { means[l] = gps[l].mean; lat[l] = to_dev(gps[l]); }
+  Uploaded Hd(Hv, st0), meansd(means, st0);
+  Buf<LatentDev> latd(m);
+  HIPCHK(hipMemcpyAsync(latd.p, lat.data(), m * sizeof(LatentDev), hipMemcpyHostToDevice, st0));
+  const int N = m * n;
+  Buf<double> Ty((size_t)N), delta((size_t)N * ncol), partial(tall_skinny_partials(n, p)), resid_dev(ncol), lml_dev(ncol);
+  for (int c = 0; c < ncol; ++c) {
+    const double* yc = yd.p + (size_t)c * n * p;
+    project_on_device(yc, n, p, Td.buf, m, 0, m, nullptr, Ty.p, st0);
+    residual_on_device(yc, n, p, Ty.p, m, Hd.buf, partial.p, resid_dev.p + c, st0);
+    project_on_device(yc, n, p, Td.buf, m, 0, m, meansd.buf.p, delta.p + (size_t)c * N, st0);      // rider c: [latent][point]
+  }
+  Dims D(N, ncol);
+  Buf<double> A(D.elems()), W((size_t)(D.NC / 64) * 4096);
+  Buf<int> info(1);
+  HIPCHK(hipMemsetAsync(info.p, 0, sizeof(int), st0));
+  DenseArgs a{};
+  a.A = A.p; a.ld = D.ld; a.nrows = D.NR; a.ncols = D.NC; a.x = xd.p; a.d = d; a.n = n; a.m = m;
+  a.lat = latd.p; a.sigmaT = STd.buf.p; a.rider = delta.p; a.rider_ld = N; a.nrider = ncol;
+  launch_dense_assemble(a, st0);
+  potrf_rec(A.p, D.ld, D.NR, 0, D.NC, W.p, N, info.p, st0);
+  launch_lml_reduce(A.p, D.ld, N, D.NC, ncol, lml_dev.p, st0);
+  std::vector<double> lml(ncol), resid(ncol);
+  int hinfo = 0;
+  HIPCHK(hipMemcpyAsync(lml.data(), lml_dev.p, ncol * sizeof(double), hipMemcpyDeviceToHost, st0));
+  HIPCHK(hipMemcpyAsync(resid.data(), resid_dev.p, ncol * sizeof(double), hipMemcpyDeviceToHost, st0));
+  HIPCHK(hipMemcpyAsync(&hinfo, info.p, sizeof(int), hipMemcpyDeviceToHost, st0));
+  HIPCHK(hipStreamSynchronize(st0));
+  if (int rc = check_info(std::vector<int>{hinfo}, 0)) return rc;
+  for (int c = 0; c < ncol; ++c)      // reference src/ilmm.jl:171-181
+    out[c] = lml[c] - ((double)n * ((double)(p - m) * kLog2Pi + ((double)p * std::log(sigma2) - logdetST)) + resid[c] / sigma2) / 2.0;
+  return LMM_OK;
+  LMM_CATCH
+}
+
 // Value and gradient of logpdf(fx::FiniteGP{<:ILMM}, y) with a dense H (reference src/ilmm.jl:150-181 differentiated; the
 // reference's tests take Zygote.gradient(logpdf, ilmmx, y), test/ilmm.jl:31) w.r.t. y, sigma2, H (p x m) and every latent's
 // (variance, lengthscale, mean).  The reference's own operation: ONE (mn) x (mn) factorisation of blockdiag(K_l) + SigmaT (x) I;

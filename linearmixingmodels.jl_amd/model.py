@@ -434,8 +434,16 @@ def _logpdf_matrix(fx: FiniteGP, Y, with_regulariser: bool = True) -> np.ndarray
         s2_eff = s2                                # log S = 0 and (p-m) = 0 terms; skip it exactly
     else:
         unpack(fx)
-        if not f.is_oilmm:
-            raise NotImplementedError("matrix-Y logpdf is built for Orthogonal H and IndependentMOGP")
+        if not f.is_oilmm:                         # dense H: one (mn) x (mn) factorisation, the columns ride it
+            if f.f._post is not None:
+                raise NotImplementedError("matrix-Y logpdf on a posterior")
+            Ha, _, p, m = _H_args(f.H)
+            if x.out_dim != p:
+                raise RuntimeError("out dim of x != out dim of f.")
+            out = np.empty(ncol)
+            L.check(lib.lmm_ilmm_logpdf_multi(x.carr().ptr, x.dim, x.n, L.Arr(Yc).ptr, p, ncol, Ha.ptr, m, C.c_double(s2),
+                                              L.gps_array([g.desc() for g in f.f.fs]), None, L.Arr(out, True).ptr))
+            return out
         descs, (Ua, Sa, p, m), shard, post, s2_eff = [g.desc() for g in f.f.fs], _H_args(f.H), f.shard, f.f._post, s2
     if post is not None:
         raise NotImplementedError("matrix-Y logpdf on a posterior")

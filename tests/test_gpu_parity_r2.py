@@ -384,3 +384,37 @@ def test_dense_ilmm_logpdf_gradient_vs_oracle_fd(lmm, n, d):
                 g2 = [dict(g) for g in gps]; g2[l][key] += t
                 return F(gps=g2)
             assert G["gps"][l][key] == pytest.approx(_fd(f1), rel=2e-5, abs=1e-6)
+
+
+def test_dense_ilmm_matrix_y_logpdf(lmm):
+    """logpdf(ilmmx, Y::Matrix) on the dense-H model (TestUtils, reference test/ilmm.jl:34-37): one factorisation, one value per
+    column, each equal to the vector logpdf of that column."""
+    rng = np.random.default_rng(71)
+    n, p, m, ncol = 90, 4, 3, 5
+    x = np.sort(rng.uniform(0, 9, n))
+    gps = _gps(["se", "matern32", "matern52"], rng)
+    H = rng.uniform(0.1, 1.0, size=(p, m))
+    Y = rng.standard_normal((n * p, ncol))
+    fx = lmm.ILMM(_to_model(lmm, gps), H)(lmm.MOInputIsotopicByOutputs(x, p), 0.2)
+    vals = lmm.logpdf(fx, Y)
+    assert vals.shape == (ncol,)
+    for c in range(ncol):
+        assert vals[c] == pytest.approx(O.ilmm_logpdf(gps, H, x, 0.2, Y[:, c]), rel=1e-9)
+
+
+def test_update_kernel_variants_agree():
+    """The round-1 update kernels stay selectable (LMM_GEMM_M16=0: v_mfma_f64_4x4x4; 1: 16x16x4 in the round-1 loop; LMM_GEMM_FLAGS=1:
+    LDS-flag synchronised 4x4x4); each must give the default kernel's logpdf."""
+    import subprocess, sys, json
+    code = ("import sys, json; sys.path.insert(0, %r); import numpy as np, lmm_amd; "
+            "from lmm_amd.workloads import synthetic_problem as sp; lmm_amd.init(0); P = sp(3, 5, 1500, 'matern52', True, seed=2); "
+            "f = lmm_amd.ILMM(lmm_amd.independent_mogp([lmm_amd.GP(lmm_amd.Matern52Kernel()) for _ in range(3)]), lmm_amd.Orthogonal(P['U'], P['S'])); "
+            "print(json.dumps(lmm_amd.logpdf(f(lmm_amd.MOInputIsotopicByOutputs(P['x'], 5), 0.1), P['y'])))") % os.path.dirname(HERE)
+    vals = {}
+    for name, env in [("default", {}), ("m16_0", {"LMM_GEMM_M16": "0"}), ("m16_1", {"LMM_GEMM_M16": "1"}), ("flags", {"LMM_GEMM_M16": "0", "LMM_GEMM_FLAGS": "1"}),
+                      ("diag_v2", {"LMM_DIAG_V2": "1"})]:
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        vals[name] = json.loads(out.stdout.strip().splitlines()[-1])
+    for name, v in vals.items():
+        assert v == pytest.approx(vals["default"], rel=1e-11), (name, vals)
