@@ -325,7 +325,10 @@ void batch_plan(int ms, int* nb_per, int* nstreams_used, double bytes_per_latent
   // behind the other's updates (C2 share of 4 latents: 108 vs 110 ms).  LMM_MIN_BATCHES overrides.
   static int minb_env = -2;
   if (minb_env == -2) { const char* e = getenv("LMM_MIN_BATCHES"); minb_env = e ? std::max(1, atoi(e)) : -1; }
-  const int minb = minb_env > 0 ? minb_env : ((bytes_per_latent > 0.0 && bytes_per_latent <= 6e8) ? 1 : 2);
+  // Round 2: with the software-pipelined update kernel one fuller lock-step batch beats two smaller ones on two streams at every
+  // size (C2 share of 4 latents: 99.5 ms as one batch, 102.3 as 2 x 2, 105.4 as 4 x 1; gpurun r2n_shard_batches.log), so the
+  // default is ONE batch per `bmax` latents; concurrent streams still carry the batches of larger shards.
+  const int minb = minb_env > 0 ? minb_env : 1;
   // small factor matrices (n <= ~2000) are latency-bound end to end: one lock-step batch of up to LMM_MAX_BATCH latents costs the
   // same leaf chain as a batch of 8 (reference notebook shape, 20 latents: 3 batches of 8/8/4 -> one of 20)
   static int bsmall = -1;
