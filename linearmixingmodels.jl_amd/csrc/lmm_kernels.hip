@@ -1316,7 +1316,56 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(BatchPtr Cb, size_t goff
 //   __builtin_amdgcn_sched_group_barrier pins the interleave (hipcc otherwise clusters the loads ahead of the MFMAs).
 // ---------------------------------------------------------------------------------------------------
 #define LMM_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
-template <int BN_, bool SET_>
+#define LMM_MFMA16(SET, V, U) acc[V][U] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[SET][V], fa[SET][U], acc[V][U], 0, 0, 0)
+#define LMM_MFMA16_ALL(SET)                                                                                   \
+    LMM_MFMA16(SET, 0, 0); LMM_MFMA16(SET, 0, 1); LMM_MFMA16(SET, 0, 2); LMM_MFMA16(SET, 0, 3);               \
+    LMM_MFMA16(SET, 1, 3); LMM_MFMA16(SET, 1, 2); LMM_MFMA16(SET, 1, 1); LMM_MFMA16(SET, 1, 0);               \
+    LMM_MFMA16(SET, 2, 0); LMM_MFMA16(SET, 2, 1); LMM_MFMA16(SET, 2, 2); LMM_MFMA16(SET, 2, 3);               \
+    LMM_MFMA16(SET, 3, 3); LMM_MFMA16(SET, 3, 2); LMM_MFMA16(SET, 3, 1); LMM_MFMA16(SET, 3, 0)
+// One k-tile of the pipeline.  RA / RB: the staging registers that hold tile t+1 on entry; they are written to the other LDS
+// buffer and immediately reloaded with tile `KLOAD` (each global load one instruction behind the ds_write that frees its
+// register), so a load has a whole tile (DEPTH 1) or two tiles (DEPTH 2, two register sets) to arrive.
+#define LMM_TILE_BODY(RA, RB, KLOAD)                                                                                              \
+  {                                                                                                                               \
+    const double* pa = ga0 + (size_t)(KLOAD) * BK * lda;                                                                          \
+    const double* pb = gb0 + (size_t)(KLOAD) * BK * ldb;                                                                          \
+    /* k-step 0: MFMAs on set 0; reads of k-step 1 into set 1; A half: ds_write of tile t+1, reload */                             \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) { fa[1][u] = as[offA + 4 * SA + 16 * u]; fb[1][u] = bs[offB + 4 * SB + 16 * u]; } \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                               \
+      *reinterpret_cast<d2*>(&asn[sa0 + 4 * q * SA]) = RA[q];                                                                     \
+      RA[q] = *reinterpret_cast<const d2*>(pa + (size_t)(4 * q) * lda);                                                           \
+    }                                                                                                                             \
+    LMM_MFMA16_ALL(0);                                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x100, 1); }                                       \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x200, 1); LMM_SGB(0x008, 1); LMM_SGB(0x020, 1); } \
+    /* k-step 1: MFMAs on set 1; reads of k-step 2 into set 0; B half: ds_write, reload */                                        \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) { fa[0][u] = as[offA + 8 * SA + 16 * u]; fb[0][u] = bs[offB + 8 * SB + 16 * u]; } \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                               \
+      *reinterpret_cast<d2*>(&bsn[sb0 + 4 * q * SB]) = RB[q];                                                                     \
+      RB[q] = *reinterpret_cast<const d2*>(pb + (size_t)(4 * q) * ldb);                                                           \
+    }                                                                                                                             \
+    LMM_MFMA16_ALL(1);                                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x100, 1); }                                       \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x200, 1); LMM_SGB(0x008, 1); LMM_SGB(0x020, 1); } \
+    /* k-step 2: MFMAs on set 0; reads of k-step 3 into set 1 */                                                                  \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) { fa[1][u] = as[offA + 12 * SA + 16 * u]; fb[1][u] = bs[offB + 12 * SB + 16 * u]; } \
+    LMM_MFMA16_ALL(0);                                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x100, 1); }                                       \
+    LMM_SGB(0x008, 8);                                                                                                            \
+    /* k-step 3, first part: 10 MFMAs on set 1, then the barrier */                                                               \
+    LMM_MFMA16(1, 0, 0); LMM_MFMA16(1, 0, 1); LMM_MFMA16(1, 0, 2); LMM_MFMA16(1, 0, 3);                                           \
+    LMM_MFMA16(1, 1, 3); LMM_MFMA16(1, 1, 2); LMM_MFMA16(1, 1, 1); LMM_MFMA16(1, 1, 0);                                           \
+    LMM_MFMA16(1, 2, 0); LMM_MFMA16(1, 2, 1);                                                                                     \
+    __syncthreads();                                                                                                              \
+    /* k-step 3, second part: 6 MFMAs on set 1, interleaved with the reads of tile t+1's k-step 0 into set 0 */                   \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) { fa[0][u] = asn[offA + 16 * u]; fb[0][u] = bsn[offB + 16 * u]; }               \
+    LMM_MFMA16(1, 2, 2); LMM_MFMA16(1, 2, 3);                                                                                     \
+    LMM_MFMA16(1, 3, 3); LMM_MFMA16(1, 3, 2); LMM_MFMA16(1, 3, 1); LMM_MFMA16(1, 3, 0);                                           \
+    _Pragma("unroll") for (int i = 0; i < 6; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x100, 1); }                                       \
+    LMM_SGB(0x100, 2);                                                                                                            \
+  }
+
+template <int DEPTH>
 __global__ __launch_bounds__(256, 1) void gemm16p_kernel(BatchPtr Cb, size_t goffC, int ldc, BatchPtr Ab, size_t goffA, int lda,
                                                           BatchPtr Bb, size_t goffB, int ldb,
                                                           int M, int N, int K, int lower, int MT, int full_items,
@@ -1349,17 +1398,22 @@ __global__ __launch_bounds__(256, 1) void gemm16p_kernel(BatchPtr Cb, size_t gof
   const double* gb0 = B + (size_t)(t >> 6) * ldb + rowb;
   const int sa0 = (t >> 6) * SA + 2 * (t & 63);
   const int sb0 = (t >> 6) * SB + 2 * (t & 63);
-  d2 ra[4], rb[4];
+  d2 ra[4], rb[4], ra2[DEPTH == 2 ? 4 : 1], rb2[DEPTH == 2 ? 4 : 1];
 #pragma unroll
   for (int q = 0; q < 4; ++q) { ra[q] = *reinterpret_cast<const d2*>(ga0 + (size_t)(4 * q) * lda); rb[q] = *reinterpret_cast<const d2*>(gb0 + (size_t)(4 * q) * ldb); }
 #pragma unroll
   for (int q = 0; q < 4; ++q) { *reinterpret_cast<d2*>(&As[0][sa0 + 4 * q * SA]) = ra[q]; *reinterpret_cast<d2*>(&Bs[0][sb0 + 4 * q * SB]) = rb[q]; }
-  {                                                  // tile 1 into registers (clamped: a one-tile product just reloads tile 0)
-    const int k1 = nk > 1 ? 1 : 0;
-    const double* pa = ga0 + (size_t)k1 * BK * lda;
-    const double* pb = gb0 + (size_t)k1 * BK * ldb;
+  {                                                  // tile 1 (and, DEPTH 2, tile 2) into registers; clamped indices reload valid tiles
+    const int k1 = nk > 1 ? 1 : 0, k2 = nk > 2 ? 2 : nk - 1;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { ra[q] = *reinterpret_cast<const d2*>(pa + (size_t)(4 * q) * lda); rb[q] = *reinterpret_cast<const d2*>(pb + (size_t)(4 * q) * ldb); }
+    for (int q = 0; q < 4; ++q) {
+      ra[q] = *reinterpret_cast<const d2*>(ga0 + (size_t)k1 * BK * lda + (size_t)(4 * q) * lda);
+      rb[q] = *reinterpret_cast<const d2*>(gb0 + (size_t)k1 * BK * ldb + (size_t)(4 * q) * ldb);
+      if (DEPTH == 2) {
+        ra2[q] = *reinterpret_cast<const d2*>(ga0 + (size_t)k2 * BK * lda + (size_t)(4 * q) * lda);
+        rb2[q] = *reinterpret_cast<const d2*>(gb0 + (size_t)k2 * BK * ldb + (size_t)(4 * q) * ldb);
+      }
+    }
   }
   __syncthreads();
 
@@ -1374,76 +1428,32 @@ __global__ __launch_bounds__(256, 1) void gemm16p_kernel(BatchPtr Cb, size_t gof
 #pragma unroll
   for (int u = 0; u < 4; ++u) { fa[0][u] = As[0][offA + 16 * u]; fb[0][u] = Bs[0][offB + 16 * u]; }
 
-#define LMM_MFMA16(SET, V, U) acc[V][U] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[SET][V], fa[SET][U], acc[V][U], 0, 0, 0)
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    const double* as = &As[buf][0];
-    const double* bs = &Bs[buf][0];
-    double* asn = &As[buf ^ 1][0];
-    double* bsn = &Bs[buf ^ 1][0];
-    const int kn2 = (kt + 2 < nk) ? kt + 2 : nk - 1;                  // clamped: the surplus loads / writes of the last tiles are unused
-    const double* pa = ga0 + (size_t)kn2 * BK * lda;
-    const double* pb = gb0 + (size_t)kn2 * BK * ldb;
-    // ---- k-step 0: MFMAs on set 0; reads of k-step 1 into set 1; ds_write of the A half of tile t+1
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { fa[1][u] = as[offA + 4 * SA + 16 * u]; fb[1][u] = bs[offB + 4 * SB + 16 * u]; }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) *reinterpret_cast<d2*>(&asn[sa0 + 4 * q * SA]) = ra[q];
-    LMM_MFMA16(0, 0, 0); LMM_MFMA16(0, 0, 1); LMM_MFMA16(0, 0, 2); LMM_MFMA16(0, 0, 3);
-    LMM_MFMA16(0, 1, 3); LMM_MFMA16(0, 1, 2); LMM_MFMA16(0, 1, 1); LMM_MFMA16(0, 1, 0);
-    LMM_MFMA16(0, 2, 0); LMM_MFMA16(0, 2, 1); LMM_MFMA16(0, 2, 2); LMM_MFMA16(0, 2, 3);
-    LMM_MFMA16(0, 3, 3); LMM_MFMA16(0, 3, 2); LMM_MFMA16(0, 3, 1); LMM_MFMA16(0, 3, 0);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x100, 1); }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x200, 1); }
-    LMM_SGB(0x008, 4);
-    // ---- k-step 1: MFMAs on set 1; reads of k-step 2 into set 0; ds_write of the B half; global loads of tile t+2 (A half)
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { fa[0][u] = as[offA + 8 * SA + 16 * u]; fb[0][u] = bs[offB + 8 * SB + 16 * u]; }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) *reinterpret_cast<d2*>(&bsn[sb0 + 4 * q * SB]) = rb[q];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) ra[q] = *reinterpret_cast<const d2*>(pa + (size_t)(4 * q) * lda);
-    LMM_MFMA16(1, 0, 0); LMM_MFMA16(1, 0, 1); LMM_MFMA16(1, 0, 2); LMM_MFMA16(1, 0, 3);
-    LMM_MFMA16(1, 1, 3); LMM_MFMA16(1, 1, 2); LMM_MFMA16(1, 1, 1); LMM_MFMA16(1, 1, 0);
-    LMM_MFMA16(1, 2, 0); LMM_MFMA16(1, 2, 1); LMM_MFMA16(1, 2, 2); LMM_MFMA16(1, 2, 3);
-    LMM_MFMA16(1, 3, 3); LMM_MFMA16(1, 3, 2); LMM_MFMA16(1, 3, 1); LMM_MFMA16(1, 3, 0);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x100, 1); }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x200, 1); }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x020, 1); }
-    // ---- k-step 2: MFMAs on set 0; reads of k-step 3 into set 1; global loads of tile t+2 (B half)
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { fa[1][u] = as[offA + 12 * SA + 16 * u]; fb[1][u] = bs[offB + 12 * SB + 16 * u]; }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) rb[q] = *reinterpret_cast<const d2*>(pb + (size_t)(4 * q) * ldb);
-    LMM_MFMA16(0, 0, 0); LMM_MFMA16(0, 0, 1); LMM_MFMA16(0, 0, 2); LMM_MFMA16(0, 0, 3);
-    LMM_MFMA16(0, 1, 3); LMM_MFMA16(0, 1, 2); LMM_MFMA16(0, 1, 1); LMM_MFMA16(0, 1, 0);
-    LMM_MFMA16(0, 2, 0); LMM_MFMA16(0, 2, 1); LMM_MFMA16(0, 2, 2); LMM_MFMA16(0, 2, 3);
-    LMM_MFMA16(0, 3, 3); LMM_MFMA16(0, 3, 2); LMM_MFMA16(0, 3, 1); LMM_MFMA16(0, 3, 0);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x100, 1); }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x020, 1); }
-    LMM_SGB(0x008, 4);
-    // ---- k-step 3, first part: 10 MFMAs on set 1, then the barrier
-    LMM_MFMA16(1, 0, 0); LMM_MFMA16(1, 0, 1); LMM_MFMA16(1, 0, 2); LMM_MFMA16(1, 0, 3);
-    LMM_MFMA16(1, 1, 3); LMM_MFMA16(1, 1, 2); LMM_MFMA16(1, 1, 1); LMM_MFMA16(1, 1, 0);
-    LMM_MFMA16(1, 2, 0); LMM_MFMA16(1, 2, 1);
-    __syncthreads();
-    // ---- k-step 3, second part: 6 MFMAs on set 1, interleaved with the reads of tile t+1's k-step 0 into set 0
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { fa[0][u] = asn[offA + 16 * u]; fb[0][u] = bsn[offB + 16 * u]; }
-    LMM_MFMA16(1, 2, 2); LMM_MFMA16(1, 2, 3);
-    LMM_MFMA16(1, 3, 3); LMM_MFMA16(1, 3, 2); LMM_MFMA16(1, 3, 1); LMM_MFMA16(1, 3, 0);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x100, 1); }
-    LMM_SGB(0x100, 2);
+  if (DEPTH == 1) {
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = kt & 1;
+      const double* as = &As[buf][0];
+      const double* bs = &Bs[buf][0];
+      double* asn = &As[buf ^ 1][0];
+      double* bsn = &Bs[buf ^ 1][0];
+      const int kn = (kt + 2 < nk) ? kt + 2 : nk - 1;              // clamped: the surplus loads / writes of the last tiles are unused
+      LMM_TILE_BODY(ra, rb, kn)
+    }
+  } else {
+    for (int kt = 0; kt < nk; kt += 2) {                           // two tiles per trip: the register sets alternate statically
+      {
+        const double* as = &As[0][0]; const double* bs = &Bs[0][0];
+        double* asn = &As[1][0]; double* bsn = &Bs[1][0];
+        const int kn = (kt + 3 < nk) ? kt + 3 : nk - 1;
+        LMM_TILE_BODY(ra, rb, kn)
+      }
+      if (kt + 1 < nk) {
+        const double* as = &As[1][0]; const double* bs = &Bs[1][0];
+        double* asn = &As[0][0]; double* bsn = &Bs[0][0];
+        const int kn = (kt + 4 < nk) ? kt + 4 : nk - 1;
+        LMM_TILE_BODY(ra2, rb2, kn)
+      }
+    }
   }
-#undef LMM_MFMA16
   if (!active) return;
 #pragma unroll
   for (int v = 0; v < 4; ++v) {
@@ -1466,6 +1476,133 @@ __global__ __launch_bounds__(256, 1) void gemm16p_kernel(BatchPtr Cb, size_t gof
     }
   }
 }
+
+// Half-height companion of gemm16p_kernel for the RAGGED last 64 rows of an update (factor matrices carry 64 rider rows, so the
+// row count of every trailing update is an odd multiple of 64: a 128-row tile there has two idle waves for a whole tile time,
+// ~1.5 % of the update).  64 x 128 block tile, 4 waves side by side (64 x 32 each: 4 x 2 MFMA blocks), same LDS image and
+// pipeline; launched behind the main grid on the same stream for the rows [M - 64, M) when they lie below every column.
+#define LMM_MFMA16H_ALL(SET)                                                                                  \
+    LMM_MFMA16(SET, 0, 0); LMM_MFMA16(SET, 0, 1); LMM_MFMA16(SET, 0, 2); LMM_MFMA16(SET, 0, 3);               \
+    LMM_MFMA16(SET, 1, 3); LMM_MFMA16(SET, 1, 2); LMM_MFMA16(SET, 1, 1); LMM_MFMA16(SET, 1, 0)
+__global__ __launch_bounds__(256, 2) void gemm16h_kernel(BatchPtr Cb, size_t goffC, int ldc, BatchPtr Ab, size_t goffA, int lda,
+                                                          BatchPtr Bb, size_t goffB, int ldb, int N, int K) {
+  double* C = Cb.p[blockIdx.y] + goffC;              // row 0 = first of the 64 rows
+  const double* A = Ab.p[blockIdx.y] + goffA;
+  const double* B = Bb.p[blockIdx.y] + goffB;
+  constexpr int BM = 64, BN = 128, BK = 16;
+  constexpr int SA = BM + 16, SB = BN + 16;
+  __shared__ __attribute__((aligned(16))) double As[2][BK * SA];
+  __shared__ __attribute__((aligned(16))) double Bs[2][BK * SB];
+  const int bn = blockIdx.x * BN;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int wc = w * 32;
+  const int nk = K / BK;
+  // staging: A tile 64 x 16 = 512 d2 (2 per thread: rows 2(t%32).., k-columns t/32 + 8q); B tile 128 x 16 (4 per thread)
+  int rowb = bn + 2 * (t & 63); if (rowb > N - 2) rowb = N - 2;
+  const double* ga0 = A + (size_t)(t >> 5) * lda + 2 * (t & 31);
+  const double* gb0 = B + (size_t)(t >> 6) * ldb + rowb;
+  const int sa0 = (t >> 5) * SA + 2 * (t & 31);
+  const int sb0 = (t >> 6) * SB + 2 * (t & 63);
+  d2 ra[2], rb[4];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) ra[q] = *reinterpret_cast<const d2*>(ga0 + (size_t)(8 * q) * lda);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) rb[q] = *reinterpret_cast<const d2*>(gb0 + (size_t)(4 * q) * ldb);
+#pragma unroll
+  for (int q = 0; q < 2; ++q) *reinterpret_cast<d2*>(&As[0][sa0 + 8 * q * SA]) = ra[q];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) *reinterpret_cast<d2*>(&Bs[0][sb0 + 4 * q * SB]) = rb[q];
+  {
+    const int k1 = nk > 1 ? 1 : 0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) ra[q] = *reinterpret_cast<const d2*>(ga0 + (size_t)k1 * BK * lda + (size_t)(8 * q) * lda);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) rb[q] = *reinterpret_cast<const d2*>(gb0 + (size_t)k1 * BK * ldb + (size_t)(4 * q) * ldb);
+  }
+  __syncthreads();
+  d4 acc[2][4];
+#pragma unroll
+  for (int v = 0; v < 2; ++v)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[v][u] = (d4){0.0, 0.0, 0.0, 0.0};
+  const int l15 = lane & 15, lk = lane >> 4;
+  const int offA = lk * SA + l15, offB = lk * SB + wc + l15;
+  double fa[2][4], fb[2][2];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) fa[0][u] = As[0][offA + 16 * u];
+#pragma unroll
+  for (int v = 0; v < 2; ++v) fb[0][v] = Bs[0][offB + 16 * v];
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    const double* as = &As[buf][0];
+    const double* bs = &Bs[buf][0];
+    double* asn = &As[buf ^ 1][0];
+    double* bsn = &Bs[buf ^ 1][0];
+    const int kn = (kt + 2 < nk) ? kt + 2 : nk - 1;
+    const double* pa = ga0 + (size_t)kn * BK * lda;
+    const double* pb = gb0 + (size_t)kn * BK * ldb;
+    // k-step 0: A half of the staging
+#pragma unroll
+    for (int u = 0; u < 4; ++u) fa[1][u] = as[offA + 4 * SA + 16 * u];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) fb[1][v] = bs[offB + 4 * SB + 16 * v];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) { *reinterpret_cast<d2*>(&asn[sa0 + 8 * q * SA]) = ra[q]; ra[q] = *reinterpret_cast<const d2*>(pa + (size_t)(8 * q) * lda); }
+    LMM_MFMA16H_ALL(0);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x100, 1); }
+    LMM_SGB(0x008, 1); LMM_SGB(0x200, 1); LMM_SGB(0x020, 1); LMM_SGB(0x008, 1); LMM_SGB(0x200, 1); LMM_SGB(0x020, 1);
+    // k-step 1 and 2: B half of the staging, two pieces each
+#pragma unroll
+    for (int u = 0; u < 4; ++u) fa[0][u] = as[offA + 8 * SA + 16 * u];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) fb[0][v] = bs[offB + 8 * SB + 16 * v];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) { *reinterpret_cast<d2*>(&bsn[sb0 + 4 * q * SB]) = rb[q]; rb[q] = *reinterpret_cast<const d2*>(pb + (size_t)(4 * q) * ldb); }
+    LMM_MFMA16H_ALL(1);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x100, 1); }
+    LMM_SGB(0x008, 1); LMM_SGB(0x200, 1); LMM_SGB(0x020, 1); LMM_SGB(0x008, 1); LMM_SGB(0x200, 1); LMM_SGB(0x020, 1);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) fa[1][u] = as[offA + 12 * SA + 16 * u];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) fb[1][v] = bs[offB + 12 * SB + 16 * v];
+#pragma unroll
+    for (int q = 2; q < 4; ++q) { *reinterpret_cast<d2*>(&bsn[sb0 + 4 * q * SB]) = rb[q]; rb[q] = *reinterpret_cast<const d2*>(pb + (size_t)(4 * q) * ldb); }
+    LMM_MFMA16H_ALL(0);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x100, 1); }
+    LMM_SGB(0x008, 1); LMM_SGB(0x200, 1); LMM_SGB(0x020, 1); LMM_SGB(0x008, 1); LMM_SGB(0x200, 1); LMM_SGB(0x020, 1);
+    // k-step 3: 5 MFMAs, barrier, 3 MFMAs covering the first reads of tile t+1
+    LMM_MFMA16(1, 0, 0); LMM_MFMA16(1, 0, 1); LMM_MFMA16(1, 0, 2); LMM_MFMA16(1, 0, 3); LMM_MFMA16(1, 1, 3);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) fa[0][u] = asn[offA + 16 * u];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) fb[0][v] = bsn[offB + 16 * v];
+    LMM_MFMA16(1, 1, 2); LMM_MFMA16(1, 1, 1); LMM_MFMA16(1, 1, 0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x100, 2); }
+  }
+  if (bn + wc >= N) return;
+#pragma unroll
+  for (int v = 0; v < 2; ++v) {
+    double* cpv = C + (size_t)(bn + wc + 16 * v + lk) * ldc + l15;
+    double cv[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cv[u][r] = cpv[(size_t)(4 * r) * ldc + 16 * u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cpv[(size_t)(4 * r) * ldc + 16 * u] = cv[u][r] - acc[v][u][r];
+  }
+}
+#undef LMM_MFMA16H_ALL
+#undef LMM_TILE_BODY
+#undef LMM_MFMA16_ALL
+#undef LMM_MFMA16
 
 // ---------------------------------------------------------------------------------------------------
 // K2b (fp32 compute mode): the same C {-=, =} A B' on v_mfma_f32_32x32x2_f32 (exact f32, 64 FLOP/clk/SIMD = 157 TFLOP/s peak:
@@ -2300,6 +2437,17 @@ void launch_gemm_nt(const BatchPtr& C, size_t offC, int ldc, const BatchPtr& A, 
                             K, 0, MT, MT, 1, 0);
     return;
   }
+  // f64 wide update with a ragged last row tile (M an odd multiple of 64, the last 64 rows below every column): the main grid takes
+  // the full 128-row tiles, gemm16h_kernel the last 64 rows
+  static int ragged_split = -1;
+  if (ragged_split < 0) { const char* e = getenv("LMM_RAGGED_SPLIT"); ragged_split = e ? (atoi(e) != 0) : 1; }
+  if (g_gemm_m16 < 0) { const char* e = getenv("LMM_GEMM_M16"); g_gemm_m16 = e ? atoi(e) : 2; }
+  if (!g_f32 && !narrow && ragged_split && g_gemm_m16 >= 2 && (M % 128) == 64 && M - 64 >= N && M > 64 && (N % 128) == 0 && K >= 1024) {   // below K ~ 1000 the extra launch costs more than the idle waves
+    launch_gemm_nt(C, offC, ldc, A, offA, lda, B, offB, ldb, M - 64, N, K, lower, false, nb, st);
+    hipLaunchKernelGGL(gemm16h_kernel, dim3(N / 128, nb), dim3(256), 0, st, C, offC + (size_t)(M - 64), ldc, A, offA + (size_t)(M - 64), lda,
+                       B, offB, ldb, N, K);
+    return;
+  }
   const int BNsel = narrow ? 64 : 128;
   const int NT = narrow ? 1 : (N + 127) / 128;
   long long T = 0;
@@ -2332,8 +2480,13 @@ void launch_gemm_nt(const BatchPtr& C, size_t offC, int ldc, const BatchPtr& A, 
   }
   if (narrow) hipLaunchKernelGGL((gemm44_kernel<64, false>), dim3(items, nb), dim3(256), 0, st, C, offC, ldc, A, offA, lda, B, offB,
                                  ldb, M, N, K, lower, MT, full_items, splitk, 0);
-  else if (g_gemm_m16 == 2) hipLaunchKernelGGL((gemm16p_kernel<128, false>), dim3(items, nb), dim3(256), 0, st, C, offC, ldc, A, offA, lda, B, offB,
-                                               ldb, M, N, K, lower, MT, full_items, splitk, 0);
+  // staging loads one tile ahead (K < 1024: less prologue) or two (+0.4 % on the long products); LMM_GEMM_M16=3 / 4 force 2 / 1
+  else if (g_gemm_m16 == 3 || (g_gemm_m16 == 2 && K >= 1024))
+    hipLaunchKernelGGL((gemm16p_kernel<2>), dim3(items, nb), dim3(256), 0, st, C, offC, ldc, A, offA, lda, B, offB, ldb, M, N, K, lower, MT,
+                       full_items, splitk, 0);
+  else if (g_gemm_m16 == 2 || g_gemm_m16 == 4)
+    hipLaunchKernelGGL((gemm16p_kernel<1>), dim3(items, nb), dim3(256), 0, st, C, offC, ldc, A, offA, lda, B, offB, ldb, M, N, K, lower, MT,
+                       full_items, splitk, 0);
   else if (g_gemm_m16) hipLaunchKernelGGL((gemm16_kernel<128, false>), dim3(items, nb), dim3(256), 0, st, C, offC, ldc, A, offA, lda, B, offB,
                                           ldb, M, N, K, lower, MT, full_items, splitk, 0);
   else if (g_gemm_flags) hipLaunchKernelGGL((gemm44_kernel<128, false, true>), dim3(items, nb), dim3(256), 0, st, C, offC, ldc, A, offA, lda,
