@@ -282,7 +282,7 @@ def main():
         # kernels bracketed by HIP events on its stream; the batch runs on ONE stream so that an event pair times its
         # kernel alone (the timed region above runs several batches on concurrent streams).  DESIGN.md "Measurement".
         lib = lmm_amd.load()
-        nprof = min(8, shard[1] - shard[0]) if orth else m      # one production-sized batch of latents
+        nprof = min(16, shard[1] - shard[0]) if orth else m     # one production-sized batch of latents (LMM_BATCH default 16)
         fprof = lmm_amd.ILMM(fs, H, shard=(shard[0], shard[0] + nprof))(xin, s2) if orth else fx
         L.check(lib.lmm_profile_begin(1))
         if sampling:

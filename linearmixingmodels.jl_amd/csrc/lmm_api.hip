@@ -319,7 +319,7 @@ void backsolve1(const double* L, int ld, const double* W, int nblk, double* z, h
 // streams second) until nb_per * nstreams * bytes_per_latent fits in 80 % of the free device memory (+ this library's cache).
 void batch_plan(int ms, int* nb_per, int* nstreams_used, double bytes_per_latent = 0.0) {
   static int bmax = -1;
-  if (bmax < 0) { const char* e = getenv("LMM_BATCH"); bmax = e ? atoi(e) : 8; if (bmax < 1) bmax = 1; if (bmax > LMM_MAX_BATCH) bmax = LMM_MAX_BATCH; }
+  if (bmax < 0) { const char* e = getenv("LMM_BATCH"); bmax = e ? atoi(e) : 16; if (bmax < 1) bmax = 1; if (bmax > LMM_MAX_BATCH) bmax = LMM_MAX_BATCH; }   // round 2: 16 (C2: 690 vs 696 ms at 8)
   // Batches kept in flight for small shards: factor matrices up to n = 8192 do best as ONE lock-step batch (fewer, fuller
   // launches: n = 2048, m = 8: 2.82 -> 2.51 ms); larger ones as two batches on two streams, so one batch's leaf chain hides
   // behind the other's updates (C2 share of 4 latents: 108 vs 110 ms).  LMM_MIN_BATCHES overrides.
