@@ -303,7 +303,7 @@ def main():
                 if tj.get("workload") == args.workload:
                     traffic = tj.get("update_kernel", {}).get("bytes_per_launch")
             roof = {"bound": "mfma", "kernel": ("gemm32_kernel<128,false> (v_mfma_f32_32x32x2_f32 SYRK/GEMM trailing update)" if args.dtype == "f32"
-                                                else "gemm16p_kernel<128,false> (v_mfma_f64_16x16x4_f64, VGPR accumulators, software-pipelined SYRK/GEMM trailing update)"),
+                                                else "gemm16p_kernel<DEPTH> + gemm16h_kernel for a ragged last 64 rows (v_mfma_f64_16x16x4_f64, VGPR accumulators, software-pipelined SYRK/GEMM trailing update)"),
                     "achieved": round(ach, 3), "peak": peak_tf, "unit": "TFLOP/s",
                     "frac": round(ach / peak_tf, 4), "traffic": traffic if args.dtype == "f64" else None,
                     "traffic_source": ("profiles/pmc_traffic.json: fabric bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
