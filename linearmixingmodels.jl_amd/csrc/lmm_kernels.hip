@@ -20,6 +20,7 @@
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
+#define LMM_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 __device__ __forceinline__ d2 mk2(double x, double y) { d2 v; v.x = x; v.y = y; return v; }
 
 #define LOG2PI 1.8378770664093453
@@ -841,6 +842,209 @@ __global__ __launch_bounds__(256) void diag64v2_kernel(BatchPtr Ab, size_t offA,
 }
 
 // ---------------------------------------------------------------------------------------------------
+// K2a, third form (round 2): ONE WAVE per 64x64 block, rank-4 steps on the matrix pipe.
+// tools/lat_probe (profiles/r02/lat_probe.log): a wave issues one f64 VALU instruction per 8 cycles whether or not it depends on
+// the previous one, so the first two forms are bound by their per-wave INSTRUCTION COUNT (~260 f64 ops per rank-4 step in every
+// wave: redundant pivot factorisation, substitution for the multipliers, 128 FMAs of rank-4 update), not by latency; one
+// v_mfma_f64_16x16x4_f64 does a 16x16 block of a rank-4 update in 64 cycles (the same FMAs cost 128 cycles of VALU issue in a
+// wave, and the MFMA leaves the VALU free).  So:
+//   * the block and the inverse being built live as 16x16 MFMA accumulator blocks of one wave (lower block triangle of each:
+//     20 blocks x 4 doubles per lane; element (4r+g, c) of a block is register r of lane 16g+c);
+//   * per step (pivots J..J+3): the four pivot columns and the four pivot rows of the W part go through 2 + 2 KB of LDS so that
+//     every lane gets the 4x4 pivot block (uniform reads) and its own row of the panel / column of the W rows (lane 16g+c: row c
+//     of each 16-row block, column c of each 16-column block);
+//   * every lane factors the pivot block (true Cholesky, v_rsq_f64 + Newton) and inverts the 4x4 factor; lane group g keeps row g
+//     of that inverse, so Y[row][g] = panel row . Linv[g][:] (the final L entries, stored straight to global) and
+//     Z[g][col] = Linv[g][:] . Wtop[:][col] (the final rows J..J+3 of W) come out ALREADY in the MFMA operand layouts
+//     (A: lane (i = c, k = g); B: lane (k = g, j = c));
+//   * trailing update S -= Y Y', W_below -= Y Z: one MFMA per live 16x16 block (10 per step on average).
+// No barrier (one wave), no D^1/2 rescaling at the end.  Compile-time register indices throughout (16 steps unrolled).
+// ---------------------------------------------------------------------------------------------------
+#ifdef LMM_DIAG_TIMING
+__device__ long long g_diag_ts[8];
+#define LMM_DIAG_TS(i) if (blockIdx.x == 0 && threadIdx.x == 0) g_diag_ts[i] = __builtin_readcyclecounter()
+#else
+#define LMM_DIAG_TS(i)
+#endif
+struct Diag64mState {
+  d4 S[4][4], V[4][4];                                             // [block row][block col], block col <= block row
+  double Ym[2][4], nY[2][4], Z[2][4];                              // operands of step s live in set s & 1 (the lagging MFMAs of step
+                                                                   // s are issued inside step s+1, under its VALU chain)
+  double e0, e1, e2, e3;                                           // lane-group indicator (row g of the 4x4 inverse)
+  unsigned long long badmask;                                      // bit k: pivot k is not > 0 (uniform)
+};
+// The MFMAs of step T in three groups, by when the NEXT step (pivot block column jn) needs their block:
+//   0: S[jn][jn], 1: S[rb > jn][jn] and V[jn][*]  -- the next panel / the next pivot rows of W: issued at the end of step T
+//   2: everything else                              -- issued inside step T+1, between its LDS reads and its VALU chain, so that the
+//                                                      LDS round trip of step T+1 is covered by matrix-pipe work
+// (f64 MFMAs and f64 VALU instructions of one wave do NOT overlap on gfx950 -- interleaving them one-for-one changed nothing,
+// profiles/r02/diag_ab_*.log -- so the kernel is bound by its instruction count: ~9 MFMAs of 64 cycles and ~60 f64 VALU
+// instructions of 8 cycles per step.)
+template <int T, int GROUP>
+__device__ __forceinline__ void diag64m_mfmas(Diag64mState& st) {
+  constexpr int jb = T >> 2, q = T & 3, jn = (T + 1) >> 2, o = T & 1;
+#pragma unroll
+  for (int rb = jb; rb < 4; ++rb) {
+    if (rb == jb && q == 3) continue;                              // no rows below the pivots in this block row
+#pragma unroll
+    for (int cb = jb; cb <= rb; ++cb) {
+      if (cb == jb && q == 3) continue;                            // block column jb is finished
+      if ((cb == jn ? (rb == jn ? 0 : 1) : 2) != GROUP) continue;
+      st.S[rb][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(st.nY[o][rb], st.Ym[o][cb], st.S[rb][cb], 0, 0, 0);
+    }
+#pragma unroll
+    for (int cb = 0; cb <= jb; ++cb) {
+      if ((rb == jn ? 1 : 2) != GROUP) continue;
+      st.V[rb][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(st.nY[o][rb], st.Z[o][cb], st.V[rb][cb], 0, 0, 0);
+    }
+  }
+}
+constexpr int DIAG_SP = 18;                                        // row stride of Sp (doubles): 16-byte aligned rows, conflict-free b128 reads
+constexpr int DIAG_LS = 68;                                        // column stride of Lo / Wl
+template <int s>
+__device__ __forceinline__ void diag64m_step(Diag64mState& st, double* __restrict__ Sp, double* __restrict__ Wt, double* __restrict__ Lo,
+                                             int c, int g) {
+  constexpr int SP = DIAG_SP, LS = DIAG_LS;
+  constexpr int J = 4 * s, jb = s >> 2, q = s & 3, o = s & 1;
+  __builtin_amdgcn_sched_barrier(0);
+  // one wave: LDS executes its instructions in order, and the compiler keeps may-aliasing LDS accesses in program order
+  // the current block column of S and the pivot rows of the W part -> LDS
+#pragma unroll
+  for (int rb = jb; rb < 4; ++rb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Sp[(16 * rb + 4 * r + g) * SP + c] = st.S[rb][jb][r];
+#pragma unroll
+  for (int cb = 0; cb <= jb; ++cb) Wt[(16 * cb + c) * 4 + g] = st.V[jb][cb][q];
+  // -> the 4x4 pivot block (uniform), my row of each 16-row block of the panel, my column of each block of the W rows
+  const d2 pr0 = *reinterpret_cast<const d2*>(&Sp[(J + 0) * SP + 4 * q]);
+  const d2 pr1 = *reinterpret_cast<const d2*>(&Sp[(J + 1) * SP + 4 * q]);
+  const d2 pr2a = *reinterpret_cast<const d2*>(&Sp[(J + 2) * SP + 4 * q]), pr2b = *reinterpret_cast<const d2*>(&Sp[(J + 2) * SP + 4 * q + 2]);
+  const d2 pr3a = *reinterpret_cast<const d2*>(&Sp[(J + 3) * SP + 4 * q]), pr3b = *reinterpret_cast<const d2*>(&Sp[(J + 3) * SP + 4 * q + 2]);
+  d2 bo[4][2], wo[4][2];
+#pragma unroll
+  for (int rb = jb; rb < 4; ++rb) {
+    bo[rb][0] = *reinterpret_cast<const d2*>(&Sp[(16 * rb + c) * SP + 4 * q]);
+    bo[rb][1] = *reinterpret_cast<const d2*>(&Sp[(16 * rb + c) * SP + 4 * q + 2]);
+  }
+#pragma unroll
+  for (int cb = 0; cb <= jb; ++cb) {
+    wo[cb][0] = *reinterpret_cast<const d2*>(&Wt[(16 * cb + c) * 4]);
+    wo[cb][1] = *reinterpret_cast<const d2*>(&Wt[(16 * cb + c) * 4 + 2]);
+  }
+  if constexpr (s > 0) diag64m_mfmas<s - 1, 2>(st);                // the previous step's lagging blocks
+  auto rsq = [](double x) {          // 1/sqrt(x): v_rsq_f64 + two Newton steps
+    double y = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    y = y * __builtin_fma(-h * y, y, 1.5);
+    y = y * __builtin_fma(-h * y, y, 1.5);
+    return y;
+  };
+  // 4x4 Cholesky P = Lp Lp'
+  const double d0 = pr0.x, r0 = rsq(d0);
+  const double l10 = pr1.x * r0, l20 = pr2a.x * r0, l30 = pr3a.x * r0;
+  const double d1 = __builtin_fma(-l10, l10, pr1.y), r1 = rsq(d1);
+  const double l21 = __builtin_fma(-l20, l10, pr2a.y) * r1, l31 = __builtin_fma(-l30, l10, pr3a.y) * r1;
+  const double d2v = __builtin_fma(-l21, l21, __builtin_fma(-l20, l20, pr2b.x)), r2 = rsq(d2v);
+  const double l32 = __builtin_fma(-l31, l21, __builtin_fma(-l30, l20, pr3b.x)) * r2;
+  const double d3 = __builtin_fma(-l32, l32, __builtin_fma(-l31, l31, __builtin_fma(-l30, l30, pr3b.y))), r3 = rsq(d3);
+  // row g of Lp^-1: x' Lp = e_g' by back substitution (zero above the diagonal by construction)
+  const double k3 = st.e3 * r3;
+  const double k2 = __builtin_fma(-k3, l32, st.e2) * r2;
+  const double k1 = __builtin_fma(-k2, l21, __builtin_fma(-k3, l31, st.e1)) * r1;
+  const double k0 = __builtin_fma(-k1, l10, __builtin_fma(-k2, l20, __builtin_fma(-k3, l30, st.e0))) * r0;
+#pragma unroll
+  for (int rb = jb; rb < 4; ++rb) {
+    const double y = __builtin_fma(bo[rb][1].y, k3, __builtin_fma(bo[rb][1].x, k2, __builtin_fma(bo[rb][0].y, k1, bo[rb][0].x * k0)));
+    const int row = 16 * rb + c;
+    Lo[(J + g) * LS + row] = y;                                    // L[row][J+g], final for row >= J+g (the rest is never stored)
+    st.Ym[o][rb] = (rb > jb || row > J + 3) ? y : 0.0;             // rows of and above the pivot block take no part in the update
+    st.nY[o][rb] = -st.Ym[o][rb];
+  }
+#pragma unroll
+  for (int cb = 0; cb <= jb; ++cb)
+    st.Z[o][cb] = __builtin_fma(wo[cb][1].y, k3, __builtin_fma(wo[cb][1].x, k2, __builtin_fma(wo[cb][0].y, k1, wo[cb][0].x * k0)));
+#pragma unroll
+  for (int cb = 0; cb <= jb; ++cb) st.V[jb][cb][q] = st.Z[o][cb];  // rows J..J+3 of W = Lp^-1 Wtop, final (the MFMAs of this step
+                                                                   // add 0 * Z to them: rows of the pivot block have Ym = 0)
+  diag64m_mfmas<s, 0>(st); diag64m_mfmas<s, 1>(st);                // the blocks the next step reads
+  __builtin_amdgcn_sched_barrier(0);
+  // non-positive (or NaN) pivots: the values are uniform, so any lane's comparison will do
+  if (__builtin_amdgcn_ballot_w64(!(d0 > 0.0) | !(d1 > 0.0) | !(d2v > 0.0) | !(d3 > 0.0)) != 0ull) {
+    const unsigned m4 = (!(d0 > 0.0) ? 1u : 0u) | (!(d1 > 0.0) ? 2u : 0u) | (!(d2v > 0.0) ? 4u : 0u) | (!(d3 > 0.0) ? 8u : 0u);
+    st.badmask |= (unsigned long long)__builtin_amdgcn_readfirstlane(m4) << J;
+  }
+}
+template <int s>
+__device__ __forceinline__ void diag64m_steps(Diag64mState& st, double* __restrict__ Sp, double* __restrict__ Wt, double* __restrict__ Lo,
+                                              int c, int g) {
+  if constexpr (s < 16) { diag64m_step<s>(st, Sp, Wt, Lo, c, g); diag64m_steps<s + 1>(st, Sp, Wt, Lo, c, g); }
+}
+
+template <typename TS>
+__global__ __launch_bounds__(64) void diag64m_kernel(BatchPtr Ab, size_t offA, int ld, BatchPtr Wb, size_t offW,
+                                                     int gcol0, int n_real, BatchInfo infob) {
+  void* __restrict__ A = Ab.p[blockIdx.x];
+  void* __restrict__ W = Wb.p[blockIdx.x];
+  int* __restrict__ info = infob.p[blockIdx.x];
+  constexpr int LS = DIAG_LS;
+  __shared__ __attribute__((aligned(16))) double Sp[64 * DIAG_SP];  // current block column of S: Sp[row][16]
+  __shared__ __attribute__((aligned(16))) double Wt[64 * 4];        // pivot rows of the W part, transposed: Wt[col][k]
+  __shared__ __attribute__((aligned(16))) double Lo[64 * LS];       // finished L entries: Lo[col][row]
+  __shared__ __attribute__((aligned(16))) double Wl[64 * LS];       // W for the coalesced store: Wl[col][row]
+  const int l = threadIdx.x, c = l & 15, g = l >> 4;
+  LMM_DIAG_TS(3);
+  Diag64mState st;
+#pragma unroll
+  for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+    for (int cb = 0; cb <= rb; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * rb + 4 * r + g, col = 16 * cb + c;
+        st.S[rb][cb][r] = (row >= col) ? MatIO<TS>::ld1(A, offA + (size_t)col * ld + row) : 0.0;
+        st.V[rb][cb][r] = (row == col) ? 1.0 : 0.0;
+      }
+  st.e0 = g == 0 ? 1.0 : 0.0; st.e1 = g == 1 ? 1.0 : 0.0; st.e2 = g == 2 ? 1.0 : 0.0; st.e3 = g == 3 ? 1.0 : 0.0;
+  st.badmask = 0ull;
+  LMM_DIAG_TS(0);
+  diag64m_steps<0>(st, Sp, Wt, Lo, c, g);
+  __builtin_amdgcn_sched_barrier(0);
+  LMM_DIAG_TS(1);
+  if (l == 0) {
+    const int lim = n_real - gcol0;                                // pivots k < lim are real columns
+    const unsigned long long m = lim >= 64 ? st.badmask : (lim <= 0 ? 0ull : (st.badmask & ((1ull << lim) - 1ull)));
+    if (m != 0ull) atomicCAS(info, 0, gcol0 + __builtin_ctzll(m) + 1);
+  }
+  // epilogue: W through LDS so that both outputs leave as 16-byte-per-lane row segments (two columns per store instruction)
+#pragma unroll
+  for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+    for (int cb = 0; cb <= rb; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Wl[(16 * cb + c) * LS + 16 * rb + 4 * r + g] = st.V[rb][cb][r];
+  const int r2 = 2 * (l & 31), ch = l >> 5;
+#pragma unroll
+  for (int it0 = 0; it0 < 32; it0 += 8) {
+    d2 wv[8], lv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int col = 2 * (it0 + i) + ch;
+      wv[i] = *reinterpret_cast<const d2*>(&Wl[col * LS + r2]);
+      lv[i] = *reinterpret_cast<const d2*>(&Lo[col * LS + r2]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int col = 2 * (it0 + i) + ch;
+      const bool lowblk = (r2 >> 4) >= (col >> 4);                 // blocks above the diagonal were never written to Wl: zeros
+      MatIO<TS>::st2(W, offW + (size_t)col * 64 + r2, lowblk ? wv[i] : mk2(0.0, 0.0));
+      if (r2 >= col) MatIO<TS>::st2(A, offA + (size_t)col * ld + r2, lv[i]);
+      else if (r2 + 1 == col) MatIO<TS>::st1(A, offA + (size_t)col * ld + r2 + 1, lv[i].y);
+    }
+  }
+  LMM_DIAG_TS(2);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // K2b: C (M x N) {-=, =} A (M x K) * B (N x K)^T  (column-major; M, N multiples of 64, K of 16), batched over up to
 // LMM_MAX_BATCH independent matrices (blockIdx.y), on v_mfma_f64_4x4x4_4b_f64 -- the FP64 MFMA form that issues at the
 // full FP64 rate on gfx950 (tools/mfma_probe3: 76.8 TFLOP/s; the 16x16x4 form issues at 36-59 depending on the
@@ -1315,7 +1519,6 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(BatchPtr Cb, size_t goff
 //                   6 MFMAs interleaved with the 8 fragment reads of tile t+1's k-step 0
 //   __builtin_amdgcn_sched_group_barrier pins the interleave (hipcc otherwise clusters the loads ahead of the MFMAs).
 // ---------------------------------------------------------------------------------------------------
-#define LMM_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 #define LMM_MFMA16(SET, V, U) acc[V][U] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[SET][V], fa[SET][U], acc[V][U], 0, 0, 0)
 #define LMM_MFMA16_ALL(SET)                                                                                   \
     LMM_MFMA16(SET, 0, 0); LMM_MFMA16(SET, 0, 1); LMM_MFMA16(SET, 0, 2); LMM_MFMA16(SET, 0, 3);               \
@@ -2406,14 +2609,16 @@ void launch_dense_assemble(const DenseArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(ilmm_dense_assemble_kernel, grid, dim3(256), 0, st, a);
 }
 
+int g_diag_form = -1;
 void launch_diag64(const BatchPtr& A, size_t offA, int ld, const BatchPtr& W, size_t offW, int gcol0, int n_real,
                    const BatchInfo& info, int nb, hipStream_t st) {
-  // LMM_DIAG_V2=1 selects the owner-only pivot-block form (correct, but measured SLOWER: 42 vs 29 us per 64x64 block -- the
-  // f64 dependency chain of the 4x4 pivot factorisation is the cost, not the redundant copies of it; profiles/r02/README)
-  static int v2 = -1;
-  if (v2 < 0) { const char* e = getenv("LMM_DIAG_V2"); v2 = (e && atoi(e) != 0) ? 1 : 0; }
-  if (v2) LMM_TS_LAUNCH((diag64v2_kernel<TS>), dim3(nb), dim3(256), 0, st, A, offA, ld, W, offW, gcol0, n_real, info);
-  else LMM_TS_LAUNCH((diag64_kernel<TS>), dim3(nb), dim3(256), 0, st, A, offA, ld, W, offW, gcol0, n_real, info);
+  // g_diag_form: 3 (default) = diag64m_kernel (one wave per block, rank-4 steps on the matrix pipe), 1 = diag64_kernel (round 1: 256
+  // threads, 4x4 register blocks), 2 = diag64v2_kernel (owner-only pivot-block form: correct but slower than form 1).  LMM_DIAG_FORM
+  // overrides; tools/diag_ab A/Bs them in one process.
+  if (g_diag_form < 0) { const char* e = getenv("LMM_DIAG_FORM"); g_diag_form = e ? atoi(e) : 3; }
+  if (g_diag_form == 2) LMM_TS_LAUNCH((diag64v2_kernel<TS>), dim3(nb), dim3(256), 0, st, A, offA, ld, W, offW, gcol0, n_real, info);
+  else if (g_diag_form == 1) LMM_TS_LAUNCH((diag64_kernel<TS>), dim3(nb), dim3(256), 0, st, A, offA, ld, W, offW, gcol0, n_real, info);
+  else LMM_TS_LAUNCH((diag64m_kernel<TS>), dim3(nb), dim3(64), 0, st, A, offA, ld, W, offW, gcol0, n_real, info);
 }
 
 // Update-kernel variant: 0 = one s_barrier per k-stage (default), 1 = LDS-flag synchronised main loop (correct, but measured
