@@ -2149,16 +2149,18 @@ __global__ __launch_bounds__(256) void backsolve_step_kernel(BatchPtr Lb, int ld
 //   mode 0: Out[i + c*ldo] = val - sub[c]                       (T*Y projection, minus latent mean)
 //   mode 1: partial[block] = sum (Ref[i + c*ldr] - val)^2       (regulariser residual |Y - H T Y|_F^2)
 // ---------------------------------------------------------------------------------------------------
-template <int CH>
-__global__ __launch_bounds__(256) void tall_skinny_kernel(const double* __restrict__ In, int ldi, int n, int K,
+template <int CH, int NW>
+__global__ __launch_bounds__(64 * NW) void tall_skinny_kernel(const double* __restrict__ In, int ldi, int n, int K,
                                                           const double* __restrict__ Mx, int ldm, int C,
                                                           double* __restrict__ Out, int ldo,
                                                           const double* __restrict__ sub,
                                                           const double* __restrict__ Ref, int ldr,
                                                           double* __restrict__ partial, int mode) {
-  // 64 rows per workgroup; the 4 waves split the K loop (k = wave, wave + 4, ...) and combine through LDS, so that
-  // short-and-wide problems (n of a few hundred, K = p of several hundred) still expose enough parallelism.
-  __shared__ double red[3][CH][64];
+  // 64 rows per workgroup; the NW waves split the K loop (k = wave, wave + NW, ...) and combine through LDS, so that
+  // short-and-wide problems (n of a few hundred, K = p of several hundred) still expose enough parallelism: NW = 16 when the
+  // grid alone would leave most CUs idle (the reference notebook's projection, n = 552, p = 600, m = 20: 27 workgroups of 4 waves
+  // each walking 150 dependent loads took 114 us of a 570-us evaluation).
+  __shared__ double red[NW - 1][CH][64];
   __shared__ double sh[4];
   const int lane = threadIdx.x & 63, ks = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + lane;
@@ -2167,8 +2169,8 @@ __global__ __launch_bounds__(256) void tall_skinny_kernel(const double* __restri
 #pragma unroll
   for (int c = 0; c < CH; ++c) acc[c] = 0.0;
   if (i < n) {
-#pragma unroll 4
-    for (int k = ks; k < K; k += 4) {
+#pragma unroll 8
+    for (int k = ks; k < K; k += NW) {
       const double v = In[(size_t)k * ldi + i];
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
@@ -2186,16 +2188,20 @@ __global__ __launch_bounds__(256) void tall_skinny_kernel(const double* __restri
   if (ks == 0 && i < n) {
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-      const double val = acc[c] + red[0][c][lane] + red[1][c][lane] + red[2][c][lane];
+      double val = acc[c];
+#pragma unroll
+      for (int w = 0; w < NW - 1; ++w) val += red[w][c][lane];
       if (c0 + c < C) {
         if (mode == 0) Out[(size_t)(c0 + c) * ldo + i] = val - (sub ? sub[c0 + c] : 0.0);
         else { const double r = Ref[(size_t)(c0 + c) * ldr + i] - val; s = __builtin_fma(r, r, s); }
       }
     }
   }
-  if (mode != 0) {
-    const double tot = block_sum_256(s, sh);
-    if (threadIdx.x == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = tot;
+  if constexpr (NW == 4) {
+    if (mode != 0) {
+      const double tot = block_sum_256(s, sh);
+      if (threadIdx.x == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = tot;
+    }
   }
 }
 
@@ -2774,8 +2780,12 @@ void launch_backsolve(const BatchPtr& L, int ld, const BatchPtr& W, int nblk, co
 void launch_tall_skinny(const double* In, int ldi, int n, int K, const double* Mx, int ldm, int C, double* Out, int ldo,
                         const double* sub, const double* Ref, int ldr, double* partial, int mode, hipStream_t st) {
   dim3 grid((n + 63) / 64, (C + 7) / 8);
-  hipLaunchKernelGGL((tall_skinny_kernel<8>), grid, dim3(256), 0, st, In, ldi, n, K, Mx, ldm, C, Out, ldo, sub, Ref, ldr,
-                     partial, mode);
+  if (mode == 0 && K >= 128 && (size_t)grid.x * grid.y < 256)      // few workgroups, long K loop: 16 waves split it
+    hipLaunchKernelGGL((tall_skinny_kernel<8, 16>), grid, dim3(1024), 0, st, In, ldi, n, K, Mx, ldm, C, Out, ldo, sub, Ref, ldr,
+                       partial, mode);
+  else
+    hipLaunchKernelGGL((tall_skinny_kernel<8, 4>), grid, dim3(256), 0, st, In, ldi, n, K, Mx, ldm, C, Out, ldo, sub, Ref, ldr,
+                       partial, mode);
 }
 
 int tall_skinny_partials(int n, int C) { return ((n + 63) / 64) * ((C + 7) / 8); }
