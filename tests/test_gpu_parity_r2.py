@@ -404,7 +404,8 @@ def test_dense_ilmm_matrix_y_logpdf(lmm):
 
 def test_update_kernel_variants_agree():
     """The round-1 update kernels stay selectable (LMM_GEMM_M16=0: v_mfma_f64_4x4x4; 1: 16x16x4 in the round-1 loop; LMM_GEMM_FLAGS=1:
-    LDS-flag synchronised 4x4x4); each must give the default kernel's logpdf."""
+    LDS-flag synchronised 4x4x4), and so do the earlier diagonal-block kernels (LMM_DIAG_FORM=1: 256-thread register blocks, 2: owner-only
+    pivot work; default 3: one wave, MFMA rank-4 steps); each must give the default kernels' logpdf."""
     import subprocess, sys, json
     code = ("import sys, json; sys.path.insert(0, %r); import numpy as np, lmm_amd; "
             "from lmm_amd.workloads import synthetic_problem as sp; lmm_amd.init(0); P = sp(3, 5, 1500, 'matern52', True, seed=2); "
@@ -412,7 +413,7 @@ def test_update_kernel_variants_agree():
             "print(json.dumps(lmm_amd.logpdf(f(lmm_amd.MOInputIsotopicByOutputs(P['x'], 5), 0.1), P['y'])))") % os.path.dirname(HERE)
     vals = {}
     for name, env in [("default", {}), ("m16_0", {"LMM_GEMM_M16": "0"}), ("m16_1", {"LMM_GEMM_M16": "1"}), ("flags", {"LMM_GEMM_M16": "0", "LMM_GEMM_FLAGS": "1"}),
-                      ("diag_v2", {"LMM_DIAG_V2": "1"})]:
+                      ("diag_form1", {"LMM_DIAG_FORM": "1"}), ("diag_form2", {"LMM_DIAG_FORM": "2"})]:
         out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr[-2000:]
         vals[name] = json.loads(out.stdout.strip().splitlines()[-1])
