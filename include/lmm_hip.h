@@ -148,6 +148,17 @@ int lmm_ilmm_logpdf_grad(const double* x, int d, int n, const double* y, int p, 
                          const lmm_gp_t* gps, const lmm_jitters_t* jit, double* out_logpdf, double* grad_y, double* grad_sigma2,
                          double* grad_H, lmm_gp_grad_t* grad_gps);
 
+/* Value and TOTAL derivatives of logpdf(posterior(f(x, sigma2), y)(xs, sigma2_s), ys) for a dense H -- what
+ * Zygote.gradient(logpdf, pi, y_test) differentiates in reference test/ilmm.jl:32 (posterior: src/ilmm.jl:184-198): the joint
+ * prior density of (y, ys) under two-block observation noise minus the prior density of y (T y is sufficient for the latents, so
+ * the reference's projected posterior is the exact conditional).  Gradients w.r.t. y (n*p), ys (ns*p), sigma2 (training noise),
+ * sigma2_s (predictive noise), H (p x m) and each latent's (variance, lengthscale, mean); any grad pointer may be NULL.
+ * m*(n + ns) <= 46000.  Does not shard. */
+int lmm_ilmm_post_logpdf_grad(const double* x, int d, int n, const double* y, const double* xs, int ns, const double* ys, int p,
+                              const double* H, int m, double sigma2, double sigma2_s, const lmm_gp_t* gps, const lmm_jitters_t* jit,
+                              double* out_logpdf, double* grad_y, double* grad_ys, double* grad_sigma2, double* grad_sigma2_s,
+                              double* grad_H, lmm_gp_grad_t* grad_gps);
+
 /* logpdf(fx, Y::AbstractMatrix): one value per column of Y ((n p) x ncol, column-major) from ONE factorisation per latent
  * (the extra columns ride the factorisation as rider rows).  The reference does not overload this (it falls to AbstractGPs'
  * dense generic path); AbstractGPs.TestUtils calls it.  out: ncol values. */

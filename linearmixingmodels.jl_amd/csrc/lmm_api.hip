@@ -1459,6 +1459,219 @@ int lmm_ilmm_logpdf_multi(const double* x, int d, int n, const double* Y, int p,
   LMM_CATCH
 }
 
+} // extern "C"
+
+namespace {
+
+struct IlmmGrad {            // host results of ilmm_grad_core
+  double value = 0.0, gs2[2] = {0.0, 0.0};
+  std::vector<double> gH;    // p x m
+  std::vector<lmm_gp_grad_t> ggps;
+};
+
+// Value and gradient of the dense-H ILMM prior logpdf over n points of which the first nsplit carry observation noise s2[0] and
+// the rest s2[1] (nsplit == n: one block).  x (d x n), y (n x p by outputs) are DEVICE pointers; gy_dev (n x p, device) may be
+// null.  The two-block form exists for the posterior's predictive density: log p(y* | y) = log p(y, y*) - log p(y)
+// (T y is sufficient for the latents, so the reference's projected posterior, src/ilmm.jl:184-198, is the exact conditional).
+int ilmm_grad_core(const double* xd, int d, int n, int nsplit, const double* yd, int p, const double* H, int m, double s2a, double s2b,
+                   const lmm_gp_t* gps, const lmm_jitters_t* jit, IlmmGrad& G, double* gy_dev) {
+  if ((long long)m * n > 46000) return fail(LMM_ERR_UNSUPPORTED, "m*n too large for the dense gradient (explicit (mn)^2 inverse)");
+  hipStream_t st0 = g.streams[0];
+  const int nblk = nsplit < n ? 2 : 1;
+  const int bi0[2] = {0, nsplit}, bn[2] = {nblk == 2 ? nsplit : n, n - nsplit};
+  const double s2[2] = {s2a, s2b};
+  std::vector<double> T[2], ST[2];
+  double logdetST[2] = {0.0, 0.0};
+  for (int b = 0; b < nblk; ++b)
+    if (int rc = project_dense(H, p, m, s2[b], jit->project_jitter, T[b], ST[b], &logdetST[b])) return rc;
+  // host copies in the layouts the kernels read: Tt = T' (p x m), Ht = H' (m x p)
+  std::vector<double> Hv(H, H + (size_t)p * m), Tt[2], Ht((size_t)m * p), means(m), STall;
+  for (int b = 0; b < nblk; ++b) {
+    Tt[b].resize((size_t)p * m);
+    for (int l = 0; l < m; ++l) for (int o = 0; o < p; ++o) Tt[b][o + (size_t)l * p] = T[b][l + (size_t)o * m];
+    STall.insert(STall.end(), ST[b].begin(), ST[b].end());
+  }
+  for (int l = 0; l < m; ++l) {
+    means[l] = gps[l].mean;
+    for (int o = 0; o < p; ++o) Ht[l + (size_t)o * m] = H[o + (size_t)l * p];
+  }
+  std::vector<LatentDev> lat(m);
+  for (int l = 0; l < m; ++l) lat[l] = to_dev(gps[l]);
+  std::vector<int> sidx(n);
+  for (int i = 0; i < n; ++i) sidx[i] = (i < nsplit) ? 0 : 1;
+  Uploaded Td0(T[0], st0), Td1(T[nblk - 1], st0), STd(STall, st0), Hd(Hv, st0), Ttd0(Tt[0], st0), Ttd1(Tt[nblk - 1], st0), Htd(Ht, st0), meansd(means, st0);
+  const double* Tdv[2] = {Td0.buf.p, Td1.buf.p};
+  const double* Ttdv[2] = {Ttd0.buf.p, Ttd1.buf.p};
+  Buf<LatentDev> latd(m);
+  Buf<int> sidxd(n);
+  HIPCHK(hipMemcpyAsync(latd.p, lat.data(), m * sizeof(LatentDev), hipMemcpyHostToDevice, st0));
+  HIPCHK(hipMemcpyAsync(sidxd.p, sidx.data(), n * sizeof(int), hipMemcpyHostToDevice, st0));
+  const int N = m * n;
+  Buf<double> Ty((size_t)N), delta((size_t)N), partial(tall_skinny_partials(n, p)), resid_dev(2);
+  for (int b = 0; b < nblk; ++b) {
+    const int i0 = bi0[b], nb_ = bn[b];
+    launch_tall_skinny(yd + i0, n, nb_, p, Tdv[b], m, m, Ty.p + i0, n, nullptr, nullptr, 0, nullptr, 0, st0);
+    launch_tall_skinny(yd + i0, n, nb_, p, Tdv[b], m, m, delta.p + i0, n, meansd.buf.p, nullptr, 0, nullptr, 0, st0);
+    // reference src/ilmm.jl:171-181: |Y - H T Y|_F^2 of the block
+    launch_tall_skinny(Ty.p + i0, n, nb_, m, Hd.buf.p, p, p, nullptr, 0, nullptr, yd + i0, n, partial.p, 1, st0);
+    launch_sum_partials(partial.p, tall_skinny_partials(nb_, p), resid_dev.p + b, st0);
+  }
+  Dims D(N, 1);
+  Buf<double> A(D.elems()), W((size_t)(D.NC / 64) * 4096), R((size_t)D.ld * D.NC), alpha((size_t)D.NC), lml_dev(1);
+  Buf<int> info(1);
+  HIPCHK(hipMemsetAsync(info.p, 0, sizeof(int), st0));
+  HIPCHK(hipMemsetAsync(alpha.p, 0, (size_t)D.NC * sizeof(double), st0));
+  DenseArgs a{};
+  a.A = A.p; a.ld = D.ld; a.nrows = D.NR; a.ncols = D.NC; a.x = xd; a.d = d; a.n = n; a.m = m;
+  a.lat = latd.p; a.sigmaT = STd.buf.p; a.sig_idx = nblk == 2 ? sidxd.p : nullptr; a.rider = delta.p; a.rider_ld = N; a.nrider = 1;
+  launch_dense_assemble(a, st0);
+  potrf_rec(A.p, D.ld, D.NR, 0, D.NC, W.p, N, info.p, st0);
+  launch_lml_reduce(A.p, D.ld, N, D.NC, 1, lml_dev.p, st0);
+  launch_extract_row(A.p, D.ld, D.NC, N, alpha.p, st0);
+  backsolve1(A.p, D.ld, W.p, D.NC / 64, alpha.p, st0);
+  launch_set_identity(R.p, D.ld, D.NC, st0);
+  trsm_rec(R.p, D.ld, D.NC, A.p, D.ld, W.p, 0, D.NC, st0, true);                 // R = L^-T
+  launch_syrk_upper_set(A.p, D.ld, R.p, D.ld, D.NC, st0);                         // lower(A) = Sigma^-1
+  const int NGR = LMM_NGRAD;
+  const size_t mm = (size_t)m * m, mp = (size_t)m * p;
+  Buf<double> red((size_t)NGR * m), gpart((size_t)grad_partials(n)), Btr(2 * mm), AAt(2 * mm), AY(2 * mp);
+  for (int l = 0; l < m; ++l)
+    launch_grad_reduce(A.p + (size_t)l * n * D.ld + (size_t)l * n, D.ld, n, n, alpha.p + (size_t)l * n, delta.p + (size_t)l * n, xd, d,
+                       lat[l], gpart.p, red.p + (size_t)NGR * l, st0);
+  // regulariser pieces: Rm = Y - (T Y)' H' (n x p), RH = Rm H (n x m), per block Rm' Ty (p x m), RH' Y (m x p)
+  Buf<double> HTY((size_t)n * p), Rm((size_t)n * p), RH((size_t)N), RtTy(2 * mp), RHtY(2 * mp);
+  launch_tall_skinny(Ty.p, n, n, m, Hd.buf.p, p, p, HTY.p, n, nullptr, nullptr, 0, nullptr, 0, st0);
+  launch_vec_lin(yd, HTY.p, -1.0, n * p, Rm.p, st0);
+  launch_tall_skinny(Rm.p, n, n, p, Htd.buf.p, m, m, RH.p, n, nullptr, nullptr, 0, nullptr, 0, st0);
+  for (int b = 0; b < nblk; ++b) {
+    const int i0 = bi0[b], nb_ = bn[b];
+    launch_block_trace(A.p, D.ld, n, m, i0, i0 + nb_, Btr.p + b * mm, st0);
+    launch_atb(alpha.p + i0, n, alpha.p + i0, n, nb_, m, m, AAt.p + b * mm, st0);      // (alpha_l . alpha_l') over the block
+    launch_atb(alpha.p + i0, n, yd + i0, n, nb_, m, p, AY.p + b * mp, st0);            // sum_i alpha_l[i] Y[i, o]   (m x p)
+    launch_atb(Rm.p + i0, n, Ty.p + i0, n, nb_, p, m, RtTy.p + b * mp, st0);
+    launch_atb(RH.p + i0, n, yd + i0, n, nb_, m, p, RHtY.p + b * mp, st0);
+  }
+  std::vector<double> hred((size_t)NGR * m), hB(2 * mm), hAAt(2 * mm), hAY(2 * mp), hRtTy(2 * mp), hRHtY(2 * mp);
+  double lml = 0.0, resid[2] = {0.0, 0.0};
+  int hinfo = 0;
+  HIPCHK(hipMemcpyAsync(&lml, lml_dev.p, sizeof(double), hipMemcpyDeviceToHost, st0));
+  HIPCHK(hipMemcpyAsync(resid, resid_dev.p, nblk * sizeof(double), hipMemcpyDeviceToHost, st0));
+  HIPCHK(hipMemcpyAsync(&hinfo, info.p, sizeof(int), hipMemcpyDeviceToHost, st0));
+  HIPCHK(hipMemcpyAsync(hred.data(), red.p, hred.size() * sizeof(double), hipMemcpyDeviceToHost, st0));
+  HIPCHK(hipMemcpyAsync(hB.data(), Btr.p, nblk * mm * sizeof(double), hipMemcpyDeviceToHost, st0));
+  HIPCHK(hipMemcpyAsync(hAAt.data(), AAt.p, nblk * mm * sizeof(double), hipMemcpyDeviceToHost, st0));
+  HIPCHK(hipMemcpyAsync(hAY.data(), AY.p, nblk * mp * sizeof(double), hipMemcpyDeviceToHost, st0));
+  HIPCHK(hipMemcpyAsync(hRtTy.data(), RtTy.p, nblk * mp * sizeof(double), hipMemcpyDeviceToHost, st0));
+  HIPCHK(hipMemcpyAsync(hRHtY.data(), RHtY.p, nblk * mp * sizeof(double), hipMemcpyDeviceToHost, st0));
+  HIPCHK(hipStreamSynchronize(st0));
+  if (int rc = check_info(std::vector<int>{hinfo}, 0)) return rc;
+  // value: reference src/ilmm.jl:150-163 + :171-181
+  G.value = lml;
+  for (int b = 0; b < nblk; ++b)
+    G.value -= ((double)bn[b] * ((double)(p - m) * kLog2Pi + ((double)p * std::log(s2[b]) - logdetST[b])) + resid[b] / s2[b]) / 2.0;
+  // ---- kernel-parameter gradients: 1/2 tr((aa' - Sigma^-1) dSigma/dtheta_l), dSigma = E_ll (x) dK_l ----
+  G.ggps.assign(m, lmm_gp_grad_t{});
+  for (int l = 0; l < m; ++l) {
+    const double* r = &hred[(size_t)NGR * l];
+    G.ggps[l].lengthscale = r[0];
+    G.ggps[l].variance = (r[7] + 0.5 * gps[l].variance * (r[2] - r[1])) / gps[l].variance;     // K_ii = variance
+    G.ggps[l].mean = r[4];
+  }
+  std::vector<double> Hb((size_t)p * m, 0.0), HtH(mm, 0.0);
+  for (int aI = 0; aI < m; ++aI)
+    for (int bb = 0; bb < m; ++bb) {
+      double acc = 0.0;
+      for (int o = 0; o < p; ++o) acc += H[o + (size_t)aI * p] * H[o + (size_t)bb * p];
+      HtH[aI + (size_t)bb * m] = acc;
+    }
+  for (int b = 0; b < nblk; ++b) {
+    const double sigma2 = s2[b], s = 1.0 / sigma2;
+    const std::vector<double>& Tq = T[b];
+    const double* bAY = &hAY[b * mp]; const double* bRHtY = &hRHtY[b * mp]; const double* bRtTy = &hRtTy[b * mp];
+    const double* bAAt = &hAAt[b * mm]; const double* bB = &hB[b * mm];
+    // ---- cotangents of T (m x p) and SigmaT (m x m) of this block ----
+    std::vector<double> Tb((size_t)m * p, 0.0), Gs(mm, 0.0);
+    double s2g = 0.0;
+    for (int l = 0; l < m; ++l)
+      for (int o = 0; o < p; ++o) Tb[l + (size_t)o * m] = -bAY[l + (size_t)o * m] + s * bRHtY[l + (size_t)o * m];   // lml + regulariser (residual)
+    // SigmaT^-1 for the +n/2 logdet SigmaT term of the regulariser
+    std::vector<double> STc = ST[b], STinv(mm, 0.0);
+    if (!host_cholesky(STc, m)) return fail(LMM_ERR_NOT_PD, "PosDefException: SigmaT not PD");
+    for (int c = 0; c < m; ++c) {       // solve (L L') col = e_c
+      std::vector<double> v(m, 0.0);
+      for (int aI = 0; aI < m; ++aI) { double t = (aI == c) ? 1.0 : 0.0; for (int k = 0; k < aI; ++k) t -= STc[aI + (size_t)k * m] * v[k]; v[aI] = t / STc[aI + (size_t)aI * m]; }
+      for (int aI = m - 1; aI >= 0; --aI) { double t = v[aI]; for (int k = aI + 1; k < m; ++k) t -= STc[k + (size_t)aI * m] * v[k]; v[aI] = t / STc[aI + (size_t)aI * m]; }
+      for (int aI = 0; aI < m; ++aI) STinv[aI + (size_t)c * m] = v[aI];
+    }
+    for (int aI = 0; aI < m; ++aI)
+      for (int bb = 0; bb < m; ++bb) Gs[aI + (size_t)bb * m] = 0.5 * (bAAt[aI + (size_t)bb * m] - bB[aI + (size_t)bb * m]) + 0.5 * (double)bn[b] * STinv[aI + (size_t)bb * m];
+    // explicit sigma2 of the regulariser and explicit H of the residual
+    s2g += -0.5 * ((double)bn[b] * (double)p / sigma2 - resid[b] / (sigma2 * sigma2));
+    for (int o = 0; o < p; ++o) for (int l = 0; l < m; ++l) Hb[o + (size_t)l * p] += s * bRtTy[o + (size_t)l * p];
+    // ---- backward through project(H, sigma2): P = s H'H + eps I,  T = P^-1 H' s,  SigmaT = sigma2 T T' ----
+    // SigmaT = sigma2 T T':  Tb += sigma2 (Gs + Gs') T;  s2g += <Gs, T T'>
+    for (int aI = 0; aI < m; ++aI)
+      for (int o = 0; o < p; ++o) {
+        double acc = 0.0;
+        for (int bb = 0; bb < m; ++bb) acc += (Gs[aI + (size_t)bb * m] + Gs[bb + (size_t)aI * m]) * Tq[bb + (size_t)o * m];
+        Tb[aI + (size_t)o * m] += sigma2 * acc;
+      }
+    for (int aI = 0; aI < m; ++aI)
+      for (int bb = 0; bb < m; ++bb) {
+        double tt = 0.0;
+        for (int o = 0; o < p; ++o) tt += Tq[aI + (size_t)o * m] * Tq[bb + (size_t)o * m];
+        s2g += Gs[aI + (size_t)bb * m] * tt;
+      }
+    // P and its Cholesky
+    std::vector<double> P(mm, 0.0);
+    for (int aI = 0; aI < m; ++aI)
+      for (int bb = 0; bb < m; ++bb) P[aI + (size_t)bb * m] = s * HtH[aI + (size_t)bb * m] + (aI == bb ? jit->project_jitter : 0.0);
+    if (!host_cholesky(P, m)) return fail(LMM_ERR_NOT_PD, "PosDefException in project(H, sigma2)");
+    // Mb = P^-1 Tb (m x p);  Pb = -Mb T'
+    std::vector<double> Mb((size_t)m * p, 0.0), Pb(mm, 0.0);
+    for (int o = 0; o < p; ++o) {
+      std::vector<double> v(m);
+      for (int aI = 0; aI < m; ++aI) { double t = Tb[aI + (size_t)o * m]; for (int k = 0; k < aI; ++k) t -= P[aI + (size_t)k * m] * v[k]; v[aI] = t / P[aI + (size_t)aI * m]; }
+      for (int aI = m - 1; aI >= 0; --aI) { double t = v[aI]; for (int k = aI + 1; k < m; ++k) t -= P[k + (size_t)aI * m] * v[k]; v[aI] = t / P[aI + (size_t)aI * m]; }
+      for (int aI = 0; aI < m; ++aI) Mb[aI + (size_t)o * m] = v[aI];
+    }
+    for (int aI = 0; aI < m; ++aI)
+      for (int bb = 0; bb < m; ++bb) {
+        double acc = 0.0;
+        for (int o = 0; o < p; ++o) acc += Mb[aI + (size_t)o * m] * Tq[bb + (size_t)o * m];
+        Pb[aI + (size_t)bb * m] = -acc;
+      }
+    double sb = 0.0;       // cotangent of s = 1 / sigma2
+    for (int o = 0; o < p; ++o)
+      for (int l = 0; l < m; ++l) {
+        Hb[o + (size_t)l * p] += s * Mb[l + (size_t)o * m];                      // M = H' s
+        sb += Mb[l + (size_t)o * m] * H[o + (size_t)l * p];
+        double acc = 0.0;                                                        // P = s H'H: Hb += s H (Pb + Pb')
+        for (int bb = 0; bb < m; ++bb) acc += H[o + (size_t)bb * p] * (Pb[bb + (size_t)l * m] + Pb[l + (size_t)bb * m]);
+        Hb[o + (size_t)l * p] += s * acc;
+      }
+    for (int aI = 0; aI < m; ++aI) for (int bb = 0; bb < m; ++bb) sb += Pb[aI + (size_t)bb * m] * HtH[aI + (size_t)bb * m];
+    s2g += -sb * s * s;
+    G.gs2[b] = s2g;
+  }
+  G.gH = Hb;
+  if (gy_dev) {
+    // dL/dY (n x p) = -((alpha - RH / sigma2_i) T_i) - Rm / sigma2_i     (alpha as the n x m matrix [point][latent])
+    Buf<double> Z((size_t)N), ZT((size_t)n * p);
+    launch_vec_lin2(alpha.p, RH.p, -1.0 / s2[0], -1.0 / s2[nblk - 1], nsplit, n, (size_t)N, Z.p, st0);
+    for (int b = 0; b < nblk; ++b)
+      launch_tall_skinny(Z.p + bi0[b], n, bn[b], m, Ttdv[b], p, p, ZT.p + bi0[b], n, nullptr, nullptr, 0, nullptr, 0, st0);
+    launch_vec_lin2(ZT.p, Rm.p, 1.0 / s2[0], 1.0 / s2[nblk - 1], nsplit, n, (size_t)n * p, ZT.p, st0);
+    launch_vec_axpby(ZT.p, -1.0, ZT.p, 0.0, (size_t)n * p, gy_dev, st0);
+    HIPCHK(hipStreamSynchronize(st0));
+  }
+  return LMM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 // Value and gradient of logpdf(fx::FiniteGP{<:ILMM}, y) with a dense H (reference src/ilmm.jl:150-181 differentiated; the
 // reference's tests take Zygote.gradient(logpdf, ilmmx, y), test/ilmm.jl:31) w.r.t. y, sigma2, H (p x m) and every latent's
 // (variance, lengthscale, mean).  The reference's own operation: ONE (mn) x (mn) factorisation of blockdiag(K_l) + SigmaT (x) I;
@@ -1476,164 +1689,69 @@ int lmm_ilmm_logpdf_grad(const double* x, int d, int n, const double* y, int p, 
   if (int rc = check_gps(gps, m)) return rc;
   if (!(sigma2 > 0.0)) return fail(LMM_ERR_ARG, "sigma2 must be > 0");
   if (!jit) jit = &kDefaultJit;
-  if ((long long)m * n > 46000) return fail(LMM_ERR_UNSUPPORTED, "m*n too large for the dense gradient (explicit (mn)^2 inverse)");
   hipStream_t st0 = g.streams[0];
-  const double s = 1.0 / sigma2;
-  std::vector<double> T, ST;
-  double logdetST = 0.0;
-  if (int rc = project_dense(H, p, m, sigma2, jit->project_jitter, T, ST, &logdetST)) return rc;
-  // host copies in the layouts the kernels read: Tt = T' (p x m), Ht = H' (m x p)
-  std::vector<double> Hv(H, H + (size_t)p * m), Tt((size_t)p * m), Ht((size_t)m * p), means(m);
-  for (int l = 0; l < m; ++l) {
-    means[l] = gps[l].mean;
-    for (int o = 0; o < p; ++o) { Tt[o + (size_t)l * p] = T[l + (size_t)o * m]; Ht[l + (size_t)o * m] = H[o + (size_t)l * p]; }
-  }
-  std::vector<LatentDev> lat(m);
-  for (int l = 0; l < m; ++l) lat[l] = to_dev(gps[l]);
   DevIn xd(x, (size_t)d * n, st0), yd(y, (size_t)n * p, st0);
-  Uploaded Td(T, st0), STd(ST, st0), Hd(Hv, st0), Ttd(Tt, st0), Htd(Ht, st0), meansd(means, st0);
-  Buf<LatentDev> latd(m);
-  HIPCHK(hipMemcpyAsync(latd.p, lat.data(), m * sizeof(LatentDev), hipMemcpyHostToDevice, st0));
-  const int N = m * n;
-  Buf<double> Ty((size_t)N), delta((size_t)N), partial(tall_skinny_partials(n, p)), resid_dev(1);
-  project_on_device(yd.p, n, p, Td.buf, m, 0, m, nullptr, Ty.p, st0);
-  project_on_device(yd.p, n, p, Td.buf, m, 0, m, meansd.buf.p, delta.p, st0);
-  residual_on_device(yd.p, n, p, Ty.p, m, Hd.buf, partial.p, resid_dev.p, st0);
-  Dims D(N, 1);
-  Buf<double> A(D.elems()), W((size_t)(D.NC / 64) * 4096), R((size_t)D.ld * D.NC), alpha((size_t)D.NC), lml_dev(1);
-  Buf<int> info(1);
-  HIPCHK(hipMemsetAsync(info.p, 0, sizeof(int), st0));
-  HIPCHK(hipMemsetAsync(alpha.p, 0, (size_t)D.NC * sizeof(double), st0));
-  DenseArgs a{};
-  a.A = A.p; a.ld = D.ld; a.nrows = D.NR; a.ncols = D.NC; a.x = xd.p; a.d = d; a.n = n; a.m = m;
-  a.lat = latd.p; a.sigmaT = STd.buf.p; a.rider = delta.p; a.rider_ld = N; a.nrider = 1;
-  launch_dense_assemble(a, st0);
-  potrf_rec(A.p, D.ld, D.NR, 0, D.NC, W.p, N, info.p, st0);
-  launch_lml_reduce(A.p, D.ld, N, D.NC, 1, lml_dev.p, st0);
-  launch_extract_row(A.p, D.ld, D.NC, N, alpha.p, st0);
-  backsolve1(A.p, D.ld, W.p, D.NC / 64, alpha.p, st0);
-  launch_set_identity(R.p, D.ld, D.NC, st0);
-  trsm_rec(R.p, D.ld, D.NC, A.p, D.ld, W.p, 0, D.NC, st0, true);                 // R = L^-T
-  launch_syrk_upper_set(A.p, D.ld, R.p, D.ld, D.NC, st0);                         // lower(A) = Sigma^-1
-  const int NGR = LMM_NGRAD;
-  Buf<double> red((size_t)NGR * m), gpart((size_t)grad_partials(n)), Btr((size_t)m * m), AAt((size_t)m * m), AY((size_t)m * p);
-  for (int l = 0; l < m; ++l)
-    launch_grad_reduce(A.p + (size_t)l * n * D.ld + (size_t)l * n, D.ld, n, n, alpha.p + (size_t)l * n, delta.p + (size_t)l * n, xd.p, d,
-                       lat[l], gpart.p, red.p + (size_t)NGR * l, st0);
-  launch_block_trace(A.p, D.ld, n, m, Btr.p, st0);
-  launch_atb(alpha.p, n, alpha.p, n, n, m, m, AAt.p, st0);                         // (alpha_l . alpha_l')
-  launch_atb(alpha.p, n, yd.p, n, n, m, p, AY.p, st0);                             // sum_i alpha_l[i] Y[i, o]   (m x p)
-  // regulariser pieces: Rm = Y - (T Y)' H' (n x p), RH = Rm H (n x m), Rm' Ty (p x m), RH' Y (m x p)
-  Buf<double> HTY((size_t)n * p), Rm((size_t)n * p), RH((size_t)N), RtTy((size_t)p * m), RHtY((size_t)m * p);
-  launch_tall_skinny(Ty.p, n, n, m, Hd.buf.p, p, p, HTY.p, n, nullptr, nullptr, 0, nullptr, 0, st0);
-  launch_vec_lin(yd.p, HTY.p, -1.0, n * p, Rm.p, st0);
-  launch_tall_skinny(Rm.p, n, n, p, Htd.buf.p, m, m, RH.p, n, nullptr, nullptr, 0, nullptr, 0, st0);
-  launch_atb(Rm.p, n, Ty.p, n, n, p, m, RtTy.p, st0);
-  launch_atb(RH.p, n, yd.p, n, n, m, p, RHtY.p, st0);
-  std::vector<double> hred((size_t)NGR * m), hB((size_t)m * m), hAAt((size_t)m * m), hAY((size_t)m * p), hRtTy((size_t)p * m), hRHtY((size_t)m * p);
-  double lml = 0.0, resid = 0.0;
-  int hinfo = 0;
-  HIPCHK(hipMemcpyAsync(&lml, lml_dev.p, sizeof(double), hipMemcpyDeviceToHost, st0));
-  HIPCHK(hipMemcpyAsync(&resid, resid_dev.p, sizeof(double), hipMemcpyDeviceToHost, st0));
-  HIPCHK(hipMemcpyAsync(&hinfo, info.p, sizeof(int), hipMemcpyDeviceToHost, st0));
-  HIPCHK(hipMemcpyAsync(hred.data(), red.p, hred.size() * sizeof(double), hipMemcpyDeviceToHost, st0));
-  HIPCHK(hipMemcpyAsync(hB.data(), Btr.p, hB.size() * sizeof(double), hipMemcpyDeviceToHost, st0));
-  HIPCHK(hipMemcpyAsync(hAAt.data(), AAt.p, hAAt.size() * sizeof(double), hipMemcpyDeviceToHost, st0));
-  HIPCHK(hipMemcpyAsync(hAY.data(), AY.p, hAY.size() * sizeof(double), hipMemcpyDeviceToHost, st0));
-  HIPCHK(hipMemcpyAsync(hRtTy.data(), RtTy.p, hRtTy.size() * sizeof(double), hipMemcpyDeviceToHost, st0));
-  HIPCHK(hipMemcpyAsync(hRHtY.data(), RHtY.p, hRHtY.size() * sizeof(double), hipMemcpyDeviceToHost, st0));
-  HIPCHK(hipStreamSynchronize(st0));
-  if (int rc = check_info(std::vector<int>{hinfo}, 0)) return rc;
-  // value: reference src/ilmm.jl:150-163 + :171-181
-  *out_logpdf = lml - ((double)n * ((double)(p - m) * kLog2Pi + ((double)p * std::log(sigma2) - logdetST)) + resid / sigma2) / 2.0;
-  // ---- kernel-parameter gradients: 1/2 tr((aa' - Sigma^-1) dSigma/dtheta_l), dSigma = E_ll (x) dK_l ----
+  DevOut gy(grad_y, (size_t)n * p);
+  IlmmGrad G;
+  if (int rc = ilmm_grad_core(xd.p, d, n, n, yd.p, p, H, m, sigma2, sigma2, gps, jit, G, gy.p)) return rc;
+  *out_logpdf = G.value;
+  if (grad_sigma2) *grad_sigma2 = G.gs2[0];
+  if (grad_H) std::copy(G.gH.begin(), G.gH.end(), grad_H);
+  if (grad_gps) for (int l = 0; l < m; ++l) grad_gps[l] = G.ggps[l];
+  if (grad_y) { gy.finish(st0); HIPCHK(hipStreamSynchronize(st0)); }
+  return LMM_OK;
+  LMM_CATCH
+}
+
+// Value and TOTAL derivatives of logpdf(posterior(f(x, sigma2), y)(xs, sigma2_s), ys) for the dense-H ILMM -- what
+// Zygote.gradient(logpdf, pi, y_test) differentiates in reference test/ilmm.jl:32 -- as the joint prior density of (y, ys) under
+// two-block noise minus the prior density of y.  Does not shard.
+int lmm_ilmm_post_logpdf_grad(const double* x, int d, int n, const double* y, const double* xs, int ns, const double* ys, int p,
+                              const double* H, int m, double sigma2, double sigma2_s, const lmm_gp_t* gps, const lmm_jitters_t* jit,
+                              double* out_logpdf, double* grad_y, double* grad_ys, double* grad_sigma2, double* grad_sigma2_s,
+                              double* grad_H, lmm_gp_grad_t* grad_gps) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  REQUIRE_INIT();
+  LMM_TRY
+  REQUIRE_F64("the dense-H predictive-logpdf gradient");
+  if (!x || !y || !xs || !ys || !H || !out_logpdf || d <= 0 || n <= 0 || ns <= 0 || p <= 0 || m <= 0) return fail(LMM_ERR_ARG, "bad arguments");
+  if (int rc = check_gps(gps, m)) return rc;
+  if (!(sigma2 > 0.0) || !(sigma2_s > 0.0)) return fail(LMM_ERR_ARG, "sigma2 must be > 0");
+  if (!jit) jit = &kDefaultJit;
+  hipStream_t st0 = g.streams[0];
+  const int N = n + ns;
+  DevIn xd(x, (size_t)d * n, st0), yd(y, (size_t)n * p, st0), xsd(xs, (size_t)d * ns, st0), ysd(ys, (size_t)ns * p, st0);
+  Buf<double> xj((size_t)d * N), yj((size_t)N * p), gj((size_t)N * p), gm((size_t)n * p);
+  HIPCHK(hipMemcpyAsync(xj.p, xd.p, (size_t)d * n * sizeof(double), hipMemcpyDeviceToDevice, st0));
+  HIPCHK(hipMemcpyAsync(xj.p + (size_t)d * n, xsd.p, (size_t)d * ns * sizeof(double), hipMemcpyDeviceToDevice, st0));
+  HIPCHK(hipMemcpy2DAsync(yj.p, (size_t)N * sizeof(double), yd.p, (size_t)n * sizeof(double), (size_t)n * sizeof(double), p, hipMemcpyDeviceToDevice, st0));
+  HIPCHK(hipMemcpy2DAsync(yj.p + n, (size_t)N * sizeof(double), ysd.p, (size_t)ns * sizeof(double), (size_t)ns * sizeof(double), p, hipMemcpyDeviceToDevice, st0));
+  const bool want_gy = grad_y != nullptr || grad_ys != nullptr;
+  IlmmGrad GJ, GM;
+  if (int rc = ilmm_grad_core(xj.p, d, N, n, yj.p, p, H, m, sigma2, sigma2_s, gps, jit, GJ, want_gy ? gj.p : nullptr)) return rc;
+  if (int rc = ilmm_grad_core(xd.p, d, n, n, yd.p, p, H, m, sigma2, sigma2, gps, jit, GM, grad_y ? gm.p : nullptr)) return rc;
+  *out_logpdf = GJ.value - GM.value;
+  if (grad_sigma2) *grad_sigma2 = GJ.gs2[0] - GM.gs2[0];
+  if (grad_sigma2_s) *grad_sigma2_s = GJ.gs2[1];
+  if (grad_H) for (size_t q = 0; q < (size_t)p * m; ++q) grad_H[q] = GJ.gH[q] - GM.gH[q];
   if (grad_gps)
     for (int l = 0; l < m; ++l) {
-      const double* r = &hred[(size_t)NGR * l];
-      grad_gps[l].lengthscale = r[0];
-      grad_gps[l].variance = (r[7] + 0.5 * gps[l].variance * (r[2] - r[1])) / gps[l].variance;     // K_ii = variance
-      grad_gps[l].mean = r[4];
+      grad_gps[l].variance = GJ.ggps[l].variance - GM.ggps[l].variance;
+      grad_gps[l].lengthscale = GJ.ggps[l].lengthscale - GM.ggps[l].lengthscale;
+      grad_gps[l].mean = GJ.ggps[l].mean - GM.ggps[l].mean;
     }
-  auto at = [](std::vector<double>& M, int rows, int i, int j) -> double& { return M[i + (size_t)j * rows]; };
-  // ---- cotangents of T (m x p) and SigmaT (m x m) ----
-  std::vector<double> Tb((size_t)m * p, 0.0), Gs((size_t)m * m, 0.0), Hb((size_t)p * m, 0.0);
-  double s2b = 0.0;
-  for (int l = 0; l < m; ++l)
-    for (int o = 0; o < p; ++o) Tb[l + (size_t)o * m] = -hAY[l + (size_t)o * m] + s * hRHtY[l + (size_t)o * m];   // lml + regulariser (residual)
-  // SigmaT^-1 for the +n/2 logdet SigmaT term of the regulariser
-  std::vector<double> STc = ST, STinv((size_t)m * m, 0.0);
-  if (!host_cholesky(STc, m)) return fail(LMM_ERR_NOT_PD, "PosDefException: SigmaT not PD");
-  for (int c = 0; c < m; ++c) {       // solve (L L') col = e_c
-    std::vector<double> v(m, 0.0);
-    for (int aI = 0; aI < m; ++aI) { double t = (aI == c) ? 1.0 : 0.0; for (int k = 0; k < aI; ++k) t -= STc[aI + (size_t)k * m] * v[k]; v[aI] = t / STc[aI + (size_t)aI * m]; }
-    for (int aI = m - 1; aI >= 0; --aI) { double t = v[aI]; for (int k = aI + 1; k < m; ++k) t -= STc[k + (size_t)aI * m] * v[k]; v[aI] = t / STc[aI + (size_t)aI * m]; }
-    for (int aI = 0; aI < m; ++aI) STinv[aI + (size_t)c * m] = v[aI];
-  }
-  for (int aI = 0; aI < m; ++aI)
-    for (int b = 0; b < m; ++b) Gs[aI + (size_t)b * m] = 0.5 * (hAAt[aI + (size_t)b * m] - hB[aI + (size_t)b * m]) + 0.5 * (double)n * STinv[aI + (size_t)b * m];
-  // explicit sigma2 of the regulariser and explicit H of the residual
-  s2b += -0.5 * ((double)n * (double)p / sigma2 - resid / (sigma2 * sigma2));
-  for (int o = 0; o < p; ++o) for (int l = 0; l < m; ++l) Hb[o + (size_t)l * p] += s * hRtTy[o + (size_t)l * p];
-  // ---- backward through project(H, sigma2): P = s H'H + eps I,  T = P^-1 H' s,  SigmaT = sigma2 T T' ----
-  // SigmaT = sigma2 T T':  Tb += sigma2 (Gs + Gs') T;  s2b += <Gs, T T'>
-  for (int aI = 0; aI < m; ++aI)
-    for (int o = 0; o < p; ++o) {
-      double acc = 0.0;
-      for (int b = 0; b < m; ++b) acc += (Gs[aI + (size_t)b * m] + Gs[b + (size_t)aI * m]) * T[b + (size_t)o * m];
-      Tb[aI + (size_t)o * m] += sigma2 * acc;
-    }
-  for (int aI = 0; aI < m; ++aI)
-    for (int b = 0; b < m; ++b) {
-      double tt = 0.0;
-      for (int o = 0; o < p; ++o) tt += T[aI + (size_t)o * m] * T[b + (size_t)o * m];
-      s2b += Gs[aI + (size_t)b * m] * tt;
-    }
-  // P and its Cholesky
-  std::vector<double> HtH((size_t)m * m, 0.0), P((size_t)m * m, 0.0);
-  for (int aI = 0; aI < m; ++aI)
-    for (int b = 0; b < m; ++b) {
-      double acc = 0.0;
-      for (int o = 0; o < p; ++o) acc += H[o + (size_t)aI * p] * H[o + (size_t)b * p];
-      HtH[aI + (size_t)b * m] = acc;
-      P[aI + (size_t)b * m] = s * acc + (aI == b ? jit->project_jitter : 0.0);
-    }
-  if (!host_cholesky(P, m)) return fail(LMM_ERR_NOT_PD, "PosDefException in project(H, sigma2)");
-  // Mb = P^-1 Tb (m x p);  Pb = -Mb T'
-  std::vector<double> Mb((size_t)m * p, 0.0), Pb((size_t)m * m, 0.0);
-  for (int o = 0; o < p; ++o) {
-    std::vector<double> v(m);
-    for (int aI = 0; aI < m; ++aI) { double t = Tb[aI + (size_t)o * m]; for (int k = 0; k < aI; ++k) t -= P[aI + (size_t)k * m] * v[k]; v[aI] = t / P[aI + (size_t)aI * m]; }
-    for (int aI = m - 1; aI >= 0; --aI) { double t = v[aI]; for (int k = aI + 1; k < m; ++k) t -= P[k + (size_t)aI * m] * v[k]; v[aI] = t / P[aI + (size_t)aI * m]; }
-    for (int aI = 0; aI < m; ++aI) Mb[aI + (size_t)o * m] = v[aI];
-  }
-  for (int aI = 0; aI < m; ++aI)
-    for (int b = 0; b < m; ++b) {
-      double acc = 0.0;
-      for (int o = 0; o < p; ++o) acc += Mb[aI + (size_t)o * m] * T[b + (size_t)o * m];
-      Pb[aI + (size_t)b * m] = -acc;
-    }
-  double sb = 0.0;       // cotangent of s = 1 / sigma2
-  for (int o = 0; o < p; ++o)
-    for (int l = 0; l < m; ++l) {
-      Hb[o + (size_t)l * p] += s * Mb[l + (size_t)o * m];                      // M = H' s
-      sb += Mb[l + (size_t)o * m] * H[o + (size_t)l * p];
-      double acc = 0.0;                                                        // P = s H'H: Hb += s H (Pb + Pb')
-      for (int b = 0; b < m; ++b) acc += H[o + (size_t)b * p] * (Pb[b + (size_t)l * m] + Pb[l + (size_t)b * m]);
-      Hb[o + (size_t)l * p] += s * acc;
-    }
-  for (int aI = 0; aI < m; ++aI) for (int b = 0; b < m; ++b) sb += Pb[aI + (size_t)b * m] * HtH[aI + (size_t)b * m];
-  s2b += -sb * s * s;
-  (void)at;
-  if (grad_sigma2) *grad_sigma2 = s2b;
-  if (grad_H) std::copy(Hb.begin(), Hb.end(), grad_H);
   if (grad_y) {
-    // dL/dY (n x p) = -((alpha - RH / sigma2) T) - Rm / sigma2     (alpha as the n x m matrix [point][latent])
     DevOut gy(grad_y, (size_t)n * p);
-    Buf<double> Z((size_t)N), ZT((size_t)n * p);
-    launch_vec_lin(alpha.p, RH.p, -s, N, Z.p, st0);
-    launch_tall_skinny(Z.p, n, n, m, Ttd.buf.p, p, p, ZT.p, n, nullptr, nullptr, 0, nullptr, 0, st0);
-    launch_vec_axpby(ZT.p, -1.0, Rm.p, -s, (size_t)n * p, gy.p, st0);
+    Buf<double> top((size_t)n * p);
+    HIPCHK(hipMemcpy2DAsync(top.p, (size_t)n * sizeof(double), gj.p, (size_t)N * sizeof(double), (size_t)n * sizeof(double), p, hipMemcpyDeviceToDevice, st0));
+    launch_vec_lin(top.p, gm.p, -1.0, n * p, gy.p, st0);
     gy.finish(st0);
+    HIPCHK(hipStreamSynchronize(st0));
+  }
+  if (grad_ys) {
+    DevOut gys(grad_ys, (size_t)ns * p);
+    HIPCHK(hipMemcpy2DAsync(gys.p, (size_t)ns * sizeof(double), gj.p + n, (size_t)N * sizeof(double), (size_t)ns * sizeof(double), p, hipMemcpyDeviceToDevice, st0));
+    gys.finish(st0);
     HIPCHK(hipStreamSynchronize(st0));
   }
   return LMM_OK;

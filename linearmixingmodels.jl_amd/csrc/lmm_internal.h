@@ -96,7 +96,7 @@ int grad_partials(int n);
 void launch_grad_reduce(const double* Kinv, int ld, int n, int nsplit, const double* alpha, const double* delta, const double* x, int d,
                         LatentDev g, double* partial, double* out7, hipStream_t st);
 void launch_vec_axpby(const double* a, double sa, const double* b, double sb, size_t n, double* out, hipStream_t st);
-void launch_block_trace(const double* Minv, int ld, int n, int m, double* out, hipStream_t st);
+void launch_block_trace(const double* Minv, int ld, int n, int m, int i0, int i1, double* out, hipStream_t st);   // points i0..i1-1
 void launch_vec_lin2(const double* a, const double* b, double sa, double sb, int nsplit, int N, size_t count, double* out, hipStream_t st);
 void launch_atb(const double* X, int ldx, const double* Z, int ldz, int n, int na, int nb, double* out, hipStream_t st);
 void launch_fill(double* p, int n, double v, hipStream_t st);

@@ -2421,13 +2421,13 @@ __global__ __launch_bounds__(256) void grad_finish_kernel(const double* __restri
 
 // out[l + l2*m] = sum_i Minv[(l n + i), (l2 n + i)]  for l >= l2 (mirrored into l < l2): the m x m matrix of traces of the diagonals of
 // the n x n blocks of a symmetric (m n) x (m n) matrix whose lower triangle is stored (dense-H ILMM gradient: dL/dSigmaT).
-__global__ __launch_bounds__(256) void block_trace_kernel(const double* __restrict__ Minv, int ld, int n, int m,
+__global__ __launch_bounds__(256) void block_trace_kernel(const double* __restrict__ Minv, int ld, int n, int m, int i0, int i1,
                                                           double* __restrict__ out) {
   __shared__ double sh[4];
   const int l = blockIdx.x, l2 = blockIdx.y;
   if (l < l2) return;
   double s = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) s += Minv[(size_t)(l2 * n + i) * ld + (l * n + i)];
+  for (int i = i0 + threadIdx.x; i < i1; i += 256) s += Minv[(size_t)(l2 * n + i) * ld + (l * n + i)];
   const double tot = block_sum_256(s, sh);
   if (threadIdx.x == 0) { out[l + (size_t)l2 * m] = tot; out[l2 + (size_t)l * m] = tot; }
 }
@@ -2853,8 +2853,8 @@ void launch_vec_axpby(const double* a, double sa, const double* b, double sb, si
   hipLaunchKernelGGL(vec_axpby_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, sa, b, sb, n, out);
 }
 
-void launch_block_trace(const double* Minv, int ld, int n, int m, double* out, hipStream_t st) {
-  hipLaunchKernelGGL(block_trace_kernel, dim3(m, m), dim3(256), 0, st, Minv, ld, n, m, out);
+void launch_block_trace(const double* Minv, int ld, int n, int m, int i0, int i1, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(block_trace_kernel, dim3(m, m), dim3(256), 0, st, Minv, ld, n, m, i0, i1, out);
 }
 
 void launch_vec_lin2(const double* a, const double* b, double sa, double sb, int nsplit, int N, size_t count, double* out, hipStream_t st) {

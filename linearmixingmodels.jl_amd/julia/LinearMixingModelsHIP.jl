@@ -362,7 +362,7 @@ AbstractGPs.rand(rng::AbstractRNG, ft::ByOutputsFill{HIPMOGP}, N::Int) = _rand_m
 # ---- gradients: ChainRulesCore.rrule around the ccall --------------------------------------------------------------------
 # The reference's tests take Zygote.gradient(logpdf, fx, y) on prior and posterior models (test/oilmm.jl:31-32,
 # test/ilmm.jl:31-32, test/independent_mogp.jl:65-66).  A ccall is opaque to Zygote, so the pullbacks come from the library
-# (lmm_oilmm_logpdf_grad, lmm_ilmm_logpdf_grad, lmm_oilmm_post_logpdf_grad) and are mapped onto the reference's structs.
+# (lmm_oilmm_logpdf_grad, lmm_ilmm_logpdf_grad, lmm_oilmm_post_logpdf_grad, lmm_ilmm_post_logpdf_grad) and are mapped onto the reference's structs.
 
 # kernel cotangent: the library differentiates w.r.t. the EFFECTIVE (variance, lengthscale); the chain rule through the
 # kernel's construction: ScaledKernel: v = v_inner σ² -> d/dσ² = gv v_inner; ScaleTransform: ℓ = ℓ_inner / s -> d/ds = -gl ℓ_inner / s².
@@ -437,17 +437,26 @@ function ChainRulesCore.rrule(::typeof(AbstractGPs.logpdf), ft::ByOutputsFill{HI
     return val[], logpdf_pullback
 end
 
-# dense-H ILMM prior (reference test/ilmm.jl:31): the reference's (mn) x (mn) operation + its explicit inverse
+# dense-H ILMM, prior and posterior (reference test/ilmm.jl:31-32): the reference's (mn) x (mn) operation + its explicit inverse;
+# the posterior's predictive logpdf as the joint density of (y, y*) under two-block noise minus the density of y
 function ChainRulesCore.rrule(::typeof(AbstractGPs.logpdf), fx::ByOutputsFill{HIPDenseILMM}, y::AbstractVector{<:Real})
     f, H, σ², x = unpack(fx)
-    isposterior(f) && error("gradient of the dense-H posterior's predictive logpdf is not built")
     X = _xmat(x); d, n = size(X); p, m = size(H); gps = _gps(f.fs); Hm = Matrix{Float64}(H); yv = Vector{Float64}(y)
-    val = Ref{Cdouble}(0.0); gσ = Ref{Cdouble}(0.0)
+    val = Ref{Cdouble}(0.0); gσ = Ref{Cdouble}(0.0); gσt = Ref{Cdouble}(0.0)
     gy = Vector{Float64}(undef, n * p); gH = Matrix{Float64}(undef, p, m); gg = Vector{LmmGpGrad}(undef, m)
-    GC.@preserve X yv Hm gps gy gH gg check(ccall((:lmm_ilmm_logpdf_grad, liblmm), Cint,
-        (Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Cint, Cdouble, Ptr{LmmGp}, Ptr{LmmJitters}, Ref{Cdouble}, Ptr{Cdouble},
-         Ref{Cdouble}, Ptr{Cdouble}, Ptr{LmmGpGrad}),
-        X, d, n, yv, p, Hm, m, σ², gps, C_NULL, val, gy, gσ, gH, gg))
+    if isposterior(f)
+        f.train === nothing && error("gradient of the predictive logpdf after sequential conditioning is not built")
+        X0, σ0, y0 = f.train; n0 = size(X0, 2); gy0 = Vector{Float64}(undef, n0 * p)
+        GC.@preserve X0 y0 X yv Hm gps gy0 gy gH gg check(ccall((:lmm_ilmm_post_logpdf_grad, liblmm), Cint,
+            (Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Cint, Cdouble, Cdouble,
+             Ptr{LmmGp}, Ptr{LmmJitters}, Ref{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Cdouble}, Ref{Cdouble}, Ptr{Cdouble}, Ptr{LmmGpGrad}),
+            X0, d, n0, y0, X, n, yv, p, Hm, m, σ0, σ², gps, C_NULL, val, gy0, gy, gσt, gσ, gH, gg))
+    else
+        GC.@preserve X yv Hm gps gy gH gg check(ccall((:lmm_ilmm_logpdf_grad, liblmm), Cint,
+            (Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Cint, Cdouble, Ptr{LmmGp}, Ptr{LmmJitters}, Ref{Cdouble}, Ptr{Cdouble},
+             Ref{Cdouble}, Ptr{Cdouble}, Ptr{LmmGpGrad}),
+            X, d, n, yv, p, Hm, m, σ², gps, C_NULL, val, gy, gσ, gH, gg))
+    end
     function logpdf_pullback(Δ)
         dfx = Tangent{typeof(fx)}(; f=Tangent{typeof(fx.f)}(; f=Tangent{typeof(f)}(; fs=_fstangent(f.fs, gg, Δ)), H=Δ .* gH),
                                   Σy=_noise_tangent(fx, Δ * gσ[]))

@@ -362,6 +362,7 @@ def logpdf_and_gradient(fx: FiniteGP, y, with_regulariser: bool = True) -> dict:
 
       prior OILMM / IndependentMOGP : {"value", "y", "sigma2", "S", "U", "gps": [{"variance","lengthscale","mean"}, ...]}
       prior dense-H ILMM            : {"value", "y", "sigma2", "H", "gps"}
+      posterior dense-H ILMM        : as the posterior OILMM below with "H" in place of "S", "U" (test/ilmm.jl:32)
       posterior OILMM / MOGP        : fx = posterior(f(x, s2), y0)(xs, s2s); TOTAL derivatives of the predictive logpdf through the
                                       posterior: {"value", "y" (= d/d ys), "y_train", "sigma2" (= d/d s2s), "sigma2_train", "S", "U", "gps"}
     Partial sums over the latent shard."""
@@ -373,14 +374,25 @@ def logpdf_and_gradient(fx: FiniteGP, y, with_regulariser: bool = True) -> dict:
     if not mogp and not isinstance(f, ILMM):
         raise TypeError("logpdf_and_gradient needs an ILMM / OILMM / IndependentMOGP FiniteGP")
     if not mogp and not f.is_oilmm:
-        if post is not None:
-            raise NotImplementedError("gradient of the dense-H posterior's predictive logpdf is not built")
         unpack(fx)
         Ha, _, p, m = _H_args(f.H)
         n = x.n
         val, gs2 = C.c_double(), C.c_double()
         gy, gH = _alloc_like(y if L._is_torch(y) else x.x, n * p), np.empty(p * m)
         gg = (L.GpGradT * m)()
+        if post is not None:          # reference test/ilmm.jl:32: gradient(logpdf, pi, y_test) on the dense-H posterior
+            if post.train is None:
+                raise NotImplementedError("gradient of the predictive logpdf after sequential conditioning is not built")
+            x0, s20, y0 = post.train
+            gs2t = C.c_double()
+            gy0 = _alloc_like(y0 if L._is_torch(y0) else x0.x, x0.n * p)
+            L.check(lib.lmm_ilmm_post_logpdf_grad(x0.carr().ptr, x0.dim, x0.n, L.Arr(y0).ptr, x.carr().ptr, n, L.Arr(y).ptr, p, Ha.ptr, m,
+                                                  C.c_double(s20), C.c_double(s2), L.gps_array([g.desc() for g in f.f.fs]), None,
+                                                  C.byref(val), L.Arr(gy0, True).ptr, L.Arr(gy, True).ptr, C.byref(gs2t), C.byref(gs2),
+                                                  L.Arr(gH, True).ptr, gg))
+            return {"value": val.value, "y": gy, "y_train": gy0, "sigma2": gs2.value, "sigma2_train": gs2t.value,
+                    "H": gH.reshape(m, p).T.copy(),
+                    "gps": [{"variance": gg[l].variance, "lengthscale": gg[l].lengthscale, "mean": gg[l].mean} for l in range(m)]}
         L.check(lib.lmm_ilmm_logpdf_grad(x.carr().ptr, x.dim, n, L.Arr(y).ptr, p, Ha.ptr, m, C.c_double(s2),
                                          L.gps_array([g.desc() for g in f.f.fs]), None, C.byref(val), L.Arr(gy, True).ptr,
                                          C.byref(gs2), L.Arr(gH, True).ptr, gg))

@@ -386,6 +386,52 @@ def test_dense_ilmm_logpdf_gradient_vs_oracle_fd(lmm, n, d):
             assert G["gps"][l][key] == pytest.approx(_fd(f1), rel=2e-5, abs=1e-6)
 
 
+def test_posterior_dense_ilmm_logpdf_gradient_vs_oracle_fd(lmm):
+    """reference test/ilmm.jl:32: gradient(logpdf, pi, y_test) on the dense-H posterior (distinct latent kernels: the coupled
+    (mn) x (mn) path).  Value == the oracle's and the handle's predictive logpdf; every component of the TOTAL derivative ==
+    central finite differences of the oracle's logpdf(posterior(...)(xs, s2s), ys)."""
+    rng = np.random.default_rng(64)
+    n, ns, p, m = 16, 7, 4, 3
+    x = np.sort(rng.uniform(0, 6, n)); xs = np.sort(rng.uniform(0, 6, ns))
+    gps = _gps(["se", "matern32", "matern52"], rng)
+    H = rng.uniform(0.2, 1.0, size=(p, m))
+    y, ys = rng.standard_normal(n * p), rng.standard_normal(ns * p)
+    s2, s2s = 0.3, 0.2
+
+    def F(gps=gps, H=H, s2=s2, s2s=s2s, y=y, ys=ys):
+        return O.ilmm_logpdf(O.ilmm_posterior(gps, H, x, s2, y), H, xs, s2s, ys)
+
+    f = lmm.ILMM(_to_model(lmm, gps), H)
+    po = lmm.posterior(f(lmm.MOInputIsotopicByOutputs(x, p), s2), y)
+    fxs = po(lmm.MOInputIsotopicByOutputs(xs, p), s2s)
+    G = lmm.logpdf_and_gradient(fxs, ys)
+    assert G["value"] == pytest.approx(F(), rel=1e-7)
+    assert G["value"] == pytest.approx(lmm.logpdf(fxs, ys), rel=1e-7)
+    assert G["sigma2"] == pytest.approx(_fd(lambda t: F(s2s=s2s + t)), rel=2e-5, abs=1e-6)
+    assert G["sigma2_train"] == pytest.approx(_fd(lambda t: F(s2=s2 + t)), rel=2e-5, abs=1e-6)
+    for k in [0, 5, ns * p - 1]:
+        e = np.zeros(ns * p); e[k] = 1.0
+        assert G["y"][k] == pytest.approx(_fd(lambda t: F(ys=ys + t * e)), rel=1e-5, abs=1e-6)
+    for k in [0, 7, n * p - 1]:
+        e = np.zeros(n * p); e[k] = 1.0
+        assert G["y_train"][k] == pytest.approx(_fd(lambda t: F(y=y + t * e)), rel=1e-5, abs=1e-6)
+    for (o, l) in [(0, 0), (1, 2), (3, 1), (2, 2)]:
+        E = np.zeros((p, m)); E[o, l] = 1.0
+        assert G["H"][o, l] == pytest.approx(_fd(lambda t: F(H=H + t * E)), rel=2e-5, abs=1e-6)
+    for l in range(m):
+        for key in ("variance", "lengthscale", "mean"):
+            def f1(t, l=l, key=key):
+                g2 = [dict(g) for g in gps]; g2[l][key] += t
+                return F(gps=g2)
+            assert G["gps"][l][key] == pytest.approx(_fd(f1), rel=2e-5, abs=1e-6)
+    # the same noise on both blocks and device inputs
+    import torch
+    fxs2 = po(lmm.MOInputIsotopicByOutputs(xs, p), s2)
+    G2 = lmm.logpdf_and_gradient(fxs2, torch.from_numpy(ys).cuda())
+    assert G2["value"] == pytest.approx(F(s2s=s2), rel=1e-7)
+    assert float(G2["y"][3]) == pytest.approx(_fd(lambda t: F(s2s=s2, ys=ys + t * np.eye(ns * p)[3])), rel=1e-5, abs=1e-6)
+
+
 def test_dense_ilmm_matrix_y_logpdf(lmm):
     """logpdf(ilmmx, Y::Matrix) on the dense-H model (TestUtils, reference test/ilmm.jl:34-37): one factorisation, one value per
     column, each equal to the vector logpdf of that column."""
