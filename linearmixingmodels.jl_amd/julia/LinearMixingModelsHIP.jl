@@ -136,6 +136,30 @@ function AbstractGPs.logpdf(fx::ByOutputsFill{HIPOILMM}, Y::AbstractMatrix{<:Rea
     return out
 end
 
+# the same for the dense-H ILMM (lmm_ilmm_logpdf_multi: the columns ride the one (mn) x (mn) factorisation) and the IndependentMOGP
+# (the OILMM with U = I, S = 1, no regulariser); on posterior models the columns are evaluated one by one on the handle
+function AbstractGPs.logpdf(fx::ByOutputsFill{HIPDenseILMM}, Y::AbstractMatrix{<:Real})
+    f, H, σ², x = unpack(fx)
+    isposterior(f) && return [logpdf(fx, Y[:, c]) for c in axes(Y, 2)]
+    X = _xmat(x); d, n = size(X); p, m = size(H); Ym = Matrix{Float64}(Y); gps = _gps(f.fs); Hm = Matrix{Float64}(H)
+    out = Vector{Float64}(undef, size(Ym, 2))
+    GC.@preserve X Ym Hm gps out check(ccall((:lmm_ilmm_logpdf_multi, liblmm), Cint,
+        (Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Cint, Cdouble, Ptr{LmmGp}, Ptr{LmmJitters}, Ptr{Cdouble}),
+        X, d, n, Ym, p, size(Ym, 2), Hm, m, σ², gps, C_NULL, out))
+    return out
+end
+function AbstractGPs.logpdf(ft::ByOutputsFill{HIPMOGP}, Y::AbstractMatrix{<:Real})
+    isposterior(ft.f) && return [logpdf(ft, Y[:, c]) for c in axes(Y, 2)]
+    X = _xmat(ft.x.x); d, n = size(X); m = length(ft.f.fs); σ² = noise_var(ft.Σy)
+    ft.x.out_dim == m || throw(ErrorException("out dim of x != out dim of f."))
+    U = Matrix{Float64}(I, m, m); S = ones(m); Ym = Matrix{Float64}(Y); gps = _gps(ft.f.fs)
+    out = Vector{Float64}(undef, size(Ym, 2))
+    GC.@preserve X Ym U S gps out check(ccall((:lmm_oilmm_logpdf_multi, liblmm), Cint,
+        (Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cdouble, Ptr{LmmGp}, Cint, Cint, Cint, Ptr{Cdouble}),
+        X, d, n, Ym, m, size(Ym, 2), U, S, m, σ², gps, 0, m, 0, out))
+    return out
+end
+
 # reference src/ilmm.jl:150-163 (prior) and test/ilmm.jl:25 (posterior), dense H
 function AbstractGPs.logpdf(fx::ByOutputsFill{HIPDenseILMM}, y::AbstractVector{<:Real})
     f, H, σ², x = unpack(fx)

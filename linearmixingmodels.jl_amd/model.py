@@ -439,6 +439,9 @@ def _logpdf_matrix(fx: FiniteGP, Y, with_regulariser: bool = True) -> np.ndarray
     f, x, s2 = fx.f, fx.x, fx.sigma2
     ncol = int(Y.shape[1])
     Yc = Y.T.contiguous() if L._is_torch(Y) else np.ascontiguousarray(np.asarray(Y, dtype=np.float64).T)   # column-major image
+    fpost = f._post if isinstance(f, IndependentMOGP) else f.f._post
+    if fpost is not None:          # posterior models (TestUtils on po(x*, s2): reference test/oilmm.jl:36, test/ilmm.jl:36): the columns
+        return np.array([logpdf(fx, Yc[c], with_regulariser) for c in range(ncol)])      # are evaluated one by one on the handle
     if isinstance(f, IndependentMOGP):
         m = len(f.fs)
         descs, Ua, Sa, p, shard, post = [g.desc() for g in f.fs], L.Arr(L.colmajor(np.eye(m))), L.Arr(np.ones(m)), m, (0, m), f._post
@@ -447,8 +450,6 @@ def _logpdf_matrix(fx: FiniteGP, Y, with_regulariser: bool = True) -> np.ndarray
     else:
         unpack(fx)
         if not f.is_oilmm:                         # dense H: one (mn) x (mn) factorisation, the columns ride it
-            if f.f._post is not None:
-                raise NotImplementedError("matrix-Y logpdf on a posterior")
             Ha, _, p, m = _H_args(f.H)
             if x.out_dim != p:
                 raise RuntimeError("out dim of x != out dim of f.")
@@ -457,8 +458,6 @@ def _logpdf_matrix(fx: FiniteGP, Y, with_regulariser: bool = True) -> np.ndarray
                                               L.gps_array([g.desc() for g in f.f.fs]), None, L.Arr(out, True).ptr))
             return out
         descs, (Ua, Sa, p, m), shard, post, s2_eff = [g.desc() for g in f.f.fs], _H_args(f.H), f.shard, f.f._post, s2
-    if post is not None:
-        raise NotImplementedError("matrix-Y logpdf on a posterior")
     if x.out_dim != p:
         raise RuntimeError("out dim of x != out dim of f.")
     out = np.empty(ncol)

@@ -432,6 +432,31 @@ def test_posterior_dense_ilmm_logpdf_gradient_vs_oracle_fd(lmm):
     assert float(G2["y"][3]) == pytest.approx(_fd(lambda t: F(s2s=s2, ys=ys + t * np.eye(ns * p)[3])), rel=1e-5, abs=1e-6)
 
 
+def test_matrix_y_logpdf_on_posteriors(lmm):
+    """TestUtils calls logpdf(fx, Y::Matrix) on the posterior FiniteGPs too (reference test/oilmm.jl:36, test/ilmm.jl:36,
+    test/independent_mogp.jl:69): one value per column, each the vector logpdf of that column."""
+    rng = np.random.default_rng(72)
+    n, ns, p, m, ncol = 30, 9, 4, 3, 3
+    x = np.sort(rng.uniform(0, 6, n)); xs = np.sort(rng.uniform(0, 6, ns))
+    gps = _gps(["se", "matern32", "matern52"], rng)
+    U, S = _orth(rng, p, m)
+    Hd = rng.uniform(0.2, 1.0, size=(p, m))
+    y = rng.standard_normal(n * p)
+    Y = rng.standard_normal((ns * p, ncol))
+    for H, ref in [(lmm.Orthogonal(U, S), lambda c: O.oilmm_logpdf(O.oilmm_posterior(gps, U, S, x, 0.2, y), U, S, xs, 0.3, Y[:, c])),
+                   (Hd, lambda c: O.ilmm_logpdf(O.ilmm_posterior(gps, Hd, x, 0.2, y), Hd, xs, 0.3, Y[:, c]))]:
+        po = lmm.posterior(lmm.ILMM(_to_model(lmm, gps), H)(lmm.MOInputIsotopicByOutputs(x, p), 0.2), y)
+        vals = lmm.logpdf(po(lmm.MOInputIsotopicByOutputs(xs, p), 0.3), Y)
+        assert vals.shape == (ncol,)
+        for c in range(ncol):
+            assert vals[c] == pytest.approx(ref(c), rel=1e-8)
+    ym = rng.standard_normal(n * m); Ym = rng.standard_normal((ns * m, ncol))
+    pm = lmm.posterior(_to_model(lmm, gps)(lmm.MOInputIsotopicByOutputs(x, m), 0.2), ym)
+    vals = lmm.logpdf(pm(lmm.MOInputIsotopicByOutputs(xs, m), 0.3), Ym)
+    for c in range(ncol):
+        assert vals[c] == pytest.approx(O.mogp_logpdf(O.mogp_posterior(gps, x, 0.2, ym), xs, 0.3, Ym[:, c]), rel=1e-8)
+
+
 def test_dense_ilmm_matrix_y_logpdf(lmm):
     """logpdf(ilmmx, Y::Matrix) on the dense-H model (TestUtils, reference test/ilmm.jl:34-37): one factorisation, one value per
     column, each equal to the vector logpdf of that column."""
