@@ -101,3 +101,16 @@ def test_reorder_indices_known_answers():
     np.testing.assert_array_equal(v_by_features[f2o], v_by_output)
     np.testing.assert_array_equal(v_by_output[o2f][f2o], v_by_output)
     np.testing.assert_array_equal(v_by_features[f2o][o2f], v_by_features)
+
+
+def test_bench_refuses_a_rank_count_it_is_not_running():
+    """bench.py --gpus N must not report a number for another rank count: under a launcher that set WORLD_SIZE != N it exits
+    non-zero before touching a GPU (with WORLD_SIZE unset it starts its own N ranks through torch.distributed.run)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    assert "does not match WORLD_SIZE" in out.stderr
+    assert out.stdout.strip() == ""
