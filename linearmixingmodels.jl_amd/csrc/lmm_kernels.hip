@@ -1015,30 +1015,44 @@ __global__ __launch_bounds__(64) void diag64m_kernel(BatchPtr Ab, size_t offA, i
     const unsigned long long m = lim >= 64 ? st.badmask : (lim <= 0 ? 0ull : (st.badmask & ((1ull << lim) - 1ull)));
     if (m != 0ull) atomicCAS(info, 0, gcol0 + __builtin_ctzll(m) + 1);
   }
-  // epilogue: W through LDS so that both outputs leave as 16-byte-per-lane row segments (two columns per store instruction)
+  // epilogue.  W: the register blocks go through LDS (blocks above the diagonal as zeros) and leave as 16-byte-per-lane row
+  // segments, two columns per store instruction.  L (lower triangle only -- the upper triangle of A is never written): column c
+  // has 64 - c entries, so columns c and 64 - c together fill exactly one wave; no execution masks, one 8-byte store per lane.
 #pragma unroll
   for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-    for (int cb = 0; cb <= rb; ++cb)
+    for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Wl[(16 * cb + c) * LS + 16 * rb + 4 * r + g] = st.V[rb][cb][r];
+      for (int r = 0; r < 4; ++r) Wl[(16 * cb + c) * LS + 16 * rb + 4 * r + g] = cb <= rb ? st.V[rb][cb][r] : 0.0;
   const int r2 = 2 * (l & 31), ch = l >> 5;
 #pragma unroll
   for (int it0 = 0; it0 < 32; it0 += 8) {
-    d2 wv[8], lv[8];
+    d2 wv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) wv[i] = *reinterpret_cast<const d2*>(&Wl[(2 * (it0 + i) + ch) * LS + r2]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) MatIO<TS>::st2(W, offW + (size_t)(2 * (it0 + i) + ch) * 64 + r2, wv[i]);
+  }
+  MatIO<TS>::st1(A, offA + l, Lo[l]);                                        // column 0: all 64 rows
+  if (l >= 32) MatIO<TS>::st1(A, offA + (size_t)32 * ld + l, Lo[32 * LS + l]);   // column 32: rows 32..63
+#pragma unroll
+  for (int c0 = 1; c0 < 32; c0 += 8) {
+    double lv[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int col = 2 * (it0 + i) + ch;
-      wv[i] = *reinterpret_cast<const d2*>(&Wl[col * LS + r2]);
-      lv[i] = *reinterpret_cast<const d2*>(&Lo[col * LS + r2]);
+      if (c0 + i < 32) {
+        const int ca = c0 + i, cz = 64 - ca;                                 // lanes 0 .. 63-ca: column ca, rows ca .. 63; the rest: column cz, rows cz .. 63
+        const bool first = l < 64 - ca;
+        lv[i] = Lo[(first ? ca : cz) * LS + (first ? ca + l : l)];
+      }
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int col = 2 * (it0 + i) + ch;
-      const bool lowblk = (r2 >> 4) >= (col >> 4);                 // blocks above the diagonal were never written to Wl: zeros
-      MatIO<TS>::st2(W, offW + (size_t)col * 64 + r2, lowblk ? wv[i] : mk2(0.0, 0.0));
-      if (r2 >= col) MatIO<TS>::st2(A, offA + (size_t)col * ld + r2, lv[i]);
-      else if (r2 + 1 == col) MatIO<TS>::st1(A, offA + (size_t)col * ld + r2 + 1, lv[i].y);
+      if (c0 + i < 32) {
+        const int ca = c0 + i, cz = 64 - ca;
+        const bool first = l < 64 - ca;
+        MatIO<TS>::st1(A, offA + (size_t)(first ? ca : cz) * ld + (first ? ca + l : l), lv[i]);
+      }
     }
   }
   LMM_DIAG_TS(2);
