@@ -329,7 +329,7 @@ typedef enum {
   LMM_PROF_UPDATE = 1,        /* gemm_nt_kernel<128,SUB>: SYRK/GEMM trailing update, flops              */
   LMM_PROF_UPDATE_NARROW = 2, /* gemm_nt_kernel<64,SUB>: 64-column update inside a 128 panel, flops     */
   LMM_PROF_TRSM = 3,          /* gemm_nt_kernel<64,SET>: panel TRSM by inverse diagonal block, flops    */
-  LMM_PROF_DIAG = 4,          /* diag64_kernel: 64x64 factor + inverse, flops                           */
+  LMM_PROF_DIAG = 4,          /* diag64m_kernel: 64x64 factor + inverse, flops                          */
   LMM_PROF_COUNT = 5
 } lmm_prof_class;
 typedef struct { long long launches; double ms; double work; double bytes; /* algorithmic HBM bytes */ } lmm_prof_entry_t;

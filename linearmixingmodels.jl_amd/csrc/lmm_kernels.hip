@@ -8,8 +8,9 @@
 //
 // Kernels:
 //   K1 gram_kernel / ilmm_dense_assemble_kernel   HBM-write bound   (A17, A6, A7)
-//   K2 diag64_kernel + gemm44_kernel<64, SET> (TRSM by inverse) + gemm44_kernel<.., SUB>
-//      (v_mfma_f64_4x4x4_4b_f64 SYRK/GEMM trailing update), batched over latents   MFMA-f64 bound (A6, A7, A10, A11, A14)
+//   K2 diag64m_kernel (64x64 factor + inverse, one wave, MFMA rank-4 steps) + gemm44_kernel<64, SET> (TRSM by inverse) +
+//      gemm16p_kernel / gemm16h_kernel (v_mfma_f64_16x16x4_f64 SYRK/GEMM trailing update; gemm44_kernel: the round-1 4x4x4 form),
+//      batched over latents   MFMA-f64 bound (A6, A7, A10, A11, A14)
 //   K3/K6 lml_reduce_kernel (logdet + quadratic form, wavefront shuffles), backsolve_step_kernel
 //   K4/K5 tall_skinny_kernel (T*Y projection, H*T*Y residual norm), mix_kernel (H unprojection)
 //   K7 trmv_lower_kernel (sample transform), axpy noise
