@@ -1543,30 +1543,52 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(BatchPtr Cb, size_t goff
 // One k-tile of the pipeline.  RA / RB: the staging registers that hold tile t+1 on entry; they are written to the other LDS
 // buffer and immediately reloaded with tile `KLOAD` (each global load one instruction behind the ds_write that frees its
 // register), so a load has a whole tile (DEPTH 1) or two tiles (DEPTH 2, two register sets) to arrive.
+// timing ablations of the pipelined kernel (tools/gemm16_ablate.sh; results are garbage, only the clock is read): each macro removes
+// one class of instructions from the tile body
+#ifdef LMM_ABL16_NOREAD
+#define LMM_ABL_RD(...)
+#else
+#define LMM_ABL_RD(...) __VA_ARGS__
+#endif
+#ifdef LMM_ABL16_NOLDSW
+#define LMM_ABL_WR(...)
+#else
+#define LMM_ABL_WR(...) __VA_ARGS__
+#endif
+#ifdef LMM_ABL16_NOGLOBAL
+#define LMM_ABL_GL(...)
+#else
+#define LMM_ABL_GL(...) __VA_ARGS__
+#endif
+#ifdef LMM_ABL16_NOBAR
+#define LMM_ABL_BAR(...)
+#else
+#define LMM_ABL_BAR(...) __VA_ARGS__
+#endif
 #define LMM_TILE_BODY(RA, RB, KLOAD)                                                                                              \
   {                                                                                                                               \
     const double* pa = ga0 + (size_t)(KLOAD) * BK * lda;                                                                          \
     const double* pb = gb0 + (size_t)(KLOAD) * BK * ldb;                                                                          \
     /* k-step 0: MFMAs on set 0; reads of k-step 1 into set 1; A half: ds_write of tile t+1, reload */                             \
-    _Pragma("unroll") for (int u = 0; u < 4; ++u) { fa[1][u] = as[offA + 4 * SA + 16 * u]; fb[1][u] = bs[offB + 4 * SB + 16 * u]; } \
+    LMM_ABL_RD(_Pragma("unroll") for (int u = 0; u < 4; ++u) { fa[1][u] = as[offA + 4 * SA + 16 * u]; fb[1][u] = bs[offB + 4 * SB + 16 * u]; }) \
     _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                               \
-      *reinterpret_cast<d2*>(&asn[sa0 + 4 * q * SA]) = RA[q];                                                                     \
-      RA[q] = *reinterpret_cast<const d2*>(pa + (size_t)(4 * q) * lda);                                                           \
+      LMM_ABL_WR(*reinterpret_cast<d2*>(&asn[sa0 + 4 * q * SA]) = RA[q];)                                                                     \
+      LMM_ABL_GL(RA[q] = *reinterpret_cast<const d2*>(pa + (size_t)(4 * q) * lda);)                                                           \
     }                                                                                                                             \
     LMM_MFMA16_ALL(0);                                                                                                            \
     _Pragma("unroll") for (int i = 0; i < 8; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x100, 1); }                                       \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x200, 1); LMM_SGB(0x008, 1); LMM_SGB(0x020, 1); } \
     /* k-step 1: MFMAs on set 1; reads of k-step 2 into set 0; B half: ds_write, reload */                                        \
-    _Pragma("unroll") for (int u = 0; u < 4; ++u) { fa[0][u] = as[offA + 8 * SA + 16 * u]; fb[0][u] = bs[offB + 8 * SB + 16 * u]; } \
+    LMM_ABL_RD(_Pragma("unroll") for (int u = 0; u < 4; ++u) { fa[0][u] = as[offA + 8 * SA + 16 * u]; fb[0][u] = bs[offB + 8 * SB + 16 * u]; }) \
     _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                               \
-      *reinterpret_cast<d2*>(&bsn[sb0 + 4 * q * SB]) = RB[q];                                                                     \
-      RB[q] = *reinterpret_cast<const d2*>(pb + (size_t)(4 * q) * ldb);                                                           \
+      LMM_ABL_WR(*reinterpret_cast<d2*>(&bsn[sb0 + 4 * q * SB]) = RB[q];)                                                                     \
+      LMM_ABL_GL(RB[q] = *reinterpret_cast<const d2*>(pb + (size_t)(4 * q) * ldb);)                                                           \
     }                                                                                                                             \
     LMM_MFMA16_ALL(1);                                                                                                            \
     _Pragma("unroll") for (int i = 0; i < 8; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x100, 1); }                                       \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x200, 1); LMM_SGB(0x008, 1); LMM_SGB(0x020, 1); } \
     /* k-step 2: MFMAs on set 0; reads of k-step 3 into set 1 */                                                                  \
-    _Pragma("unroll") for (int u = 0; u < 4; ++u) { fa[1][u] = as[offA + 12 * SA + 16 * u]; fb[1][u] = bs[offB + 12 * SB + 16 * u]; } \
+    LMM_ABL_RD(_Pragma("unroll") for (int u = 0; u < 4; ++u) { fa[1][u] = as[offA + 12 * SA + 16 * u]; fb[1][u] = bs[offB + 12 * SB + 16 * u]; }) \
     LMM_MFMA16_ALL(0);                                                                                                            \
     _Pragma("unroll") for (int i = 0; i < 8; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x100, 1); }                                       \
     LMM_SGB(0x008, 8);                                                                                                            \
@@ -1574,9 +1596,9 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(BatchPtr Cb, size_t goff
     LMM_MFMA16(1, 0, 0); LMM_MFMA16(1, 0, 1); LMM_MFMA16(1, 0, 2); LMM_MFMA16(1, 0, 3);                                           \
     LMM_MFMA16(1, 1, 3); LMM_MFMA16(1, 1, 2); LMM_MFMA16(1, 1, 1); LMM_MFMA16(1, 1, 0);                                           \
     LMM_MFMA16(1, 2, 0); LMM_MFMA16(1, 2, 1);                                                                                     \
-    __syncthreads();                                                                                                              \
+    LMM_ABL_BAR(__syncthreads();)                                                                                                 \
     /* k-step 3, second part: 6 MFMAs on set 1, interleaved with the reads of tile t+1's k-step 0 into set 0 */                   \
-    _Pragma("unroll") for (int u = 0; u < 4; ++u) { fa[0][u] = asn[offA + 16 * u]; fb[0][u] = bsn[offB + 16 * u]; }               \
+    LMM_ABL_RD(_Pragma("unroll") for (int u = 0; u < 4; ++u) { fa[0][u] = asn[offA + 16 * u]; fb[0][u] = bsn[offB + 16 * u]; })               \
     LMM_MFMA16(1, 2, 2); LMM_MFMA16(1, 2, 3);                                                                                     \
     LMM_MFMA16(1, 3, 3); LMM_MFMA16(1, 3, 2); LMM_MFMA16(1, 3, 1); LMM_MFMA16(1, 3, 0);                                           \
     _Pragma("unroll") for (int i = 0; i < 6; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x100, 1); }                                       \
@@ -1672,6 +1694,137 @@ __global__ __launch_bounds__(256, 1) void gemm16p_kernel(BatchPtr Cb, size_t gof
       }
     }
   }
+  if (!active) return;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    double* cpv = C + (size_t)(bn + wc + 16 * v + lk) * ldc + bm + wr + l15;
+    if (nparts == 1) {
+      double cv[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cv[u][r] = cpv[(size_t)(4 * r) * ldc + 16 * u];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cpv[(size_t)(4 * r) * ldc + 16 * u] = cv[u][r] - acc[v][u][r];
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) unsafeAtomicAdd(cpv + (size_t)(4 * r) * ldc + 16 * u, -acc[v][u][r]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+#define LMM_D_RD(SETN, KS, ASRC, BSRC)                                                                                  \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) { fa[SETN][u] = ASRC[offA + 4 * (KS) * SA + 16 * u]; fb[SETN][u] = BSRC[offB + 4 * (KS) * SB + 16 * u]; }
+template <int NS>
+__global__ __launch_bounds__(256, 1) void gemm16d_kernel(BatchPtr Cb, size_t goffC, int ldc, BatchPtr Ab, size_t goffA, int lda,
+                                                          BatchPtr Bb, size_t goffB, int ldb,
+                                                          int M, int N, int K, int lower, int MT, int full_items,
+                                                          int splitk, int kfrom_row) {
+  double* C = Cb.p[blockIdx.y] + goffC;
+  const double* A = Ab.p[blockIdx.y] + goffA;
+  const double* B = Bb.p[blockIdx.y] + goffB;
+  constexpr int BM = 128, BN = 128, BK = 16;
+  constexpr int SA = BM + 16, SB = BN + 16;
+  constexpr int STAGE = BK * SA + BK * SB;                         // doubles per stage: A image then B image
+  extern __shared__ __attribute__((aligned(16))) double lds_d[];   // NS stages
+
+  int part = 0, nparts = 1, tj = 0, ti = 0;
+  gemm_work_item(BM, BN, N, lower, MT, full_items, splitk, part, nparts, ti, tj);
+  const int bm = ti * BM, bn = tj * BN;
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);            // wave index, scalar: the LDS destination of a load is wave-uniform
+  const int wr = (w & 1) * 64, wc = (w >> 1) * 64;
+  const bool active = (bm + wr < M) && (bn + wc < N) && !(lower && bm + wr + 63 < bn + wc);
+  const int nk_all = K / BK;
+  int kc0 = (int)((long long)nk_all * part / nparts);
+  const int kc1 = (int)((long long)nk_all * (part + 1) / nparts);
+  if (kfrom_row && kc0 < bm / BK) kc0 = bm / BK;
+  A += (size_t)kc0 * BK * lda;
+  B += (size_t)kc0 * BK * ldb;
+  const int nk = kc1 - kc0;
+
+  int rowa = bm + 2 * lane; if (rowa > M - 2) rowa = M - 2;
+  int rowb = bn + 2 * lane; if (rowb > N - 2) rowb = N - 2;
+  const double* ga0 = A + (size_t)w * lda + rowa;                 // wave w loads k-columns w + 4q (q = 0..3) of each tile: lane i rows 2i, 2i+1
+  const double* gb0 = B + (size_t)w * ldb + rowb;
+  // one k-column of tile `kt` (clamped: surplus requests of the last tiles reload a valid tile into a free stage) into stage `st`
+  auto load_a = [&](int kt, int st, int q) {
+    __builtin_amdgcn_global_load_lds(ga0 + (size_t)kt * BK * lda + (size_t)(4 * q) * lda, lds_d + st * STAGE + (w + 4 * q) * SA, 16, 0, 0);
+  };
+  auto load_b = [&](int kt, int st, int q) {
+    __builtin_amdgcn_global_load_lds(gb0 + (size_t)kt * BK * ldb + (size_t)(4 * q) * ldb, lds_d + st * STAGE + BK * SA + (w + 4 * q) * SB, 16, 0, 0);
+  };
+  // prologue: tiles 0 .. NS-2 into stages 0 .. NS-2
+#pragma unroll
+  for (int j = 0; j < NS - 1; ++j) {
+    const int kt = j < nk ? j : nk - 1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { load_a(kt, j, q); load_b(kt, j, q); }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70 | ((8 * (NS - 2)) & 15) | (((8 * (NS - 2)) >> 4) << 14));     // vmcnt(8 (NS-2)): tile 0 has landed
+  __syncthreads();
+
+  d4 acc[4][4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[v][u] = (d4){0.0, 0.0, 0.0, 0.0};
+  const int l15 = lane & 15, lk = lane >> 4;
+  const int offA = lk * SA + wr + l15, offB = BK * SA + lk * SB + wc + l15;      // B image follows the A image inside a stage
+  double fa[2][4], fb[2][4];                          // two fragment sets: the k-step being multiplied and the next one
+#pragma unroll
+  for (int u = 0; u < 4; ++u) { fa[0][u] = lds_d[offA + 16 * u]; fb[0][u] = lds_d[offB + 16 * u]; }
+
+  int s_cur = 0, s_ld = NS - 1;                       // stage of tile kt; stage that tile kt + NS - 1 goes to (= the stage of tile kt - 1)
+  for (int kt = 0; kt < nk; ++kt) {
+    const double* as = lds_d + s_cur * STAGE;
+    const int s_nxt = (s_cur + 1 == NS) ? 0 : s_cur + 1;
+    const double* asn = lds_d + s_nxt * STAGE;
+    const int kl = (kt + NS - 1 < nk) ? kt + NS - 1 : nk - 1;
+    // k-step 0: MFMAs on set 0; reads of k-step 1 into set 1; the four A columns of tile kt + NS - 1
+    LMM_D_RD(1, 1, as, as)
+    load_a(kl, s_ld, 0); load_a(kl, s_ld, 1); load_a(kl, s_ld, 2); load_a(kl, s_ld, 3);
+    LMM_MFMA16_ALL(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x100, 1); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { LMM_SGB(0x008, 2); LMM_SGB(0x020, 1); }
+    // k-step 1: MFMAs on set 1; reads of k-step 2 into set 0; the four B columns
+    LMM_D_RD(0, 2, as, as)
+    load_b(kl, s_ld, 0); load_b(kl, s_ld, 1); load_b(kl, s_ld, 2); load_b(kl, s_ld, 3);
+    LMM_MFMA16_ALL(1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x100, 1); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { LMM_SGB(0x008, 2); LMM_SGB(0x020, 1); }
+    // k-step 2: MFMAs on set 0; reads of k-step 3 into set 1
+    LMM_D_RD(1, 3, as, as)
+    LMM_MFMA16_ALL(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x100, 1); }
+    LMM_SGB(0x008, 8);
+    // k-step 3, first part: 10 MFMAs on set 1; then this wave's columns of tile kt + 1 must have landed (the 8 (NS - 2) requests
+    // issued after them may still be in flight), and the barrier publishes the tile and retires stage s_cur
+    LMM_MFMA16(1, 0, 0); LMM_MFMA16(1, 0, 1); LMM_MFMA16(1, 0, 2); LMM_MFMA16(1, 0, 3);
+    LMM_MFMA16(1, 1, 3); LMM_MFMA16(1, 1, 2); LMM_MFMA16(1, 1, 1); LMM_MFMA16(1, 1, 0);
+    LMM_MFMA16(1, 2, 0); LMM_MFMA16(1, 2, 1);
+    __builtin_amdgcn_s_waitcnt(0x0F70 | ((8 * (NS - 2)) & 15) | (((8 * (NS - 2)) >> 4) << 14));
+    __builtin_amdgcn_s_barrier();                    // NOT __syncthreads(): its fence would wait for vmcnt(0), i.e. for the requests just issued
+    // second part: 6 MFMAs on set 1, interleaved with the reads of tile kt + 1's k-step 0 into set 0
+    LMM_D_RD(0, 0, asn, asn)
+    LMM_MFMA16(1, 2, 2); LMM_MFMA16(1, 2, 3);
+    LMM_MFMA16(1, 3, 3); LMM_MFMA16(1, 3, 2); LMM_MFMA16(1, 3, 1); LMM_MFMA16(1, 3, 0);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x100, 1); }
+    LMM_SGB(0x100, 2);
+    s_ld = s_cur; s_cur = s_nxt;
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);                // surplus requests of the last tiles: drained before the LDS is released
   if (!active) return;
 #pragma unroll
   for (int v = 0; v < 4; ++v) {
