@@ -1990,8 +1990,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // barrier issued behind it): BK = 32 per LDS stage = 16 k-pairs of TU x TV MFMAs; per k-pair the fragments of the NEXT pair are
 // read, and one staging instruction (ds_write_b128 of tile t+1 in the first half, global_load_dwordx4 of tile t+2 in the second)
 // rides along; the barrier sits before the last k-pair, whose MFMAs cover the first fragment reads of tile t+1.
-template <int BN, bool SET>
-__global__ __launch_bounds__(256, 2) void gemm32_kernel(BatchPtr Cb, size_t goffC, int ldc, BatchPtr Ab, size_t goffA, int lda,
+template <int BN, bool SET, int SCHED = 0>
+__global__ __launch_bounds__(256, SCHED == 1 ? 1 : 2) void gemm32_kernel(BatchPtr Cb, size_t goffC, int ldc, BatchPtr Ab, size_t goffA, int lda,
                                                          BatchPtr Bb, size_t goffB, int ldb,
                                                          int M, int N, int K, int lower, int MT, int full_items,
                                                          int splitk, int kfrom_row) {
@@ -2084,6 +2084,7 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(BatchPtr Cb, size_t goff
       // complete in the other buffer
       if (kp == BK / 2 - 1) __syncthreads();
       // fragments of the next k-pair (the last pair reads the first pair of tile t+1 from the other buffer)
+#ifndef LMM_ABL32_NOREAD
       if (kp + 1 < BK / 2) {
 #pragma unroll
         for (int u = 0; u < TU; ++u) fu[nxt][u] = as[offA + 2 * (kp + 1) * SA + 32 * u];
@@ -2095,9 +2096,13 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(BatchPtr Cb, size_t goff
 #pragma unroll
         for (int v = 0; v < TV; ++v) fv[nxt][v] = bsn[offB + 32 * v];
       }
+#else
+      fu[nxt][0] = fu[cur][0]; fu[nxt][1] = fu[cur][1]; fv[nxt][0] = fv[cur][0]; if (TV > 1) fv[nxt][TV - 1] = fv[cur][TV - 1];
+#endif
       // one staging instruction per k-pair: ds_write of tile t+1 (pairs 0 .. NLA+NLB-1), then the global loads of tile t+2
       if (kp < NLA) *reinterpret_cast<float4*>(&asn[sa0 + 8 * kp * SA]) = ra[kp];
       else if (kp < NLA + NLB) *reinterpret_cast<float4*>(&bsn[sb0 + KSB * (kp - NLA) * SB]) = rb[kp - NLA];
+#ifndef LMM_ABL32_NOGLOBAL
       else if (kp < 2 * NLA + NLB) {
         const int q = kp - NLA - NLB, k = kn2 * BK + ka + 8 * q;
         ra[q] = *reinterpret_cast<const float4*>(gA + (size_t)(k <= kmax ? k : kmax) * lda);
@@ -2107,6 +2112,7 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(BatchPtr Cb, size_t goff
         rb[q] = *reinterpret_cast<const float4*>(gB + (size_t)(k <= kmax ? k : kmax) * ldb);
         if (k > kmax) rb[q] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
+#endif
       if (active) {
 #pragma unroll
         for (int v = 0; v < TV; ++v)
@@ -2115,6 +2121,11 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(BatchPtr Cb, size_t goff
             const int u = (v & 1) ? TU - 1 - uu : uu;
             acc[v][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[cur][v], fu[cur][u], acc[v][u], 0, 0, 0);
           }
+      }
+      if (SCHED == 1) {          // pin: one fragment read behind each MFMA, the staging instruction behind the last
+#pragma unroll
+        for (int i = 0; i < TU + TV; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x100, 1); }
+        LMM_SGB(0x200, 1); LMM_SGB(0x020, 1);
       }
     }
   }
@@ -2798,6 +2809,7 @@ void launch_diag64(const BatchPtr& A, size_t offA, int ld, const BatchPtr& W, si
 // Update-kernel variant: 0 = one s_barrier per k-stage (default), 1 = LDS-flag synchronised main loop (correct, but measured
 // 3-6 % SLOWER: tools/gemm_ab, profiles/r02/gemm_ab_flags_vs_barrier.log -- the s_barrier is not what limits this kernel).
 // LMM_GEMM_FLAGS overrides; tools/gemm_ab flips it between timed rounds of one process.
+int g_f32_sched = 0;      // tools/gemm32_ab: 1 = sched_group_barrier-pinned interleave in the fp32 update kernel
 int g_gemm_flags = -1;
 // Wide-update kernel: 2 (default) = gemm16p_kernel (v_mfma_f64_16x16x4, VGPR accumulators, hand-pipelined), 1 = gemm16_kernel (same
 // MFMA in the round-1 loop structure), 0 = gemm44_kernel (round 1: v_mfma_f64_4x4x4_4b).  LMM_GEMM_M16 overrides; tools/gemm_ab A/Bs.
@@ -2853,6 +2865,8 @@ void launch_gemm_nt(const BatchPtr& C, size_t offC, int ldc, const BatchPtr& A, 
   if (g_f32) {
     if (narrow) hipLaunchKernelGGL((gemm32_kernel<64, false>), dim3(items, nb), dim3(256), 0, st, C, offC, ldc, A, offA, lda, B, offB,
                                    ldb, M, N, K, lower, MT, full_items, splitk, 0);
+    else if (g_f32_sched) hipLaunchKernelGGL((gemm32_kernel<128, false, 1>), dim3(items, nb), dim3(256), 0, st, C, offC, ldc, A, offA, lda, B, offB,
+                                             ldb, M, N, K, lower, MT, full_items, splitk, 0);
     else hipLaunchKernelGGL((gemm32_kernel<128, false>), dim3(items, nb), dim3(256), 0, st, C, offC, ldc, A, offA, lda, B, offB,
                             ldb, M, N, K, lower, MT, full_items, splitk, 0);
     return;
