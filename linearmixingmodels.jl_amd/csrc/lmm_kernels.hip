@@ -1855,16 +1855,28 @@ __global__ __launch_bounds__(256, 1) void gemm16d_kernel(BatchPtr Cb, size_t gof
 #define LMM_MFMA16H_ALL(SET)                                                                                  \
     LMM_MFMA16(SET, 0, 0); LMM_MFMA16(SET, 0, 1); LMM_MFMA16(SET, 0, 2); LMM_MFMA16(SET, 0, 3);               \
     LMM_MFMA16(SET, 1, 3); LMM_MFMA16(SET, 1, 2); LMM_MFMA16(SET, 1, 1); LMM_MFMA16(SET, 1, 0)
+// STRIP = true: the ragged strip (blockIdx.x = column tile; A, C already point at its 64 rows).  STRIP = false (round 2): ANY 64-row
+// tile of a lower-trapezoid update -- blockIdx.x enumerates the tiles (ti64, tj128) with 64 ti + 63 >= 128 tj column tile by column
+// tile; used for launches whose 128 x 128 tiles would leave CUs idle (few latents per GPU, low recursion levels): twice the
+// workgroups, half the time per workgroup.
+template <bool STRIP>
 __global__ __launch_bounds__(256, 2) void gemm16h_kernel(BatchPtr Cb, size_t goffC, int ldc, BatchPtr Ab, size_t goffA, int lda,
-                                                          BatchPtr Bb, size_t goffB, int ldb, int N, int K) {
-  double* C = Cb.p[blockIdx.y] + goffC;              // row 0 = first of the 64 rows
+                                                          BatchPtr Bb, size_t goffB, int ldb, int N, int K, int MT64) {
+  double* C = Cb.p[blockIdx.y] + goffC;              // STRIP: row 0 = first of the 64 rows
   const double* A = Ab.p[blockIdx.y] + goffA;
   const double* B = Bb.p[blockIdx.y] + goffB;
   constexpr int BM = 64, BN = 128, BK = 16;
   constexpr int SA = BM + 16, SB = BN + 16;
   __shared__ __attribute__((aligned(16))) double As[2][BK * SA];
   __shared__ __attribute__((aligned(16))) double Bs[2][BK * SB];
-  const int bn = blockIdx.x * BN;
+  int tjx = blockIdx.x, ti64 = 0;
+  if (!STRIP) {                                      // column tile tj holds the row tiles 2 tj .. MT64 - 1
+    int rem = blockIdx.x; tjx = 0;
+    while (rem >= MT64 - 2 * tjx) { rem -= MT64 - 2 * tjx; ++tjx; }
+    ti64 = 2 * tjx + rem;
+    A += (size_t)64 * ti64; C += (size_t)64 * ti64;
+  }
+  const int bn = tjx * BN;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int wc = w * 32;
   const int nk = K / BK;
@@ -1956,6 +1968,7 @@ __global__ __launch_bounds__(256, 2) void gemm16h_kernel(BatchPtr Cb, size_t gof
     for (int i = 0; i < 3; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x100, 2); }
   }
   if (bn + wc >= N) return;
+  if (!STRIP && 64 * ti64 + 63 < bn + wc) return;     // this wave's 64 x 32 piece lies wholly above the diagonal
 #pragma unroll
   for (int v = 0; v < 2; ++v) {
     double* cpv = C + (size_t)(bn + wc + 16 * v + lk) * ldc + l15;
@@ -2835,9 +2848,25 @@ void launch_gemm_nt(const BatchPtr& C, size_t offC, int ldc, const BatchPtr& A, 
   if (g_gemm_m16 < 0) { const char* e = getenv("LMM_GEMM_M16"); g_gemm_m16 = e ? atoi(e) : 2; }
   if (!g_f32 && !narrow && ragged_split && g_gemm_m16 >= 2 && (M % 128) == 64 && M - 64 >= N && M > 64 && (N % 128) == 0 && K >= 1024) {   // below K ~ 1000 the extra launch costs more than the idle waves
     launch_gemm_nt(C, offC, ldc, A, offA, lda, B, offB, ldb, M - 64, N, K, lower, false, nb, st);
-    hipLaunchKernelGGL(gemm16h_kernel, dim3(N / 128, nb), dim3(256), 0, st, C, offC + (size_t)(M - 64), ldc, A, offA + (size_t)(M - 64), lda,
-                       B, offB, ldb, N, K);
+    hipLaunchKernelGGL((gemm16h_kernel<true>), dim3(N / 128, nb), dim3(256), 0, st, C, offC + (size_t)(M - 64), ldc, A, offA + (size_t)(M - 64), lda,
+                       B, offB, ldb, N, K, 0);
     return;
+  }
+  // underfilled wide update (the 128 x 128 tiles of all nb matrices together do not fill the CUs once): 64 x 128 tiles instead
+  static int half_tiles = -1;
+  if (half_tiles < 0) { const char* e = getenv("LMM_HALF_TILES"); half_tiles = e ? (atoi(e) != 0) : 1; }
+  if (!g_f32 && !narrow && half_tiles && g_gemm_m16 >= 2 && lower && (N % 128) == 0 && (M % 64) == 0 && K >= 64 && K < 1024) {
+    static int cus_h = 0;
+    if (cus_h == 0) { int dev = 0; cus_h = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus_h, hipDeviceAttributeMultiprocessorCount, dev); }
+    long long T128 = 0;
+    for (int tj = 0; tj < N / 128; ++tj) T128 += MT - tj;
+    if (T128 * nb <= cus_h) {
+      const int MT64 = M / 64;
+      long long T64 = 0;
+      for (int tj = 0; tj < N / 128; ++tj) T64 += MT64 - 2 * tj;
+      hipLaunchKernelGGL((gemm16h_kernel<false>), dim3((unsigned)T64, nb), dim3(256), 0, st, C, offC, ldc, A, offA, lda, B, offB, ldb, N, K, MT64);
+      return;
+    }
   }
   const int BNsel = narrow ? 64 : 128;
   const int NT = narrow ? 1 : (N + 127) / 128;

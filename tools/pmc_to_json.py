@@ -13,7 +13,8 @@ def aggregate_update(out):
     if not wide:
         return
     parts = wide + [k for k in out if isinstance(out[k], dict) and k.startswith("gemm16h_kernel")]
-    n = sum(out[k]["launches"] for k in wide)
+    # update launches = gemm16p launches + the launches made of 64-row tiles alone (gemm16h_kernel<false>: underfilled updates)
+    n = sum(out[k]["launches"] for k in wide) + sum(out[k]["launches"] for k in out if isinstance(out[k], dict) and k.startswith("gemm16h_kernel<false>"))
     agg = {f: sum(out[k][f] * out[k]["launches"] for k in parts) / n
            for f in ("fetch_bytes_per_launch_x2", "write_bytes_per_launch", "bytes_per_launch")}
     out["update_kernel"] = dict(agg, launches=n, kernel=" + ".join(parts))
