@@ -484,7 +484,8 @@ def test_update_kernel_variants_agree():
             "print(json.dumps(lmm_amd.logpdf(f(lmm_amd.MOInputIsotopicByOutputs(P['x'], 5), 0.1), P['y'])))") % os.path.dirname(HERE)
     vals = {}
     for name, env in [("default", {}), ("m16_0", {"LMM_GEMM_M16": "0"}), ("m16_1", {"LMM_GEMM_M16": "1"}), ("flags", {"LMM_GEMM_M16": "0", "LMM_GEMM_FLAGS": "1"}),
-                      ("diag_form1", {"LMM_DIAG_FORM": "1"}), ("diag_form2", {"LMM_DIAG_FORM": "2"})]:
+                      ("diag_form1", {"LMM_DIAG_FORM": "1"}), ("diag_form2", {"LMM_DIAG_FORM": "2"}), ("full_tiles", {"LMM_HALF_TILES": "0"}),
+                      ("no_ragged_split", {"LMM_RAGGED_SPLIT": "0"})]:
         out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr[-2000:]
         vals[name] = json.loads(out.stdout.strip().splitlines()[-1])
