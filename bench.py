@@ -34,10 +34,10 @@ WORKLOADS = {
     "c0": (3, 5, 200, "se", True, "configs[0]: OILMM, 3 SEKernel latents, p=5, n=200, f64"),
     "small": (8, 16, 2048, "matern52", True, "reduced smoke workload (NOT a BASELINE config)"),
     # secondary metric: one step = posterior(fx, y) + marginals at n* = n test points, latents sharded, ONE
-    # all-reduce of the p x n* partial means / variances per step.  Float64 (the bf16-projection variant of
-    # configs[3] is not built).
-    "c3": (64, 128, 8192, "matern52", True, "configs[3] shape in f64: OILMM posterior predictive, H 128x64, n_train = n_test = 8192 "
-                                            "(step = posterior + mean_and_var at x*)"),
+    # all-reduce of the p x n* partial means / variances per step.  `--proj bf16` runs the configuration as named:
+    # the H unprojection of the marginals on v_mfma_f32_16x16x32_bf16 (lmm_set_projection_dtype; latent marginals stay f64).
+    "c3": (64, 128, 8192, "matern52", True, "configs[3]: OILMM posterior predictive, H 128x64, n_train = n_test = 8192 "
+                                            "(step = posterior + mean_and_var at x*; --proj bf16 = the bf16 MFMA covariance projection)"),
     # the reference notebook's timing shape (examples/oilmm_and_ilmm.ipynb:124-129, 226-235): the only published number
     "notebook": (20, 600, 552, "matern52", True, "reference notebook: OILMM logpdf, p=600, m=20, n=552 Matern52, sigma2=1e-6, f64"),
     # secondary metric: BASELINE configs[4] -- one step = ONE prior sample rand(rng, fx) of the whole model: a Cholesky of every
@@ -133,6 +133,8 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"],
                     help="compute dtype of the per-latent matrices (lmm_set_compute_dtype); f64 is the parity mode")
+    ap.add_argument("--proj", default="native", choices=["native", "bf16", "bf16x2"],
+                    help="dtype of the H unprojection of predictive marginals (lmm_set_projection_dtype); bf16 = BASELINE configs[3] as named")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -168,23 +170,23 @@ def main():
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+        # no device_id: torch creates its NCCL communicator lazily at its first collective, i.e. AFTER the C ABI's communicator
+        # below has been created and probed -- the two RCCL initialisations never interleave
+        dist.init_process_group(backend)
     import lmm_amd
     from lmm_amd import _lib as L
     from lmm_amd.workloads import synthetic_problem      # input generation only; the oracle is imported by the cpu_baseline leg alone
     lmm_amd.init(local_rank)
     lmm_amd.set_compute_dtype(args.dtype)
+    lmm_amd.set_projection_dtype(args.proj)
     dev = torch.device("cuda", local_rank)
     # The data-path collective is the C ABI's own RCCL communicator (lmm_allreduce_sum_f64: what a Julia / C caller binds);
-    # torch.distributed is kept for the rendezvous (it ships the RCCL unique id), the fence barrier and the max-over-ranks clock.
-    abi_comm = world > 1 and backend == "nccl"
-    if abi_comm:
-        L.comm_init_from_torch()
-        if L.comm_world() != world:
-            sys.exit(f"[bench] ABI communicator has {L.comm_world()} ranks, expected {world}")
+    # torch.distributed is kept for the rendezvous (its store ships the RCCL unique id), the fence barrier and the max-over-ranks
+    # clock.  select_collective creates and PROBES that communicator; if that fails on any rank, every rank falls back to
+    # torch.distributed's all-reduce and the JSON line says why -- an N > 1 run reports a number either way.
+    abi_comm, collective = lmm_amd.select_collective(backend, world)
+    if world > 1 and rank == 0:
+        print(f"[bench] collective: {collective}", file=sys.stderr, flush=True)
     from lmm_amd import model as lmm_model
     lmm_model.ILMM_ALLOW_DECOUPLED = (args.workload != "c1dense")
 
@@ -211,6 +213,7 @@ def main():
     rdev = dev if backend == "nccl" else torch.device("cpu")      # where the collectives' tensors live
     red = torch.zeros(1, dtype=torch.float64, device=rdev)
     red_host = np.zeros(1)
+    stats = {"allreduce_s": 0.0, "nonfinite_partials": 0, "last_partial": None}      # this rank's diagnostics (per_rank in the JSON line)
 
     predictive = (args.workload == "c3")
     sampling = (args.workload == "c4")
@@ -221,10 +224,14 @@ def main():
     def step_sampling():
         part = lmm_amd.rand(normals, fx, jitters=jit_rand, add_noise=(rank == 0))     # this rank's latents mixed through its H columns
         if world > 1:
+            ta = time.perf_counter()
             if abi_comm:
                 L.allreduce_sum(part)                        # ONE all-reduce of the n x p partial sample
+            elif backend == "nccl":
+                dist.all_reduce(part)
             else:
                 pc = part.cpu(); dist.all_reduce(pc); part = pc
+            stats["allreduce_s"] += time.perf_counter() - ta
         return float(part[0])
 
     if predictive:
@@ -241,14 +248,21 @@ def main():
         if sampling:
             return step_sampling()
         part = lmm_amd.logpdf(fx, yd, rank == 0)
+        stats["last_partial"] = part
+        if not np.isfinite(part):
+            stats["nonfinite_partials"] += 1
         if world > 1 and orth:
+            ta = time.perf_counter()
             if abi_comm:
                 red_host[0] = part
                 L.allreduce_sum(red_host)    # ONE scalar RCCL all-reduce per evaluation, inside liblmm_hip.so
-                return float(red_host[0])
-            red[0] = part
-            dist.all_reduce(red)             # gloo rehearsal (LMM_BENCH_BACKEND=gloo)
-            return float(red[0])
+                out = float(red_host[0])
+            else:
+                red[0] = part
+                dist.all_reduce(red)         # torch.distributed: gloo rehearsal, or nccl after an ABI-communicator failure
+                out = float(red[0])
+            stats["allreduce_s"] += time.perf_counter() - ta
+            return out
         return part
 
     def fence():
@@ -261,9 +275,11 @@ def main():
     for _ in range(args.warmup):
         val = step()
     fence()
+    stats["allreduce_s"] = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         val = step()
+    dt_local = time.perf_counter() - t0          # this rank's own clock up to its last result (before the closing barrier)
     fence()
     dt = time.perf_counter() - t0
     tt = torch.tensor([dt], dtype=torch.float64, device=rdev)
@@ -277,12 +293,14 @@ def main():
     roof = None
     extra = {}
     peak_tf = FP32_MFMA_PEAK_TFLOPS if args.dtype == "f32" else FP64_MFMA_PEAK_TFLOPS
-    if rank == 0 and not args.no_roofline and not predictive:
-        # Roofline leg: one more evaluation of one batch of latents of the same workload with every launch of the hot
-        # kernels bracketed by HIP events on its stream; the batch runs on ONE stream so that an event pair times its
-        # kernel alone (the timed region above runs several batches on concurrent streams).  DESIGN.md "Measurement".
+    prof = None
+    nprof = min(16, shard[1] - shard[0]) if orth else m     # one production-sized batch of latents (LMM_BATCH default 16)
+    if (rank == 0 or world > 1) and not args.no_roofline and not predictive and nprof > 0:
+        # Instrumented pass: one more evaluation of one batch of this rank's latents with every launch of the hot kernels
+        # bracketed by HIP events on its stream; the batch runs on ONE stream so that an event pair times its kernel alone (the
+        # timed region above runs several batches on concurrent streams).  Rank 0's pass is the roofline leg (DESIGN.md
+        # "Measurement"); at N > 1 every rank runs it on its own shard so that per_rank carries each rank's kernel class times.
         lib = lmm_amd.load()
-        nprof = min(16, shard[1] - shard[0]) if orth else m     # one production-sized batch of latents (LMM_BATCH default 16)
         fprof = lmm_amd.ILMM(fs, H, shard=(shard[0], shard[0] + nprof))(xin, s2) if orth else fx
         L.check(lib.lmm_profile_begin(1))
         if sampling:
@@ -293,6 +311,8 @@ def main():
         L.check(lib.lmm_profile_end(ent))
         prof = {c: {"launches": int(ent[i].launches), "ms": float(ent[i].ms), "work": float(ent[i].work),
                     "bytes": float(ent[i].bytes)} for i, c in enumerate(L.PROF_CLASSES)}
+    if rank == 0 and prof is not None:
+        lib = lmm_amd.load()
         up = prof["update"]
         if up["launches"] and up["ms"] > 0:
             ach = up["work"] / (up["ms"] * 1e-3) / 1e12
@@ -341,6 +361,18 @@ def main():
                                           "frac_of_fp64_peak": round(tfs / FP64_MFMA_PEAK_TFLOPS, 4),
                                           "implied_speedup_at_8_gpus": round((dt / steps) / dts, 2)}
 
+    # per-rank diagnostics: when an N > 1 run misses its scaling target the line must say which rank or phase was slow
+    mine = {"rank": rank, "latents": [int(shard[0]), int(shard[1])], "ms_per_step": dt_local / steps * 1e3,
+            "allreduce_ms_per_step": stats["allreduce_s"] / steps * 1e3, "last_partial": stats["last_partial"],
+            "nonfinite_partials": stats["nonfinite_partials"],
+            "kernel_classes_ms": ({c: round(v["ms"], 3) for c, v in prof.items()} if prof else None),
+            "instrumented_latents": nprof if prof else 0}
+    per_rank = [mine]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+    bad = sum(r["nonfinite_partials"] for r in per_rank)
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline_predictive(P) if predictive else (cpu_baseline_sampling(P) if sampling else cpu_baseline(P, orth))
@@ -354,13 +386,13 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if orth else "replicas",
             "vs_baseline": (evals_per_s / NOTEBOOK_PUBLISHED_EVALS_PER_S) if (args.workload == "notebook" and evals_per_s) else None,
-            "dtype": args.dtype, "data": "synthetic",
+            "dtype": args.dtype + ("" if args.proj == "native" else f"+{args.proj}proj"), "data": "synthetic",
             "config": {"workload": desc, "m": m, "p": p, "n": n, "kernel": kind, "sigma2": s2,
                        "latents_per_gpu": (shard[1] - shard[0]), "parallelism": f"latent-shard x{world}" if orth else "replicas",
-                       "collective": ("lmm_allreduce_sum_f64 (RCCL inside liblmm_hip.so)" if abi_comm else
-                                      ("torch.distributed/" + backend if world > 1 else None))},
+                       "collective": collective, "rccl_ranks": L.comm_world(),
+                       "projection_dtype": args.proj},
             ("first_predictive_mean" if predictive else ("first_sample_value" if sampling else "logpdf")): val,
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "per_rank": per_rank,
         }
         line.update(extra)
         print(json.dumps(line), flush=True)
@@ -369,6 +401,8 @@ def main():
         if abi_comm:
             L.comm_destroy()
         dist.destroy_process_group()
+    if bad:
+        sys.exit(f"[bench] rank {rank}: {bad} non-finite logpdf partial(s) over the ranks: the value above is not a measurement")
 
 
 if __name__ == "__main__":

@@ -87,6 +87,18 @@ typedef enum { LMM_F64 = 0, LMM_F32 = 1 } lmm_dtype;
 int lmm_set_compute_dtype(int dtype);
 int lmm_get_compute_dtype(void);
 
+/* Dtype of the H unprojection of predictive marginals,  M = H M_latent,  V = abs2.(H) V_latent .+ sigma2  (reference
+ * src/oilmm.jl:69-72; lmm_oilmm_mean_and_var) -- BASELINE configs[3] "bf16 MFMA covariance projection".
+ *   LMM_PROJ_NATIVE (default): Float64 FMAs (the parity mode).
+ *   LMM_PROJ_BF16: H (or abs2.(H)) and the latent marginals are rounded to bfloat16 (round-to-nearest-even) and multiplied on
+ *     v_mfma_f32_16x16x32_bf16 with Float32 accumulation; sigma2 is added in Float64.  STATED TOLERANCE: each operand carries a
+ *     relative rounding error <= 2^-9, so |M - M_f64| <= 2^-8 * sum_l |H[o,l]| |M_latent[l,s]| (plus Float32 accumulation,
+ *     ~m 2^-24) and likewise for V; the latent marginals themselves (Gram, Cholesky, triangular solves) stay in the compute dtype.
+ *   LMM_PROJ_BF16X2: the same pipe with each operand split into two bfloat16 terms (hi + lo), three MFMA products: error ~2^-16. */
+typedef enum { LMM_PROJ_NATIVE = 0, LMM_PROJ_BF16 = 1, LMM_PROJ_BF16X2 = 2 } lmm_proj_dtype;
+int lmm_set_projection_dtype(int dtype);
+int lmm_get_projection_dtype(void);
+
 /* Order the library's streams behind everything queued so far on `hip_stream` (a hipStream_t; NULL = the legacy default
  * stream): the NEXT entry point may then be handed device pointers that stream is still producing, or output buffers it is
  * still reading.  Entry points are blocking, so no ordering is needed in the other direction. */
@@ -222,6 +234,13 @@ int lmm_ilmm_posterior_create(const double* x, int d, int n, const double* y, in
                               const double* H, int m, double sigma2, const lmm_gp_t* gps,
                               const lmm_jitters_t* jit, lmm_post_t** out);
 int lmm_post_destroy(lmm_post_t* post);
+/* get_latent_gp(posterior(fx::FiniteGP{<:ILMM}, y)) for a dense H: reference src/ilmm.jl:39 applied to the ILMM of :196-197 -- the
+ * latent PosteriorGP{IndependentMOGP}.  Returns a handle that SHARES the device state of `post` and has H = I_m (p = m): the
+ * lmm_ilmm_post_* entry points below then answer mean / var / cov / logpdf / rand / posterior for the m latent outputs at
+ * MOInputIsotopicByOutputs(xs, m).  Pass jitters {0, sigma2, 0}: with project_jitter = 0 the projection is the identity and the
+ * regulariser vanishes (logpdf = the generic Gaussian of the latent posterior + sigma2 I); rand with ilmm_rand_jitter = sigma2 and
+ * add_noise = 0 is AbstractGPs' mean + chol(cov + sigma2 I).U' z.  Either handle may be destroyed first. */
+int lmm_ilmm_post_latent_view(const lmm_post_t* post, lmm_post_t** out);
 /* logpdf(pi(xs, sigma2), ys) on the dense-H posterior ILMM: reference test/ilmm.jl:25 (src/ilmm.jl:150-163 applied to the
  * PosteriorGP latent of :196-197).  One (m ns) x (m ns) factorisation. */
 int lmm_ilmm_post_logpdf(const lmm_post_t* post, double sigma2, const double* xs, int d, int ns, const double* ys,

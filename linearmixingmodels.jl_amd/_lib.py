@@ -18,10 +18,10 @@ KERNEL_KINDS = {"se": 0, "matern32": 1, "matern52": 2}
 # Every symbol include/lmm_hip.h declares (tests/test_abi.py checks the library exports each one).
 SYMBOLS = [
     "lmm_init", "lmm_shutdown", "lmm_last_error_string", "lmm_last_error_detail", "lmm_device_synchronize", "lmm_release_cached_memory",
-    "lmm_stream_wait_caller", "lmm_set_compute_dtype", "lmm_get_compute_dtype", "lmm_comm_get_unique_id", "lmm_comm_init_rank", "lmm_comm_info", "lmm_allreduce_sum_f64", "lmm_allreduce_max_f64",
+    "lmm_stream_wait_caller", "lmm_set_compute_dtype", "lmm_get_compute_dtype", "lmm_set_projection_dtype", "lmm_get_projection_dtype", "lmm_comm_get_unique_id", "lmm_comm_init_rank", "lmm_comm_info", "lmm_allreduce_sum_f64", "lmm_allreduce_max_f64",
     "lmm_comm_destroy",
     "lmm_orthogonal_validate", "lmm_oilmm_logpdf", "lmm_oilmm_logpdf_grad", "lmm_oilmm_post_logpdf_grad", "lmm_ilmm_logpdf_grad", "lmm_ilmm_post_logpdf_grad", "lmm_oilmm_logpdf_multi", "lmm_reorder", "lmm_ilmm_logpdf", "lmm_ilmm_logpdf_ex", "lmm_ilmm_logpdf_multi", "lmm_mogp_logpdf", "lmm_mogp_logpdf_diag",
-    "lmm_oilmm_posterior_create", "lmm_mogp_posterior_create", "lmm_post_condition", "lmm_ilmm_posterior_create", "lmm_post_destroy", "lmm_ilmm_post_mean_and_var", "lmm_ilmm_post_mean_and_cov", "lmm_ilmm_post_condition", "lmm_ilmm_post_logpdf", "lmm_ilmm_post_rand",
+    "lmm_oilmm_posterior_create", "lmm_mogp_posterior_create", "lmm_post_condition", "lmm_ilmm_posterior_create", "lmm_post_destroy", "lmm_ilmm_post_latent_view", "lmm_ilmm_post_mean_and_var", "lmm_ilmm_post_mean_and_cov", "lmm_ilmm_post_condition", "lmm_ilmm_post_logpdf", "lmm_ilmm_post_rand",
     "lmm_latent_marginals", "lmm_oilmm_mean_and_var", "lmm_lmm_mean_and_cov", "lmm_oilmm_post_logpdf", "lmm_lmm_rand", "lmm_lmm_rand_multi", "lmm_normals",
     "lmm_profile_begin", "lmm_profile_end",
     "lmm_dev_potrf", "lmm_dev_gemm_nt_sub", "lmm_dev_gram", "lmm_dev_mfma_f64_peak",
@@ -160,6 +160,19 @@ def get_compute_dtype() -> str:
     return "f32" if load().lmm_get_compute_dtype() == 1 else "f64"
 
 
+_PROJ = {"f64": 0, "native": 0, "bf16": 1, "bf16x2": 2}
+
+
+def set_projection_dtype(dtype: str) -> None:
+    """Dtype of the H unprojection of predictive marginals (reference src/oilmm.jl:69-72): "native" (Float64, default), "bf16"
+    (v_mfma_f32_16x16x32_bf16, BASELINE configs[3]; tolerance 2^-8 * sum_l |H||M_lat|, include/lmm_hip.h) or "bf16x2"."""
+    check(load().lmm_set_projection_dtype(C.c_int(_PROJ[dtype])))
+
+
+def get_projection_dtype() -> str:
+    return ["native", "bf16", "bf16x2"][load().lmm_get_projection_dtype()]
+
+
 def order_after_torch() -> None:
     """The library runs on its own non-blocking HIP streams; torch produces (and recycles) device tensors asynchronously on ITS
     current stream.  Before a device pointer crosses the ABI, make the library's streams wait for everything torch has queued
@@ -196,13 +209,32 @@ def comm_init_rank(uid: bytes, rank: int, world: int) -> None:
 
 
 def comm_init_from_torch() -> None:
-    """Create the ABI's RCCL communicator for the ranks of torch.distributed's default group: rank 0 draws the unique id and
-    ships it through the group's store-backed object broadcast (the out-of-band step a Julia caller does with MPI.bcast)."""
+    """Create the ABI's RCCL communicator for the ranks of torch.distributed's default group.  Rank 0 draws the unique id and
+    ships it through the group's rendezvous STORE (a TCP key-value store: the out-of-band step a Julia caller does with
+    MPI.bcast) -- no torch collective is involved, so torch's own NCCL communicator need not exist yet and the two RCCL
+    initialisations never interleave.  Falls back to the object broadcast when the process group exposes no store."""
     import torch.distributed as dist
+    global _comm_generation
     rank, world = dist.get_rank(), dist.get_world_size()
-    box = [comm_get_unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(box, src=0)
-    comm_init_rank(box[0], rank, world)
+    _comm_generation += 1
+    store = None
+    try:
+        store = dist.distributed_c10d._get_default_store()
+    except Exception:
+        store = None
+    if store is not None:
+        key = f"lmm_rccl_unique_id/{_comm_generation}"
+        if rank == 0:
+            store.set(key, comm_get_unique_id())
+        uid = bytes(store.get(key))          # blocks until rank 0 has set it
+    else:
+        box = [comm_get_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        uid = box[0]
+    comm_init_rank(uid, rank, world)
+
+
+_comm_generation = 0
 
 
 def comm_destroy() -> None:

@@ -58,6 +58,14 @@ struct Ctx {
 };
 Ctx g;
 std::mutex g_mu;
+int g_proj = 0;   // lmm_proj_dtype of the H unprojection of predictive marginals (lmm_set_projection_dtype)
+
+// H unprojection of latent marginals (reference src/oilmm.jl:69,72) in the selected projection dtype
+void mix_marginals(const double* lat, int ns, int ml, const double* Hm, int p, int pw, double lat_add, double out_add, double* out,
+                   hipStream_t st) {
+  if (g_proj == LMM_PROJ_NATIVE || ml == 0) launch_mix(lat, ns, ml, Hm, p, pw, lat_add, out_add, nullptr, 0.0, out, st);
+  else launch_mix_bf16(lat, ns, ml, Hm, p, pw, lat_add, out_add, g_proj == LMM_PROJ_BF16X2 ? 2 : 1, out, st);
+}
 
 int fail(int code, const char* fmt, ...) {
   char buf[512];
@@ -631,7 +639,15 @@ struct lmm_post {
   std::vector<int> sigidx;      // n: batch index of every training point (host)
   std::vector<double> H;        // p x m column-major (host)
   Buf<LatentDev> latd;          // device latent descriptors
+  // latent view of a dense-H posterior (lmm_ilmm_post_latent_view): the device state belongs to `base`; this handle only replaces
+  // H by I_m (p = m).  `views` counts the views alive on a base handle; destroying a base that still has views defers its release
+  // (zombie) until the last view is destroyed.
+  lmm_post* base = nullptr;
+  int views = 0;
+  bool zombie = false;
 };
+// the handle that owns the device state of a dense-H posterior (itself, or the base of a latent view)
+static inline const lmm_post* dense_state(const lmm_post* P) { return P->base ? P->base : P; }
 
 #define LMM_TRY try {
 // A throw unwinds through Buf destructors, which hand device blocks back to the caching pool while slot streams may still be
@@ -805,6 +821,15 @@ int lmm_set_compute_dtype(int dtype) {
   return LMM_OK;
 }
 int lmm_get_compute_dtype(void) { return g_f32 ? LMM_F32 : LMM_F64; }
+
+int lmm_set_projection_dtype(int dtype) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (dtype != LMM_PROJ_NATIVE && dtype != LMM_PROJ_BF16 && dtype != LMM_PROJ_BF16X2)
+    return fail(LMM_ERR_ARG, "projection dtype must be LMM_PROJ_NATIVE, LMM_PROJ_BF16 or LMM_PROJ_BF16X2");
+  g_proj = dtype;
+  return LMM_OK;
+}
+int lmm_get_projection_dtype(void) { return g_proj; }
 
 int lmm_device_synchronize(void) {
   std::lock_guard<std::mutex> lk(g_mu);
@@ -2002,6 +2027,7 @@ int lmm_ilmm_post_condition(const lmm_post_t* post, double sigma2, const double*
   if (!post || !x2 || !y2 || !out || d <= 0 || n2 <= 0) return fail(LMM_ERR_ARG, "bad arguments");
   const lmm_post* P = post;
   if (P->kind != 1) return fail(LMM_ERR_ARG, "not a dense-H ILMM posterior");
+  const lmm_post* D = dense_state(P);
   if (P->d != d) return fail(LMM_ERR_DIM, "input dimension mismatch");
   if (!jit) jit = &kDefaultJit;
   hipStream_t st0 = g.streams[0];
@@ -2015,10 +2041,10 @@ int lmm_ilmm_post_condition(const lmm_post_t* post, double sigma2, const double*
   Uploaded meansd(means, st0);
   Buf<double> d2((size_t)n2 * m), delta((size_t)n * m), xall((size_t)d * n);
   project_on_device(y2d.p, n2, p, Td.buf, m, 0, m, meansd.buf.p, d2.p, st0);
-  HIPCHK(hipMemcpyAsync(xall.p, P->x.p, (size_t)d * n1 * sizeof(double), hipMemcpyDeviceToDevice, st0));
+  HIPCHK(hipMemcpyAsync(xall.p, D->x.p, (size_t)d * n1 * sizeof(double), hipMemcpyDeviceToDevice, st0));
   HIPCHK(hipMemcpyAsync(xall.p + (size_t)d * n1, x2d.p, (size_t)d * n2 * sizeof(double), hipMemcpyDeviceToDevice, st0));
   for (int l = 0; l < m; ++l) {
-    HIPCHK(hipMemcpyAsync(delta.p + (size_t)l * n, P->ddelta.p + (size_t)l * n1, (size_t)n1 * sizeof(double), hipMemcpyDeviceToDevice, st0));
+    HIPCHK(hipMemcpyAsync(delta.p + (size_t)l * n, D->ddelta.p + (size_t)l * n1, (size_t)n1 * sizeof(double), hipMemcpyDeviceToDevice, st0));
     HIPCHK(hipMemcpyAsync(delta.p + (size_t)l * n + n1, d2.p + (size_t)l * n2, (size_t)n2 * sizeof(double), hipMemcpyDeviceToDevice, st0));
   }
   std::vector<double> sigs = P->sigs;
@@ -2038,6 +2064,7 @@ int lmm_ilmm_post_mean_and_var(const lmm_post_t* post, double sigma2, const doub
   if (!post || !xs || !mean_out || !var_out || d <= 0 || ns <= 0) return fail(LMM_ERR_ARG, "bad arguments");
   const lmm_post* P = post;
   if (P->kind != 1) return fail(LMM_ERR_ARG, "not a dense-H ILMM posterior");
+  const lmm_post* D = dense_state(P);
   if (P->d != d) return fail(LMM_ERR_DIM, "input dimension mismatch");
   if (!jit) jit = &kDefaultJit;
   hipStream_t st0 = g.streams[0];
@@ -2047,16 +2074,16 @@ int lmm_ilmm_post_mean_and_var(const lmm_post_t* post, double sigma2, const doub
   Buf<double> ml((size_t)ns * m);
   Buf<double> pm_part(post_mean_partial_elems(ns, n));
   for (int l = 0; l < m; ++l)
-    launch_post_mean(xsd.p, ns, P->x.p, n, d, P->alpha[0].p + (size_t)l * n, to_dev(P->gps[l]), pm_part.p, ml.p + (size_t)l * ns, st0);
+    launch_post_mean(xsd.p, ns, D->x.p, n, d, D->alpha[0].p + (size_t)l * n, to_dev(P->gps[l]), pm_part.p, ml.p + (size_t)l * ns, st0);
   const int nr = rup(m * ns, 64);
   int ldr = nr; if ((ldr % 512) == 0) ldr += 16;
   Buf<double> R((size_t)ldr * P->NC);
-  launch_dense_cross(R.p, ldr, nr, P->NC, xsd.p, ns, P->x.p, n, d, m, P->latd.p, st0);
-  trsm_rec(R.p, ldr, nr, P->L[0].p, P->ld, P->W[0].p, 0, P->NC, st0);
+  launch_dense_cross(R.p, ldr, nr, P->NC, xsd.p, ns, D->x.p, n, d, m, D->latd.p, st0);
+  trsm_rec(R.p, ldr, nr, D->L[0].p, P->ld, D->W[0].p, 0, P->NC, st0);
   DevOut mo(mean_out, (size_t)ns * p), vo(var_out, (size_t)ns * p);
   launch_mix(ml.p, ns, m, Hd.buf.p, p, 1, 0.0, 0.0, nullptr, 0.0, mo.p, st0);
   Buf<double> dv_part(dense_var_partial_elems(ns, p, N));
-  launch_dense_var(R.p, ldr, ns, m, N, Hd.buf.p, p, P->latd.p, jit->default_jitter, sigma2, dv_part.p, vo.p, st0);
+  launch_dense_var(R.p, ldr, ns, m, N, Hd.buf.p, p, D->latd.p, jit->default_jitter, sigma2, dv_part.p, vo.p, st0);
   mo.finish(st0); vo.finish(st0);
   HIPCHK(hipStreamSynchronize(st0));
   return LMM_OK;
@@ -2069,12 +2096,13 @@ static void dense_post_cov_factor(const lmm_post* P, const double* xsd, int d, i
                                   const double* rider, const Dims& Ds, double* A, double* WA, double* R, int ldr, int* info,
                                   hipStream_t st, bool factor = true) {
   const int m = P->m;
+  const lmm_post* D = dense_state(P);
   DenseArgs a{};
   a.A = A; a.ld = Ds.ld; a.nrows = Ds.NR; a.ncols = Ds.NC; a.x = xsd; a.d = d; a.n = ns; a.m = m;
-  a.lat = P->latd.p; a.sigmaT = sigadd_dev; a.rider = rider; a.rider_ld = m * ns; a.nrider = rider ? 1 : 0;
+  a.lat = D->latd.p; a.sigmaT = sigadd_dev; a.rider = rider; a.rider_ld = m * ns; a.nrider = rider ? 1 : 0;
   launch_dense_assemble(a, st);
-  launch_dense_cross(R, ldr, Ds.NC, P->NC, xsd, ns, P->x.p, P->n, d, m, P->latd.p, st);
-  trsm_rec(R, ldr, Ds.NC, P->L[0].p, P->ld, P->W[0].p, 0, P->NC, st);
+  launch_dense_cross(R, ldr, Ds.NC, P->NC, xsd, ns, D->x.p, P->n, d, m, D->latd.p, st);
+  trsm_rec(R, ldr, Ds.NC, D->L[0].p, P->ld, D->W[0].p, 0, P->NC, st);
   launch_gemm_nt(A, Ds.ld, R, ldr, R, ldr, Ds.NC, Ds.NC, P->NC, 1, false, st);
   if (factor) potrf_rec(A, Ds.ld, Ds.NR, 0, Ds.NC, WA, m * ns, info, st);
 }
@@ -2091,6 +2119,7 @@ int lmm_ilmm_post_mean_and_cov(const lmm_post_t* post, double sigma2, const doub
   if (!post || !xs || !mean_out || !cov_out || d <= 0 || ns <= 0) return fail(LMM_ERR_ARG, "bad arguments");
   const lmm_post* P = post;
   if (P->kind != 1) return fail(LMM_ERR_ARG, "not a dense-H ILMM posterior");
+  const lmm_post* D = dense_state(P);
   if (P->d != d) return fail(LMM_ERR_DIM, "input dimension mismatch");
   if (!jit) jit = &kDefaultJit;
   const int m = P->m, p = P->p, n = P->n, Ns = m * ns;
@@ -2100,7 +2129,7 @@ int lmm_ilmm_post_mean_and_cov(const lmm_post_t* post, double sigma2, const doub
   Uploaded Hd(P->H, st0), Zd(std::vector<double>((size_t)m * m, 0.0), st0);
   Buf<double> ml((size_t)Ns), pm_part(post_mean_partial_elems(ns, n));
   for (int l = 0; l < m; ++l)
-    launch_post_mean(xsd.p, ns, P->x.p, n, d, P->alpha[0].p + (size_t)l * n, to_dev(P->gps[l]), pm_part.p, ml.p + (size_t)l * ns, st0);
+    launch_post_mean(xsd.p, ns, D->x.p, n, d, D->alpha[0].p + (size_t)l * n, to_dev(P->gps[l]), pm_part.p, ml.p + (size_t)l * ns, st0);
   Dims Ds(Ns, 0);
   int ldr = Ds.NC; if ((ldr % 512) == 0) ldr += 16;
   Buf<double> A(Ds.elems()), R((size_t)ldr * P->NC), T((size_t)p * ns * Ns);
@@ -2125,6 +2154,7 @@ int lmm_ilmm_post_logpdf(const lmm_post_t* post, double sigma2, const double* xs
   if (!post || !xs || !ys || !out || d <= 0 || ns <= 0) return fail(LMM_ERR_ARG, "bad arguments");
   const lmm_post* P = post;
   if (P->kind != 1) return fail(LMM_ERR_ARG, "not a dense-H ILMM posterior");
+  const lmm_post* D = dense_state(P);
   if (P->d != d) return fail(LMM_ERR_DIM, "input dimension mismatch");
   if (!jit) jit = &kDefaultJit;
   hipStream_t st0 = g.streams[0];
@@ -2139,7 +2169,7 @@ int lmm_ilmm_post_logpdf(const lmm_post_t* post, double sigma2, const double* xs
   residual_on_device(ysd.p, ns, p, Ty.p, m, Hd.buf, partial.p, resid_dev.p, st0);
   Buf<double> pm_part(post_mean_partial_elems(ns, n));
   for (int l = 0; l < m; ++l)
-    launch_post_mean(xsd.p, ns, P->x.p, n, d, P->alpha[0].p + (size_t)l * n, to_dev(P->gps[l]), pm_part.p, ml.p + (size_t)l * ns, st0);
+    launch_post_mean(xsd.p, ns, D->x.p, n, d, D->alpha[0].p + (size_t)l * n, to_dev(P->gps[l]), pm_part.p, ml.p + (size_t)l * ns, st0);
   launch_vec_lin(Ty.p, ml.p, -1.0, Ns, delta.p, st0);
   Dims Ds(Ns, 1);
   int ldr = Ds.NC; if ((ldr % 512) == 0) ldr += 16;
@@ -2171,6 +2201,7 @@ int lmm_ilmm_post_rand(const lmm_post_t* post, double sigma2, int add_noise, con
   if (!post || !xs || !z_lat || !out || d <= 0 || ns <= 0 || (add_noise && !eps)) return fail(LMM_ERR_ARG, "bad arguments");
   const lmm_post* P = post;
   if (P->kind != 1) return fail(LMM_ERR_ARG, "not a dense-H ILMM posterior");
+  const lmm_post* D = dense_state(P);
   if (P->d != d) return fail(LMM_ERR_DIM, "input dimension mismatch");
   if (!jit) jit = &kDefaultJit;
   hipStream_t st0 = g.streams[0];
@@ -2182,7 +2213,7 @@ int lmm_ilmm_post_rand(const lmm_post_t* post, double sigma2, int add_noise, con
   Buf<double> ml((size_t)Ns), X((size_t)Ns);
   Buf<double> pm_part(post_mean_partial_elems(ns, n));
   for (int l = 0; l < m; ++l)
-    launch_post_mean(xsd.p, ns, P->x.p, n, d, P->alpha[0].p + (size_t)l * n, to_dev(P->gps[l]), pm_part.p, ml.p + (size_t)l * ns, st0);
+    launch_post_mean(xsd.p, ns, D->x.p, n, d, D->alpha[0].p + (size_t)l * n, to_dev(P->gps[l]), pm_part.p, ml.p + (size_t)l * ns, st0);
   Dims Ds(Ns, 0);
   int ldr = Ds.NC; if ((ldr % 512) == 0) ldr += 16;
   Buf<double> A(Ds.elems()), WA((size_t)(Ds.NC / 64) * 4096), R((size_t)ldr * P->NC), part(strip_partial_elems(Ns, Ns, 1));
@@ -2201,11 +2232,45 @@ int lmm_ilmm_post_rand(const lmm_post_t* post, double sigma2, int add_noise, con
   LMM_CATCH
 }
 
+// get_latent_gp(posterior(fx::FiniteGP{<:ILMM}, y)) for a dense H (reference src/ilmm.jl:39 on the ILMM of :196-197): the latent
+// PosteriorGP{IndependentMOGP} as a handle of its own.  It SHARES the device state of `post` (the (mn) x (mn) factor, alpha, x)
+// and differs only in H = I_m, p = m, so every lmm_ilmm_post_* entry point answers for the m latent outputs at
+// MOInputIsotopicByOutputs(xs, m): with project_jitter = 0 the projection is the identity, SigmaT = sigma2 I and the regulariser
+// vanishes, i.e. logpdf is the generic Gaussian of the latent posterior + sigma2 I; rand with ilmm_rand_jitter = sigma2 and
+// add_noise = 0 is AbstractGPs' mean + chol(cov + sigma2 I).U' z.  Destroy it with lmm_post_destroy (either order w.r.t. `post`).
+int lmm_ilmm_post_latent_view(const lmm_post_t* post, lmm_post_t** out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  REQUIRE_INIT();
+  LMM_TRY
+  if (!post || !out) return fail(LMM_ERR_ARG, "bad arguments");
+  if (post->kind != 1) return fail(LMM_ERR_ARG, "not a dense-H ILMM posterior");
+  lmm_post* B = const_cast<lmm_post*>(dense_state(post));
+  lmm_post* V = new lmm_post();
+  V->f32 = B->f32; V->kind = 1; V->n = B->n; V->d = B->d; V->l0 = 0; V->l1 = B->m; V->m = B->m; V->p = B->m;
+  V->NC = B->NC; V->NR = B->NR; V->ld = B->ld;
+  V->gps = B->gps; V->sigs = B->sigs; V->sigidx = B->sigidx;
+  V->H.assign((size_t)B->m * B->m, 0.0);
+  for (int l = 0; l < B->m; ++l) V->H[l + (size_t)l * B->m] = 1.0;
+  V->base = B;
+  ++B->views;
+  *out = V;
+  return LMM_OK;
+  LMM_CATCH
+}
+
 int lmm_post_destroy(lmm_post_t* post) {
   std::lock_guard<std::mutex> lk(g_mu);
   if (post) {
     if (g.init) (void)hipDeviceSynchronize();
-    delete post;
+    if (post->base) {                                   // a latent view: release the base if it was waiting for its last view
+      lmm_post* B = post->base;
+      if (--B->views == 0 && B->zombie) delete B;
+      delete post;
+    } else if (post->views > 0) {
+      post->zombie = true;                              // views still use this state: freed with the last of them
+    } else {
+      delete post;
+    }
   }
   return LMM_OK;
 }
@@ -2334,16 +2399,17 @@ int lmm_oilmm_mean_and_var(const lmm_post_t* post, const lmm_gp_t* gps, const do
                        pm_part.p, ml.p + (size_t)k * ns, st0);
     }
     DevOut mo(mean_out, (size_t)ns * p);
-    launch_mix(ml.p, ns, ms, Hd.buf.p, p, 1, 0.0, 0.0, nullptr, 0.0, mo.p, st0);
+    mix_marginals(ml.p, ns, ms, Hd.buf.p, p, 1, 0.0, 0.0, mo.p, st0);
     mo.finish(st0);
     HIPCHK(hipStreamSynchronize(st0));
     return LMM_OK;
   }
   if (int rc = latent_marginals_dev(post, post ? nullptr : gps + l0, ms, xsd.p, d, ns, ml.p, vl.p)) return rc;
   DevOut mo(mean_out, (size_t)ns * p), vo(var_out, (size_t)ns * p);
-  // reference src/oilmm.jl:69,72: M = H M_latent;  V = abs2.(H) V_latent .+ sigma2   (V_latent carries the 1e-18 jitter)
-  launch_mix(ml.p, ns, ms, Hd.buf.p, p, 1, 0.0, 0.0, nullptr, 0.0, mo.p, st0);
-  if (var_out) launch_mix(vl.p, ns, ms, Hd.buf.p, p, 2, jit->default_jitter, add_noise ? sigma2 : 0.0, nullptr, 0.0, vo.p, st0);
+  // reference src/oilmm.jl:69,72: M = H M_latent;  V = abs2.(H) V_latent .+ sigma2   (V_latent carries the 1e-18 jitter);
+  // Float64 VALU by default, v_mfma_f32_16x16x32_bf16 under lmm_set_projection_dtype(LMM_PROJ_BF16 / _BF16X2)
+  mix_marginals(ml.p, ns, ms, Hd.buf.p, p, 1, 0.0, 0.0, mo.p, st0);
+  if (var_out) mix_marginals(vl.p, ns, ms, Hd.buf.p, p, 2, jit->default_jitter, add_noise ? sigma2 : 0.0, vo.p, st0);
   mo.finish(st0); vo.finish(st0);
   HIPCHK(hipStreamSynchronize(st0));
   return LMM_OK;
@@ -2677,8 +2743,13 @@ int lmm_dev_gemm_nt_sub(double* C, int ldc, const double* A, int lda, const doub
   std::lock_guard<std::mutex> lk(g_mu);
   REQUIRE_INIT();
   LMM_TRY
-  if (!C || !A || !B || M % 64 || N % 64 || K % 16 || (ldc & 1) || (lda & 1) || (ldb & 1)) return fail(LMM_ERR_ARG, "bad arguments");
+  if (!C || !A || !B || M <= 0 || N <= 0 || K <= 0 || M % 64 || N % 64 || K % 16 || (ldc & 1) || (lda & 1) || (ldb & 1) || ldc < M || lda < M || ldb < N)
+    return fail(LMM_ERR_ARG, "bad arguments");
+  // lower: the tile enumeration (MT - tj row tiles under column tile tj of a common-origin region) assumes a trapezoid at least as
+  // tall as it is wide
+  if (lower && M < N) return fail(LMM_ERR_ARG, "lower != 0 needs M >= N (lower trapezoid of a common-origin region)");
   launch_gemm_nt(C, ldc, A, lda, B, ldb, M, N, K, lower, false, g.streams[0]);
+  HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(g.streams[0]));
   return LMM_OK;
   LMM_CATCH

@@ -84,6 +84,8 @@ void launch_post_mean(const double* xs, int ns, const double* x, int n, int d, c
                       double* partial, double* out, hipStream_t st);
 void launch_mix(const double* lat, int ns, int ml, const double* Hm, int p, int pw, double lat_add, double out_add,
                 const double* eps, double eps_scale, double* out, hipStream_t st);
+void launch_mix_bf16(const double* lat, int ns, int ml, const double* Hm, int p, int pw, double lat_add, double out_add,
+                     int terms, double* out, hipStream_t st);
 void launch_cov_mix(const BatchPtr& Cl, int ldcl, int nl, const double* Hs, int p, int ns, double jitter, double sigma2,
                     int init, double* out, hipStream_t st);
 void launch_trmv_lower(const double* L, int ld, int n, const double* z, double mu, double* partial, double* out,

@@ -2466,6 +2466,69 @@ __global__ __launch_bounds__(256) void mix_kernel(const double* __restrict__ lat
   out[(size_t)o * ns + s] = acc;
 }
 
+// K4, bf16 projection (BASELINE configs[3]: "bf16 MFMA covariance projection"; lmm_set_projection_dtype): the same unprojection
+//     out[s + o*ns] = out_add + sum_l Hm[o,l]^pw * (lat[s + l*ns] + lat_add)          (reference src/oilmm.jl:69,72)
+// on v_mfma_f32_16x16x32_bf16: both operands are rounded to bfloat16 (round-to-nearest-even of the Float32 image; for pw = 2 the
+// SQUARED entry abs2(H) is what is rounded, as abs2.(H) * V in the reference's order of operations), products and the sum over l
+// accumulate in Float32 on the matrix pipe, out_add (sigma2) is added in Float64.  TERMS = 1: plain bf16 (relative input error
+// <= 2^-9 each, so |error| <= ~2^-8 sum_l |H^pw| |lat|); TERMS = 2: each operand split hi + lo into two bf16 values and the three
+// leading products hi hi + hi lo + lo hi summed (~2^-16: Float32-class), for callers who want the bf16 pipe without the loss.
+// Lane map (cdna_hip_programming.md section 3): lane l holds A[row l&15][k = 8(l>>4) + j], B[k = 8(l>>4) + j][col l&15], j = 0..7,
+// D[row 4(l>>4) + r][col l&15].  A = H^pw (16 outputs x 32 latents), B = lat (32 latents x 16 points): D's lanes run along the
+// points, so every store is eight 128-byte segments.  One wave per 16 points, looping over the output tiles.
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);   // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+template <int TERMS>
+__global__ __launch_bounds__(256) void mix_bf16_kernel(const double* __restrict__ lat, int ns, int ml,
+                                                       const double* __restrict__ Hm, int p, int pw,
+                                                       double lat_add, double out_add, double* __restrict__ out) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int s0 = (blockIdx.x * 4 + w) * 16;
+  if (s0 >= ns) return;                                            // whole wave
+  const int c = lane & 15, kg = lane >> 4;
+  const int s = s0 + c;
+  for (int o0 = 0; o0 < p; o0 += 16) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < ml; k0 += 32) {
+      bf16x8 a[TERMS], b[TERMS];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int l = k0 + 8 * kg + j;
+        double hv = 0.0, bv = 0.0;
+        if (l < ml) {
+          if (o0 + c < p) { hv = Hm[(o0 + c) + (size_t)l * p]; if (pw == 2) hv = hv * hv; }
+          if (s < ns) bv = lat[(size_t)l * ns + s] + lat_add;
+        }
+        const unsigned short ah = f32_to_bf16_rne((float)hv), bh = f32_to_bf16_rne((float)bv);
+        a[0][j] = (short)ah; b[0][j] = (short)bh;
+        if (TERMS == 2) {
+          a[1][j] = (short)f32_to_bf16_rne((float)(hv - (double)bf16_to_f32(ah)));
+          b[1][j] = (short)f32_to_bf16_rne((float)(bv - (double)bf16_to_f32(bh)));
+        }
+      }
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
+      if (TERMS == 2) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc, 0, 0, 0);
+      }
+    }
+    if (s < ns) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = o0 + 4 * kg + r;
+        if (o < p) out[(size_t)o * ns + s] = out_add + (double)acc[r];
+      }
+    }
+  }
+}
+
 // Dense-H posterior full covariance (reference src/ilmm.jl:132-139 with coupled latents): C = H_full S H_full' + sigma2 I
 // for the latent joint covariance S ((m ns) x (m ns), lower triangle of a factor-layout buffer, index l*ns + i), in two
 // passes:  T[(o,i), (l',j)] = sum_l H[o,l] S[(l,i),(l',j)]   then   C[(o,i),(o',j)] = sum_l' T[(o,i),(l',j)] H[o',l'].
@@ -2855,15 +2918,15 @@ void launch_gemm_nt(const BatchPtr& C, size_t offC, int ldc, const BatchPtr& A, 
   // underfilled wide update (the 128 x 128 tiles of all nb matrices together do not fill the CUs once): 64 x 128 tiles instead
   static int half_tiles = -1;
   if (half_tiles < 0) { const char* e = getenv("LMM_HALF_TILES"); half_tiles = e ? (atoi(e) != 0) : 1; }
-  if (!g_f32 && !narrow && half_tiles && g_gemm_m16 >= 2 && lower && (N % 128) == 0 && (M % 64) == 0 && K >= 64 && K < 1024) {
+  if (!g_f32 && !narrow && half_tiles && g_gemm_m16 >= 2 && lower && M >= N && (N % 128) == 0 && (M % 64) == 0 && K >= 64 && K < 1024) {
     static int cus_h = 0;
     if (cus_h == 0) { int dev = 0; cus_h = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus_h, hipDeviceAttributeMultiprocessorCount, dev); }
     long long T128 = 0;
     for (int tj = 0; tj < N / 128; ++tj) T128 += MT - tj;
-    if (T128 * nb <= cus_h) {
-      const int MT64 = M / 64;
-      long long T64 = 0;
-      for (int tj = 0; tj < N / 128; ++tj) T64 += MT64 - 2 * tj;
+    const int MT64 = M / 64;
+    long long T64 = 0;
+    for (int tj = 0; tj < N / 128; ++tj) T64 += MT64 - 2 * tj;
+    if (T128 * nb <= cus_h && T64 > 0) {
       hipLaunchKernelGGL((gemm16h_kernel<false>), dim3((unsigned)T64, nb), dim3(256), 0, st, C, offC, ldc, A, offA, lda, B, offB, ldb, N, K, MT64);
       return;
     }
@@ -3028,6 +3091,14 @@ void launch_mix(const double* lat, int ns, int ml, const double* Hm, int p, int 
                 const double* eps, double eps_scale, double* out, hipStream_t st) {
   dim3 grid((ns + 255) / 256, p);
   hipLaunchKernelGGL(mix_kernel, grid, dim3(256), 0, st, lat, ns, ml, Hm, p, pw, lat_add, out_add, eps, eps_scale, out);
+}
+
+// terms: 1 = plain bf16 operands, 2 = hi + lo split (three products)
+void launch_mix_bf16(const double* lat, int ns, int ml, const double* Hm, int p, int pw, double lat_add, double out_add,
+                     int terms, double* out, hipStream_t st) {
+  dim3 grid((ns + 63) / 64);
+  if (terms == 2) hipLaunchKernelGGL((mix_bf16_kernel<2>), grid, dim3(256), 0, st, lat, ns, ml, Hm, p, pw, lat_add, out_add, out);
+  else hipLaunchKernelGGL((mix_bf16_kernel<1>), grid, dim3(256), 0, st, lat, ns, ml, Hm, p, pw, lat_add, out_add, out);
 }
 
 void launch_cov_mix(const BatchPtr& Cl, int ldcl, int nl, const double* Hs, int p, int ns, double jitter, double sigma2,

@@ -73,11 +73,8 @@ class IndependentMOGP:
 
     def __call__(self, x: "MOInputIsotopicByOutputs", sigma2=1e-18) -> "FiniteGP":
         """f(x, sigma2) or f(x, diag) with the diagonal of a general Diagonal noise (length n*p, ordered like x)."""
-        if self._post is not None and self._post.dense:
-            # get_latent_gp(posterior(ilmm_dense(x, s2), y)): the latents of a dense-H posterior are COUPLED (one (mn) x (mn)
-            # state); the per-latent entry points would index past its single factor.  Use the ILMM posterior itself.
-            raise NotImplementedError("the latent GP of a dense-H ILMM posterior is a coupled PosteriorGP; query the ILMM "
-                                      "posterior (mean_and_var / rand / logpdf on posterior(fx, y)(x*, s2)) instead")
+        # get_latent_gp(posterior(ilmm_dense(x, s2), y)): the latents of a dense-H posterior are COUPLED (one (mn) x (mn) state,
+        # reference src/ilmm.jl:196-197); the verbs below serve them through the handle's latent view (H = I_m)
         if np.isscalar(sigma2) or getattr(sigma2, "ndim", 1) == 0:
             return FiniteGP(self, x, float(sigma2))
         return FiniteGP(self, x, sigma2)
@@ -182,11 +179,25 @@ class _PostHandle:
     """Owns an lmm_post_t* (device-resident posterior state); freed with the Python object, as the Julia
     shim does with a finalizer."""
 
-    def __init__(self, ptr: C.c_void_p, l0: int, l1: int, dense: bool = False, train=None):
+    def __init__(self, ptr: C.c_void_p, l0: int, l1: int, dense: bool = False, train=None, latent: bool = False, parent=None):
         self.ptr, self.l0, self.l1, self.dense = ptr, l0, l1, dense      # dense: coupled (mn) x (mn) state of a dense-H ILMM
         # (x, sigma2, y) the posterior was built from (references, no copies): the gradient of the predictive logpdf is a total
         # derivative through the posterior and needs them; None after sequential conditioning
         self.train = train
+        self.latent = latent          # dense only: this handle's H is I_m (it IS the latent PosteriorGP{IndependentMOGP})
+        self._parent = parent         # a latent view keeps the handle whose device state it shares alive
+        self._view = None
+
+    def latent_view(self) -> "_PostHandle":
+        """The latent PosteriorGP{IndependentMOGP} of a dense-H posterior (reference src/ilmm.jl:39 on :196-197) as a handle of
+        its own: lmm_ilmm_post_latent_view (shares the factor, H = I_m)."""
+        if self.latent:
+            return self
+        if self._view is None:
+            h = C.c_void_p()
+            L.check(L.load().lmm_ilmm_post_latent_view(self.ptr, C.byref(h)))
+            self._view = _PostHandle(h, self.l0, self.l1, dense=True, latent=True, parent=self)
+        return self._view
 
     def __del__(self):
         try:
@@ -325,6 +336,10 @@ def logpdf(fx: FiniteGP, y, with_regulariser: bool = True) -> float:
             raise RuntimeError("out dim of x != out dim of f.")
         if ya.size != x.n * x.out_dim:
             raise ValueError("length(y) != n * out_dim")
+        if f._post is not None and f._post.dense:      # latent PosteriorGP of a dense-H posterior: generic Gaussian logpdf
+            L.check(lib.lmm_ilmm_post_logpdf(f._post.latent_view().ptr, C.c_double(s2), xa.ptr, x.dim, x.n, ya.ptr,
+                                             L.jitters((0.0, s2, 0.0)), C.byref(out)))
+            return out.value
         if f._post is not None:
             return _post_logpdf(f._post, [g.desc() for g in f.fs], np.eye(len(f.fs)), np.ones(len(f.fs)), x, s2, ya, False)
         gps = L.gps_array([g.desc() for g in f.fs])
@@ -373,6 +388,8 @@ def logpdf_and_gradient(fx: FiniteGP, y, with_regulariser: bool = True) -> dict:
     post = f._post if mogp else (f.f._post if isinstance(f, ILMM) else None)
     if not mogp and not isinstance(f, ILMM):
         raise TypeError("logpdf_and_gradient needs an ILMM / OILMM / IndependentMOGP FiniteGP")
+    if mogp and post is not None and post.dense:
+        raise NotImplementedError("gradient of the logpdf of the coupled latent PosteriorGP of a dense-H posterior is not built")
     if not mogp and not f.is_oilmm:
         unpack(fx)
         Ha, _, p, m = _H_args(f.H)
@@ -488,6 +505,10 @@ def posterior(fx: FiniteGP, y):
     handle = C.c_void_p()
     if isinstance(f, IndependentMOGP):
         m = len(f.fs)
+        if f._post is not None and f._post.dense:      # posterior(f_latent(x2, s2), y2) on the coupled latent PosteriorGP
+            L.check(lib.lmm_ilmm_post_condition(f._post.latent_view().ptr, C.c_double(s2), xa.ptr, x.dim, x.n, ya.ptr,
+                                                L.jitters((0.0, s2, 0.0)), C.byref(handle)))
+            return IndependentMOGP(f.fs, _PostHandle(handle, 0, m, dense=True, latent=True))
         if f._post is not None:        # sequential conditioning: posterior(po(x2, s2), y2)
             Ui, Si = L.Arr(L.colmajor(np.eye(m))), L.Arr(np.ones(m))
             L.check(lib.lmm_post_condition(f._post.ptr, Ui.ptr, Si.ptr, m, m, C.c_double(s2), xa.ptr, x.dim, x.n, ya.ptr,
@@ -532,6 +553,10 @@ def mean_and_var(fx: FiniteGP, add_noise: bool = True):
             raise RuntimeError("out dim of x != out dim of f.")
         mean, var = _alloc_like(x.x, x.n * m), _alloc_like(x.x, x.n * m)
         ma, va = L.Arr(mean, True), L.Arr(var, True)
+        if f._post is not None and f._post.dense:      # coupled latent PosteriorGP: diag of its joint covariance + sigma2
+            L.check(lib.lmm_ilmm_post_mean_and_var(f._post.latent_view().ptr, C.c_double(s2), xa.ptr, x.dim, x.n,
+                                                   L.jitters((0.0, s2, 0.0)), ma.ptr, va.ptr))
+            return mean, var
         post = f._post.ptr if f._post is not None else None
         gps = L.gps_array([g.desc() for g in f.fs])
         L.check(lib.lmm_latent_marginals(post, gps, m, xa.ptr, x.dim, x.n, ma.ptr, va.ptr))
@@ -566,6 +591,12 @@ def mean_and_cov(fx: FiniteGP):
         m = len(f.fs)
         if x.out_dim != m:
             raise RuntimeError("out dim of x != out dim of f.")
+        if f._post is not None and f._post.dense:      # coupled latent PosteriorGP: its joint covariance + sigma2 I
+            n = x.n
+            mean, cov = np.empty(n * m), np.empty((n * m) * (n * m))
+            L.check(lib.lmm_ilmm_post_mean_and_cov(f._post.latent_view().ptr, C.c_double(s2), xa.ptr, x.dim, n,
+                                                   L.jitters((0.0, s2, 0.0)), L.Arr(mean, True).ptr, L.Arr(cov, True).ptr))
+            return mean, cov.reshape(n * m, n * m).T
         Ua, Sa, p, post, descs, shard = L.Arr(L.colmajor(np.eye(m))), None, m, f._post, [g.desc() for g in f.fs], (0, m)
         jit = L.jitters((1e-9, 0.0, 0.0))          # cov(f, x) + Sigma_y: no latent jitter for a bare MOGP
     else:
@@ -660,6 +691,23 @@ def rand(rng, fx: FiniteGP, N: Optional[int] = None, jitters=None, add_noise: bo
     lib = L.load()
     xa = x.carr()
     n = x.n
+    if isinstance(f, IndependentMOGP) and f._post is not None and f._post.dense:
+        # rand(rng, f_latent(x, s2)) on the coupled latent PosteriorGP of a dense-H posterior: AbstractGPs' generic
+        # mean + chol(cov + s2 I).U' z, one draw of m n normals per sample (N samples = N repeats, as the reference does)
+        m = len(f.fs)
+        view = f._post.latent_view()
+
+        def one():
+            z = rng.standard_normal(m * n)
+            o = _empty_for(rng, n * m)
+            L.check(lib.lmm_ilmm_post_rand(view.ptr, C.c_double(s2), 0, xa.ptr, x.dim, n, L.Arr(z).ptr, None,
+                                           L.jitters((0.0, s2, 0.0)), L.Arr(o, True).ptr))
+            return o
+        if N is None:
+            return one()
+        cols = [one() for _ in range(N)]
+        import torch
+        return torch.stack(cols, dim=1) if L._is_torch(cols[0]) else np.stack(cols, axis=1)
     if N is not None:
         # reference src/ilmm.jl:90-92 / src/independent_mogp.jl:92-96 repeat the whole call N times; here ONE factorisation
         # serves all N samples (lmm_lmm_rand_multi).  Normals are still drawn sample by sample in the reference's order.

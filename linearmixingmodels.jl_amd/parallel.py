@@ -42,6 +42,71 @@ def _world() -> Tuple[int, int]:
     return (d.get_rank(), d.get_world_size()) if d else (0, 1)
 
 
+ABI_COLLECTIVE = "lmm_allreduce_sum_f64 (RCCL inside liblmm_hip.so)"
+
+
+def _default_abi_init() -> int:
+    L.comm_init_from_torch()
+    return L.comm_world()
+
+
+def _default_abi_probe(world: int) -> None:
+    """First collective on the new communicator, on a host AND a device buffer: sum of (rank + 1) must be world (world + 1) / 2."""
+    import torch
+    rank = _abi_comm()[0]
+    want = world * (world + 1) / 2.0
+    h = np.array([rank + 1.0])
+    L.allreduce_sum(h)
+    d = torch.full((3,), rank + 1.0, dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()))
+    L.allreduce_sum(d)
+    if h[0] != want or not bool((d == want).all()):
+        raise RuntimeError(f"ABI all-reduce probe returned {h[0]} / {d.tolist()}, expected {want}")
+
+
+def _default_agree(ok: bool) -> bool:
+    """True iff EVERY rank reports ok (MIN all-reduce through torch.distributed), so that all ranks take the same branch."""
+    import torch
+    d = _dist()
+    if d is None or d.get_world_size() == 1:
+        return ok
+    dev = torch.device("cuda", torch.cuda.current_device()) if d.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=dev)
+    d.all_reduce(t, op=d.ReduceOp.MIN)
+    return bool(t.item() > 0.5)
+
+
+def select_collective(backend: str, world: int, init_fn: Optional[Callable] = None, probe_fn: Optional[Callable] = None,
+                      agree_fn: Optional[Callable] = None, destroy_fn: Optional[Callable] = None) -> Tuple[bool, Optional[str]]:
+    """Which all-reduce finishes an N > 1 evaluation.  backend "nccl" (one process per GPU over RCCL): the C ABI's own
+    communicator -- what a Julia / C caller binds -- created from torch's rendezvous store and PROVED by one probe collective;
+    if creating or probing it fails on ANY rank, every rank drops it and reduces through torch.distributed instead, and the
+    description carries the reason, so a multi-GPU run still reports a number.  Other backends (gloo rehearsals, CPU tests)
+    reduce through torch.distributed.  Returns (use_abi_collective, description); the hooks exist for the CPU tests."""
+    if world <= 1:
+        return False, None
+    if backend != "nccl":
+        return False, "torch.distributed/" + backend
+    init_fn = init_fn or _default_abi_init
+    probe_fn = probe_fn or _default_abi_probe
+    agree_fn = agree_fn or _default_agree
+    destroy_fn = destroy_fn or L.comm_destroy
+    err = None
+    try:
+        got = init_fn()
+        if got != world:
+            raise RuntimeError(f"ABI communicator has {got} ranks, expected {world}")
+        probe_fn(world)
+    except Exception as e:          # noqa: BLE001 -- any failure means "fall back", the reason is reported
+        err = f"{type(e).__name__}: {e}"
+    if agree_fn(err is None):
+        return True, ABI_COLLECTIVE
+    try:
+        destroy_fn()
+    except Exception:               # noqa: BLE001
+        pass
+    return False, f"torch.distributed/nccl (ABI RCCL failed: {err or 'on another rank'})"
+
+
 def _all_reduce_sum(t):
     """Sum over ranks, in place.  The product path is lmm_allreduce_sum_f64 -- RCCL inside liblmm_hip.so, the same call a Julia
     or C caller makes -- whenever the ABI communicator exists; torch.distributed (gloo in the CPU tests) otherwise."""

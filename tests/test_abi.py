@@ -114,3 +114,60 @@ def test_bench_refuses_a_rank_count_it_is_not_running():
     assert out.returncode != 0
     assert "does not match WORLD_SIZE" in out.stderr
     assert out.stdout.strip() == ""
+
+
+def test_select_collective_branches():
+    """parallel.select_collective (what bench.py --gpus N and the sharded_* helpers use to pick the N > 1 all-reduce):
+    backend nccl -> the C ABI's RCCL communicator is created AND probed, and is the data-path collective; a failure of either step
+    on any rank -> every rank drops it, torch.distributed carries the reduce and the description says why; gloo -> torch.
+    (RCCL itself needs one GPU per rank; the first hardware N > 1 run is the driver's.)"""
+    import lmm_amd
+    from lmm_amd import parallel as PP
+    calls = []
+
+    def ok_init():
+        calls.append("init"); return 2
+
+    def ok_probe(world):
+        calls.append(("probe", world))
+
+    def agree(ok):
+        calls.append(("agree", ok)); return ok
+
+    def destroy():
+        calls.append("destroy")
+
+    assert PP.select_collective("nccl", 1) == (False, None)
+    assert PP.select_collective("gloo", 2) == (False, "torch.distributed/gloo")
+    assert PP.select_collective("nccl", 2, ok_init, ok_probe, agree, destroy) == (True, PP.ABI_COLLECTIVE)
+    assert calls == ["init", ("probe", 2), ("agree", True)]
+    # the communicator comes up with the wrong size
+    calls.clear()
+    use, desc = PP.select_collective("nccl", 4, ok_init, ok_probe, agree, destroy)
+    assert not use and "ABI RCCL failed" in desc and "2 ranks, expected 4" in desc and calls[-1] == "destroy"
+    # init raises (e.g. LMM_ERR_RCCL from ncclCommInitRank)
+
+    def bad_init():
+        raise lmm_amd.LMMError("ncclCommInitRank failed: unhandled system error")
+
+    use, desc = PP.select_collective("nccl", 2, bad_init, ok_probe, agree, destroy)
+    assert not use and desc.startswith("torch.distributed/nccl (ABI RCCL failed: LMMError: ncclCommInitRank failed")
+    # the first collective fails
+
+    def bad_probe(world):
+        raise RuntimeError("ABI all-reduce probe returned 1.0")
+
+    use, desc = PP.select_collective("nccl", 2, ok_init, bad_probe, agree, destroy)
+    assert not use and "probe returned" in desc
+    # this rank is fine but another one is not: still fall back (all ranks must take the same branch)
+    use, desc = PP.select_collective("nccl", 2, ok_init, ok_probe, lambda ok: False, destroy)
+    assert not use and "on another rank" in desc
+
+
+def test_bench_uses_select_collective():
+    """bench.py must route its N > 1 collective choice through select_collective (no unguarded comm_init_from_torch)."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "bench.py")).read()
+    assert "select_collective(backend, world)" in src and "comm_init_from_torch" not in src
+    assert '"per_rank": per_rank' in src and "rccl_ranks" in src

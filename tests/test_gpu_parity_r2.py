@@ -238,9 +238,10 @@ def test_dense_handle_refused_by_per_latent_entry_points(lmm):
     xs2 = np.zeros((5, 2))
     assert lib.lmm_lmm_rand(po.f._post.ptr, ga, Ua.ptr, Sa.ptr, p, m, 0, m, C.c_double(0.1), 1, L.Arr(xs2).ptr, 2, 5, L.Arr(z).ptr,
                             L.Arr(eps).ptr, None, L.Arr(mo, True).ptr) == L.LMM_ERR_DIM
-    # the mirror refuses the coupled latent GP instead of routing it to the per-latent functions
-    with pytest.raises(NotImplementedError):
-        lmm.get_latent_gp(post)(lmm.MOInputIsotopicByOutputs(xs, m), 0.1)
+    # the mirror serves the coupled latent GP through the handle's latent view (H = I_m), never through the per-latent functions
+    # (values: tests/test_gpu_r3.py::test_dense_posterior_latent_gp_vs_oracle)
+    ml_, vl_ = lmm.mean_and_var(lmm.get_latent_gp(post)(lmm.MOInputIsotopicByOutputs(xs, m), 0.1))
+    assert ml_.shape == (5 * m,) and np.all(vl_ > 0.1)
     # and the dense posterior itself still answers
     mu, v = lmm.mean_and_var(post(lmm.MOInputIsotopicByOutputs(xs, p), 0.1))
     assert np.all(np.isfinite(mu)) and np.all(v > 0)

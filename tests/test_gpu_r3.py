@@ -1,0 +1,346 @@
+"""-m gpu, round 3: (a) the bf16-MFMA covariance projection of BASELINE configs[3] (lmm_set_projection_dtype) against the
+oracle at a small shape and against the Float64 path at configs[3]'s own shape, at the tolerance the header states;
+(b) Gram assembly branches that no earlier test reached (lmm_kernels.hip gram_body): the separable-Matern guard fallback
+(unsorted / widely spaced d = 1 inputs with a short lengthscale), strips that mix guarded and unguarded tiles, the LDS
+fast path at its widest (d = 8) and the generic tiles beyond it (d = 9)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import lmm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lmm():
+    import lmm_amd
+    lmm_amd.init(0)
+    return lmm_amd
+
+
+def _model(lmm, gps):
+    K = {"se": lmm.SEKernel, "matern32": lmm.Matern32Kernel, "matern52": lmm.Matern52Kernel}
+    return lmm.independent_mogp([lmm.GP(g["mean"], K[g["kind"]](g["variance"], g["lengthscale"])) for g in gps])
+
+
+def _bf16(a):
+    """Round-to-nearest-even bfloat16 image of a float64 array (through float32, as the kernel does)."""
+    u = np.asarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) >> 16
+    return (u.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+
+
+# ---------------------------------------------------------------------------------------------------
+# (a) bf16 projection
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["bf16", "bf16x2"])
+def test_bf16_projection_small_vs_oracle(lmm, mode):
+    """M = H M_lat, V = abs2.(H) V_lat .+ sigma2 (reference src/oilmm.jl:69-72) with bf16 operands on the matrix pipe:
+    posterior AND prior marginals of a 7-output / 5-latent OILMM (ragged against the 16 x 16 x 32 tile in every direction)
+    against the oracle, inside the header's bound 2^-8 sum_l |H^pw| |lat| (bf16x2: 2^-15); and, for plain bf16, EQUAL (to
+    Float32 accumulation error) to the same sum over bf16-rounded operands computed on the host."""
+    from lmm_amd import _lib as L
+    rng = np.random.default_rng(11)
+    n, ns, p, m = 90, 37, 7, 5
+    x = np.sort(rng.uniform(0, 6, n)); xs = rng.uniform(0, 6, ns)
+    gps = [{"kind": k, "variance": float(rng.uniform(0.5, 2)), "lengthscale": float(rng.uniform(0.5, 2)), "mean": float(rng.normal())}
+           for k in ["se", "matern32", "matern52", "se", "matern52"]]
+    U, S, _ = np.linalg.svd(rng.uniform(size=(p, m)), full_matrices=False)
+    S = np.linspace(2, 1, m)
+    y = rng.standard_normal(n * p)
+    f = lmm.ILMM(_model(lmm, gps), lmm.Orthogonal(U, S))
+    post = lmm.posterior(f(lmm.MOInputIsotopicByOutputs(x, p), 0.1), y)
+    pox = post(lmm.MOInputIsotopicByOutputs(xs, p), 0.1)
+    mo, vo = O.oilmm_mean_var(O.oilmm_posterior(gps, U, S, x, 0.1, y), U, S, xs, 0.1)
+    H = O.orthogonal_dense(U, S)
+    lib = lmm.load()
+    ml, vl = np.empty(m * ns), np.empty(m * ns)
+    L.check(lib.lmm_latent_marginals(post.f._post.ptr, None, m, L.Arr(xs).ptr, 1, ns, L.Arr(ml, True).ptr, L.Arr(vl, True).ptr))
+    ml, vl = ml.reshape(m, ns), vl.reshape(m, ns)
+    try:
+        lmm.set_projection_dtype(mode)
+        assert lmm.get_projection_dtype() == mode
+        mu, v = lmm.mean_and_var(pox)
+        mu_only = lmm.mean(pox)
+        pmu, pv = lmm.mean_and_var(f(lmm.MOInputIsotopicByOutputs(xs, p), 0.1))
+    finally:
+        lmm.set_projection_dtype("native")
+    eps = 2.0 ** -8 if mode == "bf16" else 2.0 ** -15
+    bm = (eps * (np.abs(H) @ np.abs(ml))).reshape(-1)
+    bv = (eps * ((H * H) @ np.abs(vl))).reshape(-1)
+    assert np.all(np.abs(mu - mo) <= 1.01 * bm + 1e-12)
+    assert np.all(np.abs(v - vo) <= 1.01 * bv + 1e-12)
+    assert np.max(np.abs(mu - mo)) > 1e-9 or mode == "bf16x2"       # the bf16 path really ran (Float64 agrees to 1e-12)
+    # mean(fx) alone (mu + K(x*, x) alpha, no solve) takes the same projection; the latent means of the two forms agree to 1e-9
+    assert np.all(np.abs(mu_only - mo) <= 1.01 * bm + 1e-7)
+    if mode == "bf16":
+        np.testing.assert_allclose(mu, (_bf16(H) @ _bf16(ml)).reshape(-1), rtol=0, atol=2e-6 * np.max(np.abs(H) @ np.abs(ml)))
+        np.testing.assert_allclose(v, (_bf16(H * H) @ _bf16(vl + 1e-18)).reshape(-1) + 0.1, rtol=0, atol=2e-6 * np.max((H * H) @ vl))
+    # prior marginals: mean = H mean_l, var = abs2.(H) (variance_l + 1e-18) + sigma2
+    means = np.array([g["mean"] for g in gps]); vars_ = np.array([g["variance"] for g in gps])
+    assert np.all(np.abs(pmu.reshape(p, ns) - (H @ means)[:, None]) <= 1.01 * eps * (np.abs(H) @ np.abs(means))[:, None] + 1e-12)
+    assert np.all(np.abs(pv.reshape(p, ns) - ((H * H) @ vars_ + 0.1)[:, None]) <= 1.01 * eps * ((H * H) @ vars_)[:, None] + 1e-12)
+
+
+def test_c3_bf16_projection_full_size(lmm):
+    """configs[3] AS NAMED: posterior predictive with a 128 x 64 mixing matrix, n_train = n_test = 8192, bf16 MFMA covariance
+    projection -- one GPU's share (8 of the 64 latents; the latent marginals stay Float64).  The Float64 path of the same
+    handle is the reference value (itself checked against host LAPACK on latent 0 by test_c3_shape_posterior_predictive);
+    tolerance: the header's 2^-8 sum_l |H^pw| |lat| bound, elementwise."""
+    import torch
+    from lmm_amd import _lib as L
+    n = 8192
+    P = O.synthetic_problem(64, 128, n, "matern52", True, s2=0.1, seed=0)
+    f = lmm.ILMM(_model(lmm, P["gps"]), lmm.Orthogonal(P["U"], P["S"]), shard=(0, 8))
+    xd = torch.from_numpy(P["x"]).cuda()
+    post = lmm.posterior(f(lmm.MOInputIsotopicByOutputs(xd, 128), 0.1), torch.from_numpy(P["y"]).cuda())
+    xs = P["x"] + 0.5 * 20.0 / 575.0
+    pox = post(lmm.MOInputIsotopicByOutputs(xs, 128), 0.1)
+    mu64, v64 = lmm.mean_and_var(pox, add_noise=True)
+    try:
+        lmm.set_projection_dtype("bf16")
+        mu16, v16 = lmm.mean_and_var(pox, add_noise=True)
+    finally:
+        lmm.set_projection_dtype("native")
+    ml, vl = np.empty(8 * n), np.empty(8 * n)
+    L.check(lmm.load().lmm_latent_marginals(post.f._post.ptr, None, 8, L.Arr(xs).ptr, 1, n, L.Arr(ml, True).ptr, L.Arr(vl, True).ptr))
+    Hs = O.orthogonal_dense(P["U"], P["S"])[:, :8]
+    bm = (2.0 ** -8 * (np.abs(Hs) @ np.abs(ml.reshape(8, n)))).reshape(-1)
+    bv = (2.0 ** -8 * ((Hs * Hs) @ vl.reshape(8, n))).reshape(-1)
+    assert np.all(np.abs(mu16 - mu64) <= 1.01 * bm + 1e-12)
+    assert np.all(np.abs(v16 - v64) <= 1.01 * bv + 1e-12)
+    assert np.max(np.abs(mu16 - mu64)) > 1e-8                                 # not the Float64 kernel in disguise
+    assert np.all(v16 > 0.1 - 1e-12)                                          # sigma2 is added in Float64, after the MFMA sum
+
+
+# ---------------------------------------------------------------------------------------------------
+# (b) Gram assembly branches (lmm_kernels.hip gram_body)
+# ---------------------------------------------------------------------------------------------------
+def _gram(lmm, gp, x, d, n, diag=0.25):
+    import torch
+    from lmm_amd import _lib as L
+    NC = NR = (n + 63) // 64 * 64
+    ld = NR + 16
+    A = torch.full((NC, ld), float("nan"), dtype=torch.float64, device="cuda")
+    xd = torch.from_numpy(np.ascontiguousarray(x.T if d > 1 else x)).cuda()
+    rc = lmm.load().lmm_dev_gram(C.c_void_p(A.data_ptr()), ld, NR, NC, C.c_void_p(xd.data_ptr()), d, n, L.gps_array([gp]), C.c_double(diag))
+    assert rc == 0, lmm.load().lmm_last_error_string()
+    return A.T.cpu().numpy()[:NR]
+
+
+@pytest.mark.parametrize("kind", ["matern32", "matern52"])
+@pytest.mark.parametrize("layout", ["unsorted", "mixed", "sorted_wide"])
+def test_gram_separable_matern_guard(lmm, kind, layout):
+    """d = 1 Matern with a SHORT lengthscale (0.3) on [0, 200]: a |x - c| / l beyond 40 trips the guard of the separable
+    exp(-a|xi - xj|) = min(E_i F_j, F_i E_j) form, and the tile falls back to the per-element exponential.
+      unsorted    : every 64-point strip spans the whole range -> the guard trips in (almost) every interior tile;
+      mixed       : the first 256 points are dense and sorted (guard holds), the rest unsorted -> strips whose tiles take
+                    different branches, and row strips that pass the guard against column tiles that do not;
+      sorted_wide : sorted with spacing 0.5 (a 64-strip spans 32 = 107 lengthscales, a sqrt(5)/0.3 x 32 > 40 -> trips) next to
+                    sorted_dense strips that pass."""
+    rng = np.random.default_rng({"unsorted": 1, "mixed": 2, "sorted_wide": 3}[layout])
+    n = 640 + 37                                   # ragged last strip: border tiles take the generic routine
+    if layout == "unsorted":
+        x = rng.uniform(0, 200, n)
+    elif layout == "mixed":
+        x = np.concatenate([np.sort(rng.uniform(0, 1.5, 256)), rng.uniform(0, 200, n - 256)])
+    else:
+        x = np.concatenate([np.arange(320) * 0.5, 160.0 + np.sort(rng.uniform(0, 2.0, n - 320))])
+    gp = {"kind": kind, "variance": 1.3, "lengthscale": 0.3, "mean": 0.0}
+    got = _gram(lmm, gp, x, 1, n)
+    ref = O.kernelmatrix(gp, x) + 0.25 * np.eye(n)
+    il = np.tril_indices(n)
+    # exp(-s) carries the rounding of its ARGUMENT (s = sqrt(5) |xi - xj| / l, formed as r / l by the oracle and r * (1 / l) by
+    # the kernel: a few ulps of s, i.e. a relative 1e-15 s in the value): 2e-13 down to s ~ 100 (values >= 1e-40), 2e-12 for
+    # the far tail; entries below 1e-290 approach the subnormal range of v_ldexp: absolute there
+    g, r = got[:n, :n][il], ref[il]
+    near = r > 1e-40
+    np.testing.assert_allclose(g[near], r[near], rtol=2e-13, atol=0)
+    np.testing.assert_allclose(g[~near], r[~near], rtol=2e-12, atol=1e-290)
+    NC = got.shape[0]
+    np.testing.assert_array_equal(np.tril(got[n:, n:NC]), np.eye(NC - n))
+
+
+@pytest.mark.parametrize("kind", ["se", "matern32", "matern52"])
+@pytest.mark.parametrize("d", [8, 9, 12])
+def test_gram_high_dimensional_inputs(lmm, kind, d):
+    """d = 8: the widest input dimension of the LDS fast path (column points pre-scaled in LDS, row points in registers);
+    d = 9, 12: beyond it, every tile takes the generic routine.  n = 300 (interior AND border tiles)."""
+    rng = np.random.default_rng(40 + d)
+    n = 300
+    x = rng.uniform(0, 2.5, size=(d, n))
+    gp = {"kind": kind, "variance": 0.7, "lengthscale": 1.9, "mean": 0.0}
+    got = _gram(lmm, gp, x, d, n)
+    ref = O.kernelmatrix(gp, x) + 0.25 * np.eye(n)
+    il = np.tril_indices(n)
+    np.testing.assert_allclose(got[:n, :n][il], ref[il], rtol=2e-13, atol=1e-300)
+
+
+# ---------------------------------------------------------------------------------------------------
+# (c) get_latent_gp(posterior(dense-H ILMM)): the coupled latent PosteriorGP{IndependentMOGP}
+# ---------------------------------------------------------------------------------------------------
+def test_dense_posterior_latent_gp_vs_oracle(lmm):
+    """reference src/ilmm.jl:39 applied to the ILMM that posterior(fx, y) returns (:196-197): get_latent_gp gives the latent
+    PosteriorGP{IndependentMOGP}, which answers the AbstractGPs verbs on MOInputIsotopicByOutputs(x*, m) like any other FiniteGP:
+    mean / var / cov = the latent posterior's joint moments + sigma2 I, logpdf = the generic Gaussian, rand = mean +
+    chol(cov + sigma2 I).U' z, posterior = conditioning on further LATENT observations.  Oracle: O._ilmm_latent_joint on
+    O.ilmm_posterior (the dense (mn) x (mn) restatement)."""
+    import scipy.linalg as sla
+    rng = np.random.default_rng(5)
+    n, ns, p, m = 70, 9, 4, 3                       # m n = 210: four 64-column blocks in the coupled factor
+    x = np.sort(rng.uniform(0, 6, n)); xs = rng.uniform(0, 6, ns)
+    gps = [{"kind": k, "variance": float(rng.uniform(0.5, 2)), "lengthscale": float(rng.uniform(0.5, 2)), "mean": float(rng.normal())}
+           for k in ["se", "matern32", "matern52"]]
+    H = rng.uniform(size=(p, m)); y = rng.standard_normal(n * p)
+    post = lmm.posterior(lmm.ILMM(_model(lmm, gps), H)(lmm.MOInputIsotopicByOutputs(x, p), 0.1), y)
+    fl = lmm.get_latent_gp(post)
+    assert isinstance(fl, lmm.IndependentMOGP)
+    s2 = 0.07
+    flx = fl(lmm.MOInputIsotopicByOutputs(xs, m), s2)
+    po = O.ilmm_posterior(gps, H, x, 0.1, y)
+    mo, Co = O._ilmm_latent_joint(po, xs)
+    Co = Co + s2 * np.eye(m * ns)
+    mu, v = lmm.mean_and_var(flx)
+    np.testing.assert_allclose(mu, mo, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(v, np.diag(Co), rtol=1e-8)
+    mu2, Cg = lmm.mean_and_cov(flx)
+    np.testing.assert_allclose(mu2, mo, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(Cg, Co, rtol=1e-7, atol=1e-10)
+    ys = rng.standard_normal(m * ns)
+    assert lmm.logpdf(flx, ys) == pytest.approx(O.gaussian_logpdf(mo, Co, ys), rel=1e-8)
+    Ym = rng.standard_normal((m * ns, 2))            # matrix-Y: one value per column
+    np.testing.assert_allclose(lmm.logpdf(flx, Ym), [O.gaussian_logpdf(mo, Co, Ym[:, c]) for c in range(2)], rtol=1e-8)
+    z = np.random.default_rng(77).standard_normal(m * ns)
+    smp = lmm.rand(np.random.default_rng(77), flx)
+    np.testing.assert_allclose(smp, mo + np.linalg.cholesky(Co) @ z, rtol=1e-7, atol=1e-9)
+    S2 = lmm.rand(np.random.default_rng(78), flx, 2)
+    assert S2.shape == (m * ns, 2)
+    # conditioning the latent GP on latent observations at x2: Gaussian conditioning of (mo, Co) -- checked through the
+    # predictive mean at a third set of points, which is linear in the joint latent moments
+    x3 = rng.uniform(0, 6, 5)
+    pl2 = lmm.posterior(flx, ys)
+    m3, v3 = lmm.mean_and_var(pl2(lmm.MOInputIsotopicByOutputs(x3, m), 0.0))
+    xall = np.concatenate([xs, x3])
+    ma, Ca = O._ilmm_latent_joint(po, xall)
+    idx_s = np.concatenate([np.arange(ns) + l * (ns + 5) for l in range(m)])
+    idx_3 = np.concatenate([np.arange(5) + ns + l * (ns + 5) for l in range(m)])
+    Kss = Ca[np.ix_(idx_s, idx_s)] + s2 * np.eye(m * ns)
+    K3s = Ca[np.ix_(idx_3, idx_s)]
+    sol = sla.cho_solve(sla.cho_factor(Kss, lower=True), np.column_stack([ys - ma[idx_s], K3s.T]))
+    np.testing.assert_allclose(m3, ma[idx_3] + K3s @ sol[:, 0], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(v3, np.diag(Ca[np.ix_(idx_3, idx_3)] - K3s @ sol[:, 1:]), rtol=1e-5, atol=1e-9)
+    # destroying the ILMM posterior first must not invalidate the latent view (the base's release is deferred)
+    view = fl._post.latent_view()
+    del post, flx, pl2
+    import gc; gc.collect()
+    mu_again, _ = lmm.mean_and_var(fl(lmm.MOInputIsotopicByOutputs(xs, m), s2))
+    np.testing.assert_allclose(mu_again, mo, rtol=1e-8, atol=1e-10)
+    assert view.ptr
+
+
+# ---------------------------------------------------------------------------------------------------
+# (d) predictive-logpdf gradients across a tile boundary: n = 90, ns = 37 => N = 127 joint points, two 64-tiles, the training /
+#     test split (nsplit = 90) unaligned with them, m = 3 latents (round-2 tests stopped at n + ns <= 25: one tile)
+# ---------------------------------------------------------------------------------------------------
+def _fd(f, h=1e-6):
+    return (f(h) - f(-h)) / (2.0 * h)
+
+
+def _gps3(rng):
+    return [{"kind": k, "variance": float(rng.uniform(0.5, 2)), "lengthscale": float(rng.uniform(0.7, 2)), "mean": float(rng.normal())}
+            for k in ["se", "matern32", "matern52"]]
+
+
+def _check_gps_grad(G, F, gps, idx, rel, ab):
+    for l in idx:
+        for key in ("variance", "lengthscale", "mean"):
+            def f1(t, l=l, key=key):
+                g2 = [dict(g) for g in gps]; g2[l][key] += t
+                return F(gps=g2)
+            assert G["gps"][l][key] == pytest.approx(_fd(f1), rel=rel, abs=ab), (l, key)
+
+
+def test_posterior_oilmm_gradient_two_tiles(lmm):
+    rng = np.random.default_rng(71)
+    n, ns, p, m = 90, 37, 4, 3
+    x = np.sort(rng.uniform(0, 9, n)); xs = np.sort(rng.uniform(0, 9, ns))
+    gps = _gps3(rng)
+    U, S, _ = np.linalg.svd(rng.uniform(size=(p, m)), full_matrices=False)
+    y, ys = rng.standard_normal(n * p), rng.standard_normal(ns * p)
+    s2, s2s = 0.3, 0.2
+
+    def F(gps=gps, U=U, S=S, s2=s2, s2s=s2s, y=y, ys=ys):
+        return O.oilmm_logpdf(O.oilmm_posterior(gps, U, S, x, s2, y), U, S, xs, s2s, ys)
+
+    f = lmm.ILMM(_model(lmm, gps), lmm.Orthogonal(U, S))
+    fxs = lmm.posterior(f(lmm.MOInputIsotopicByOutputs(x, p), s2), y)(lmm.MOInputIsotopicByOutputs(xs, p), s2s)
+    G = lmm.logpdf_and_gradient(fxs, ys)
+    assert G["value"] == pytest.approx(F(), rel=1e-9)
+    assert G["sigma2"] == pytest.approx(_fd(lambda t: F(s2s=s2s + t)), rel=2e-5, abs=1e-6)
+    assert G["sigma2_train"] == pytest.approx(_fd(lambda t: F(s2=s2 + t)), rel=2e-5, abs=1e-6)
+    for k in [0, ns + 30, ns * p - 1]:
+        e = np.zeros(ns * p); e[k] = 1.0
+        assert G["y"][k] == pytest.approx(_fd(lambda t: F(ys=ys + t * e)), rel=2e-5, abs=1e-6)
+    for k in [0, n + 70, n * p - 1]:                    # a training point beyond the first tile
+        e = np.zeros(n * p); e[k] = 1.0
+        assert G["y_train"][k] == pytest.approx(_fd(lambda t: F(y=y + t * e)), rel=2e-5, abs=1e-6)
+    _check_gps_grad(G, F, gps, [1], 2e-5, 1e-6)
+    e = np.zeros(m); e[2] = 1.0
+    assert G["S"][2] == pytest.approx(_fd(lambda t: F(S=S + t * e)), rel=2e-5, abs=1e-6)
+
+
+def test_posterior_mogp_gradient_two_tiles(lmm):
+    rng = np.random.default_rng(72)
+    n, ns, m = 90, 37, 3
+    x = np.sort(rng.uniform(0, 9, n)); xs = np.sort(rng.uniform(0, 9, ns))
+    gps = _gps3(rng)
+    y, ys = rng.standard_normal(n * m), rng.standard_normal(ns * m)
+    s2, s2s = 0.4, 0.25
+
+    def F(gps=gps, s2=s2, s2s=s2s, y=y, ys=ys):
+        return O.mogp_logpdf(O.mogp_posterior(gps, x, s2, y), xs, s2s, ys)
+
+    fxs = lmm.posterior(_model(lmm, gps)(lmm.MOInputIsotopicByOutputs(x, m), s2), y)(lmm.MOInputIsotopicByOutputs(xs, m), s2s)
+    G = lmm.logpdf_and_gradient(fxs, ys)
+    assert G["value"] == pytest.approx(F(), rel=1e-9)
+    assert G["sigma2"] == pytest.approx(_fd(lambda t: F(s2s=s2s + t)), rel=2e-5, abs=1e-6)
+    assert G["sigma2_train"] == pytest.approx(_fd(lambda t: F(s2=s2 + t)), rel=2e-5, abs=1e-6)
+    for k in [3, ns + 36, ns * m - 1]:
+        e = np.zeros(ns * m); e[k] = 1.0
+        assert G["y"][k] == pytest.approx(_fd(lambda t: F(ys=ys + t * e)), rel=2e-5, abs=1e-6)
+    for k in [5, 2 * n + 80]:
+        e = np.zeros(n * m); e[k] = 1.0
+        assert G["y_train"][k] == pytest.approx(_fd(lambda t: F(y=y + t * e)), rel=2e-5, abs=1e-6)
+    _check_gps_grad(G, F, gps, [0, 2], 2e-5, 1e-6)
+
+
+def test_posterior_dense_ilmm_gradient_two_tiles(lmm):
+    """the dense two-noise-block core at m N = 381 coupled unknowns (six 64-blocks), nsplit = 90 unaligned."""
+    rng = np.random.default_rng(73)
+    n, ns, p, m = 90, 37, 4, 3
+    x = np.sort(rng.uniform(0, 9, n)); xs = np.sort(rng.uniform(0, 9, ns))
+    gps = _gps3(rng)
+    H = rng.uniform(0.2, 1.0, size=(p, m))
+    y, ys = rng.standard_normal(n * p), rng.standard_normal(ns * p)
+    s2, s2s = 0.3, 0.2
+
+    def F(gps=gps, H=H, s2=s2, s2s=s2s, y=y, ys=ys):
+        return O.ilmm_logpdf(O.ilmm_posterior(gps, H, x, s2, y), H, xs, s2s, ys)
+
+    f = lmm.ILMM(_model(lmm, gps), H)
+    fxs = lmm.posterior(f(lmm.MOInputIsotopicByOutputs(x, p), s2), y)(lmm.MOInputIsotopicByOutputs(xs, p), s2s)
+    G = lmm.logpdf_and_gradient(fxs, ys)
+    assert G["value"] == pytest.approx(F(), rel=1e-7)
+    assert G["sigma2"] == pytest.approx(_fd(lambda t: F(s2s=s2s + t)), rel=5e-5, abs=1e-5)
+    assert G["sigma2_train"] == pytest.approx(_fd(lambda t: F(s2=s2 + t)), rel=5e-5, abs=1e-5)
+    for k in [0, ns + 30, ns * p - 1]:
+        e = np.zeros(ns * p); e[k] = 1.0
+        assert G["y"][k] == pytest.approx(_fd(lambda t: F(ys=ys + t * e)), rel=2e-5, abs=1e-6)
+    for k in [0, n + 70, n * p - 1]:
+        e = np.zeros(n * p); e[k] = 1.0
+        assert G["y_train"][k] == pytest.approx(_fd(lambda t: F(y=y + t * e)), rel=2e-5, abs=1e-6)
+    E = np.zeros((p, m)); E[1, 2] = 1.0
+    assert G["H"][1, 2] == pytest.approx(_fd(lambda t: F(H=H + t * E)), rel=5e-5, abs=1e-5)
+    _check_gps_grad(G, F, gps, [1], 5e-5, 1e-5)
