@@ -92,7 +92,7 @@ int lmm_get_compute_dtype(void);
  *   LMM_PROJ_NATIVE (default): Float64 FMAs (the parity mode).
  *   LMM_PROJ_BF16: H (or abs2.(H)) and the latent marginals are rounded to bfloat16 (round-to-nearest-even) and multiplied on
  *     v_mfma_f32_16x16x32_bf16 with Float32 accumulation; sigma2 is added in Float64.  STATED TOLERANCE: each operand carries a
- *     relative rounding error <= 2^-9, so |M - M_f64| <= 2^-8 * sum_l |H[o,l]| |M_latent[l,s]| (plus Float32 accumulation,
+ *     relative rounding error <= 2^-8 (bfloat16 keeps 8 significant bits), so |M - M_f64| <= 2^-7 * sum_l |H[o,l]| |M_latent[l,s]| (plus Float32 accumulation,
  *     ~m 2^-24) and likewise for V; the latent marginals themselves (Gram, Cholesky, triangular solves) stay in the compute dtype.
  *   LMM_PROJ_BF16X2: the same pipe with each operand split into two bfloat16 terms (hi + lo), three MFMA products: error ~2^-16. */
 typedef enum { LMM_PROJ_NATIVE = 0, LMM_PROJ_BF16 = 1, LMM_PROJ_BF16X2 = 2 } lmm_proj_dtype;

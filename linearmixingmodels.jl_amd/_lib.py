@@ -165,7 +165,7 @@ _PROJ = {"f64": 0, "native": 0, "bf16": 1, "bf16x2": 2}
 
 def set_projection_dtype(dtype: str) -> None:
     """Dtype of the H unprojection of predictive marginals (reference src/oilmm.jl:69-72): "native" (Float64, default), "bf16"
-    (v_mfma_f32_16x16x32_bf16, BASELINE configs[3]; tolerance 2^-8 * sum_l |H||M_lat|, include/lmm_hip.h) or "bf16x2"."""
+    (v_mfma_f32_16x16x32_bf16, BASELINE configs[3]; tolerance 2^-7 * sum_l |H||M_lat|, include/lmm_hip.h) or "bf16x2"."""
     check(load().lmm_set_projection_dtype(C.c_int(_PROJ[dtype])))
 
 

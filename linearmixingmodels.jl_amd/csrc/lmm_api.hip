@@ -42,6 +42,7 @@ struct Ctx {
   // pinned memory are truly asynchronous, pageable ones stall the calling thread until the stream has drained
   char* pin = nullptr;
   size_t pin_cap = 0, pin_off = 0;
+  std::vector<void*> scratch;          // device blocks that live until the NEXT API call starts (call_scratch)
   std::multimap<size_t, void*> pool;   // cached device blocks (size -> ptr)
   std::map<void*, size_t> live;
   std::string err;
@@ -121,6 +122,18 @@ void dev_free(void* p) {
   if (it == g.live.end()) return;
   g.pool.insert({it->second, p});
   g.live.erase(it);
+}
+
+// Scratch that kernels queued by this API call use: handed back to the pool when the NEXT call starts (every entry point returns
+// with its streams drained, and error paths drain the device), so it is never recycled while in flight.
+double* call_scratch(size_t count) {
+  void* p = dev_alloc(count * sizeof(double));
+  g.scratch.push_back(p);
+  return static_cast<double*>(p);
+}
+void release_call_scratch() {
+  for (void* p : g.scratch) dev_free(p);
+  g.scratch.clear();
 }
 
 template <typename T>
@@ -274,9 +287,63 @@ void potrf_rec(const Batch& B, int ld, int NR, int j0, int w, int n_real, hipStr
   potrf_rec(B, ld, NR, r0, w - h, n_real, st);
 }
 
+// Round 3: the same recursion with 128-column panels (lmm_kernels.hip K2c).  A panel = leaf128 (its 128 x 128 diagonal block: factor,
+// 64 x 64 inverse blocks, full inverse into the W2 scratch) + ONE bulk GEMM (rows below: X = P Dinv'); and every trailing update
+// also runs the leaf of the panel that follows it (launch_update_leaf), so that per 128 columns the stream sees two launches
+// (update + leaf, bulk) instead of six.  first_done: the diagonal block of the first panel of [j0, j0 + w) is already factored.
+// Widths that are not multiples of 128 (NC = 64 mod 128) end in the round-2 path for their last 64 columns.
+void potrf_rec_panel(const Batch& B, const BatchPtr& W2, int ld, int NR, int j0, int w, int n_real, hipStream_t st, bool first_done) {
+  const double nb = B.nb;
+  if (w == 128) {
+    if (!first_done) {
+      ProfScope ps(LMM_PROF_DIAG, nb * 2.0 * 128.0 * 128.0 * 128.0 / 3.0, st);
+      launch_leaf128(B.A, (size_t)j0 * ld + j0, ld, B.W, (size_t)(j0 / 64) * 4096, W2, (size_t)(j0 / 128) * 16384, j0, n_real, B.info, B.nb, st);
+    }
+    const int M = NR - (j0 + 128);
+    if (M > 0) {
+      ProfScope ps(LMM_PROF_TRSM, nb * (double)M * 128.0 * 128.0, st);       // triangular solve: M * 128^2 flops
+      launch_panel_bulk(B.A, W2, ld, NR, j0, B.nb, st);
+    }
+    return;
+  }
+  if (w <= 64) { potrf_rec(B, ld, NR, j0, w, n_real, st); return; }          // a trailing 64-column leaf (never pre-factored)
+  const int h = split(w);
+  potrf_rec_panel(B, W2, ld, NR, j0, h, n_real, st, first_done);
+  const int r0 = j0 + h, Nc = w - h;
+  const double Mr = NR - r0;
+  const double outs = (double)Nc * (Nc + 1.0) / 2.0 + (Mr - Nc) * Nc;
+  const size_t offA = (size_t)j0 * ld + r0;
+  if (Nc >= 128) {
+    // + the leaf's 2 * 128^3 / 3 flops, run by one workgroup of this launch
+    ProfScope ps(LMM_PROF_UPDATE, nb * (2.0 * h * outs + 2.0 * 128.0 * 128.0 * 128.0 / 3.0), st, NR - r0, Nc, h, nb * (16.0 * outs + 8.0 * Mr * h));
+    launch_update_leaf(B.A, B.W, W2, B.info, ld, NR, j0, h, Nc, n_real, B.nb, st);
+    potrf_rec_panel(B, W2, ld, NR, r0, Nc, n_real, st, true);
+  } else {
+    {
+      ProfScope ps(LMM_PROF_UPDATE_NARROW, nb * 2.0 * h * outs, st, NR - r0, Nc, h, nb * (16.0 * outs + 8.0 * Mr * h));
+      launch_gemm_nt(B.A, (size_t)r0 * ld + r0, ld, B.A, offA, ld, B.A, offA, ld, NR - r0, Nc, h, 1, false, B.nb, st);
+    }
+    potrf_rec(B, ld, NR, r0, Nc, n_real, st);
+  }
+}
+
+// Entry point of the factorisation of a batch: columns [0, NC) of every matrix.  Float64 batches take the 128-column panel path
+// (LMM_PANEL128=0: the round-2 path); its W2 scratch -- one 128 x 128 inverse per panel and matrix -- lives until the API call ends.
+void potrf_batch(const Batch& B, int ld, int NR, int NC, int n_real, hipStream_t st) {
+  static int panel128 = -1;
+  if (panel128 < 0) { const char* e = getenv("LMM_PANEL128"); panel128 = e ? (atoi(e) != 0) : 1; }
+  if (g_f32 || !panel128 || NC < 128 || (ld & 1)) { potrf_rec(B, ld, NR, 0, NC, n_real, st); return; }
+  const size_t per = (size_t)(NC / 128) * 16384;
+  double* w2 = call_scratch(per * B.nb);
+  BatchPtr W2{};
+  for (int j = 0; j < B.nb; ++j) W2.p[j] = w2 + per * j;
+  potrf_rec_panel(B, W2, ld, NR, 0, NC, n_real, st, false);
+}
+
 void potrf_rec(double* A, int ld, int NR, int j0, int w, double* W, int n_real, int* info, hipStream_t st) {
   Batch B; B.add(A, W, info);
-  potrf_rec(B, ld, NR, j0, w, n_real, st);
+  if (j0 == 0) potrf_batch(B, ld, NR, w, n_real, st);
+  else potrf_rec(B, ld, NR, j0, w, n_real, st);
 }
 
 // R (nr x NC, ldr) <- R * L^-T for an already factored L (ld) with inverse diagonal blocks W.
@@ -591,7 +658,7 @@ int latent_lmls(const double* xd, int d, int n, const lmm_gp_t* gps, const doubl
     }
     launch_gram_batch(ga, nb, s.st);       // one launch per run of equal kernel kinds (blockIdx.z = latent)
     }
-    potrf_rec(B, D.ld, D.NR, 0, D.NC, n, s.st);
+    potrf_batch(B, D.ld, D.NR, D.NC, n, s.st);
     launch_lml_reduce(B.A, nb, D.ld, n, D.NC, nrhs, out.p + (size_t)k0 * nrhs, s.st);
   }
   join_slots(nslots);
@@ -659,6 +726,7 @@ static inline const lmm_post* dense_state(const lmm_post* P) { return P->base ? 
 
 #define REQUIRE_INIT()                                                           \
   if (!g.init) return fail(LMM_ERR_ARG, "lmm_init() has not been called");      \
+  release_call_scratch();                                                        \
   g.pin_off = 0
 
 extern "C" {
@@ -696,6 +764,7 @@ int lmm_shutdown(void) {
   (void)hipDeviceSynchronize();
   if (g.comm) { (void)ncclCommDestroy(g.comm); g.comm = nullptr; g.comm_world = 0; }
   if (g.ev_caller) { (void)hipEventDestroy(g.ev_caller); g.ev_caller = nullptr; }
+  release_call_scratch();
   for (auto& kv : g.pool) (void)hipFree(kv.second);
   g.pool.clear();
   for (int s = 0; s < kMaxStreams; ++s) { (void)hipStreamDestroy(g.streams[s]); (void)hipEventDestroy(g.ev_slot[s]); }
@@ -993,7 +1062,7 @@ int oilmm_grad_core(const double* xd, int d, int N, int nsplit, const double* yd
       Rb.p[j] = Rm[s][j].p; alb.p[j] = alpha.p + (size_t)k * D.NC;
     }
     launch_gram_batch(ga, nb, st);
-    potrf_rec(B, D.ld, D.NR, 0, D.NC, n, st);
+    potrf_batch(B, D.ld, D.NR, D.NC, n, st);
     launch_lml_reduce(B.A, nb, D.ld, n, D.NC, 1, lmld.p + k0, st);
     for (int j = 0; j < nb; ++j) {
       launch_extract_row(Am[s][j].p, D.ld, D.NC, n, alb.p[j], st);
@@ -1837,7 +1906,7 @@ static int posterior_create_common(const double* xd, int d, int n, const lmm_gp_
         B.add(P->L[k].p, P->W[k].p, info.p + k);
       }
       launch_gram_batch(ga, nb, st);
-      potrf_rec(B, D.ld, D.NR, 0, D.NC, n, st);
+      potrf_batch(B, D.ld, D.NR, D.NC, n, st);
       // alpha = L^-T (L^-1 delta): the rider row is z = L^-1 delta (kept as P->z, zero-padded to NC)
       BatchPtr ab{}, zb{};
       for (int j = 0; j < nb; ++j) { ab.p[j] = P->alpha[k0 + j].p; zb.p[j] = P->z[k0 + j].p; }
@@ -2599,7 +2668,7 @@ int lmm_oilmm_post_logpdf(const lmm_post_t* post, const double* U, const double*
       Bt.add(X.B[s][j].p, X.WB[s][j].p, info.p + k);
     }
     cov_at_xs_batch(P, ga, nb, Ds, Bb, Rb, X.ldr, st);
-    potrf_rec(Bt, Ds.ld, Ds.NR, 0, Ds.NC, ns, st);
+    potrf_batch(Bt, Ds.ld, Ds.NR, Ds.NC, ns, st);
     launch_lml_reduce(Bt.A, nb, Ds.ld, ns, Ds.NC, 1, outd.p + k0, st);
   }
   join_slots(nslots);
@@ -2674,7 +2743,7 @@ int lmm_lmm_rand_multi(const lmm_post_t* post, const lmm_gp_t* gps, const double
       Bt.add(Xs.B[s][j].p, Xs.WB[s][j].p, info.p + k);
     }
     cov_at_xs_batch(P, ga, nb, Ds, Bb, Rb, Xs.ldr, st);
-    potrf_rec(Bt, Ds.ld, Ds.NR, 0, Ds.NC, ns, st);      // ONE factorisation per latent, nsamples triangular products
+    potrf_batch(Bt, Ds.ld, Ds.NR, Ds.NC, ns, st);      // ONE factorisation per latent, nsamples triangular products
     for (int j = 0; j < nb; ++j) {
       const int k = k0 + j;
       const double mu_const = P ? 0.0 : gps[l0 + k].mean;

@@ -59,6 +59,23 @@ void launch_dense_cross(double* R, int ldr, int nrows, int ncols, const double* 
 size_t dense_var_partial_elems(int ns, int p, int Ncols);
 void launch_dense_var(const double* R, int ldr, int ns, int m, int Ncols, const double* Hm, int p, const LatentDev* lat,
                       double jitter, double sigma2, double* partial, double* out, hipStream_t st);
+// Arguments of potrf_node_kernel (lmm_kernels.hip K2c): the trailing update of the columns [j0 + h, j0 + h + N) with the factored
+// columns [j0, j0 + h), fused with the factorisation of the next 128-column panel's diagonal block; or that panel's bulk rows.
+struct NodeArgs {
+  BatchPtr A, W, W2;      // factor matrices; 64 x 64 inverse blocks; 128 x 128 inverse panels (scratch)
+  BatchInfo info;
+  int ld, NR, j0, h, N, n_real;
+  int MT;                 // 128-row tiles of the region (rows j0 + h .. NR - 1)
+  int rest_items, full_items, splitk;     // work items of the column tiles 1.. (gemm_work_item's enumeration and split-K tail)
+  int mode;               // NODE_UPDATE | NODE_LEAF, or NODE_BULK
+};
+void launch_leaf128(const BatchPtr& A, size_t offD, int ld, const BatchPtr& W, size_t offW, const BatchPtr& W2, size_t offW2,
+                    int gcol0, int n_real, const BatchInfo& info, int nb, hipStream_t st);
+// bulk rows of the panel at column r0 (its diagonal block factored, its inverse in W2): X = P Dinv' in place
+void launch_panel_bulk(const BatchPtr& A, const BatchPtr& W2, int ld, int NR, int r0, int nb, hipStream_t st);
+// C -= A B' for the region at r0 = j0 + h (N columns, multiple of 128) + leaf128 on its top-left block
+void launch_update_leaf(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2, const BatchInfo& info, int ld, int NR, int j0, int h,
+                        int N, int n_real, int nb, hipStream_t st);
 void launch_diag64(const BatchPtr& A, size_t offA, int ld, const BatchPtr& W, size_t offW, int gcol0, int n_real,
                    const BatchInfo& info, int nb, hipStream_t st);
 void launch_gemm_nt(const BatchPtr& C, size_t offC, int ldc, const BatchPtr& A, size_t offA, int lda, const BatchPtr& B,

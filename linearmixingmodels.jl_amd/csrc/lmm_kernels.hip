@@ -902,9 +902,12 @@ __device__ __forceinline__ void diag64m_mfmas(Diag64mState& st) {
 }
 constexpr int DIAG_SP = 18;                                        // row stride of Sp (doubles): 16-byte aligned rows, conflict-free b128 reads
 constexpr int DIAG_LS = 68;                                        // column stride of Lo / Wl
-template <int s>
+// DIRECT: the finished L entries of a step leave for global memory straight from the registers (four columns x sixteen consecutive
+// rows per store instruction: four 128-byte segments) instead of being collected in the Lo image for a coalesced epilogue --
+// the form leaf128 uses, which has no LDS to spare for Lo.
+template <int s, bool DIRECT = false, typename TS = double>
 __device__ __forceinline__ void diag64m_step(Diag64mState& st, double* __restrict__ Sp, double* __restrict__ Wt, double* __restrict__ Lo,
-                                             int c, int g) {
+                                             int c, int g, void* __restrict__ Ag = nullptr, size_t offAg = 0, int ldg = 0) {
   constexpr int SP = DIAG_SP, LS = DIAG_LS;
   constexpr int J = 4 * s, jb = s >> 2, q = s & 3, o = s & 1;
   __builtin_amdgcn_sched_barrier(0);
@@ -957,7 +960,8 @@ __device__ __forceinline__ void diag64m_step(Diag64mState& st, double* __restric
   for (int rb = jb; rb < 4; ++rb) {
     const double y = __builtin_fma(bo[rb][1].y, k3, __builtin_fma(bo[rb][1].x, k2, __builtin_fma(bo[rb][0].y, k1, bo[rb][0].x * k0)));
     const int row = 16 * rb + c;
-    Lo[(J + g) * LS + row] = y;                                    // L[row][J+g], final for row >= J+g (the rest is never stored)
+    if constexpr (DIRECT) { if (row >= J + g) MatIO<TS>::st1(Ag, offAg + (size_t)(J + g) * ldg + row, y); }
+    else Lo[(J + g) * LS + row] = y;                               // L[row][J+g], final for row >= J+g (the rest is never stored)
     st.Ym[o][rb] = (rb > jb || row > J + 3) ? y : 0.0;             // rows of and above the pivot block take no part in the update
     st.nY[o][rb] = -st.Ym[o][rb];
   }
@@ -979,6 +983,51 @@ template <int s>
 __device__ __forceinline__ void diag64m_steps(Diag64mState& st, double* __restrict__ Sp, double* __restrict__ Wt, double* __restrict__ Lo,
                                               int c, int g) {
   if constexpr (s < 16) { diag64m_step<s>(st, Sp, Wt, Lo, c, g); diag64m_steps<s + 1>(st, Sp, Wt, Lo, c, g); }
+}
+template <int s, typename TS>
+__device__ __forceinline__ void diag64m_steps_direct(Diag64mState& st, double* __restrict__ Sp, double* __restrict__ Wt, int c, int g,
+                                                     void* __restrict__ Ag, size_t offAg, int ldg) {
+  if constexpr (s < 16) {
+    diag64m_step<s, true, TS>(st, Sp, Wt, nullptr, c, g, Ag, offAg, ldg);
+    diag64m_steps_direct<s + 1, TS>(st, Sp, Wt, c, g, Ag, offAg, ldg);
+  }
+}
+
+// One wave factors the 64 x 64 block at (A, offA, ld) in place (lower triangle) and leaves W = L^-1 in the LDS image
+// Wl[col * DIAG_LS + row] (zeros above the diagonal).  Sp: 64 * DIAG_SP doubles, Wt: 256 doubles of LDS work area.  Returns the mask of
+// non-positive (or NaN) pivots.  l = lane.  The last step's lagging MFMAs (group 2 of step 15) do not exist: nothing is pending.
+template <typename TS>
+__device__ __forceinline__ unsigned long long diag64m_wave(void* __restrict__ A, size_t offA, int ld, double* __restrict__ Sp,
+                                                           double* __restrict__ Wt, double* __restrict__ Wl, int l) {
+  const int c = l & 15, g = l >> 4;
+  Diag64mState st;
+#pragma unroll
+  for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+    for (int cb = 0; cb <= rb; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * rb + 4 * r + g, col = 16 * cb + c;
+        st.S[rb][cb][r] = (row >= col) ? MatIO<TS>::ld1(A, offA + (size_t)col * ld + row) : 0.0;
+        st.V[rb][cb][r] = (row == col) ? 1.0 : 0.0;
+      }
+  st.e0 = g == 0 ? 1.0 : 0.0; st.e1 = g == 1 ? 1.0 : 0.0; st.e2 = g == 2 ? 1.0 : 0.0; st.e3 = g == 3 ? 1.0 : 0.0;
+  st.badmask = 0ull;
+  diag64m_steps_direct<0, TS>(st, Sp, Wt, c, g, A, offA, ld);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Wl[(16 * cb + c) * DIAG_LS + 16 * rb + 4 * r + g] = cb <= rb ? st.V[rb][cb][r] : 0.0;
+  return st.badmask;
+}
+// first non-positive pivot among the real columns gcol0 .. of a 64-pivot mask -> LAPACK-style info (0: none)
+__device__ __forceinline__ int diag_info_of(unsigned long long badmask, int gcol0, int n_real) {
+  const int lim = n_real - gcol0;                                  // pivots k < lim are real columns
+  const unsigned long long m = lim >= 64 ? badmask : (lim <= 0 ? 0ull : (badmask & ((1ull << lim) - 1ull)));
+  return m != 0ull ? gcol0 + __builtin_ctzll(m) + 1 : 0;
 }
 
 template <typename TS>
@@ -1080,12 +1129,19 @@ __device__ unsigned long long g_clk_probe[4];     // tools/gemm_ablate: shader-c
 #endif
 
 // Work item -> (tile, k-part) of the update kernels (shared by the f64 and f32 variants).
+__device__ __forceinline__ void gemm_work_item_from(int item, int c0, int BM, int BN, int N, int lower, int MT, int full_items, int splitk,
+                                                    int& part, int& nparts, int& ti, int& tj);
 __device__ __forceinline__ void gemm_work_item(int BM, int BN, int N, int lower, int MT, int full_items, int splitk, int& part,
                                                int& nparts, int& ti, int& tj) {
+  gemm_work_item_from(blockIdx.x, 0, BM, BN, N, lower, MT, full_items, splitk, part, nparts, ti, tj);
+}
+// item: work-item index; c0: first column tile of the enumeration (the fused node kernel hands column tile 0 out separately)
+__device__ __forceinline__ void gemm_work_item_from(int item, int c0, int BM, int BN, int N, int lower, int MT, int full_items, int splitk,
+                                                    int& part, int& nparts, int& ti, int& tj) {
   // Work item -> (tile, k-part).  Tiles on/below the diagonal are enumerated column by column; the first
   // `full_items` tiles run their whole K range, the remaining ones (the last, partial round of workgroups over the
   // chip) are split `splitk`-ways along K and combined with f64 atomics, so the launch ends without a long tail.
-  int tile = blockIdx.x;
+  int tile = item;
   part = 0; nparts = 1;
   {
     // XCD-aware order (speed only): workgroups are dealt round-robin over the 8 XCDs, so workgroup 8q + g runs on the XCD
@@ -1112,7 +1168,7 @@ __device__ __forceinline__ void gemm_work_item(int BM, int BN, int N, int lower,
     for (int r0 = 0; r0 < MT; r0 += 8) {
       const int r1 = (r0 + 8 < MT) ? r0 + 8 : MT;             // band rows [r0, r1)
       bool found = false;
-      for (int c = 0; c < NTc; ++c) {
+      for (int c = c0; c < NTc; ++c) {
         int first = lower ? (c * BN) / BM : 0;                 // first active row tile of column c
         if (first < r0) first = r0;
         const int cnt = r1 - first;
@@ -1983,6 +2039,305 @@ __global__ __launch_bounds__(256, 2) void gemm16h_kernel(BatchPtr Cb, size_t gof
       for (int r = 0; r < 4; ++r) cpv[(size_t)(4 * r) * ldc + 16 * u] = cv[u][r] - acc[v][u][r];
   }
 }
+// ---------------------------------------------------------------------------------------------------
+// K2c (round 3): the 128-column PANEL as part of the update launch that precedes it.
+// Until round 2 every 128 columns cost five latency-bound launches behind each trailing update (diag64, TRSM, 64-column update,
+// diag64, TRSM: 11.5 ms of the 96 ms a rank's 4-latent share of the C2 job takes, all of it serial).  Now:
+//   leaf128 (device function, one workgroup): the 128 x 128 diagonal block D = [A11 .; A21 A22] -> L (in place), the two 64 x 64
+//       inverse blocks W11, W22 (what the solves downstream use) AND the full inverse Dinv = [W11 0; W21 W22],
+//       W21 = -W22 L21 W11, into a 128 x 128 panel of the W2 scratch:
+//         A  wave 0: diag64m on A11 (L11 straight to global, W11 -> LDS X)   | waves 1-3: A21 -> LDS Y
+//         B  all   : L21 = A21 W11'  -> global and Y;   T = L21 W11 -> X;   A22 -= L21 L21' -> global
+//         C  wave 0: diag64m on A22' (L22 to global, W22 -> LDS Y)
+//         D  all   : W21 = -W22 T -> W2
+//       LDS: Sp + Wt + X + Y = 80 896 bytes, so two workgroups of the node kernel still share a CU.
+//   bulk (the rows below the block): X = P Dinv' in place -- ONE pipelined MFMA GEMM with K = 128 (two passes over the panel rows
+//       instead of seven).
+//   potrf_node_kernel: the trailing update  C -= A B'  of gemm16p_kernel, in which the workgroup that owns the top-left tile of
+//       the target region -- the diagonal block of the NEXT panel -- goes on to factor it (leaf128) while the other workgroups of
+//       the launch are still updating: for every update of more than one scheduling round the leaf disappears from the critical
+//       path.  Column tile 0 of the region is handed out first (items 0 .. MT-1, never split along K); the remaining tiles follow
+//       in gemm_work_item's band order with its split-K tail.  mode NODE_BULK: the same kernel runs the bulk tiles.
+// ---------------------------------------------------------------------------------------------------
+// D (64 x 64) = A R on four waves (wave w: rows 32 (w & 1).., columns 32 (w >> 1)..), operands in LDS with element strides
+// (A[i][k] = As[i sai + k sak], R[k][j] = Rs[k srk + j srj]); emit(u, v, r, row, col, value) receives every entry once, (u, v, r)
+// being compile-time after unrolling (so that callers can keep per-entry registers).
+template <typename Emit>
+__device__ __forceinline__ void wg_mm64(const double* __restrict__ As, int sai, int sak, const double* __restrict__ Rs, int srk, int srj,
+                                        int w, int l, Emit emit) {
+  const int c = l & 15, g = l >> 4, wi = 32 * (w & 1), wj = 32 * (w >> 1);
+  d4 acc[2][2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int v = 0; v < 2; ++v) acc[u][v] = (d4){0.0, 0.0, 0.0, 0.0};
+  // all 64 operand values of the wave first (the reads are independent of the MFMAs), then 64 MFMAs back to back
+  double fa[16][2], fr[16][2];
+  const double* pa = As + (wi + c) * sai + g * sak;
+  const double* pr = Rs + g * srk + (wj + c) * srj;
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) fa[ks][u] = pa[16 * u * sai + 4 * ks * sak];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) fr[ks][v] = pr[4 * ks * srk + 16 * v * srj];
+  }
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int v = 0; v < 2; ++v) acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ks][u], fr[ks][v], acc[u][v], 0, 0, 0);
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int v = 0; v < 2; ++v)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) emit(u, v, r, wi + 16 * u + 4 * r + g, wj + 16 * v + c, acc[u][v][r]);
+}
+
+constexpr int LEAF_LDS_DOUBLES = 64 * DIAG_SP + 256 + 2 * 64 * DIAG_LS;      // 10112 doubles = 80 896 bytes
+// lds: LEAF_LDS_DOUBLES doubles.  A: the matrix (double), offD: element offset of the diagonal block; W: 64 x 64 inverse blocks
+// (offW: block of the first 64 columns; the second follows at + 4096); W2p: this panel's 128 x 128 inverse (column-major, ld 128).
+// All 256 threads of the workgroup call it; it starts and ends with everything in LDS free for reuse.
+__device__ __forceinline__ void leaf128_dev(double* __restrict__ lds, double* __restrict__ A, size_t offD, int ld,
+                                            double* __restrict__ W, size_t offW, double* __restrict__ W2p, int gcol0, int n_real,
+                                            int* __restrict__ info) {
+  constexpr int LS = DIAG_LS;
+  double* Sp = lds;
+  double* Wt = Sp + 64 * DIAG_SP;
+  double* X = Wt + 256;
+  double* Y = X + 64 * LS;
+  const int t = threadIdx.x, l = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const size_t off21 = offD + 64, off22 = offD + (size_t)64 * ld + 64;
+  unsigned long long bad1 = 0ull, bad2 = 0ull;
+  // A
+  if (w == 0) {
+    bad1 = diag64m_wave<double>(A, offD, ld, Sp, Wt, X, l);
+  } else {
+    for (int e = t - 64; e < 4096; e += 192) { const int row = e & 63, col = e >> 6; Y[col * LS + row] = A[off21 + (size_t)col * ld + row]; }
+  }
+  __syncthreads();
+  // W11 (X) -> the 64 x 64 inverse block and the top-left block of the panel inverse; zeros into the panel's top-right block
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int e = t + 256 * i, row = e & 63, col = e >> 6;
+    const double v = X[col * LS + row];
+    W[offW + (size_t)col * 64 + row] = v;
+    W2p[(size_t)col * 128 + row] = v;
+    W2p[(size_t)(64 + col) * 128 + row] = 0.0;
+  }
+  // B: L21 = A21 W11'   (A[i][k] = Y[k][i]; R[k][j] = W11[j][k] = X[k][j])
+  double l21[2][2][4];
+  wg_mm64(Y, 1, LS, X, LS, 1, w, l, [&](int u, int v, int r, int, int, double x) { l21[u][v][r] = x; });
+  // this lane's entries of A22 (the D layout of wg_mm64), requested before the barrier
+  double a22[2][2][4];
+  {
+    const int c_ = l & 15, g_ = l >> 4, wi = 32 * (w & 1), wj = 32 * (w >> 1);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int v = 0; v < 2; ++v)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = wi + 16 * u + 4 * r + g_, col = wj + 16 * v + c_;
+          a22[u][v][r] = row >= col ? A[off22 + (size_t)col * ld + row] : 0.0;
+        }
+  }
+  __syncthreads();                                               // every wave has read A21 from Y
+  {
+    const int c_ = l & 15, g_ = l >> 4, wi = 32 * (w & 1), wj = 32 * (w >> 1);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int v = 0; v < 2; ++v)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = wi + 16 * u + 4 * r + g_, col = wj + 16 * v + c_;
+          Y[col * LS + row] = l21[u][v][r];
+          A[off21 + (size_t)col * ld + row] = l21[u][v][r];
+        }
+  }
+  __syncthreads();                                               // Y = L21
+  // T = L21 W11   (A[i][k] = Y[k][i]; R[k][j] = W11[k][j] = X[j][k])   and   A22 -= L21 L21'   (R[k][j] = L21[j][k] = Y[k][j])
+  double tt[2][2][4];
+  wg_mm64(Y, 1, LS, X, 1, LS, w, l, [&](int u, int v, int r, int, int, double x) { tt[u][v][r] = x; });
+  wg_mm64(Y, 1, LS, Y, LS, 1, w, l, [&](int u, int v, int r, int row, int col, double x) {
+    if (row >= col) A[off22 + (size_t)col * ld + row] = a22[u][v][r] - x;
+  });
+  __syncthreads();                                               // reads of X (W11) and Y (L21) done; A22' is in global memory
+  {
+    const int c_ = l & 15, g_ = l >> 4, wi = 32 * (w & 1), wj = 32 * (w >> 1);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int v = 0; v < 2; ++v)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) X[(wj + 16 * v + c_) * LS + wi + 16 * u + 4 * r + g_] = tt[u][v][r];
+  }
+  // C
+  if (w == 0) bad2 = diag64m_wave<double>(A, off22, ld, Sp, Wt, Y, l);
+  __syncthreads();                                               // X = T, Y = W22
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int e = t + 256 * i, row = e & 63, col = e >> 6;
+    const double v = Y[col * LS + row];
+    W[offW + 4096 + (size_t)col * 64 + row] = v;
+    W2p[(size_t)(64 + col) * 128 + 64 + row] = v;
+  }
+  // D: W21 = -W22 T   (A[i][k] = W22[i][k] = Y[k][i]; R[k][j] = T[k][j] = X[j][k])
+  wg_mm64(Y, 1, LS, X, 1, LS, w, l, [&](int, int, int, int row, int col, double x) { W2p[(size_t)col * 128 + 64 + row] = -x; });
+  if (t == 0) {
+    int i = diag_info_of(bad1, gcol0, n_real);
+    if (i == 0) i = diag_info_of(bad2, gcol0 + 64, n_real);
+    if (i) atomicCAS(info, 0, i);
+  }
+  __syncthreads();                                               // LDS free again
+}
+
+#define NODE_UPDATE 1
+#define NODE_LEAF 2
+#define NODE_BULK 4
+__global__ __launch_bounds__(256) void leaf128_kernel(BatchPtr Ab, size_t offD, int ld, BatchPtr Wb, size_t offW, BatchPtr W2b, size_t offW2,
+                                                      int gcol0, int n_real, BatchInfo infob) {
+  extern __shared__ __attribute__((aligned(16))) double node_lds[];
+  leaf128_dev(node_lds, Ab.p[blockIdx.x], offD, ld, Wb.p[blockIdx.x], offW, W2b.p[blockIdx.x] + offW2, gcol0, n_real, infob.p[blockIdx.x]);
+}
+
+template <int DEPTH>
+__global__ __launch_bounds__(256, 2) void potrf_node_kernel(NodeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double node_lds[];
+  constexpr int BM = 128, BN = 128, BK = 16;
+  constexpr int SA = BM + 16, SB = BN + 16;
+  double (*As)[BK * SA] = reinterpret_cast<double (*)[BK * SA]>(node_lds);
+  double (*Bs)[BK * SB] = reinterpret_cast<double (*)[BK * SB]>(node_lds + 2 * BK * SA);
+  double* Am = a.A.p[blockIdx.y];
+  const int r0 = a.j0 + a.h;
+  const int M = a.NR - r0;
+  // role of this workgroup
+  int part = 0, nparts = 1, tj = 0, ti = 0;
+  bool bulk = false;
+  {
+    int item = blockIdx.x;
+    const int n_upd = (a.mode & NODE_UPDATE) ? a.MT + a.rest_items : 0;
+    if (item < n_upd) {
+      if (item < a.MT) ti = item;                                  // column tile 0, top to bottom: the next panel
+      else gemm_work_item_from(item - a.MT, 1, BM, BN, a.N, 1, a.MT, a.full_items, a.splitk, part, nparts, ti, tj);
+    } else { bulk = true; ti = item - n_upd + 1; }
+  }
+  double* C = Am + (size_t)r0 * a.ld + r0;
+  const double* A = bulk ? C : Am + (size_t)a.j0 * a.ld + r0;
+  const double* B = bulk ? a.W2.p[blockIdx.y] + (size_t)(r0 / 128) * 16384 : A;
+  const int lda = a.ld, ldb = bulk ? 128 : a.ld, ldc = a.ld;
+  const int N = bulk ? 128 : a.N, K = bulk ? 128 : a.h;
+  const int bm = ti * BM, bn = tj * BN;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int wr = (w & 1) * 64, wc = (w >> 1) * 64;
+  const bool active = (bm + wr < M) && (bn + wc < N) && (bulk || !(bm + wr + 63 < bn + wc));
+  const int nk_all = K / BK;
+  const int kc0 = (int)((long long)nk_all * part / nparts);
+  const int kc1 = (int)((long long)nk_all * (part + 1) / nparts);
+  A += (size_t)kc0 * BK * lda;
+  B += (size_t)kc0 * BK * ldb;
+  const int nk = kc1 - kc0;
+
+  int rowa = bm + 2 * (t & 63); if (rowa > M - 2) rowa = M - 2;
+  int rowb = bn + 2 * (t & 63); if (rowb > N - 2) rowb = N - 2;
+  const double* ga0 = A + (size_t)(t >> 6) * lda + rowa;       // thread t stages rows 2(t%64).. of k-columns t/64 + 4q
+  const double* gb0 = B + (size_t)(t >> 6) * ldb + rowb;
+  const int sa0 = (t >> 6) * SA + 2 * (t & 63);
+  const int sb0 = (t >> 6) * SB + 2 * (t & 63);
+  d2 ra[4], rb[4], ra2[DEPTH == 2 ? 4 : 1], rb2[DEPTH == 2 ? 4 : 1];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { ra[q] = *reinterpret_cast<const d2*>(ga0 + (size_t)(4 * q) * lda); rb[q] = *reinterpret_cast<const d2*>(gb0 + (size_t)(4 * q) * ldb); }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { *reinterpret_cast<d2*>(&As[0][sa0 + 4 * q * SA]) = ra[q]; *reinterpret_cast<d2*>(&Bs[0][sb0 + 4 * q * SB]) = rb[q]; }
+  {
+    const int k1 = nk > 1 ? 1 : 0, k2 = nk > 2 ? 2 : nk - 1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      ra[q] = *reinterpret_cast<const d2*>(ga0 + (size_t)k1 * BK * lda + (size_t)(4 * q) * lda);
+      rb[q] = *reinterpret_cast<const d2*>(gb0 + (size_t)k1 * BK * ldb + (size_t)(4 * q) * ldb);
+      if (DEPTH == 2) {
+        ra2[q] = *reinterpret_cast<const d2*>(ga0 + (size_t)k2 * BK * lda + (size_t)(4 * q) * lda);
+        rb2[q] = *reinterpret_cast<const d2*>(gb0 + (size_t)k2 * BK * ldb + (size_t)(4 * q) * ldb);
+      }
+    }
+  }
+  __syncthreads();
+
+  d4 acc[4][4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[v][u] = (d4){0.0, 0.0, 0.0, 0.0};
+  const int l15 = lane & 15, lk = lane >> 4;
+  const int offA = lk * SA + wr + l15, offB = lk * SB + wc + l15;
+  double fa[2][4], fb[2][4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) { fa[0][u] = As[0][offA + 16 * u]; fb[0][u] = Bs[0][offB + 16 * u]; }
+
+  if (DEPTH == 1) {
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = kt & 1;
+      const double* as = &As[buf][0];
+      const double* bs = &Bs[buf][0];
+      double* asn = &As[buf ^ 1][0];
+      double* bsn = &Bs[buf ^ 1][0];
+      const int kn = (kt + 2 < nk) ? kt + 2 : nk - 1;
+      LMM_TILE_BODY(ra, rb, kn)
+    }
+  } else {
+    for (int kt = 0; kt < nk; kt += 2) {
+      {
+        const double* as = &As[0][0]; const double* bs = &Bs[0][0];
+        double* asn = &As[1][0]; double* bsn = &Bs[1][0];
+        const int kn = (kt + 3 < nk) ? kt + 3 : nk - 1;
+        LMM_TILE_BODY(ra, rb, kn)
+      }
+      if (kt + 1 < nk) {
+        const double* as = &As[1][0]; const double* bs = &Bs[1][0];
+        double* asn = &As[0][0]; double* bsn = &Bs[0][0];
+        const int kn = (kt + 4 < nk) ? kt + 4 : nk - 1;
+        LMM_TILE_BODY(ra2, rb2, kn)
+      }
+    }
+  }
+  if (active) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      double* cpv = C + (size_t)(bn + wc + 16 * v + lk) * ldc + bm + wr + l15;
+      if (bulk) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) cpv[(size_t)(4 * r) * ldc + 16 * u] = acc[v][u][r];
+      } else if (nparts == 1) {
+        double cv[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) cv[u][r] = cpv[(size_t)(4 * r) * ldc + 16 * u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) cpv[(size_t)(4 * r) * ldc + 16 * u] = cv[u][r] - acc[v][u][r];
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) unsafeAtomicAdd(cpv + (size_t)(4 * r) * ldc + 16 * u, -acc[v][u][r]);
+      }
+    }
+  }
+  if ((a.mode & NODE_LEAF) && !bulk && ti == 0 && tj == 0) {       // uniform over the workgroup
+    __syncthreads();                                               // the tile's stores are issued; the staging LDS is free
+    leaf128_dev(node_lds, Am, (size_t)r0 * a.ld + r0, a.ld, a.W.p[blockIdx.y], (size_t)(r0 / 64) * 4096,
+                a.W2.p[blockIdx.y] + (size_t)(r0 / 128) * 16384, r0, a.n_real, a.info.p[blockIdx.y]);
+  }
+}
+
 #undef LMM_MFMA16H_ALL
 #undef LMM_TILE_BODY
 #undef LMM_MFMA16_ALL
@@ -2471,7 +2826,7 @@ __global__ __launch_bounds__(256) void mix_kernel(const double* __restrict__ lat
 // on v_mfma_f32_16x16x32_bf16: both operands are rounded to bfloat16 (round-to-nearest-even of the Float32 image; for pw = 2 the
 // SQUARED entry abs2(H) is what is rounded, as abs2.(H) * V in the reference's order of operations), products and the sum over l
 // accumulate in Float32 on the matrix pipe, out_add (sigma2) is added in Float64.  TERMS = 1: plain bf16 (relative input error
-// <= 2^-9 each, so |error| <= ~2^-8 sum_l |H^pw| |lat|); TERMS = 2: each operand split hi + lo into two bf16 values and the three
+// <= 2^-8 each, so |error| <= ~2^-7 sum_l |H^pw| |lat|); TERMS = 2: each operand split hi + lo into two bf16 values and the three
 // leading products hi hi + hi lo + lo hi summed (~2^-16: Float32-class), for callers who want the bf16 pipe without the loss.
 // Lane map (cdna_hip_programming.md section 3): lane l holds A[row l&15][k = 8(l>>4) + j], B[k = 8(l>>4) + j][col l&15], j = 0..7,
 // D[row 4(l>>4) + r][col l&15].  A = H^pw (16 outputs x 32 latents), B = lat (32 latents x 16 points): D's lanes run along the
@@ -2868,6 +3223,58 @@ void launch_dense_cov(const double* S, int lds, int ns, int m, const double* Hm,
 void launch_dense_assemble(const DenseArgs& a, hipStream_t st) {
   dim3 grid(a.nrows / 64, a.ncols / 64);
   hipLaunchKernelGGL(ilmm_dense_assemble_kernel, grid, dim3(256), 0, st, a);
+}
+
+// ---- round 3: 128-column panels (leaf128 / bulk) and the update fused with the next panel's leaf (K2c) ----
+static void node_lds_attr() {
+  static bool done = false;
+  if (done) return;
+  const int bytes = LEAF_LDS_DOUBLES * 8;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(leaf128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_node_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_node_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  done = true;
+}
+void launch_leaf128(const BatchPtr& A, size_t offD, int ld, const BatchPtr& W, size_t offW, const BatchPtr& W2, size_t offW2,
+                    int gcol0, int n_real, const BatchInfo& info, int nb, hipStream_t st) {
+  node_lds_attr();
+  hipLaunchKernelGGL(leaf128_kernel, dim3(nb), dim3(256), LEAF_LDS_DOUBLES * 8, st, A, offD, ld, W, offW, W2, offW2, gcol0, n_real, info);
+}
+void launch_panel_bulk(const BatchPtr& A, const BatchPtr& W2, int ld, int NR, int r0, int nb, hipStream_t st) {
+  const int M = NR - r0, MT = (M + 127) / 128;
+  if (MT <= 1 || nb <= 0) return;
+  node_lds_attr();
+  NodeArgs a{};
+  a.A = A; a.W2 = W2; a.ld = ld; a.NR = NR; a.j0 = r0; a.h = 0; a.N = 128; a.MT = MT; a.mode = NODE_BULK;
+  hipLaunchKernelGGL(potrf_node_kernel<1>, dim3(MT - 1, nb), dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
+}
+void launch_update_leaf(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2, const BatchInfo& info, int ld, int NR, int j0, int h,
+                        int N, int n_real, int nb, hipStream_t st) {
+  const int r0 = j0 + h, M = NR - r0, MT = (M + 127) / 128, NT = N / 128;
+  if (nb <= 0 || N <= 0 || h <= 0) return;
+  node_lds_attr();
+  static int cus = 0;
+  if (cus == 0) { int dev = 0; cus = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); }
+  long long T = 0;                                            // tiles of the column tiles 1 .. NT-1 (lower trapezoid)
+  for (int tj = 1; tj < NT; ++tj) T += MT - tj;
+  // split-K tail of the last partial scheduling round, as in launch_gemm_nt (a round = one tile per CU, cus / nb per matrix)
+  const int slots = (cus / nb) > 0 ? (cus / nb) : 1;
+  const int nk = h / 16;
+  int full_items = (int)(T / slots) * slots, splitk = 1;
+  const int R = (int)(T - full_items);
+  static int deterministic = -1;
+  if (deterministic < 0) { const char* e = getenv("LMM_DETERMINISTIC"); deterministic = (e && atoi(e) != 0) ? 1 : 0; }
+  if (!deterministic && R > 0 && R <= slots / 2 && nk >= 8) {
+    splitk = slots / R; if (splitk > nk / 4) splitk = nk / 4; if (splitk < 1) splitk = 1;
+  }
+  if (splitk == 1) full_items = (int)T;
+  NodeArgs a{};
+  a.A = A; a.W = W; a.W2 = W2; a.info = info; a.ld = ld; a.NR = NR; a.j0 = j0; a.h = h; a.N = N; a.n_real = n_real; a.MT = MT;
+  a.full_items = full_items; a.splitk = splitk; a.rest_items = full_items + (int)(T - full_items) * splitk;
+  a.mode = NODE_UPDATE | NODE_LEAF;
+  const dim3 grid(MT + a.rest_items, nb);
+  if (h >= 1024) hipLaunchKernelGGL(potrf_node_kernel<2>, grid, dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
+  else hipLaunchKernelGGL(potrf_node_kernel<1>, grid, dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
 }
 
 int g_diag_form = -1;

@@ -484,9 +484,13 @@ def test_update_kernel_variants_agree():
             "f = lmm_amd.ILMM(lmm_amd.independent_mogp([lmm_amd.GP(lmm_amd.Matern52Kernel()) for _ in range(3)]), lmm_amd.Orthogonal(P['U'], P['S'])); "
             "print(json.dumps(lmm_amd.logpdf(f(lmm_amd.MOInputIsotopicByOutputs(P['x'], 5), 0.1), P['y'])))") % os.path.dirname(HERE)
     vals = {}
-    for name, env in [("default", {}), ("m16_0", {"LMM_GEMM_M16": "0"}), ("m16_1", {"LMM_GEMM_M16": "1"}), ("flags", {"LMM_GEMM_M16": "0", "LMM_GEMM_FLAGS": "1"}),
-                      ("diag_form1", {"LMM_DIAG_FORM": "1"}), ("diag_form2", {"LMM_DIAG_FORM": "2"}), ("full_tiles", {"LMM_HALF_TILES": "0"}),
-                      ("no_ragged_split", {"LMM_RAGGED_SPLIT": "0"})]:
+    # round 3: the default factorisation takes the 128-column panel path (potrf_node_kernel / leaf128); LMM_PANEL128=0 is the
+    # round-2 path, which the older kernel switches act on
+    r2 = {"LMM_PANEL128": "0"}
+    for name, env in [("default", {}), ("round2_path", r2), ("m16_0", dict(r2, LMM_GEMM_M16="0")), ("m16_1", dict(r2, LMM_GEMM_M16="1")),
+                      ("flags", dict(r2, LMM_GEMM_M16="0", LMM_GEMM_FLAGS="1")),
+                      ("diag_form1", dict(r2, LMM_DIAG_FORM="1")), ("diag_form2", dict(r2, LMM_DIAG_FORM="2")), ("full_tiles", dict(r2, LMM_HALF_TILES="0")),
+                      ("no_ragged_split", dict(r2, LMM_RAGGED_SPLIT="0")), ("deterministic", {"LMM_DETERMINISTIC": "1"})]:
         out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr[-2000:]
         vals[name] = json.loads(out.stdout.strip().splitlines()[-1])

@@ -39,7 +39,7 @@ def _bf16(a):
 def test_bf16_projection_small_vs_oracle(lmm, mode):
     """M = H M_lat, V = abs2.(H) V_lat .+ sigma2 (reference src/oilmm.jl:69-72) with bf16 operands on the matrix pipe:
     posterior AND prior marginals of a 7-output / 5-latent OILMM (ragged against the 16 x 16 x 32 tile in every direction)
-    against the oracle, inside the header's bound 2^-8 sum_l |H^pw| |lat| (bf16x2: 2^-15); and, for plain bf16, EQUAL (to
+    against the oracle, inside the header's bound 2^-7 sum_l |H^pw| |lat| (each bf16 operand carries 2^-8; bf16x2: 2^-15); and, for plain bf16, EQUAL (to
     Float32 accumulation error) to the same sum over bf16-rounded operands computed on the host."""
     from lmm_amd import _lib as L
     rng = np.random.default_rng(11)
@@ -67,7 +67,7 @@ def test_bf16_projection_small_vs_oracle(lmm, mode):
         pmu, pv = lmm.mean_and_var(f(lmm.MOInputIsotopicByOutputs(xs, p), 0.1))
     finally:
         lmm.set_projection_dtype("native")
-    eps = 2.0 ** -8 if mode == "bf16" else 2.0 ** -15
+    eps = 2.0 ** -7 if mode == "bf16" else 2.0 ** -15
     bm = (eps * (np.abs(H) @ np.abs(ml))).reshape(-1)
     bv = (eps * ((H * H) @ np.abs(vl))).reshape(-1)
     assert np.all(np.abs(mu - mo) <= 1.01 * bm + 1e-12)
@@ -88,7 +88,7 @@ def test_c3_bf16_projection_full_size(lmm):
     """configs[3] AS NAMED: posterior predictive with a 128 x 64 mixing matrix, n_train = n_test = 8192, bf16 MFMA covariance
     projection -- one GPU's share (8 of the 64 latents; the latent marginals stay Float64).  The Float64 path of the same
     handle is the reference value (itself checked against host LAPACK on latent 0 by test_c3_shape_posterior_predictive);
-    tolerance: the header's 2^-8 sum_l |H^pw| |lat| bound, elementwise."""
+    tolerance: the header's 2^-7 sum_l |H^pw| |lat| bound, elementwise."""
     import torch
     from lmm_amd import _lib as L
     n = 8192
@@ -107,8 +107,8 @@ def test_c3_bf16_projection_full_size(lmm):
     ml, vl = np.empty(8 * n), np.empty(8 * n)
     L.check(lmm.load().lmm_latent_marginals(post.f._post.ptr, None, 8, L.Arr(xs).ptr, 1, n, L.Arr(ml, True).ptr, L.Arr(vl, True).ptr))
     Hs = O.orthogonal_dense(P["U"], P["S"])[:, :8]
-    bm = (2.0 ** -8 * (np.abs(Hs) @ np.abs(ml.reshape(8, n)))).reshape(-1)
-    bv = (2.0 ** -8 * ((Hs * Hs) @ vl.reshape(8, n))).reshape(-1)
+    bm = (2.0 ** -7 * (np.abs(Hs) @ np.abs(ml.reshape(8, n)))).reshape(-1)
+    bv = (2.0 ** -7 * ((Hs * Hs) @ vl.reshape(8, n))).reshape(-1)
     assert np.all(np.abs(mu16 - mu64) <= 1.01 * bm + 1e-12)
     assert np.all(np.abs(v16 - v64) <= 1.01 * bv + 1e-12)
     assert np.max(np.abs(mu16 - mu64)) > 1e-8                                 # not the Float64 kernel in disguise
@@ -344,3 +344,67 @@ def test_posterior_dense_ilmm_gradient_two_tiles(lmm):
     E = np.zeros((p, m)); E[1, 2] = 1.0
     assert G["H"][1, 2] == pytest.approx(_fd(lambda t: F(H=H + t * E)), rel=5e-5, abs=1e-5)
     _check_gps_grad(G, F, gps, [1], 5e-5, 1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------
+# (e) the 128-column panel path of the factorisation (lmm_kernels.hip K2c: leaf128, bulk GEMM by the panel inverse, the trailing
+#     update fused with the next panel's leaf) against host LAPACK, through the exported building block lmm_dev_potrf
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,nrider", [(128, 0), (128, 64), (192, 64), (256, 128), (500, 3), (576, 64), (1000, 1), (1536, 192), (2111, 5)])
+def test_panel_factorisation_vs_lapack(lmm, n, nrider):
+    """L (lower triangle, in place), the rider rows R L^-T and the 64 x 64 inverse diagonal blocks W_b = L_bb^-1 for widths that
+    are 0 and 64 mod 128, with rider counts that make the row count an even and an odd multiple of 64 (half row tiles), one to
+    twenty-four 64-column blocks (one to five recursion levels; n = 2111: updates of K >= 1024 take the two-tile-deep prefetch)."""
+    import torch
+    import scipy.linalg as sla
+    rng = np.random.default_rng(n + nrider)
+    NC = (n + 63) // 64 * 64
+    NR = (NC + nrider + 63) // 64 * 64
+    ld = NR + 16
+    G = rng.standard_normal((n, n + 8))
+    K = G @ G.T / (n + 8) + 0.5 * np.eye(n)
+    R = rng.standard_normal((NR - NC, NC))
+    full = np.zeros((NR, NC))
+    full[:n, :n] = np.tril(K)
+    full[n:NC, n:] = np.eye(NC - n)
+    full[NC:, :] = R
+    A = torch.full((NC, ld), float("nan"), dtype=torch.float64, device="cuda")      # column-major: A[col][row]; upper triangle stays NaN
+    At = torch.from_numpy(np.ascontiguousarray(full.T))
+    A[:, :NR] = At.cuda()
+    iu = np.triu_indices(NC, 1)
+    Ah = A.cpu().numpy(); Ah[iu[1], iu[0]] = np.nan; A = torch.from_numpy(Ah).cuda()   # never-read upper triangle: NaN
+    W = torch.full((NC // 64, 64, 64), float("nan"), dtype=torch.float64, device="cuda")
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    lib = lmm.load()
+    rc = lib.lmm_dev_potrf(C.c_void_p(A.data_ptr()), NR, NC, ld, C.c_void_p(W.data_ptr()), n, C.c_void_p(info.data_ptr()))
+    assert rc == 0, lib.lmm_last_error_string()
+    assert int(info.item()) == 0
+    got = A.cpu().numpy().T[:NR]                                  # [row][col]
+    Kp = np.eye(NC); Kp[:n, :n] = K
+    Lref = np.linalg.cholesky(Kp)
+    il = np.tril_indices(NC)
+    np.testing.assert_allclose(got[:NC][il], Lref[il], rtol=0, atol=2e-12 * np.abs(Lref).max())
+    if NR > NC:
+        Xref = sla.solve_triangular(Lref, R.T, lower=True).T      # R L^-T
+        np.testing.assert_allclose(got[NC:], Xref, rtol=0, atol=1e-10 * max(1.0, np.abs(Xref).max()))
+    Wh = W.cpu().numpy()                                          # [block][col][row]
+    for b in range(NC // 64):
+        Lbb = Lref[64 * b:64 * b + 64, 64 * b:64 * b + 64]
+        np.testing.assert_allclose(Wh[b].T @ Lbb, np.eye(64), rtol=0, atol=1e-10)
+        assert np.all(np.triu(Wh[b].T, 1) == 0.0)
+
+
+def test_panel_path_reports_the_failing_pivot(lmm):
+    """a non-positive pivot inside a fused leaf (second panel, second 64-block) surfaces as the LAPACK-style 1-based info."""
+    import torch
+    n = 384
+    K = np.eye(n) * 2.0
+    K[300, 300] = -1.0
+    ld = n + 16
+    A = torch.zeros((n, ld), dtype=torch.float64, device="cuda")
+    A[:, :n] = torch.from_numpy(np.ascontiguousarray(np.tril(K).T)).cuda()
+    W = torch.zeros((n // 64, 64, 64), dtype=torch.float64, device="cuda")
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    rc = lmm.load().lmm_dev_potrf(C.c_void_p(A.data_ptr()), n, n, ld, C.c_void_p(W.data_ptr()), n, C.c_void_p(info.data_ptr()))
+    assert rc == 0
+    assert int(info.item()) == 301
