@@ -49,8 +49,8 @@ WORKLOADS = {
 NOTEBOOK_PUBLISHED_EVALS_PER_S = 1.0 / 0.172541   # median 172.541 ms, unstated CPU, Julia 1.6.1
 FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD (155 measured)
 FP64_MFMA_PEAK_TFLOPS = 78.6      # AMD MI355X datasheet FP64 matrix (= vector) peak; the local guide lists no FP64 MFMA
-                                  # rate.  Measured here: v_mfma_f64_4x4x4_4b_f64 issues at 76.8 TFLOP/s (tools/mfma_probe3,
-                                  # profiles/r01_probes/probe3.log) = 97.7 % of it, so 78.6 is the denominator.
+                                  # rate.  Measured here: v_mfma_f64_16x16x4_f64 with VGPR accumulators issues at 77.7 TFLOP/s
+                                  # (tools/mfma_probe4, profiles/r02) = 98.9 % of it, so 78.6 is the denominator.
 HBM_PEAK_GBS = 8000.0             # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
@@ -323,7 +323,8 @@ def main():
                 if tj.get("workload") == args.workload:
                     traffic = tj.get("update_kernel", {}).get("bytes_per_launch")
             roof = {"bound": "mfma", "kernel": ("gemm32_kernel<128,false> (v_mfma_f32_32x32x2_f32 SYRK/GEMM trailing update)" if args.dtype == "f32"
-                                                else "gemm16p_kernel<DEPTH> + gemm16h_kernel for a ragged last 64 rows (v_mfma_f64_16x16x4_f64, VGPR accumulators, software-pipelined SYRK/GEMM trailing update)"),
+                                                else "potrf_node_kernel<DEPTH> (v_mfma_f64_16x16x4_f64, VGPR accumulators, software-pipelined SYRK/GEMM trailing update; "
+                                                     "one workgroup per matrix also factors the next panel's 128 x 128 diagonal block)"),
                     "achieved": round(ach, 3), "peak": peak_tf, "unit": "TFLOP/s",
                     "frac": round(ach / peak_tf, 4), "traffic": traffic if args.dtype == "f64" else None,
                     "traffic_source": ("profiles/pmc_traffic.json: fabric bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
@@ -343,7 +344,7 @@ def main():
         extra["kernel_classes_ms"] = {c: round(v["ms"], 3) for c, v in prof.items()}
         tf = C.c_double()
         if lib.lmm_dev_mfma_f64_peak(C.byref(tf)) == 0:
-            extra["mfma_f64_issue_rate_measured_tflops"] = round(tf.value, 2)
+            extra["mfma_f64_16x16x4_issue_rate_measured_tflops"] = round(tf.value, 2)
         fl = m * n ** 3 / 3.0 if orth else (m * n) ** 3 / 3.0
         if evals_per_s:
             extra["end_to_end_cholesky_tflops"] = round(fl * evals_per_s / 1e12 / (1 if orth else world), 3)

@@ -21,6 +21,9 @@
  *     lmm_last_error_detail() the failing latent and LAPACK-style pivot `info`
  *     (-> Julia `PosDefException(info)`).  Nothing is ever NaN-and-continue.
  *   - calls are blocking; the library never keeps a caller pointer after returning.
+ *   - reproducibility: by default the last partial scheduling round of a trailing update is split along K and combined with f64
+ *     atomics, so results are reproducible to ~1e-13 relative, NOT bitwise; LMM_DETERMINISTIC=1 (environment) disables the split
+ *     and makes every result bitwise reproducible (slower tail of the large updates).
  *   - threading: one context per process (= one GPU).  Every entry point takes the context lock, so calls from several
  *     threads are safe but execute one at a time (the context owns ONE set of HIP streams, one device-memory pool and one
  *     pinned staging arena, which concurrent calls would have to share).  Concurrency across GPUs = one process per GPU.
@@ -344,19 +347,22 @@ int lmm_normals(unsigned long long seed, unsigned long long stream, size_t count
  * kernel alone (the production path runs latents on concurrent streams, where durations overlap).
  * work = algorithmic flops (MFMA classes) or algorithmic HBM bytes (Gram assembly) summed over launches. */
 typedef enum {
-  LMM_PROF_GRAM = 0,          /* gram_kernel: lower-triangular f64 write, bytes                        */
-  LMM_PROF_UPDATE = 1,        /* gemm_nt_kernel<128,SUB>: SYRK/GEMM trailing update, flops              */
-  LMM_PROF_UPDATE_NARROW = 2, /* gemm_nt_kernel<64,SUB>: 64-column update inside a 128 panel, flops     */
-  LMM_PROF_TRSM = 3,          /* gemm_nt_kernel<64,SET>: panel TRSM by inverse diagonal block, flops    */
-  LMM_PROF_DIAG = 4,          /* diag64m_kernel: 64x64 factor + inverse, flops                          */
+  LMM_PROF_GRAM = 0,          /* gram_batch_kernel: lower-triangular f64 write, bytes                                          */
+  LMM_PROF_UPDATE = 1,        /* potrf_node_kernel<DEPTH> (round 3: SYRK/GEMM trailing update + the next panel's leaf128 in one
+                                 launch; LMM_PANEL128=0 / fp32: gemm16p_kernel / gemm16h_kernel / gemm32_kernel), flops         */
+  LMM_PROF_UPDATE_NARROW = 2, /* gemm44_kernel<64,false>: 64-column update (round-2 path; trailing 64 columns), flops           */
+  LMM_PROF_TRSM = 3,          /* potrf_node_kernel<1> in bulk mode: panel rows x 128 x 128 inverse (round-2 path:
+                                 gemm44_kernel<64,true>, TRSM by the 64 x 64 inverse block), flops                              */
+  LMM_PROF_DIAG = 4,          /* leaf128_kernel (first panel) / diag64m_kernel: diagonal-block factor + inverse, flops          */
   LMM_PROF_COUNT = 5
 } lmm_prof_class;
 typedef struct { long long launches; double ms; double work; double bytes; /* algorithmic HBM bytes */ } lmm_prof_entry_t;
 int lmm_profile_begin(int serial);
 int lmm_profile_end(lmm_prof_entry_t* out /* LMM_PROF_COUNT entries */);
 
-/* f64 MFMA issue-rate microbenchmark: returns measured TFLOP/s of v_mfma_f64_4x4x4_4b_f64 (the form the update kernel
- * issues; its 4 A x 16 B operand pattern). */
+/* f64 MFMA issue-rate microbenchmark: measured TFLOP/s of v_mfma_f64_16x16x4_f64 in the form the update kernels issue it (16
+ * accumulator blocks in architectural VGPRs, 4 + 4 operand fragments per k-step; tools/mfma_probe4: 77.7 = 98.9 % of the 78.6
+ * datasheet peak -- the same instruction with AccVGPR accumulators issues at 36). */
 int lmm_dev_mfma_f64_peak(double* tflops);
 
 #ifdef __cplusplus

@@ -296,12 +296,12 @@ void potrf_rec_panel(const Batch& B, const BatchPtr& W2, int ld, int NR, int j0,
   const double nb = B.nb;
   if (w == 128) {
     if (!first_done) {
-      ProfScope ps(LMM_PROF_DIAG, nb * 2.0 * 128.0 * 128.0 * 128.0 / 3.0, st);
+      ProfScope ps(LMM_PROF_DIAG, nb * 2.0 * 128.0 * 128.0 * 128.0 / 3.0, st, 128, 128, 128);
       launch_leaf128(B.A, (size_t)j0 * ld + j0, ld, B.W, (size_t)(j0 / 64) * 4096, W2, (size_t)(j0 / 128) * 16384, j0, n_real, B.info, B.nb, st);
     }
     const int M = NR - (j0 + 128);
     if (M > 0) {
-      ProfScope ps(LMM_PROF_TRSM, nb * (double)M * 128.0 * 128.0, st);       // triangular solve: M * 128^2 flops
+      ProfScope ps(LMM_PROF_TRSM, nb * (double)M * 128.0 * 128.0, st, M, 128, 128);       // triangular solve: M * 128^2 flops
       launch_panel_bulk(B.A, W2, ld, NR, j0, B.nb, st);
     }
     return;
@@ -2872,7 +2872,7 @@ int lmm_dev_mfma_f64_peak(double* tflops) {
   std::lock_guard<std::mutex> lk(g_mu);
   REQUIRE_INIT();
   LMM_TRY
-  const int blocks = 256 * 2, iters = 20000;
+  const int blocks = 256 * 2, iters = 5000;
   Buf<double> out((size_t)blocks * 256);
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
@@ -2883,7 +2883,7 @@ int lmm_dev_mfma_f64_peak(double* tflops) {
   HIPCHK(hipEventSynchronize(e1));
   float ms = 0.f;
   HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-  const double flops = (double)blocks * 4 /*waves*/ * iters * 64.0 * 512.0;
+  const double flops = (double)blocks * 4 /*waves*/ * iters * 16.0 * 2048.0;      // 16 MFMAs of 16 x 16 x 4 x 2 flops per iteration
   *tflops = flops / (ms * 1e-3) / 1e12;
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return LMM_OK;

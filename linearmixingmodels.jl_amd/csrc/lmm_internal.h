@@ -68,6 +68,7 @@ struct NodeArgs {
   int MT;                 // 128-row tiles of the region (rows j0 + h .. NR - 1)
   int rest_items, full_items, splitk;     // work items of the column tiles 1.. (gemm_work_item's enumeration and split-K tail)
   int mode;               // NODE_UPDATE | NODE_LEAF, or NODE_BULK
+  int xcds;               // XCDs the consecutive items of one matrix are dealt over (8 / gcd(batch size, 8))
 };
 void launch_leaf128(const BatchPtr& A, size_t offD, int ld, const BatchPtr& W, size_t offW, const BatchPtr& W2, size_t offW2,
                     int gcol0, int n_real, const BatchInfo& info, int nb, hipStream_t st);

@@ -1130,14 +1130,16 @@ __device__ unsigned long long g_clk_probe[4];     // tools/gemm_ablate: shader-c
 
 // Work item -> (tile, k-part) of the update kernels (shared by the f64 and f32 variants).
 __device__ __forceinline__ void gemm_work_item_from(int item, int c0, int BM, int BN, int N, int lower, int MT, int full_items, int splitk,
-                                                    int& part, int& nparts, int& ti, int& tj);
+                                                    int& part, int& nparts, int& ti, int& tj, int xcds = 8);
 __device__ __forceinline__ void gemm_work_item(int BM, int BN, int N, int lower, int MT, int full_items, int splitk, int& part,
                                                int& nparts, int& ti, int& tj) {
   gemm_work_item_from(blockIdx.x, 0, BM, BN, N, lower, MT, full_items, splitk, part, nparts, ti, tj);
 }
 // item: work-item index; c0: first column tile of the enumeration (the fused node kernel hands column tile 0 out separately)
+// xcds: over how many XCDs consecutive items of ONE matrix are dealt (8 when blockIdx.x = item; the node kernel, whose dispatch order
+// is matrix-fastest, passes 8 / gcd(batch size, 8): with 8 or 16 matrices per batch a matrix stays on one XCD and no remap is needed)
 __device__ __forceinline__ void gemm_work_item_from(int item, int c0, int BM, int BN, int N, int lower, int MT, int full_items, int splitk,
-                                                    int& part, int& nparts, int& ti, int& tj) {
+                                                    int& part, int& nparts, int& ti, int& tj, int xcds) {
   // Work item -> (tile, k-part).  Tiles on/below the diagonal are enumerated column by column; the first
   // `full_items` tiles run their whole K range, the remaining ones (the last, partial round of workgroups over the
   // chip) are split `splitk`-ways along K and combined with f64 atomics, so the launch ends without a long tail.
@@ -1148,10 +1150,10 @@ __device__ __forceinline__ void gemm_work_item_from(int item, int c0, int BM, in
     // of group g.  Give group g the contiguous logical tiles [32g, 32g + 32) of every round of 256: with bands of 8 row
     // tiles that is an 8-row x 4-column patch of C per XCD (12 operand panels through that XCD's L2 instead of 18+;
     // measured FETCH_SIZE of the K = 8192 SYRK: 11.9 -> 7.3 GB; 64-tile patches measured no better).
-    const int nfull = (full_items / 256) * 256;
-    if (tile < nfull) {
-      const int g8 = tile & 7, q = tile >> 3;
-      tile = (q >> 5) * 256 + g8 * 32 + (q & 31);
+    const int win = 32 * xcds, nfull = (full_items / win) * win;
+    if (tile < nfull && xcds > 1) {
+      const int g8 = tile % xcds, q = tile / xcds;
+      tile = (q >> 5) * win + g8 * 32 + (q & 31);
     }
   }
   if (tile >= full_items) {
@@ -1773,136 +1775,7 @@ __global__ __launch_bounds__(256, 1) void gemm16p_kernel(BatchPtr Cb, size_t gof
   }
 }
 
-// ---------------------------------------------------------------------------------------------------
-#define LMM_D_RD(SETN, KS, ASRC, BSRC)                                                                                  \
-    _Pragma("unroll") for (int u = 0; u < 4; ++u) { fa[SETN][u] = ASRC[offA + 4 * (KS) * SA + 16 * u]; fb[SETN][u] = BSRC[offB + 4 * (KS) * SB + 16 * u]; }
-template <int NS>
-__global__ __launch_bounds__(256, 1) void gemm16d_kernel(BatchPtr Cb, size_t goffC, int ldc, BatchPtr Ab, size_t goffA, int lda,
-                                                          BatchPtr Bb, size_t goffB, int ldb,
-                                                          int M, int N, int K, int lower, int MT, int full_items,
-                                                          int splitk, int kfrom_row) {
-  double* C = Cb.p[blockIdx.y] + goffC;
-  const double* A = Ab.p[blockIdx.y] + goffA;
-  const double* B = Bb.p[blockIdx.y] + goffB;
-  constexpr int BM = 128, BN = 128, BK = 16;
-  constexpr int SA = BM + 16, SB = BN + 16;
-  constexpr int STAGE = BK * SA + BK * SB;                         // doubles per stage: A image then B image
-  extern __shared__ __attribute__((aligned(16))) double lds_d[];   // NS stages
-
-  int part = 0, nparts = 1, tj = 0, ti = 0;
-  gemm_work_item(BM, BN, N, lower, MT, full_items, splitk, part, nparts, ti, tj);
-  const int bm = ti * BM, bn = tj * BN;
-  const int t = threadIdx.x, lane = t & 63;
-  const int w = __builtin_amdgcn_readfirstlane(t >> 6);            // wave index, scalar: the LDS destination of a load is wave-uniform
-  const int wr = (w & 1) * 64, wc = (w >> 1) * 64;
-  const bool active = (bm + wr < M) && (bn + wc < N) && !(lower && bm + wr + 63 < bn + wc);
-  const int nk_all = K / BK;
-  int kc0 = (int)((long long)nk_all * part / nparts);
-  const int kc1 = (int)((long long)nk_all * (part + 1) / nparts);
-  if (kfrom_row && kc0 < bm / BK) kc0 = bm / BK;
-  A += (size_t)kc0 * BK * lda;
-  B += (size_t)kc0 * BK * ldb;
-  const int nk = kc1 - kc0;
-
-  int rowa = bm + 2 * lane; if (rowa > M - 2) rowa = M - 2;
-  int rowb = bn + 2 * lane; if (rowb > N - 2) rowb = N - 2;
-  const double* ga0 = A + (size_t)w * lda + rowa;                 // wave w loads k-columns w + 4q (q = 0..3) of each tile: lane i rows 2i, 2i+1
-  const double* gb0 = B + (size_t)w * ldb + rowb;
-  // one k-column of tile `kt` (clamped: surplus requests of the last tiles reload a valid tile into a free stage) into stage `st`
-  auto load_a = [&](int kt, int st, int q) {
-    __builtin_amdgcn_global_load_lds(ga0 + (size_t)kt * BK * lda + (size_t)(4 * q) * lda, lds_d + st * STAGE + (w + 4 * q) * SA, 16, 0, 0);
-  };
-  auto load_b = [&](int kt, int st, int q) {
-    __builtin_amdgcn_global_load_lds(gb0 + (size_t)kt * BK * ldb + (size_t)(4 * q) * ldb, lds_d + st * STAGE + BK * SA + (w + 4 * q) * SB, 16, 0, 0);
-  };
-  // prologue: tiles 0 .. NS-2 into stages 0 .. NS-2
-#pragma unroll
-  for (int j = 0; j < NS - 1; ++j) {
-    const int kt = j < nk ? j : nk - 1;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { load_a(kt, j, q); load_b(kt, j, q); }
-  }
-  __builtin_amdgcn_s_waitcnt(0x0F70 | ((8 * (NS - 2)) & 15) | (((8 * (NS - 2)) >> 4) << 14));     // vmcnt(8 (NS-2)): tile 0 has landed
-  __syncthreads();
-
-  d4 acc[4][4];
-#pragma unroll
-  for (int v = 0; v < 4; ++v)
-#pragma unroll
-    for (int u = 0; u < 4; ++u) acc[v][u] = (d4){0.0, 0.0, 0.0, 0.0};
-  const int l15 = lane & 15, lk = lane >> 4;
-  const int offA = lk * SA + wr + l15, offB = BK * SA + lk * SB + wc + l15;      // B image follows the A image inside a stage
-  double fa[2][4], fb[2][4];                          // two fragment sets: the k-step being multiplied and the next one
-#pragma unroll
-  for (int u = 0; u < 4; ++u) { fa[0][u] = lds_d[offA + 16 * u]; fb[0][u] = lds_d[offB + 16 * u]; }
-
-  int s_cur = 0, s_ld = NS - 1;                       // stage of tile kt; stage that tile kt + NS - 1 goes to (= the stage of tile kt - 1)
-  for (int kt = 0; kt < nk; ++kt) {
-    const double* as = lds_d + s_cur * STAGE;
-    const int s_nxt = (s_cur + 1 == NS) ? 0 : s_cur + 1;
-    const double* asn = lds_d + s_nxt * STAGE;
-    const int kl = (kt + NS - 1 < nk) ? kt + NS - 1 : nk - 1;
-    // k-step 0: MFMAs on set 0; reads of k-step 1 into set 1; the four A columns of tile kt + NS - 1
-    LMM_D_RD(1, 1, as, as)
-    load_a(kl, s_ld, 0); load_a(kl, s_ld, 1); load_a(kl, s_ld, 2); load_a(kl, s_ld, 3);
-    LMM_MFMA16_ALL(0);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x100, 1); }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { LMM_SGB(0x008, 2); LMM_SGB(0x020, 1); }
-    // k-step 1: MFMAs on set 1; reads of k-step 2 into set 0; the four B columns
-    LMM_D_RD(0, 2, as, as)
-    load_b(kl, s_ld, 0); load_b(kl, s_ld, 1); load_b(kl, s_ld, 2); load_b(kl, s_ld, 3);
-    LMM_MFMA16_ALL(1);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x100, 1); }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { LMM_SGB(0x008, 2); LMM_SGB(0x020, 1); }
-    // k-step 2: MFMAs on set 0; reads of k-step 3 into set 1
-    LMM_D_RD(1, 3, as, as)
-    LMM_MFMA16_ALL(0);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x100, 1); }
-    LMM_SGB(0x008, 8);
-    // k-step 3, first part: 10 MFMAs on set 1; then this wave's columns of tile kt + 1 must have landed (the 8 (NS - 2) requests
-    // issued after them may still be in flight), and the barrier publishes the tile and retires stage s_cur
-    LMM_MFMA16(1, 0, 0); LMM_MFMA16(1, 0, 1); LMM_MFMA16(1, 0, 2); LMM_MFMA16(1, 0, 3);
-    LMM_MFMA16(1, 1, 3); LMM_MFMA16(1, 1, 2); LMM_MFMA16(1, 1, 1); LMM_MFMA16(1, 1, 0);
-    LMM_MFMA16(1, 2, 0); LMM_MFMA16(1, 2, 1);
-    __builtin_amdgcn_s_waitcnt(0x0F70 | ((8 * (NS - 2)) & 15) | (((8 * (NS - 2)) >> 4) << 14));
-    __builtin_amdgcn_s_barrier();                    // NOT __syncthreads(): its fence would wait for vmcnt(0), i.e. for the requests just issued
-    // second part: 6 MFMAs on set 1, interleaved with the reads of tile kt + 1's k-step 0 into set 0
-    LMM_D_RD(0, 0, asn, asn)
-    LMM_MFMA16(1, 2, 2); LMM_MFMA16(1, 2, 3);
-    LMM_MFMA16(1, 3, 3); LMM_MFMA16(1, 3, 2); LMM_MFMA16(1, 3, 1); LMM_MFMA16(1, 3, 0);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x100, 1); }
-    LMM_SGB(0x100, 2);
-    s_ld = s_cur; s_cur = s_nxt;
-  }
-  __builtin_amdgcn_s_waitcnt(0x0F70);                // surplus requests of the last tiles: drained before the LDS is released
-  if (!active) return;
-#pragma unroll
-  for (int v = 0; v < 4; ++v) {
-    double* cpv = C + (size_t)(bn + wc + 16 * v + lk) * ldc + bm + wr + l15;
-    if (nparts == 1) {
-      double cv[4][4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) cv[u][r] = cpv[(size_t)(4 * r) * ldc + 16 * u];
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) cpv[(size_t)(4 * r) * ldc + 16 * u] = cv[u][r] - acc[v][u][r];
-    } else {
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) unsafeAtomicAdd(cpv + (size_t)(4 * r) * ldc + 16 * u, -acc[v][u][r]);
-    }
-  }
-}
+// (the direct-to-LDS variant of this kernel, gemm16d_kernel, measured slower; it lives in profiles/r02/gemm16d_direct_to_lds_rejected.hip.txt)
 
 // Half-height companion of gemm16p_kernel for the RAGGED last 64 rows of an update (factor matrices carry 64 rider rows, so the
 // row count of every trailing update is an odd multiple of 64: a 128-row tile there has two idle waves for a whole tile time,
@@ -2212,23 +2085,27 @@ __global__ __launch_bounds__(256, 2) void potrf_node_kernel(NodeArgs a) {
   constexpr int SA = BM + 16, SB = BN + 16;
   double (*As)[BK * SA] = reinterpret_cast<double (*)[BK * SA]>(node_lds);
   double (*Bs)[BK * SB] = reinterpret_cast<double (*)[BK * SB]>(node_lds + 2 * BK * SA);
-  double* Am = a.A.p[blockIdx.y];
+  // grid: x = matrix (fastest in dispatch order), y = work item: the items of all matrices of the batch interleave, so that every
+  // matrix's column tile 0 -- and with it the leaf of the next panel -- is dispatched in the FIRST scheduling round and the split-K
+  // tail of every matrix lands in the last one (with x = item the last matrix's unsplit column tiles ran in the tail: +1.6 ms per
+  // launch at C2 sizes).  With nb >= 8 matrices, workgroup (b, item) has linear id item nb + b, i.e. matrix b stays on XCD b mod 8.
+  double* Am = a.A.p[blockIdx.x];
   const int r0 = a.j0 + a.h;
   const int M = a.NR - r0;
   // role of this workgroup
   int part = 0, nparts = 1, tj = 0, ti = 0;
   bool bulk = false;
   {
-    int item = blockIdx.x;
+    int item = blockIdx.y;
     const int n_upd = (a.mode & NODE_UPDATE) ? a.MT + a.rest_items : 0;
     if (item < n_upd) {
       if (item < a.MT) ti = item;                                  // column tile 0, top to bottom: the next panel
-      else gemm_work_item_from(item - a.MT, 1, BM, BN, a.N, 1, a.MT, a.full_items, a.splitk, part, nparts, ti, tj);
+      else gemm_work_item_from(item - a.MT, 1, BM, BN, a.N, 1, a.MT, a.full_items, a.splitk, part, nparts, ti, tj, a.xcds);
     } else { bulk = true; ti = item - n_upd + 1; }
   }
   double* C = Am + (size_t)r0 * a.ld + r0;
   const double* A = bulk ? C : Am + (size_t)a.j0 * a.ld + r0;
-  const double* B = bulk ? a.W2.p[blockIdx.y] + (size_t)(r0 / 128) * 16384 : A;
+  const double* B = bulk ? a.W2.p[blockIdx.x] + (size_t)(r0 / 128) * 16384 : A;
   const int lda = a.ld, ldb = bulk ? 128 : a.ld, ldc = a.ld;
   const int N = bulk ? 128 : a.N, K = bulk ? 128 : a.h;
   const int bm = ti * BM, bn = tj * BN;
@@ -2333,8 +2210,8 @@ __global__ __launch_bounds__(256, 2) void potrf_node_kernel(NodeArgs a) {
   }
   if ((a.mode & NODE_LEAF) && !bulk && ti == 0 && tj == 0) {       // uniform over the workgroup
     __syncthreads();                                               // the tile's stores are issued; the staging LDS is free
-    leaf128_dev(node_lds, Am, (size_t)r0 * a.ld + r0, a.ld, a.W.p[blockIdx.y], (size_t)(r0 / 64) * 4096,
-                a.W2.p[blockIdx.y] + (size_t)(r0 / 128) * 16384, r0, a.n_real, a.info.p[blockIdx.y]);
+    leaf128_dev(node_lds, Am, (size_t)r0 * a.ld + r0, a.ld, a.W.p[blockIdx.x], (size_t)(r0 / 64) * 4096,
+                a.W2.p[blockIdx.x] + (size_t)(r0 / 128) * 16384, r0, a.n_real, a.info.p[blockIdx.x]);
   }
 }
 
@@ -3108,32 +2985,31 @@ __global__ void normals_kernel(unsigned long long seed, unsigned long long strea
 // f64 MFMA issue-rate microbenchmark (the guide gives no FP64 matrix peak).
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mfma_f64_peak_kernel(double* out, int iters) {
-  // v_mfma_f64_4x4x4_4b_f64 with the update kernel's operand pattern: 4 A-fragments x 16 B-fragments, 64 accumulators
-#ifdef LMM_CLOCK_PROBE
-  const unsigned long long clk0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
-#endif
-  double acc[64], a[4], b[16];
+  // v_mfma_f64_16x16x4_f64 exactly as the update kernels issue it: 16 accumulators of 16 x 16 in architectural VGPRs (the library is
+  // compiled with -amdgpu-mfma-vgpr-form=1), 4 + 4 operand fragments, serpentine order; one wave per SIMD is enough (64-cycle MFMAs)
+  d4 acc[4][4];
+  double fa[4], fb[4];
 #pragma unroll
-  for (int q = 0; q < 64; ++q) acc[q] = 0.0;
+  for (int v = 0; v < 4; ++v)
 #pragma unroll
-  for (int q = 0; q < 4; ++q) a[q] = 1.0 + (threadIdx.x + 7 * q) * 1e-3;
+    for (int u = 0; u < 4; ++u) acc[v][u] = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int q = 0; q < 16; ++q) b[q] = 1.0 - (threadIdx.x + 3 * q) * 1e-3;
+  for (int q = 0; q < 4; ++q) { fa[q] = 1.0 + (threadIdx.x + 7 * q) * 1e-3; fb[q] = 1.0 - (threadIdx.x + 3 * q) * 1e-3; }
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int v = 0; v < 4; ++v)
 #pragma unroll
-      for (int v = 0; v < 16; ++v) acc[u * 16 + v] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[u], b[v], acc[u * 16 + v], 0, 0, 0);
+      for (int uu = 0; uu < 4; ++uu) {
+        const int u = (v & 1) ? 3 - uu : uu;
+        acc[v][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[v], fa[u], acc[v][u], 0, 0, 0);
+      }
   }
   double s = 0.0;
 #pragma unroll
-  for (int q = 0; q < 64; ++q) s += acc[q];
+  for (int v = 0; v < 4; ++v)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s += acc[v][u][0] + acc[v][u][1] + acc[v][u][2] + acc[v][u][3];
   out[blockIdx.x * 256 + threadIdx.x] = s;
-#ifdef LMM_CLOCK_PROBE
-  if (blockIdx.x == 100 && threadIdx.x == 0) {
-    g_clk_probe[2] = __builtin_readcyclecounter() - clk0; g_clk_probe[3] = __builtin_amdgcn_s_memrealtime() - rt0;
-  }
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -3246,11 +3122,11 @@ void launch_panel_bulk(const BatchPtr& A, const BatchPtr& W2, int ld, int NR, in
   node_lds_attr();
   NodeArgs a{};
   a.A = A; a.W2 = W2; a.ld = ld; a.NR = NR; a.j0 = r0; a.h = 0; a.N = 128; a.MT = MT; a.mode = NODE_BULK;
-  hipLaunchKernelGGL(potrf_node_kernel<1>, dim3(MT - 1, nb), dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
+  hipLaunchKernelGGL(potrf_node_kernel<1>, dim3(nb, MT - 1), dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
 }
 void launch_update_leaf(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2, const BatchInfo& info, int ld, int NR, int j0, int h,
                         int N, int n_real, int nb, hipStream_t st) {
-  const int r0 = j0 + h, M = NR - r0, MT = (M + 127) / 128, NT = N / 128;
+  const int r0 = j0 + h, M = NR - r0, MT = (M + 127) / 128, NT = (N + 127) / 128;     // N may end in a 64-column half tile
   if (nb <= 0 || N <= 0 || h <= 0) return;
   node_lds_attr();
   static int cus = 0;
@@ -3272,7 +3148,8 @@ void launch_update_leaf(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2
   a.A = A; a.W = W; a.W2 = W2; a.info = info; a.ld = ld; a.NR = NR; a.j0 = j0; a.h = h; a.N = N; a.n_real = n_real; a.MT = MT;
   a.full_items = full_items; a.splitk = splitk; a.rest_items = full_items + (int)(T - full_items) * splitk;
   a.mode = NODE_UPDATE | NODE_LEAF;
-  const dim3 grid(MT + a.rest_items, nb);
+  { int g = nb, e = 8; while (e) { const int r = g % e; g = e; e = r; } a.xcds = 8 / g; }      // 8 / gcd(nb, 8)
+  const dim3 grid(nb, MT + a.rest_items);
   if (h >= 1024) hipLaunchKernelGGL(potrf_node_kernel<2>, grid, dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
   else hipLaunchKernelGGL(potrf_node_kernel<1>, grid, dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
 }

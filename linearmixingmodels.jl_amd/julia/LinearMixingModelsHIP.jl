@@ -67,8 +67,11 @@ mutable struct HIPMOGP{Tfs<:Vector{<:AbstractGP}} <: AbstractGPs.AbstractGP
     fs::Tfs
     handle::Ptr{Cvoid}
     train::Any               # nothing | (X::Matrix{Float64}, σ²::Float64, y::Vector{Float64})
+    # filled by the posterior logpdf rrule: the total-derivative cotangents of the predictive logpdf w.r.t. the training data and
+    # training noise, (y_train = ..., sigma2_train = ...), which the pullback itself cannot route anywhere (see the rrule)
+    last_train_cotangents::Base.RefValue{Any}
     function HIPMOGP(fs::Tfs, h::Ptr{Cvoid}=C_NULL, train=nothing) where {Tfs<:Vector{<:AbstractGP}}
-        obj = new{Tfs}(fs, h, train)
+        obj = new{Tfs}(fs, h, train, Ref{Any}(nothing))
         h == C_NULL || finalizer(o -> ccall((:lmm_post_destroy, liblmm), Cint, (Ptr{Cvoid},), o.handle), obj)
         return obj
     end
@@ -419,8 +422,12 @@ function ChainRulesCore.rrule(::typeof(AbstractGPs.logpdf), fx::ByOutputsFill{HI
             (Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cdouble, Cdouble,
              Ptr{LmmGp}, Cint, Cint, Cint, Ref{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Cdouble}, Ref{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{LmmGpGrad}),
             X0, d, n0, y0, X, n, yv, p, U, S, m, σ0, σ², gps, 0, m, 1, val, gy0, gy, gσt, gσ, gS, gU, gg))
-        # total derivatives through the posterior: the cotangents w.r.t. the training data / noise are exposed on the handle
-        # holder's `train` slot (a maintainer differentiating θ -> logpdf(posterior(f_θ(x, σ²), y)(x*, σ²), y*) reads them there)
+        # The library returns TOTAL derivatives through the posterior, including those w.r.t. the training data (gy0) and the
+        # training noise (gσt).  The posterior model object has no differentiable slot for (x, σ², y) -- they entered through
+        # `posterior`, whose own rrule would be the place to receive them -- so THIS pullback propagates the cotangents of the
+        # latent GPs, H, the predictive noise and y* only; gy0 / gσt are NOT propagated by it.  Callers who differentiate
+        # θ -> logpdf(posterior(f_θ(x, σ²), y)(x*, σ²*), y*) end to end use `predictive_logpdf_and_gradient` below, which returns them.
+        fs.last_train_cotangents[] = (y_train=gy0, sigma2_train=gσt[])
     else
         GC.@preserve X yv U S gps gy gS gU gg check(ccall((:lmm_oilmm_logpdf_grad, liblmm), Cint,
             (Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cdouble, Ptr{LmmGp}, Cint, Cint, Cint,
@@ -433,6 +440,15 @@ function ChainRulesCore.rrule(::typeof(AbstractGPs.logpdf), fx::ByOutputsFill{HI
         return NoTangent(), dfx, Δ .* gy
     end
     return val[], logpdf_pullback
+end
+
+# Value, pullback-at-1 and the training cotangents of the predictive logpdf in one call: what an end-to-end differentiation of
+# θ -> logpdf(posterior(f_θ(x, σ²), y)(x*, σ²*), y*) needs beyond the rrule above (whose pullback cannot return d/dy_train, d/dσ²_train).
+function predictive_logpdf_and_gradient(fx::ByOutputsFill{HIPOILMM}, y::AbstractVector{<:Real})
+    val, back = ChainRulesCore.rrule(AbstractGPs.logpdf, fx, y)
+    _, dfx, dy = back(1.0)
+    tr = unpack(fx)[1].last_train_cotangents[]
+    return (value=val, fx=dfx, y=dy, y_train=(tr === nothing ? nothing : tr.y_train), sigma2_train=(tr === nothing ? nothing : tr.sigma2_train))
 end
 
 # IndependentMOGP (reference test/independent_mogp.jl:65-66): the OILMM with U = I, S = 1 and no regulariser
@@ -487,6 +503,24 @@ function ChainRulesCore.rrule(::typeof(AbstractGPs.logpdf), fx::ByOutputsFill{HI
         return NoTangent(), dfx, Δ .* gy
     end
     return val[], logpdf_pullback
+end
+
+# ---- modes -------------------------------------------------------------------------------------------------------------
+# compute dtype of the per-latent matrices: :f64 (parity mode) | :f32 (BASELINE configs[4])
+set_compute_dtype(d::Symbol) = check(ccall((:lmm_set_compute_dtype, liblmm), Cint, (Cint,), d === :f32 ? 1 : 0))
+# dtype of the H unprojection of predictive marginals (reference src/oilmm.jl:69-72): :native | :bf16 (BASELINE configs[3]:
+# v_mfma_f32_16x16x32_bf16, tolerance 2^-7 Σ_l |H||M_lat|) | :bf16x2 (hi + lo split, ~2^-15)
+set_projection_dtype(d::Symbol) =
+    check(ccall((:lmm_set_projection_dtype, liblmm), Cint, (Cint,), d === :bf16 ? 1 : (d === :bf16x2 ? 2 : 0)))
+
+# get_latent_gp(posterior(fx::FiniteGP{<:ILMM}, y)) for a dense H (reference src/ilmm.jl:39 on the ILMM of :196-197): the coupled
+# latent PosteriorGP{IndependentMOGP} as a handle that shares the posterior's device state with H = I_m; the lmm_ilmm_post_*
+# entry points then answer for the m latent outputs (jitters {0, σ², 0}: see include/lmm_hip.h).
+function latent_view(f::ILMM{<:HIPMOGP,<:Matrix})
+    isposterior(f.f) || return f.f
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:lmm_ilmm_post_latent_view, liblmm), Cint, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}), f.f.handle, h))
+    return ILMM(HIPMOGP(f.f.fs, h[], nothing), Matrix{Float64}(I, length(f.f.fs), length(f.f.fs)))
 end
 
 # ---- multi-GPU: one Julia process per GPU; the collective lives in the library (RCCL over xGMI) ----------------------------

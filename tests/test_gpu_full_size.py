@@ -1,6 +1,7 @@
 """-m gpu: BASELINE.json configs at (one GPU's share of) their full sizes, checked through size-independent properties and,
-where a host LAPACK run stays within seconds, against the oracle on ONE latent.  Float64 throughout (configs[3]/[4] name
-bf16 / fp32 variants that are not built; their SHAPES are exercised here in Float64)."""
+where a host LAPACK run stays within seconds, against the oracle on ONE latent.  Float64 here; the variants configs[3] / [4]
+name are tested as named elsewhere: the bf16 MFMA projection in tests/test_gpu_r3.py::test_c3_bf16_projection_full_size, the fp32
+compute mode in tests/test_gpu_f32.py::test_f32_c4_share_full_size."""
 import numpy as np
 import pytest
 
