@@ -354,7 +354,9 @@ typedef enum {
   LMM_PROF_TRSM = 3,          /* potrf_node_kernel<1> in bulk mode: panel rows x 128 x 128 inverse (round-2 path:
                                  gemm44_kernel<64,true>, TRSM by the 64 x 64 inverse block), flops                              */
   LMM_PROF_DIAG = 4,          /* leaf128_kernel (first panel) / diag64m_kernel: diagonal-block factor + inverse, flops          */
-  LMM_PROF_COUNT = 5
+  LMM_PROF_REGION = 5,        /* potrf_region_kernel: a block column of <= 8 panels (leaves, bulk products, inner updates) in one
+                                 dataflow launch, flops                                                                         */
+  LMM_PROF_COUNT = 6
 } lmm_prof_class;
 typedef struct { long long launches; double ms; double work; double bytes; /* algorithmic HBM bytes */ } lmm_prof_entry_t;
 int lmm_profile_begin(int serial);

@@ -292,8 +292,18 @@ void potrf_rec(const Batch& B, int ld, int NR, int j0, int w, int n_real, hipStr
 // also runs the leaf of the panel that follows it (launch_update_leaf), so that per 128 columns the stream sees two launches
 // (update + leaf, bulk) instead of six.  first_done: the diagonal block of the first panel of [j0, j0 + w) is already factored.
 // Widths that are not multiples of 128 (NC = 64 mod 128) end in the round-2 path for their last 64 columns.
-void potrf_rec_panel(const Batch& B, const BatchPtr& W2, int ld, int NR, int j0, int w, int n_real, hipStream_t st, bool first_done) {
+static int g_region_cols = -1;          // widest block column potrf_region_kernel takes in one launch (LMM_REGION=<columns>, up to 1024; default 0: off)
+void potrf_rec_panel(const Batch& B, const BatchPtr& W2, const BatchInfo& flags, int ld, int NR, int j0, int w, int n_real, hipStream_t st,
+                     bool first_done) {
   const double nb = B.nb;
+  if (g_region_cols > 0 && w <= g_region_cols && w >= 128 && (w % 128) == 0 && flags.p[0] != nullptr) {
+    // the whole block column as ONE dataflow launch (lmm_kernels.hip K2d): leaves, bulk products and all updates inside it
+    const double Mr = NR - j0, Wd = w;
+    const double fl = Mr * Wd * Wd - 2.0 * Wd * Wd * Wd / 3.0;           // flops of factoring an Mr x Wd tall panel: Mr Wd^2 - 2 Wd^3 / 3
+    ProfScope ps(LMM_PROF_REGION, nb * fl, st, NR - j0, w, w);
+    launch_region(B.A, B.W, W2, B.info, flags, ld, NR, j0, w, n_real, B.nb, first_done, st);
+    return;
+  }
   if (w == 128) {
     if (!first_done) {
       ProfScope ps(LMM_PROF_DIAG, nb * 2.0 * 128.0 * 128.0 * 128.0 / 3.0, st, 128, 128, 128);
@@ -308,16 +318,18 @@ void potrf_rec_panel(const Batch& B, const BatchPtr& W2, int ld, int NR, int j0,
   }
   if (w <= 64) { potrf_rec(B, ld, NR, j0, w, n_real, st); return; }          // a trailing 64-column leaf (never pre-factored)
   const int h = split(w);
-  potrf_rec_panel(B, W2, ld, NR, j0, h, n_real, st, first_done);
+  potrf_rec_panel(B, W2, flags, ld, NR, j0, h, n_real, st, first_done);
   const int r0 = j0 + h, Nc = w - h;
   const double Mr = NR - r0;
   const double outs = (double)Nc * (Nc + 1.0) / 2.0 + (Mr - Nc) * Nc;
   const size_t offA = (size_t)j0 * ld + r0;
   if (Nc >= 128) {
     // + the leaf's 2 * 128^3 / 3 flops, run by one workgroup of this launch
-    ProfScope ps(LMM_PROF_UPDATE, nb * (2.0 * h * outs + 2.0 * 128.0 * 128.0 * 128.0 / 3.0), st, NR - r0, Nc, h, nb * (16.0 * outs + 8.0 * Mr * h));
-    launch_update_leaf(B.A, B.W, W2, B.info, ld, NR, j0, h, Nc, n_real, B.nb, st);
-    potrf_rec_panel(B, W2, ld, NR, r0, Nc, n_real, st, true);
+    {
+      ProfScope ps(LMM_PROF_UPDATE, nb * (2.0 * h * outs + 2.0 * 128.0 * 128.0 * 128.0 / 3.0), st, NR - r0, Nc, h, nb * (16.0 * outs + 8.0 * Mr * h));
+      launch_update_leaf(B.A, B.W, W2, B.info, ld, NR, j0, h, Nc, n_real, B.nb, st);
+    }
+    potrf_rec_panel(B, W2, flags, ld, NR, r0, Nc, n_real, st, true);
   } else {
     {
       ProfScope ps(LMM_PROF_UPDATE_NARROW, nb * 2.0 * h * outs, st, NR - r0, Nc, h, nb * (16.0 * outs + 8.0 * Mr * h));
@@ -333,11 +345,19 @@ void potrf_batch(const Batch& B, int ld, int NR, int NC, int n_real, hipStream_t
   static int panel128 = -1;
   if (panel128 < 0) { const char* e = getenv("LMM_PANEL128"); panel128 = e ? (atoi(e) != 0) : 1; }
   if (g_f32 || !panel128 || NC < 128 || (ld & 1)) { potrf_rec(B, ld, NR, 0, NC, n_real, st); return; }
+  if (g_region_cols < 0) { const char* e = getenv("LMM_REGION"); g_region_cols = e ? atoi(e) : 0; if (g_region_cols > 128 * LMM_REGION_MAX_PANELS) g_region_cols = 128 * LMM_REGION_MAX_PANELS; }
   const size_t per = (size_t)(NC / 128) * 16384;
   double* w2 = call_scratch(per * B.nb);
   BatchPtr W2{};
   for (int j = 0; j < B.nb; ++j) W2.p[j] = w2 + per * j;
-  potrf_rec_panel(B, W2, ld, NR, 0, NC, n_real, st, false);
+  BatchInfo flags{};
+  if (g_region_cols > 0) {                 // dependency flags of the region launches: zeroed once, then told apart by launch epoch
+    const size_t fi = (region_flag_ints(NR) + 1) / 2 * 2;
+    int* fl = reinterpret_cast<int*>(call_scratch(fi / 2 * B.nb));
+    HIPCHK(hipMemsetAsync(fl, 0, fi * sizeof(int) * B.nb, st));
+    for (int j = 0; j < B.nb; ++j) flags.p[j] = fl + fi * j;
+  }
+  potrf_rec_panel(B, W2, flags, ld, NR, 0, NC, n_real, st, false);
 }
 
 void potrf_rec(double* A, int ld, int NR, int j0, int w, double* W, int n_real, int* info, hipStream_t st) {
@@ -460,6 +480,9 @@ void join_slots(int count) {       // main stream waits for every slot stream
 
 int check_info(const std::vector<int>& info, int latent_begin) {
   for (size_t k = 0; k < info.size(); ++k) {
+    if (info[k] == LMM_INFO_SYNC_TIMEOUT)
+      return fail(LMM_ERR_HIP, "potrf_region_kernel: a dependency wait timed out (latent %d); the grid was drained, results are invalid",
+                  latent_begin + (int)k);
     if (info[k] != 0) {
       g.err_latent = latent_begin + (int)k;
       g.err_info = info[k];

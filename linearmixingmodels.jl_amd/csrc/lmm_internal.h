@@ -64,12 +64,24 @@ void launch_dense_var(const double* R, int ldr, int ns, int m, int Ncols, const 
 struct NodeArgs {
   BatchPtr A, W, W2;      // factor matrices; 64 x 64 inverse blocks; 128 x 128 inverse panels (scratch)
   BatchInfo info;
-  int ld, NR, j0, h, N, n_real;
-  int MT;                 // 128-row tiles of the region (rows j0 + h .. NR - 1)
+  int ld, M, j0, h, N, n_real;   // M: rows of the region (from row j0 + h) this launch covers
+  int MT, nb;             // 128-row tiles of the region; matrices in the batch
   int rest_items, full_items, splitk;     // work items of the column tiles 1.. (gemm_work_item's enumeration and split-K tail)
+  int full_items_last, splitk_last;       // the same for the LAST matrix of the batch, which carries the launch's tail
   int mode;               // NODE_UPDATE | NODE_LEAF, or NODE_BULK
-  int xcds;               // XCDs the consecutive items of one matrix are dealt over (8 / gcd(batch size, 8))
 };
+// Arguments of potrf_region_kernel (lmm_kernels.hip K2d): the columns [c0, c0 + 128 P) of every matrix of the batch, rows c0 .. c0 + M - 1.
+struct RegionArgs {
+  BatchPtr A, W, W2;
+  BatchInfo info, flags;  // flags: P * R readiness words + 1 abort word per matrix (zeroed once per factorisation)
+  int ld, M, c0, P, R, n_real, nb, epoch, first_done;
+};
+#define LMM_REGION_MAX_PANELS 8
+#define LMM_INFO_SYNC_TIMEOUT (-7777)     // pivot-info value a region launch leaves when a dependency wait timed out (never expected)
+size_t region_flag_ints(int NR);          // ints per matrix that the flags of any region of a matrix with NR rows need
+void launch_region(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2, const BatchInfo& info, const BatchInfo& flags, int ld, int NR,
+                   int c0, int width, int n_real, int nb, bool first_done, hipStream_t st);
+// plain trailing update (no leaf) through the node kernel: C -= A B' for the region at j0 + h
 void launch_leaf128(const BatchPtr& A, size_t offD, int ld, const BatchPtr& W, size_t offW, const BatchPtr& W2, size_t offW2,
                     int gcol0, int n_real, const BatchInfo& info, int nb, hipStream_t st);
 // bulk rows of the panel at column r0 (its diagonal block factored, its inverse in W2): X = P Dinv' in place

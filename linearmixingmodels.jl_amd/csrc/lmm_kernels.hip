@@ -996,9 +996,9 @@ __device__ __forceinline__ void diag64m_steps_direct(Diag64mState& st, double* _
 // One wave factors the 64 x 64 block at (A, offA, ld) in place (lower triangle) and leaves W = L^-1 in the LDS image
 // Wl[col * DIAG_LS + row] (zeros above the diagonal).  Sp: 64 * DIAG_SP doubles, Wt: 256 doubles of LDS work area.  Returns the mask of
 // non-positive (or NaN) pivots.  l = lane.  The last step's lagging MFMAs (group 2 of step 15) do not exist: nothing is pending.
+// Wl MAY overlap Sp / Wt (leaf128 does that to stay inside the update kernel's LDS footprint): it is written only after the last step.
 template <typename TS>
-__device__ __forceinline__ unsigned long long diag64m_wave(void* __restrict__ A, size_t offA, int ld, double* __restrict__ Sp,
-                                                           double* __restrict__ Wt, double* __restrict__ Wl, int l) {
+__device__ __forceinline__ unsigned long long diag64m_wave(void* __restrict__ A, size_t offA, int ld, double* Sp, double* Wt, double* Wl, int l) {
   const int c = l & 15, g = l >> 4;
   Diag64mState st;
 #pragma unroll
@@ -1923,7 +1923,8 @@ __global__ __launch_bounds__(256, 2) void gemm16h_kernel(BatchPtr Cb, size_t gof
 //         B  all   : L21 = A21 W11'  -> global and Y;   T = L21 W11 -> X;   A22 -= L21 L21' -> global
 //         C  wave 0: diag64m on A22' (L22 to global, W22 -> LDS Y)
 //         D  all   : W21 = -W22 T -> W2
-//       LDS: Sp + Wt + X + Y = 80 896 bytes, so two workgroups of the node kernel still share a CU.
+//       LDS: X + Y (the work areas Sp / Wt of each diag64m sit inside the image it will overwrite) = 69 632 bytes < the 73 728 of the
+//       update's staging buffers, so the node kernel has exactly gemm16p_kernel's footprint (two workgroups per CU).
 //   bulk (the rows below the block): X = P Dinv' in place -- ONE pipelined MFMA GEMM with K = 128 (two passes over the panel rows
 //       instead of seven).
 //   potrf_node_kernel: the trailing update  C -= A B'  of gemm16p_kernel, in which the workgroup that owns the top-left tile of
@@ -1969,7 +1970,10 @@ __device__ __forceinline__ void wg_mm64(const double* __restrict__ As, int sai, 
       for (int r = 0; r < 4; ++r) emit(u, v, r, wi + 16 * u + 4 * r + g, wj + 16 * v + c, acc[u][v][r]);
 }
 
-constexpr int LEAF_LDS_DOUBLES = 64 * DIAG_SP + 256 + 2 * 64 * DIAG_LS;      // 10112 doubles = 80 896 bytes
+// LDS of the node kernel: the update's staging (2 x 2 x 16 x 144 doubles = 73 728 bytes, as gemm16p_kernel) >= the leaf's two 64 x 64
+// images X, Y (2 x 64 x 68 doubles); the diagonal-block work areas Sp / Wt live inside whichever image is dead in that phase.
+constexpr int LEAF_LDS_DOUBLES = 4 * 16 * 144;
+static_assert(2 * 64 * DIAG_LS <= LEAF_LDS_DOUBLES && 64 * DIAG_SP + 256 <= 64 * DIAG_LS, "leaf128 LDS layout");
 // lds: LEAF_LDS_DOUBLES doubles.  A: the matrix (double), offD: element offset of the diagonal block; W: 64 x 64 inverse blocks
 // (offW: block of the first 64 columns; the second follows at + 4096); W2p: this panel's 128 x 128 inverse (column-major, ld 128).
 // All 256 threads of the workgroup call it; it starts and ends with everything in LDS free for reuse.
@@ -1977,17 +1981,15 @@ __device__ __forceinline__ void leaf128_dev(double* __restrict__ lds, double* __
                                             double* __restrict__ W, size_t offW, double* __restrict__ W2p, int gcol0, int n_real,
                                             int* __restrict__ info) {
   constexpr int LS = DIAG_LS;
-  double* Sp = lds;
-  double* Wt = Sp + 64 * DIAG_SP;
-  double* X = Wt + 256;
+  double* X = lds;
   double* Y = X + 64 * LS;
   const int t = threadIdx.x, l = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const size_t off21 = offD + 64, off22 = offD + (size_t)64 * ld + 64;
   unsigned long long bad1 = 0ull, bad2 = 0ull;
-  // A
+  // A   (work areas of the diagonal-block factorisation inside X, which is dead until W11 lands in it after the last step)
   if (w == 0) {
-    bad1 = diag64m_wave<double>(A, offD, ld, Sp, Wt, X, l);
+    bad1 = diag64m_wave<double>(A, offD, ld, X, X + 64 * DIAG_SP, X, l);
   } else {
     for (int e = t - 64; e < 4096; e += 192) { const int row = e & 63, col = e >> 6; Y[col * LS + row] = A[off21 + (size_t)col * ld + row]; }
   }
@@ -2050,7 +2052,7 @@ __device__ __forceinline__ void leaf128_dev(double* __restrict__ lds, double* __
         for (int r = 0; r < 4; ++r) X[(wj + 16 * v + c_) * LS + wi + 16 * u + 4 * r + g_] = tt[u][v][r];
   }
   // C
-  if (w == 0) bad2 = diag64m_wave<double>(A, off22, ld, Sp, Wt, Y, l);
+  if (w == 0) bad2 = diag64m_wave<double>(A, off22, ld, Y, Y + 64 * DIAG_SP, Y, l);       // work areas inside Y (L21 is in global memory)
   __syncthreads();                                               // X = T, Y = W22
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
@@ -2085,27 +2087,38 @@ __global__ __launch_bounds__(256, 2) void potrf_node_kernel(NodeArgs a) {
   constexpr int SA = BM + 16, SB = BN + 16;
   double (*As)[BK * SA] = reinterpret_cast<double (*)[BK * SA]>(node_lds);
   double (*Bs)[BK * SB] = reinterpret_cast<double (*)[BK * SB]>(node_lds + 2 * BK * SA);
-  // grid: x = matrix (fastest in dispatch order), y = work item: the items of all matrices of the batch interleave, so that every
-  // matrix's column tile 0 -- and with it the leaf of the next panel -- is dispatched in the FIRST scheduling round and the split-K
-  // tail of every matrix lands in the last one (with x = item the last matrix's unsplit column tiles ran in the tail: +1.6 ms per
-  // launch at C2 sizes).  With nb >= 8 matrices, workgroup (b, item) has linear id item nb + b, i.e. matrix b stays on XCD b mod 8.
-  double* Am = a.A.p[blockIdx.x];
-  const int r0 = a.j0 + a.h;
-  const int M = a.NR - r0;
-  // role of this workgroup
-  int part = 0, nparts = 1, tj = 0, ti = 0;
+  // 1-D grid, dispatched in index order:
+  //   update mode: [column tile 0 of every matrix, row tile by row tile: item = ti nb + b]  then  [matrix by matrix, the remaining tiles
+  //     in gemm_work_item's band order with its XCD-aware remap and split-K tail].  Every matrix's tile (0, 0) -- and with it the
+  //     leaf of the next panel -- thus starts in the FIRST scheduling round (with the column-0 tiles inside each matrix's own range
+  //     the last matrix's unsplit K-long tiles ran in the tail of the launch: +1.6 ms per launch at C2 sizes), while the bulk of the
+  //     tiles keeps the matrix-after-matrix order of gemm16p_kernel (interleaving the matrices of a batch instead measured 2-3 %
+  //     slower on the K >= 2048 levels: sixteen operand panels of 0.5 GB compete for the caches instead of one).
+  //   bulk mode: matrix by matrix, row tiles 1 .. MT-1.
+  int part = 0, nparts = 1, tj = 0, ti = 0, bidx = 0;
   bool bulk = false;
   {
-    int item = blockIdx.y;
-    const int n_upd = (a.mode & NODE_UPDATE) ? a.MT + a.rest_items : 0;
-    if (item < n_upd) {
-      if (item < a.MT) ti = item;                                  // column tile 0, top to bottom: the next panel
-      else gemm_work_item_from(item - a.MT, 1, BM, BN, a.N, 1, a.MT, a.full_items, a.splitk, part, nparts, ti, tj, a.xcds);
-    } else { bulk = true; ti = item - n_upd + 1; }
+    const int item = blockIdx.x;
+    if (a.mode & NODE_UPDATE) {
+      const int n0 = a.nb * a.MT;
+      if (item < n0) { ti = item / a.nb; bidx = item - ti * a.nb; }
+      else {
+        const int q = item - n0;
+        bidx = q / a.rest_items;
+        if (bidx < a.nb - 1) gemm_work_item_from(q - bidx * a.rest_items, 1, BM, BN, a.N, 1, a.MT, a.full_items, a.splitk, part, nparts, ti, tj);
+        else {                                                     // the last matrix carries the launch's split-K tail
+          bidx = a.nb - 1;
+          gemm_work_item_from(q - bidx * a.rest_items, 1, BM, BN, a.N, 1, a.MT, a.full_items_last, a.splitk_last, part, nparts, ti, tj);
+        }
+      }
+    } else { bulk = true; bidx = item / (a.MT - 1); ti = item - bidx * (a.MT - 1) + 1; }
   }
+  double* Am = a.A.p[bidx];
+  const int r0 = a.j0 + a.h;
+  const int M = a.M;
   double* C = Am + (size_t)r0 * a.ld + r0;
   const double* A = bulk ? C : Am + (size_t)a.j0 * a.ld + r0;
-  const double* B = bulk ? a.W2.p[blockIdx.x] + (size_t)(r0 / 128) * 16384 : A;
+  const double* B = bulk ? a.W2.p[bidx] + (size_t)(r0 / 128) * 16384 : A;
   const int lda = a.ld, ldb = bulk ? 128 : a.ld, ldc = a.ld;
   const int N = bulk ? 128 : a.N, K = bulk ? 128 : a.h;
   const int bm = ti * BM, bn = tj * BN;
@@ -2210,9 +2223,245 @@ __global__ __launch_bounds__(256, 2) void potrf_node_kernel(NodeArgs a) {
   }
   if ((a.mode & NODE_LEAF) && !bulk && ti == 0 && tj == 0) {       // uniform over the workgroup
     __syncthreads();                                               // the tile's stores are issued; the staging LDS is free
-    leaf128_dev(node_lds, Am, (size_t)r0 * a.ld + r0, a.ld, a.W.p[blockIdx.x], (size_t)(r0 / 64) * 4096,
-                a.W2.p[blockIdx.x] + (size_t)(r0 / 128) * 16384, r0, a.n_real, a.info.p[blockIdx.x]);
+    leaf128_dev(node_lds, Am, (size_t)r0 * a.ld + r0, a.ld, a.W.p[bidx], (size_t)(r0 / 64) * 4096,
+                a.W2.p[bidx] + (size_t)(r0 / 128) * 16384, r0, a.n_real, a.info.p[bidx]);
   }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K2d (round 3): a whole block column of panels in ONE launch -- potrf_region_kernel.
+// The columns [c0, c0 + 128 P) of the factor matrix (P <= 8 panels: everything the recursion used to do below its K = 1024 level,
+// i.e. per 1024 columns 8 bulk launches + 7 update launches whose K <= 512 products ran at 15-55 TFLOP/s with the leaf of every
+// panel exposed; or the WHOLE factorisation of a matrix of up to 1024 columns) as a dataflow over 128 x 128 tiles:
+//   task (i, j), 0 <= j < P, j <= i < R (R row tiles from row c0 down, rider rows included), one workgroup each, LEFT-LOOKING with the
+//   tile in registers: acc = sum_{p < j} X[i, p] X[j, p]'  (one K = 128 pass of the pipelined MFMA loop per finished panel p, as
+//   soon as the two operand tiles are flagged ready), then  C[i, j] -= acc  (the ONLY read-modify-write of the tile), then
+//     i == j :  leaf128 (factor the diagonal block, its 64 x 64 inverse blocks and the panel inverse)            -> flag F[j][j]
+//     i >  j :  wait F[j][j];  X[i, j] = C[i, j] Dinv_j'  (one more K = 128 pass, in place)                       -> flag F[j][i]
+//   Flags are per matrix and carry the launch's epoch (no reset between launches); release = agent-scope fence + store, acquire =
+//   spin on thread 0 + agent-scope fence (tools/fence_probe: 1-4 us per hand-off, profiles/r03).
+//   Order of the 1-D grid = order of dispatch: wavefronts s = i + j, inside a wavefront the tile nearest the diagonal first, matrices
+//   interleaved.  Every dependency of a task -- (i, p), (j, p) for p < j and (j, j) -- lies on an earlier wavefront, so a waiting
+//   workgroup only ever waits for workgroups dispatched before it (already resident or finished): no deadlock however many are
+//   resident; and the critical path leaf(j) -> X[j+1, j] -> tile (j+1, j+1) -> leaf(j+1) is at the FRONT of each wavefront.
+//   Every spin is bounded (1 s): on a timeout the abort word is raised, all spinners leave, the grid drains and the host reports it.
+// ---------------------------------------------------------------------------------------------------
+// acc += A (128 rows x 128 k-columns, from row pointer A, leading dimension lda; rows >= rows_a are clamped) * B' (likewise), through
+// the LDS staging buffers `lds` (4 x 16 x 144 doubles) with gemm16p_kernel's one-tile-ahead pipeline.  All 256 threads.
+__device__ __forceinline__ void pipe128_accumulate(d4 (&acc)[4][4], double* __restrict__ lds, const double* __restrict__ A, int lda, int rows_a,
+                                                   const double* __restrict__ B, int ldb, int rows_b, int nk = 8) {
+  constexpr int BK = 16, SA = 144, SB = 144;
+  double (*As)[BK * SA] = reinterpret_cast<double (*)[BK * SA]>(lds);
+  double (*Bs)[BK * SB] = reinterpret_cast<double (*)[BK * SB]>(lds + 2 * BK * SA);
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int wr = (w & 1) * 64, wc = (w >> 1) * 64;
+  int rowa = 2 * (t & 63); if (rowa > rows_a - 2) rowa = rows_a - 2;
+  int rowb = 2 * (t & 63); if (rowb > rows_b - 2) rowb = rows_b - 2;
+  const double* ga0 = A + (size_t)(t >> 6) * lda + rowa;
+  const double* gb0 = B + (size_t)(t >> 6) * ldb + rowb;
+  const int sa0 = (t >> 6) * SA + 2 * (t & 63);
+  const int sb0 = (t >> 6) * SB + 2 * (t & 63);
+  d2 ra[4], rb[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { ra[q] = *reinterpret_cast<const d2*>(ga0 + (size_t)(4 * q) * lda); rb[q] = *reinterpret_cast<const d2*>(gb0 + (size_t)(4 * q) * ldb); }
+  __syncthreads();                                       // the previous user of the staging buffers is done with them
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { *reinterpret_cast<d2*>(&As[0][sa0 + 4 * q * SA]) = ra[q]; *reinterpret_cast<d2*>(&Bs[0][sb0 + 4 * q * SB]) = rb[q]; }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    ra[q] = *reinterpret_cast<const d2*>(ga0 + (size_t)BK * lda + (size_t)(4 * q) * lda);
+    rb[q] = *reinterpret_cast<const d2*>(gb0 + (size_t)BK * ldb + (size_t)(4 * q) * ldb);
+  }
+  __syncthreads();
+  const int l15 = lane & 15, lk = lane >> 4;
+  const int offA = lk * SA + wr + l15, offB = lk * SB + wc + l15;
+  double fa[2][4], fb[2][4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) { fa[0][u] = As[0][offA + 16 * u]; fb[0][u] = Bs[0][offB + 16 * u]; }
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    const double* as = &As[buf][0];
+    const double* bs = &Bs[buf][0];
+    double* asn = &As[buf ^ 1][0];
+    double* bsn = &Bs[buf ^ 1][0];
+    const int kn = (kt + 2 < nk) ? kt + 2 : nk - 1;
+    LMM_TILE_BODY(ra, rb, kn)
+  }
+}
+
+// spin (thread 0) until *f == epoch, then make the producer's data visible to the whole workgroup.  Bounded: 1 s of the 100 MHz
+// wall clock, or until another workgroup raised *abort_word.
+__device__ __forceinline__ void region_wait(const int* f, int epoch, int* abort_word, int* info) {
+  if (threadIdx.x == 0) {
+    const long long t0 = wall_clock64();
+    int polls = 0;
+    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+      __builtin_amdgcn_s_sleep(2);
+      if ((++polls & 63) == 0) {
+        if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+        if (wall_clock64() - t0 > 100000000LL) {
+          __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          atomicCAS(info, 0, LMM_INFO_SYNC_TIMEOUT);               // surfaces through the host's check of the pivot info word
+          break;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+__device__ __forceinline__ void region_signal(int* f, int epoch) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // every thread: its stores are performed device-wide
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(f, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ROW task of potrf_region_kernel: row tile i >= P of matrix b, columns j = 0 .. P-1 left to right.  It consumes only the square's
+// tiles X[j, p] (p < j) and the leaves, produces only its own row -- which nobody else reads inside this launch -- so it signals
+// nothing: no release fence, no flag traffic beyond P leaf flags and the square's readiness words.
+//   column j:  acc = X[i, 0:j] X[j, 0:j]'  as ONE pass over K = 128 j (own earlier outputs + the square's row j);  C[i, j] -= acc;
+//              wait leaf(j);  X[i, j] = C[i, j] Dinv_j'.
+__device__ __forceinline__ void potrf_region_row(const RegionArgs& a, double* __restrict__ lds, double* __restrict__ Am, int b, int ti) {
+  int* abort_word = a.flags.p[b];
+  int* F = abort_word + 2;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int wr = (w & 1) * 64, wc = (w >> 1) * 64;
+  const int l15 = lane & 15, lk = lane >> 4;
+  const int rows_i = min(128, a.M - 128 * ti);
+  const size_t row_i = (size_t)a.c0 + 128 * (size_t)ti;
+  const bool active = wr < rows_i;
+  for (int tj = 0; tj < a.P; ++tj) {
+    const size_t row_j = (size_t)a.c0 + 128 * (size_t)tj;
+    double* C = Am + row_j * a.ld + row_i;
+    d4 acc[4][4];
+    if (tj > 0) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[v][u] = (d4){0.0, 0.0, 0.0, 0.0};
+      for (int p = 0; p < tj; ++p) region_wait(F + p * a.R + tj, a.epoch, abort_word, a.info.p[b]);      // the square's X[j, p]
+      const size_t col0 = (size_t)a.c0 * a.ld;
+      pipe128_accumulate(acc, lds, Am + col0 + row_i, a.ld, rows_i, Am + col0 + row_j, a.ld, 128, 8 * tj);
+      if (active) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          double* cpv = C + (size_t)(wc + 16 * v + lk) * a.ld + wr + l15;
+          double cv[4][4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cv[u][r] = cpv[(size_t)(4 * r) * a.ld + 16 * u];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cpv[(size_t)(4 * r) * a.ld + 16 * u] = cv[u][r] - acc[v][u][r];
+        }
+      }
+      __syncthreads();
+    }
+    region_wait(F + tj * a.R + tj, a.epoch, abort_word, a.info.p[b]);                                     // leaf(j): Dinv_j
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[v][u] = (d4){0.0, 0.0, 0.0, 0.0};
+    pipe128_accumulate(acc, lds, C, a.ld, rows_i, a.W2.p[b] + (size_t)(row_j / 128) * 16384, 128, 128);
+    if (active) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        double* cpv = C + (size_t)(wc + 16 * v + lk) * a.ld + wr + l15;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) cpv[(size_t)(4 * r) * a.ld + 16 * u] = acc[v][u][r];
+      }
+    }
+    __syncthreads();                                               // X[i, j] is in memory for this workgroup's own later passes
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void potrf_region_kernel(RegionArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double node_lds[];
+  // task decode.  TOP tasks first: tiles (i, j) of the region's P x P diagonal square, item -> (matrix b, wavefront s, column j);
+  // wavefront s holds the tiles (s - j, j), j from min(P-1, s/2) down to max(0, s - (P-1)).  Then the ROW tasks: one workgroup per
+  // row tile i >= P (the rows below the square, riders included), which walks its row left to right on its own.
+  const int b = blockIdx.x % a.nb;
+  int idx = blockIdx.x / a.nb, ti = 0, tj = 0;
+  const int ntop = a.P * (a.P + 1) / 2;
+  double* Am = a.A.p[b];
+  if (idx >= ntop) { potrf_region_row(a, node_lds, Am, b, a.P + idx - ntop); return; }
+  for (int sft = 0; sft <= 2 * a.P - 2; ++sft) {
+    const int jhi = min(a.P - 1, sft >> 1), jlo = max(0, sft - (a.P - 1));
+    const int cnt = jhi - jlo + 1;
+    if (cnt <= 0) continue;
+    if (idx < cnt) { tj = jhi - idx; ti = sft - tj; break; }
+    idx -= cnt;
+  }
+  int* abort_word = a.flags.p[b];                                 // word 0: raised on a dependency timeout (host checks it)
+  int* F = abort_word + 2;                                        // F[p * R + i]: tile (i, p) of this launch is final (== epoch)
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int wr = (w & 1) * 64, wc = (w >> 1) * 64;
+  const int l15 = lane & 15, lk = lane >> 4;
+  const int rows_i = min(128, a.M - 128 * ti);                    // valid rows of row tile ti (64 for a ragged last tile)
+  const size_t row_i = (size_t)a.c0 + 128 * (size_t)ti, row_j = (size_t)a.c0 + 128 * (size_t)tj;
+  double* C = Am + row_j * a.ld + row_i;                          // tile (ti, tj)
+  const bool active = (wr < rows_i) && !(ti == tj && wr + 63 < wc);
+  if (tj > 0) {
+    d4 acc[4][4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[v][u] = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int p = 0; p < tj; ++p) {
+      region_wait(F + p * a.R + ti, a.epoch, abort_word, a.info.p[b]);
+      if (ti != tj) region_wait(F + p * a.R + tj, a.epoch, abort_word, a.info.p[b]);
+      const size_t colp = ((size_t)a.c0 + 128 * (size_t)p) * a.ld;
+      pipe128_accumulate(acc, node_lds, Am + colp + row_i, a.ld, rows_i, Am + colp + row_j, a.ld, 128);
+    }
+    if (active) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        double* cpv = C + (size_t)(wc + 16 * v + lk) * a.ld + wr + l15;
+        double cv[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) cv[u][r] = cpv[(size_t)(4 * r) * a.ld + 16 * u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) cpv[(size_t)(4 * r) * a.ld + 16 * u] = cv[u][r] - acc[v][u][r];
+      }
+    }
+    __syncthreads();                                              // the tile is in global memory for this workgroup's own reads
+  }
+  const size_t r0 = row_j;                                        // global column (= row) of panel tj's diagonal block
+  double* W2p = a.W2.p[b] + (size_t)(r0 / 128) * 16384;
+  if (ti == tj) {
+    if (!(tj == 0 && a.first_done))
+      leaf128_dev(node_lds, Am, r0 * a.ld + r0, a.ld, a.W.p[b], (size_t)(r0 / 64) * 4096, W2p, (int)r0, a.n_real, a.info.p[b]);
+    region_signal(F + tj * a.R + ti, a.epoch);
+    return;
+  }
+  region_wait(F + tj * a.R + tj, a.epoch, abort_word, a.info.p[b]);
+  {
+    d4 acc[4][4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[v][u] = (d4){0.0, 0.0, 0.0, 0.0};
+    pipe128_accumulate(acc, node_lds, C, a.ld, rows_i, W2p, 128, 128);
+    if (active) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        double* cpv = C + (size_t)(wc + 16 * v + lk) * a.ld + wr + l15;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) cpv[(size_t)(4 * r) * a.ld + 16 * u] = acc[v][u][r];
+      }
+    }
+  }
+  region_signal(F + tj * a.R + ti, a.epoch);
 }
 
 #undef LMM_MFMA16H_ALL
@@ -3109,6 +3358,7 @@ static void node_lds_attr() {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(leaf128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_node_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_node_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_region_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   done = true;
 }
 void launch_leaf128(const BatchPtr& A, size_t offD, int ld, const BatchPtr& W, size_t offW, const BatchPtr& W2, size_t offW2,
@@ -3121,37 +3371,74 @@ void launch_panel_bulk(const BatchPtr& A, const BatchPtr& W2, int ld, int NR, in
   if (MT <= 1 || nb <= 0) return;
   node_lds_attr();
   NodeArgs a{};
-  a.A = A; a.W2 = W2; a.ld = ld; a.NR = NR; a.j0 = r0; a.h = 0; a.N = 128; a.MT = MT; a.mode = NODE_BULK;
-  hipLaunchKernelGGL(potrf_node_kernel<1>, dim3(nb, MT - 1), dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
+  a.A = A; a.W2 = W2; a.ld = ld; a.M = M; a.j0 = r0; a.h = 0; a.N = 128; a.MT = MT; a.nb = nb; a.mode = NODE_BULK;
+  hipLaunchKernelGGL(potrf_node_kernel<1>, dim3((unsigned)nb * (MT - 1)), dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
 }
 void launch_update_leaf(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2, const BatchInfo& info, int ld, int NR, int j0, int h,
                         int N, int n_real, int nb, hipStream_t st) {
-  const int r0 = j0 + h, M = NR - r0, MT = (M + 127) / 128, NT = (N + 127) / 128;     // N may end in a 64-column half tile
+  const int r0 = j0 + h, NT = (N + 127) / 128;     // N may end in a 64-column half tile
   if (nb <= 0 || N <= 0 || h <= 0) return;
   node_lds_attr();
+  // ragged last row tile (the rider rows make the row count an odd multiple of 64): on the long products the node kernel takes the
+  // full 128-row tiles and gemm16h_kernel the last 64 rows, as in launch_gemm_nt (two idle waves for a whole tile time otherwise)
+  int M = NR - r0;
+  const bool strip = (M % 128) == 64 && M - 64 >= N && (N % 128) == 0 && h >= 1024;
+  if (strip) M -= 64;
+  const int MT = (M + 127) / 128;
   static int cus = 0;
   if (cus == 0) { int dev = 0; cus = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); }
   long long T = 0;                                            // tiles of the column tiles 1 .. NT-1 (lower trapezoid)
   for (int tj = 1; tj < NT; ++tj) T += MT - tj;
-  // split-K tail of the last partial scheduling round, as in launch_gemm_nt (a round = one tile per CU, cus / nb per matrix)
-  const int slots = (cus / nb) > 0 ? (cus / nb) : 1;
-  const int nk = h / 16;
-  int full_items = (int)(T / slots) * slots, splitk = 1;
-  const int R = (int)(T - full_items);
+  // Split-K tail.  The matrices of the batch run back to back (the next matrix's tiles fill the CUs as the previous one's drain), so
+  // only the END of the launch can leave CUs idle: up to a whole tile time with unsplit tiles.  cap = workgroups resident at once
+  // (two per CU).  (a) a launch that does not even fill half of that is split uniformly; (b) otherwise the LAST cap / s tiles of
+  // the last matrix are split s ways, so that the final cap work items are short (drain ~ a tile time / s) and nothing else pays
+  // for atomics.  LMM_DETERMINISTIC=1: no split (bitwise reproducible sums).
+  const int cap = 2 * cus, nk = h / 16;
   static int deterministic = -1;
   if (deterministic < 0) { const char* e = getenv("LMM_DETERMINISTIC"); deterministic = (e && atoi(e) != 0) ? 1 : 0; }
-  if (!deterministic && R > 0 && R <= slots / 2 && nk >= 8) {
-    splitk = slots / R; if (splitk > nk / 4) splitk = nk / 4; if (splitk < 1) splitk = 1;
+  int full_a = (int)T, split_a = 1, full_l = (int)T, split_l = 1;
+  if (!deterministic && T > 0 && nk >= 8) {
+    const long long all = (long long)nb * T + (long long)nb * MT;
+    if (all <= cap / 2) {
+      int sk = (int)(cap / all); if (sk > nk / 4) sk = nk / 4; if (sk < 1) sk = 1;
+      if (sk > 1) { full_a = full_l = 0; split_a = split_l = sk; }
+    } else {
+      int sk = nk >= 16 ? 4 : 2;
+      long long tail = cap / sk; if (tail > T) tail = T;
+      full_l = (int)(T - tail); split_l = sk;
+    }
   }
-  if (splitk == 1) full_items = (int)T;
   NodeArgs a{};
-  a.A = A; a.W = W; a.W2 = W2; a.info = info; a.ld = ld; a.NR = NR; a.j0 = j0; a.h = h; a.N = N; a.n_real = n_real; a.MT = MT;
-  a.full_items = full_items; a.splitk = splitk; a.rest_items = full_items + (int)(T - full_items) * splitk;
+  a.A = A; a.W = W; a.W2 = W2; a.info = info; a.ld = ld; a.M = M; a.j0 = j0; a.h = h; a.N = N; a.n_real = n_real; a.MT = MT; a.nb = nb;
+  a.full_items = full_a; a.splitk = split_a; a.rest_items = full_a + (int)(T - full_a) * split_a;
+  a.full_items_last = full_l; a.splitk_last = split_l;
+  const int rest_last = full_l + (int)(T - full_l) * split_l;
+  if (a.rest_items < 1) a.rest_items = 1;          // divisor in the kernel's item decode (no item reaches it when T = 0)
   a.mode = NODE_UPDATE | NODE_LEAF;
-  { int g = nb, e = 8; while (e) { const int r = g % e; g = e; e = r; } a.xcds = 8 / g; }      // 8 / gcd(nb, 8)
-  const dim3 grid(nb, MT + a.rest_items);
+  const dim3 grid((unsigned)(nb * MT + (T > 0 ? (long long)(nb - 1) * a.rest_items + rest_last : 0)));
   if (h >= 1024) hipLaunchKernelGGL(potrf_node_kernel<2>, grid, dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
   else hipLaunchKernelGGL(potrf_node_kernel<1>, grid, dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
+  if (strip) {
+    const size_t offA = (size_t)j0 * ld + r0 + (size_t)M;
+    hipLaunchKernelGGL((gemm16h_kernel<true>), dim3(N / 128, nb), dim3(256), 0, st, A, (size_t)r0 * ld + r0 + (size_t)M, ld, A, offA, ld,
+                       A, (size_t)j0 * ld + r0, ld, N, h, 0);
+  }
+}
+
+size_t region_flag_ints(int NR) { return (size_t)LMM_REGION_MAX_PANELS * ((NR + 127) / 128) + 2; }
+static int g_region_epoch = 0;
+void launch_region(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2, const BatchInfo& info, const BatchInfo& flags, int ld, int NR,
+                   int c0, int width, int n_real, int nb, bool first_done, hipStream_t st) {
+  const int P = width / 128, M = NR - c0, R = (M + 127) / 128;
+  if (nb <= 0 || P <= 0) return;
+  node_lds_attr();
+  RegionArgs a{};
+  a.A = A; a.W = W; a.W2 = W2; a.info = info; a.flags = flags; a.ld = ld; a.M = M; a.c0 = c0; a.P = P; a.R = R; a.n_real = n_real; a.nb = nb;
+  if (++g_region_epoch <= 0) g_region_epoch = 1;
+  a.epoch = g_region_epoch; a.first_done = first_done ? 1 : 0;
+  const long long tasks = (long long)P * (P + 1) / 2 + (R - P);       // the square's tiles + one task per row tile below it
+  hipLaunchKernelGGL(potrf_region_kernel, dim3((unsigned)(tasks * nb)), dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
 }
 
 int g_diag_form = -1;
