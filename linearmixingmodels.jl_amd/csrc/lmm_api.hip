@@ -292,6 +292,7 @@ void potrf_rec(const Batch& B, int ld, int NR, int j0, int w, int n_real, hipStr
 // also runs the leaf of the panel that follows it (launch_update_leaf), so that per 128 columns the stream sees two launches
 // (update + leaf, bulk) instead of six.  first_done: the diagonal block of the first panel of [j0, j0 + w) is already factored.
 // Widths that are not multiples of 128 (NC = 64 mod 128) end in the round-2 path for their last 64 columns.
+static int g_region_whole = 1;          // LMM_REGION_ALL=1: also as the base case of the recursion for larger matrices (measured: no gain)
 static int g_region_cols = -1;          // widest block column potrf_region_kernel takes in one launch (LMM_REGION=<columns>, up to 1024; default 0: off)
 void potrf_rec_panel(const Batch& B, const BatchPtr& W2, const BatchInfo& flags, int ld, int NR, int j0, int w, int n_real, hipStream_t st,
                      bool first_done) {
@@ -345,13 +346,17 @@ void potrf_batch(const Batch& B, int ld, int NR, int NC, int n_real, hipStream_t
   static int panel128 = -1;
   if (panel128 < 0) { const char* e = getenv("LMM_PANEL128"); panel128 = e ? (atoi(e) != 0) : 1; }
   if (g_f32 || !panel128 || NC < 128 || (ld & 1)) { potrf_rec(B, ld, NR, 0, NC, n_real, st); return; }
-  if (g_region_cols < 0) { const char* e = getenv("LMM_REGION"); g_region_cols = e ? atoi(e) : 0; if (g_region_cols > 128 * LMM_REGION_MAX_PANELS) g_region_cols = 128 * LMM_REGION_MAX_PANELS; }
+  if (g_region_cols < 0) { const char* e = getenv("LMM_REGION"); g_region_cols = e ? atoi(e) : 1024; const char* ea = getenv("LMM_REGION_ALL"); g_region_whole = (ea && atoi(ea) != 0) ? 0 : 1; if (g_region_cols > 128 * LMM_REGION_MAX_PANELS) g_region_cols = 128 * LMM_REGION_MAX_PANELS; }
   const size_t per = (size_t)(NC / 128) * 16384;
   double* w2 = call_scratch(per * B.nb);
   BatchPtr W2{};
   for (int j = 0; j < B.nb; ++j) W2.p[j] = w2 + per * j;
   BatchInfo flags{};
-  if (g_region_cols > 0) {                 // dependency flags of the region launches: zeroed once, then told apart by launch epoch
+  // Default: the region kernel serves matrices that are ONE region (NC <= 1024: the whole factorisation in one launch, the small-n
+  // path); larger matrices take the panel recursion throughout (as their base case the region kernel measured no faster than the
+  // panel launches: DESIGN.md).  LMM_REGION_ALL=1 enables it there too, LMM_REGION=0 disables it.
+  const bool region_here = g_region_cols > 0 && (!g_region_whole || (NC <= g_region_cols && (NC % 128) == 0));
+  if (region_here) {                       // dependency flags of the region launches: zeroed once, then told apart by launch epoch
     const size_t fi = (region_flag_ints(NR) + 1) / 2 * 2;
     int* fl = reinterpret_cast<int*>(call_scratch(fi / 2 * B.nb));
     HIPCHK(hipMemsetAsync(fl, 0, fi * sizeof(int) * B.nb, st));

@@ -16,6 +16,8 @@
 //   K7 trmv_lower_kernel (sample transform), axpy noise
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstdio>
+#include <vector>
 #include <cstdlib>
 #include "lmm_internal.h"
 
@@ -997,8 +999,10 @@ __device__ __forceinline__ void diag64m_steps_direct(Diag64mState& st, double* _
 // Wl[col * DIAG_LS + row] (zeros above the diagonal).  Sp: 64 * DIAG_SP doubles, Wt: 256 doubles of LDS work area.  Returns the mask of
 // non-positive (or NaN) pivots.  l = lane.  The last step's lagging MFMAs (group 2 of step 15) do not exist: nothing is pending.
 // Wl MAY overlap Sp / Wt (leaf128 does that to stay inside the update kernel's LDS footprint): it is written only after the last step.
+// src != nullptr: the block is taken from the LDS image src[col * DIAG_LS + row] instead of global memory (L still goes to A).
 template <typename TS>
-__device__ __forceinline__ unsigned long long diag64m_wave(void* __restrict__ A, size_t offA, int ld, double* Sp, double* Wt, double* Wl, int l) {
+__device__ __forceinline__ unsigned long long diag64m_wave(void* __restrict__ A, size_t offA, int ld, double* Sp, double* Wt, double* Wl, int l,
+                                                           const double* src = nullptr) {
   const int c = l & 15, g = l >> 4;
   Diag64mState st;
 #pragma unroll
@@ -1008,7 +1012,7 @@ __device__ __forceinline__ unsigned long long diag64m_wave(void* __restrict__ A,
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = 16 * rb + 4 * r + g, col = 16 * cb + c;
-        st.S[rb][cb][r] = (row >= col) ? MatIO<TS>::ld1(A, offA + (size_t)col * ld + row) : 0.0;
+        st.S[rb][cb][r] = (row >= col) ? (src ? src[col * DIAG_LS + row] : MatIO<TS>::ld1(A, offA + (size_t)col * ld + row)) : 0.0;
         st.V[rb][cb][r] = (row == col) ? 1.0 : 0.0;
       }
   st.e0 = g == 0 ? 1.0 : 0.0; st.e1 = g == 1 ? 1.0 : 0.0; st.e2 = g == 2 ? 1.0 : 0.0; st.e3 = g == 3 ? 1.0 : 0.0;
@@ -1936,6 +1940,49 @@ __global__ __launch_bounds__(256, 2) void gemm16h_kernel(BatchPtr Cb, size_t gof
 // D (64 x 64) = A R on four waves (wave w: rows 32 (w & 1).., columns 32 (w >> 1)..), operands in LDS with element strides
 // (A[i][k] = As[i sai + k sak], R[k][j] = Rs[k srk + j srj]); emit(u, v, r, row, col, value) receives every entry once, (u, v, r)
 // being compile-time after unrolling (so that callers can keep per-entry registers).
+// acc += A R over K = 64 nblk (operand pointers advance with sak / srk per k), in chunks of 32 k: the 32 operand values a lane needs
+// for a chunk are loaded (independent loads -- the operands may sit in global memory) while the 32 MFMAs of the previous chunk run.
+__device__ __forceinline__ void wg_mm64_core(d4 (&acc)[2][2], const double* As, size_t sai, size_t sak, const double* Rs, size_t srk, size_t srj,
+                                             int w, int l, int nblk = 1) {
+  const int c = l & 15, g = l >> 4, wi = 32 * (w & 1), wj = 32 * (w >> 1);
+  const double* pa = As + (wi + c) * sai + g * sak;
+  const double* pr = Rs + g * srk + (wj + c) * srj;
+  double fa[8][2], fr[8][2];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) fa[ks][u] = pa[16 * u * sai + 4 * ks * sak];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) fr[ks][v] = pr[4 * ks * srk + 16 * v * srj];
+  }
+  const int nch = 2 * nblk;
+  for (int ch = 0; ch < nch; ++ch) {
+    double fa2[8][2], fr2[8][2];
+    if (ch + 1 < nch) {
+      pa += 32 * sak; pr += 32 * srk;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) fa2[ks][u] = pa[16 * u * sai + 4 * ks * sak];
+#pragma unroll
+        for (int v = 0; v < 2; ++v) fr2[ks][v] = pr[4 * ks * srk + 16 * v * srj];
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ks][u], fr[ks][v], acc[u][v], 0, 0, 0);
+    if (ch + 1 < nch) {
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { fa[ks][u] = fa2[ks][u]; fr[ks][u] = fr2[ks][u]; }
+    }
+  }
+}
+
 template <typename Emit>
 __device__ __forceinline__ void wg_mm64(const double* __restrict__ As, int sai, int sak, const double* __restrict__ Rs, int srk, int srj,
                                         int w, int l, Emit emit) {
@@ -2289,14 +2336,22 @@ __device__ __forceinline__ void pipe128_accumulate(d4 (&acc)[4][4], double* __re
   }
 }
 
-// spin (thread 0) until *f == epoch, then make the producer's data visible to the whole workgroup.  Bounded: 1 s of the 100 MHz
-// wall clock, or until another workgroup raised *abort_word.
-__device__ __forceinline__ void region_wait(const int* f, int epoch, int* abort_word, int* info) {
+// ---- flags of a region launch (per matrix, ints; every value is epoch * 32 + count, so words left by earlier launches never match):
+//   [0] abort word (plain 0 / 1)      [1] wk: blocks the WALKER has finished -- count r means W_0 .. W_{r-1} and L[c, c-1], c <= r, are final
+//   [2 + r]  trs[r]:  64-column blocks of square row r that its HELPER has solved (count k + 1: L[r, 0 .. k] final), r >= 2
+//   [18 + r] upd[r]:  steps whose updates helper r has applied to its two rightmost tiles (r, r-1), (r, r) -- what the walker waits for
+//   [34 + j] dinv[j]: the 128 x 128 inverse of panel j is in the W2 scratch (count 0)
+// A wait spins on thread 0 (bounded: 1 s of the 100 MHz wall clock, or until another workgroup raised the abort word -- the grid
+// always drains), then an agent-scope acquire fence makes the producer's data visible to the whole workgroup.
+#define REGION_FLAG_INTS (34 + LMM_REGION_MAX_PANELS)
+__device__ __forceinline__ void region_wait_ge(const int* f, int epoch, int need, int* abort_word, int* info) {
   if (threadIdx.x == 0) {
     const long long t0 = wall_clock64();
     int polls = 0;
-    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
-      __builtin_amdgcn_s_sleep(2);
+    for (;;) {
+      const int v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((v >> 5) == epoch && (v & 31) >= need) break;
+      __builtin_amdgcn_s_sleep(1);
       if ((++polls & 63) == 0) {
         if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
         if (wall_clock64() - t0 > 100000000LL) {
@@ -2310,20 +2365,198 @@ __device__ __forceinline__ void region_wait(const int* f, int epoch, int* abort_
   __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
-__device__ __forceinline__ void region_signal(int* f, int epoch) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // every thread: its stores are performed device-wide
+// Publishing.  An agent-scope release fence writes back EVERY dirty line of the XCD's L2 -- including the megabytes the row streams
+// of the same launch keep producing -- and costs 4-13 us under load (tools/fence_probe, profiles/r03), twice per 64-column block of
+// the chain.  So everything the square publishes (L blocks, inverse blocks, the pair tiles) is stored WRITE-THROUGH (ST_PUB: agent-
+// scope relaxed atomic stores, `global_store ... sc1`), and publishing only waits for those stores to be acknowledged
+// (s_waitcnt vmcnt(0)) before the flag goes out.  Consumers still take an agent-scope ACQUIRE fence after seeing the flag (an L2
+// invalidate: 0.03-1.4 us), so their ordinary loads fetch the written-through data.
+#define ST_PUB(PTR, VAL) __hip_atomic_store((PTR), (VAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+__device__ __forceinline__ void region_publish(int* f, int epoch, int count) {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // every thread: its write-through stores are acknowledged
   __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_store(f, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) __hip_atomic_store(f, epoch * 32 + count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// ROW task of potrf_region_kernel: row tile i >= P of matrix b, columns j = 0 .. P-1 left to right.  It consumes only the square's
-// tiles X[j, p] (p < j) and the leaves, produces only its own row -- which nobody else reads inside this launch -- so it signals
-// nothing: no release fence, no flag traffic beyond P leaf flags and the square's readiness words.
-//   column j:  acc = X[i, 0:j] X[j, 0:j]'  as ONE pass over K = 128 j (own earlier outputs + the square's row j);  C[i, j] -= acc;
-//              wait leaf(j);  X[i, j] = C[i, j] Dinv_j'.
+// 64 x 64 block G (column-major, leading dimension ldg) -> LDS image img[col * DIAG_LS + row]; all 256 threads, 512-byte row runs
+__device__ __forceinline__ void img_load(double* __restrict__ img, const double* __restrict__ G, int ldg) {
+  const int t = threadIdx.x;
+  double v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { const int e = t + 256 * i; v[i] = G[(size_t)(e >> 6) * ldg + (e & 63)]; }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { const int e = t + 256 * i; img[(e >> 6) * DIAG_LS + (e & 63)] = v[i]; }
+}
+
+// The region's diagonal square (Q = 2P blocks of 64) is factored RIGHT-LOOKING at 64-column granularity -- the granularity that
+// keeps the serial chain of a Cholesky short -- by one WALKER workgroup per matrix plus one HELPER per block row:
+//   WALKER, block r:  [r > 0:  wait upd[r] >= r - 1;  L[r, r-1] = A[r, r-1] W_{r-1}'  (W_{r-1} is still in LDS from the previous
+//                      diagonal block);  A[r, r] -= L[r, r-1] L[r, r-1]';  publish wk = r]   diag64m -> L[r, r], W_r.
+//       The chain from one diagonal block to the next crosses NO flag and NO fence: ~10 us of diag64m + two 64^3 products.
+//   HELPER r (r >= 2), step k = 0 .. r-2 as soon as wk > k:  L[r, k] = A[r, k] W_k';  publish trs[r] = k + 1;  then its tiles
+//       A[r, c] -= L[r, k] L[c, k]'  -- (r, r-1) and (r, r) first (publish upd[r] = k + 1: the walker needs them at block r), then
+//       c = k+1 .. r-2.  L[c, k] comes from the walker (c = k + 1) or helper c (wait trs[c] > k).
+//   HELPER of an odd row b = 2j + 1 finally forms the panel inverse Dinv_j = [W_a 0; -W_b (L[b, a] W_a)  W_b] for the row streams.
+// Operands of every 64^3 product are read straight from global memory into MFMA fragments where they are only used once; the
+// operand reused across a step's updates (L[r, k]) sits in an LDS image.  Products are formed TRANSPOSED (D' = R' A') so that D's lane
+// index runs along the rows of the stored tile: four 128-byte segments per store / read-modify-write instruction.
+__device__ __forceinline__ void region_store_W(const RegionArgs& a, int b, const double* __restrict__ X, size_t grow, bool second) {
+  constexpr int LS = DIAG_LS;
+  double* Wm = a.W.p[b];
+  double* W2p = a.W2.p[b] + (size_t)(grow / 128) * 16384;
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int e = t + 256 * i, row = e & 63, col = e >> 6;
+    const double v = X[col * LS + row];
+    ST_PUB(&Wm[(size_t)(grow / 64) * 4096 + (size_t)col * 64 + row], v);
+    if (!second) { ST_PUB(&W2p[(size_t)col * 128 + row], v); ST_PUB(&W2p[(size_t)(64 + col) * 128 + row], 0.0); }
+    else ST_PUB(&W2p[(size_t)(64 + col) * 128 + 64 + row], v);
+  }
+}
+
+#define MM64_ZERO(ACC) _Pragma("unroll") for (int u_ = 0; u_ < 2; ++u_) _Pragma("unroll") for (int v_ = 0; v_ < 2; ++v_) ACC[u_][v_] = (d4){0.0, 0.0, 0.0, 0.0}
+// lane (c_, g_) of wave w holds D[i][j], i = wi + 16 u + 4 q + g_, j = wj + 16 v + c_, of a wg_mm64 product in acc[u][v][q]
+#define MM64_FOREACH(BODY) _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int v = 0; v < 2; ++v) _Pragma("unroll") \
+    for (int q = 0; q < 4; ++q) { const int i = wi + 16 * u + 4 * q + g_, j = wj + 16 * v + c_; BODY }
+
+__device__ __forceinline__ void potrf_region_walker(const RegionArgs& a, double* __restrict__ lds, double* __restrict__ Am, int b) {
+  constexpr int LS = DIAG_LS;
+  int* fl = a.flags.p[b];
+  int* abort_word = fl; int* wk = fl + 1; int* upd = fl + 18;
+  int* info = a.info.p[b];
+  double* X = lds;                          // image of W_{r-1} (left there by diag64m), then of the updated diagonal tile
+  double* Y = lds + 64 * LS;                // image of L[r, r-1], then diag64m's work areas
+  const int t = threadIdx.x, l = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int c_ = l & 15, g_ = l >> 4, wi = 32 * (w & 1), wj = 32 * (w >> 1);
+  const int Q = 2 * a.P;
+  int r0 = 0;
+  if (a.first_done) {                        // panel 0 came factored out of the preceding update launch (leaf128)
+    r0 = 2;
+    img_load(X, a.W.p[b] + (size_t)((a.c0 + 64) / 64) * 4096, 64);     // W_1
+    region_publish(wk, a.epoch, 1);            // W_0, L[1, 0]; wk = 2 (W_1 AND L[2, 1]) follows from block 2 below, as always
+  }
+  for (int r = r0; r < Q; ++r) {
+    const size_t grow = (size_t)a.c0 + 64 * (size_t)r;
+    const double* src = nullptr;
+    if (r > 0) {
+      const size_t gcol = grow - 64;
+      if (r >= 2) region_wait_ge(upd + r, a.epoch, r - 1, abort_word, info);     // tiles (r, r-1), (r, r) updated through block r - 2
+      // the diagonal tile (row j, column i) in the lanes that will hold its update D[i][j]
+      double dt[2][2][4];
+      const double* Ct = Am + grow * a.ld + grow;
+      MM64_FOREACH(dt[u][v][q] = (j >= i) ? Ct[(size_t)i * a.ld + j] : 0.0;)
+      // L[r, r-1]' = W_{r-1} A[r, r-1]'   (A-operand W = X: (1, LS); R[k'][j] = A[r, r-1][j][k'], straight from global: (ld, 1))
+      d4 acc[2][2];
+      MM64_ZERO(acc);
+      wg_mm64_core(acc, X, 1, LS, Am + gcol * a.ld + grow, a.ld, 1, w, l);
+      __syncthreads();                                                   // previous readers of Y (work areas of the last diag64m) are done
+      MM64_FOREACH(Y[i * LS + j] = acc[u][v][q]; ST_PUB(&Am[(gcol + i) * a.ld + grow + j], acc[u][v][q]);)        // D[i][j] = L[r, r-1][j][i]
+      region_publish(wk, a.epoch, r);                                    // W_{r-1} (stored last iteration) and L[r, r-1] are final;
+                                                                         // its barrier also completes Y = L[r, r-1] and ends the reads of X
+      // (A[r, r] update)' = L L'   (A-operand Y: (1, LS); R[k'][j] = L[j][k'] = Y[k' LS + j]: (LS, 1)) -> the tile, as an image in X
+      MM64_ZERO(acc);
+      wg_mm64_core(acc, Y, 1, LS, Y, LS, 1, w, l);
+      MM64_FOREACH(X[i * LS + j] = dt[u][v][q] - acc[u][v][q];)          // element (row j, column i); entries above the diagonal are never read
+      src = X;
+    }
+    __syncthreads();                                                     // the image (r > 0) is complete, Y is free
+    unsigned long long bad = 0ull;
+    if (w == 0) bad = diag64m_wave<double>(Am, grow * a.ld + grow, a.ld, Y, Y + 64 * DIAG_SP, X, l, src);      // L[r, r] -> global, W_r -> X
+    __syncthreads();
+    region_store_W(a, b, X, grow, (r & 1) != 0);
+    if (t == 0) { const int i = diag_info_of(bad, (int)grow, a.n_real); if (i) atomicCAS(info, 0, i); }
+  }
+  region_publish(wk, a.epoch, Q);
+}
+
+// HELPER of square row r >= 2, LEFT-LOOKING: column blocks c = 0 .. r-2 in turn,
+//     tile = A[r, c] - L[r, 0:c] L[c, 0:c]'    (ONE product over K = 64 c, operands straight from global, formed before W_c is needed)
+//     L[r, c] = tile W_c'                       (as soon as the walker publishes W_c);  publish trs[r] = c + 1
+//     pair accumulators (registers):  pa += L[r, c] L[r-1, c]',  pd += L[r, c] L[r, c]'
+// and once c = r - 2 is done:  A[r, r-1] -= pa,  A[r, r] -= pd  (their only read-modify-write);  publish upd[r] = r - 1.
+// The walker's request "tiles (r, r-1), (r, r) updated through block r - 2" thus costs, after W_{r-2} arrives, one solve, two 64^3
+// products in registers and one write -- about the time the walker spends in diag64m of block r - 1.
+__device__ __forceinline__ void potrf_region_helper(const RegionArgs& a, double* __restrict__ lds, double* __restrict__ Am, int b, int r) {
+  constexpr int LS = DIAG_LS;
+  int* fl = a.flags.p[b];
+  int* abort_word = fl; int* wk = fl + 1; int* trs = fl + 2; int* upd = fl + 18; int* dinv = fl + 34;
+  int* info = a.info.p[b];
+  double* Y = lds + 64 * LS;                // image of the tile, then of L[r, c]
+  const int t = threadIdx.x, l = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int c_ = l & 15, g_ = l >> 4, wi = 32 * (w & 1), wj = 32 * (w >> 1);
+  const size_t grow = (size_t)a.c0 + 64 * (size_t)r;
+  const size_t col0 = (size_t)a.c0 * a.ld;
+  const double* Wm = a.W.p[b];
+  const bool skip = a.first_done && r < 2;
+  if (r >= 2) {
+    d4 pa[2][2], pd[2][2];
+    MM64_ZERO(pa); MM64_ZERO(pd);
+    for (int c = 0; c <= r - 2; ++c) {
+      const size_t gcol = (size_t)a.c0 + 64 * (size_t)c;
+      d4 acc[2][2];
+      MM64_ZERO(acc);
+      if (c > 0) {
+        // row c final through block c - 1: its helper's blocks (c >= 2) and the walker's subdiagonal block
+        if (c >= 2) region_wait_ge(trs + c, a.epoch, c - 1, abort_word, info);
+        region_wait_ge(wk, a.epoch, c, abort_word, info);
+        // (tile update)' = L[c, 0:c] L[r, 0:c]'   (A[i][k'] = L[c][i][k']: (1, ld); R[k'][j] = L[r][j][k']: (ld, 1)), K = 64 c
+        wg_mm64_core(acc, Am + col0 + gcol, 1, a.ld, Am + col0 + grow, a.ld, 1, w, l, c);
+      }
+      const double* Ct = Am + gcol * a.ld + grow;
+      __syncthreads();                                                   // the previous column's readers of Y are done
+      MM64_FOREACH(Y[i * LS + j] = Ct[(size_t)i * a.ld + j] - acc[u][v][q];)       // tile element (row j, column i) -> image Y[col][row]
+      region_wait_ge(wk, a.epoch, c + 1, abort_word, info);              // W_c (its barrier completes the image)
+      // L[r, c]' = W_c tile'   (A[i][k'] = W_c[i][k'] global: (1, 64); R[k'][j] = tile[j][k'] = Y[k' LS + j]: (LS, 1))
+      MM64_ZERO(acc);
+      wg_mm64_core(acc, Wm + (size_t)(gcol / 64) * 4096, 1, 64, Y, LS, 1, w, l);
+      __syncthreads();                                                   // reads of the tile image done
+      MM64_FOREACH(Y[i * LS + j] = acc[u][v][q]; ST_PUB(&Am[(gcol + i) * a.ld + grow + j], acc[u][v][q]);)        // D[i][j] = L[r, c][j][i]
+      region_publish(trs + r, a.epoch, c + 1);                           // (release; its barrier completes Y = L[r, c])
+      // pair accumulators:  (r, r-1): D[i][j] += L[r-1, c][i][k'] L[r, c][j][k'];   (r, r): D[i][j] += L[r, c][i][k'] L[r, c][j][k']
+      if (c <= r - 3) region_wait_ge(trs + r - 1, a.epoch, c + 1, abort_word, info);      // helper r-1's L[r-1, c]; c = r-2: the walker's
+      wg_mm64_core(pa, Am + gcol * a.ld + grow - 64, 1, a.ld, Y, LS, 1, w, l);
+      wg_mm64_core(pd, Y, 1, LS, Y, LS, 1, w, l);
+    }
+    double* C1 = Am + (grow - 64) * a.ld + grow;
+    double* C2 = Am + grow * a.ld + grow;
+    MM64_FOREACH(ST_PUB(&C1[(size_t)i * a.ld + j], C1[(size_t)i * a.ld + j] - pa[u][v][q]);
+                 if (j >= i) ST_PUB(&C2[(size_t)i * a.ld + j], C2[(size_t)i * a.ld + j] - pd[u][v][q]);)
+    region_publish(upd + r, a.epoch, r - 1);
+  }
+  if ((r & 1) && !skip) {
+    // Dinv of panel j = r / 2 (a = r - 1, b = r), once the walker has published W_b:  T = L[b, a] W_a;  W21 = -W_b T
+    region_wait_ge(wk, a.epoch, r + 1, abort_word, info);
+    const size_t gcol = grow - 64;
+    d4 acc[2][2];
+    MM64_ZERO(acc);
+    // T = L[b, a] W_a   (A[i][k'] = L[i][k'] global: (1, ld); R[k'][j] = W_a[k'][j] global: (1, 64))
+    wg_mm64_core(acc, Am + gcol * a.ld + grow, 1, a.ld, Wm + (size_t)(gcol / 64) * 4096, 1, 64, w, l);
+    __syncthreads();
+    MM64_FOREACH(Y[j * LS + i] = acc[u][v][q];)                          // Y = image of T: T[row i][col j] -> Y[col * LS + row]
+    __syncthreads();
+    double* W2p = a.W2.p[b] + (size_t)(grow / 128) * 16384;
+    // D = T' W_b'  (A[i][k'] = T[k'][i] = Y[i LS + k']: (LS, 1); R[k'][j] = W_b[j][k'] global: (64, 1))  ->  W21[j][i] = -D[i][j]
+    MM64_ZERO(acc);
+    wg_mm64_core(acc, Y, LS, 1, Wm + (size_t)(grow / 64) * 4096, 64, 1, w, l);
+    MM64_FOREACH(ST_PUB(&W2p[(size_t)i * 128 + 64 + j], -acc[u][v][q]);)
+    region_publish(dinv + (r >> 1), a.epoch, 0);
+  } else if (skip && r == 1) {
+    region_publish(dinv + 0, a.epoch, 0);                                // the fused leaf left Dinv_0 in the scratch
+  }
+}
+
+// ROW task of potrf_region_kernel: row tile i >= P of matrix b (128 rows below the square, riders included), columns j = 0 .. P-1
+// left to right.  It consumes only the square's rows 2j, 2j+1 (final through block column 2j - 1) and the panel inverses, produces
+// only its own row -- which nobody else reads inside this launch -- so it signals nothing: no release fence, no flag traffic beyond
+// 3 P waits.
+//   column j:  acc = X[i, 0:j] X[j, 0:j]'  as ONE pass over K = 128 j (own earlier outputs + the square's rows);  C[i, j] -= acc;
+//              wait Dinv_j;  X[i, j] = C[i, j] Dinv_j'.
 __device__ __forceinline__ void potrf_region_row(const RegionArgs& a, double* __restrict__ lds, double* __restrict__ Am, int b, int ti) {
   int* abort_word = a.flags.p[b];
-  int* F = abort_word + 2;
+  int* wk = abort_word + 1; int* trs = abort_word + 2; int* dinv = abort_word + 34;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int wr = (w & 1) * 64, wc = (w >> 1) * 64;
   const int l15 = lane & 15, lk = lane >> 4;
@@ -2339,7 +2572,10 @@ __device__ __forceinline__ void potrf_region_row(const RegionArgs& a, double* __
       for (int v = 0; v < 4; ++v)
 #pragma unroll
         for (int u = 0; u < 4; ++u) acc[v][u] = (d4){0.0, 0.0, 0.0, 0.0};
-      for (int p = 0; p < tj; ++p) region_wait(F + p * a.R + tj, a.epoch, abort_word, a.info.p[b]);      // the square's X[j, p]
+      // the square's rows 2 tj, 2 tj + 1 final through block column 2 tj - 1: helpers' blocks + the walker's subdiagonal block
+      region_wait_ge(trs + 2 * tj, a.epoch, 2 * tj - 1, abort_word, a.info.p[b]);
+      region_wait_ge(wk, a.epoch, 2 * tj, abort_word, a.info.p[b]);
+      region_wait_ge(trs + 2 * tj + 1, a.epoch, 2 * tj, abort_word, a.info.p[b]);
       const size_t col0 = (size_t)a.c0 * a.ld;
       pipe128_accumulate(acc, lds, Am + col0 + row_i, a.ld, rows_i, Am + col0 + row_j, a.ld, 128, 8 * tj);
       if (active) {
@@ -2359,7 +2595,7 @@ __device__ __forceinline__ void potrf_region_row(const RegionArgs& a, double* __
       }
       __syncthreads();
     }
-    region_wait(F + tj * a.R + tj, a.epoch, abort_word, a.info.p[b]);                                     // leaf(j): Dinv_j
+    region_wait_ge(dinv + tj, a.epoch, 0, abort_word, a.info.p[b]);                          // Dinv_j
 #pragma unroll
     for (int v = 0; v < 4; ++v)
 #pragma unroll
@@ -2379,89 +2615,22 @@ __device__ __forceinline__ void potrf_region_row(const RegionArgs& a, double* __
   }
 }
 
-__global__ __launch_bounds__(256, 2) void potrf_region_kernel(RegionArgs a) {
+// 1-D grid in dispatch order (matrices interleaved): the walkers, the helpers of square rows 1 .. 2P-1, then the row streams.
+// Deadlock freedom: helper r waits only for the walker and for helpers of rows above it, a row stream only for the square -- all
+// dispatched before it.  The walker is the one workgroup that waits for a LATER one (helper r, at block r); but by then it has
+// published everything the helpers of rows < r need to finish (they never wait beyond wk = r - 1), so they complete and free their
+// slots however few workgroups are resident, helper r gets dispatched and runs.  One workgroup per CU (414 registers per lane).
+template <int OCC>       // 1: one workgroup per CU (no register spills in the walker); 2: two (the row streams' natural occupancy)
+__global__ __launch_bounds__(256, OCC) void potrf_region_kernel(RegionArgs a) {
   extern __shared__ __attribute__((aligned(16))) double node_lds[];
-  // task decode.  TOP tasks first: tiles (i, j) of the region's P x P diagonal square, item -> (matrix b, wavefront s, column j);
-  // wavefront s holds the tiles (s - j, j), j from min(P-1, s/2) down to max(0, s - (P-1)).  Then the ROW tasks: one workgroup per
-  // row tile i >= P (the rows below the square, riders included), which walks its row left to right on its own.
-  const int b = blockIdx.x % a.nb;
-  int idx = blockIdx.x / a.nb, ti = 0, tj = 0;
-  const int ntop = a.P * (a.P + 1) / 2;
+  const int b = blockIdx.x % a.nb, idx = blockIdx.x / a.nb;
   double* Am = a.A.p[b];
-  if (idx >= ntop) { potrf_region_row(a, node_lds, Am, b, a.P + idx - ntop); return; }
-  for (int sft = 0; sft <= 2 * a.P - 2; ++sft) {
-    const int jhi = min(a.P - 1, sft >> 1), jlo = max(0, sft - (a.P - 1));
-    const int cnt = jhi - jlo + 1;
-    if (cnt <= 0) continue;
-    if (idx < cnt) { tj = jhi - idx; ti = sft - tj; break; }
-    idx -= cnt;
-  }
-  int* abort_word = a.flags.p[b];                                 // word 0: raised on a dependency timeout (host checks it)
-  int* F = abort_word + 2;                                        // F[p * R + i]: tile (i, p) of this launch is final (== epoch)
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const int wr = (w & 1) * 64, wc = (w >> 1) * 64;
-  const int l15 = lane & 15, lk = lane >> 4;
-  const int rows_i = min(128, a.M - 128 * ti);                    // valid rows of row tile ti (64 for a ragged last tile)
-  const size_t row_i = (size_t)a.c0 + 128 * (size_t)ti, row_j = (size_t)a.c0 + 128 * (size_t)tj;
-  double* C = Am + row_j * a.ld + row_i;                          // tile (ti, tj)
-  const bool active = (wr < rows_i) && !(ti == tj && wr + 63 < wc);
-  if (tj > 0) {
-    d4 acc[4][4];
-#pragma unroll
-    for (int v = 0; v < 4; ++v)
-#pragma unroll
-      for (int u = 0; u < 4; ++u) acc[v][u] = (d4){0.0, 0.0, 0.0, 0.0};
-    for (int p = 0; p < tj; ++p) {
-      region_wait(F + p * a.R + ti, a.epoch, abort_word, a.info.p[b]);
-      if (ti != tj) region_wait(F + p * a.R + tj, a.epoch, abort_word, a.info.p[b]);
-      const size_t colp = ((size_t)a.c0 + 128 * (size_t)p) * a.ld;
-      pipe128_accumulate(acc, node_lds, Am + colp + row_i, a.ld, rows_i, Am + colp + row_j, a.ld, 128);
-    }
-    if (active) {
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        double* cpv = C + (size_t)(wc + 16 * v + lk) * a.ld + wr + l15;
-        double cv[4][4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) cv[u][r] = cpv[(size_t)(4 * r) * a.ld + 16 * u];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) cpv[(size_t)(4 * r) * a.ld + 16 * u] = cv[u][r] - acc[v][u][r];
-      }
-    }
-    __syncthreads();                                              // the tile is in global memory for this workgroup's own reads
-  }
-  const size_t r0 = row_j;                                        // global column (= row) of panel tj's diagonal block
-  double* W2p = a.W2.p[b] + (size_t)(r0 / 128) * 16384;
-  if (ti == tj) {
-    if (!(tj == 0 && a.first_done))
-      leaf128_dev(node_lds, Am, r0 * a.ld + r0, a.ld, a.W.p[b], (size_t)(r0 / 64) * 4096, W2p, (int)r0, a.n_real, a.info.p[b]);
-    region_signal(F + tj * a.R + ti, a.epoch);
-    return;
-  }
-  region_wait(F + tj * a.R + tj, a.epoch, abort_word, a.info.p[b]);
-  {
-    d4 acc[4][4];
-#pragma unroll
-    for (int v = 0; v < 4; ++v)
-#pragma unroll
-      for (int u = 0; u < 4; ++u) acc[v][u] = (d4){0.0, 0.0, 0.0, 0.0};
-    pipe128_accumulate(acc, node_lds, C, a.ld, rows_i, W2p, 128, 128);
-    if (active) {
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        double* cpv = C + (size_t)(wc + 16 * v + lk) * a.ld + wr + l15;
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) cpv[(size_t)(4 * r) * a.ld + 16 * u] = acc[v][u][r];
-      }
-    }
-  }
-  region_signal(F + tj * a.R + ti, a.epoch);
+  const int Q = 2 * a.P;
+  if (a.trace && threadIdx.x == 0) a.trace[2 * blockIdx.x] = wall_clock64();
+  if (idx == 0) potrf_region_walker(a, node_lds, Am, b);
+  else if (idx < Q) potrf_region_helper(a, node_lds, Am, b, idx);
+  else potrf_region_row(a, node_lds, Am, b, a.P + idx - Q);
+  if (a.trace && threadIdx.x == 0) a.trace[2 * blockIdx.x + 1] = wall_clock64();
 }
 
 #undef LMM_MFMA16H_ALL
@@ -3358,7 +3527,8 @@ static void node_lds_attr() {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(leaf128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_node_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_node_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_region_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_region_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_region_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   done = true;
 }
 void launch_leaf128(const BatchPtr& A, size_t offD, int ld, const BatchPtr& W, size_t offW, const BatchPtr& W2, size_t offW2,
@@ -3426,7 +3596,7 @@ void launch_update_leaf(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2
   }
 }
 
-size_t region_flag_ints(int NR) { return (size_t)LMM_REGION_MAX_PANELS * ((NR + 127) / 128) + 2; }
+size_t region_flag_ints(int) { return REGION_FLAG_INTS; }
 static int g_region_epoch = 0;
 void launch_region(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2, const BatchInfo& info, const BatchInfo& flags, int ld, int NR,
                    int c0, int width, int n_real, int nb, bool first_done, hipStream_t st) {
@@ -3435,10 +3605,34 @@ void launch_region(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2, con
   node_lds_attr();
   RegionArgs a{};
   a.A = A; a.W = W; a.W2 = W2; a.info = info; a.flags = flags; a.ld = ld; a.M = M; a.c0 = c0; a.P = P; a.R = R; a.n_real = n_real; a.nb = nb;
-  if (++g_region_epoch <= 0) g_region_epoch = 1;
+  if (++g_region_epoch >= (1 << 26)) g_region_epoch = 1;
   a.epoch = g_region_epoch; a.first_done = first_done ? 1 : 0;
-  const long long tasks = (long long)P * (P + 1) / 2 + (R - P);       // the square's tiles + one task per row tile below it
-  hipLaunchKernelGGL(potrf_region_kernel, dim3((unsigned)(tasks * nb)), dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
+  const long long tasks = 2LL * P + (R - P);       // the square's 64-row blocks + one task per 128-row tile below it
+  // LMM_REGION_OCC=1 / 2 forces a build; default: one workgroup per CU while the whole launch is resident that way, else two
+  static int occ_env = -1, cus = 0;
+  if (occ_env < 0) { const char* e = getenv("LMM_REGION_OCC"); occ_env = e ? atoi(e) : 0; }
+  if (cus == 0) { int dev = 0; cus = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); }
+  const int occ = occ_env ? occ_env : (tasks * nb <= cus ? 1 : 2);
+  // LMM_REGION_TRACE=1: per-workgroup start / end ticks (100 MHz) of every region launch, printed to stderr (a debugging aid: it
+  // synchronises the stream after each launch)
+  static int trace_env = -1;
+  if (trace_env < 0) { const char* e = getenv("LMM_REGION_TRACE"); trace_env = e ? atoi(e) : 0; }
+  long long* tr = nullptr;
+  if (trace_env) { if (hipMalloc((void**)&tr, (size_t)tasks * nb * 2 * sizeof(long long)) != hipSuccess) tr = nullptr; }
+  a.trace = tr;
+  if (occ == 1) hipLaunchKernelGGL(potrf_region_kernel<1>, dim3((unsigned)(tasks * nb)), dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
+  else hipLaunchKernelGGL(potrf_region_kernel<2>, dim3((unsigned)(tasks * nb)), dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
+  if (tr) {
+    (void)hipStreamSynchronize(st);
+    std::vector<long long> h((size_t)tasks * nb * 2);
+    (void)hipMemcpy(h.data(), tr, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+    long long t0 = h[0];
+    for (size_t i = 0; i < h.size(); i += 2) if (h[i] < t0) t0 = h[i];
+    fprintf(stderr, "[region-trace] c0=%d P=%d R=%d nb=%d occ=%d\n", c0, P, R, nb, occ);
+    for (long long i = 0; i < tasks * nb; ++i)
+      fprintf(stderr, "[region-trace] wg=%lld b=%lld idx=%lld start_us=%.2f end_us=%.2f\n", i, i % nb, i / nb, (h[2 * i] - t0) / 100.0, (h[2 * i + 1] - t0) / 100.0);
+    (void)hipFree(tr);
+  }
 }
 
 int g_diag_form = -1;
