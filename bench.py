@@ -323,8 +323,9 @@ def main():
                 if tj.get("workload") == args.workload:
                     traffic = tj.get("update_kernel", {}).get("bytes_per_launch")
             roof = {"bound": "mfma", "kernel": ("gemm32_kernel<128,false> (v_mfma_f32_32x32x2_f32 SYRK/GEMM trailing update)" if args.dtype == "f32"
-                                                else "potrf_node_kernel<DEPTH> (v_mfma_f64_16x16x4_f64, VGPR accumulators, software-pipelined SYRK/GEMM trailing update; "
-                                                     "one workgroup per matrix also factors the next panel's 128 x 128 diagonal block)"),
+                                                else "potrf_node_kernel<2> (v_mfma_f64_16x16x4_f64, VGPR accumulators, software-pipelined SYRK/GEMM trailing update, K >= 1024; "
+                                                     "one workgroup per matrix also factors the next panel's 128 x 128 diagonal block; + gemm16h_kernel<true> "
+                                                     "on a ragged last 64 rows)"),
                     "achieved": round(ach, 3), "peak": peak_tf, "unit": "TFLOP/s",
                     "frac": round(ach / peak_tf, 4), "traffic": traffic if args.dtype == "f64" else None,
                     "traffic_source": ("profiles/pmc_traffic.json: fabric bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
@@ -333,6 +334,12 @@ def main():
                     "flops_per_launch": up["work"] / up["launches"],
                     "algorithmic_bytes_per_launch": up["bytes"] / up["launches"],
                     "mode": f"serial-stream instrumented pass over {nprof} latent(s)"}
+        us = prof.get("update_short")
+        if us and us["launches"] and us["ms"] > 0:
+            extra["roofline_update_short"] = {"bound": "mfma", "kernel": "potrf_node_kernel<1> (the same fused update + leaf, K < 1024: epilogue- and latency-bound levels)",
+                                               "achieved": round(us["work"] / (us["ms"] * 1e-3) / 1e12, 3), "peak": peak_tf, "unit": "TFLOP/s",
+                                               "frac": round(us["work"] / (us["ms"] * 1e-3) / 1e12 / peak_tf, 4), "launches": us["launches"],
+                                               "avg_launch_ms": round(us["ms"] / us["launches"], 4)}
         gr = prof["gram"]
         if gr["launches"] and gr["ms"] > 0:
             gbs = gr["work"] / (gr["ms"] * 1e-3) / 1e9

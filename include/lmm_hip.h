@@ -348,15 +348,17 @@ int lmm_normals(unsigned long long seed, unsigned long long stream, size_t count
  * work = algorithmic flops (MFMA classes) or algorithmic HBM bytes (Gram assembly) summed over launches. */
 typedef enum {
   LMM_PROF_GRAM = 0,          /* gram_batch_kernel: lower-triangular f64 write, bytes                                          */
-  LMM_PROF_UPDATE = 1,        /* potrf_node_kernel<DEPTH> (round 3: SYRK/GEMM trailing update + the next panel's leaf128 in one
-                                 launch; LMM_PANEL128=0 / fp32: gemm16p_kernel / gemm16h_kernel / gemm32_kernel), flops         */
+  LMM_PROF_UPDATE = 1,        /* potrf_node_kernel<2> (round 3: SYRK/GEMM trailing update with K >= 1024 + the next panel's leaf128 in
+                                 one launch, + gemm16h_kernel<true> for a ragged last 64 rows; LMM_PANEL128=0 / fp32: every wide
+                                 update: gemm16p_kernel / gemm16h_kernel / gemm32_kernel), flops                                */
   LMM_PROF_UPDATE_NARROW = 2, /* gemm44_kernel<64,false>: 64-column update (round-2 path; trailing 64 columns), flops           */
   LMM_PROF_TRSM = 3,          /* potrf_node_kernel<1> in bulk mode: panel rows x 128 x 128 inverse (round-2 path:
                                  gemm44_kernel<64,true>, TRSM by the 64 x 64 inverse block), flops                              */
   LMM_PROF_DIAG = 4,          /* leaf128_kernel (first panel) / diag64m_kernel: diagonal-block factor + inverse, flops          */
   LMM_PROF_REGION = 5,        /* potrf_region_kernel: a block column of <= 8 panels (leaves, bulk products, inner updates) in one
                                  dataflow launch, flops                                                                         */
-  LMM_PROF_COUNT = 6
+  LMM_PROF_UPDATE_SHORT = 6,  /* potrf_node_kernel<1>: the same fused update + leaf for K < 1024 (latency- and epilogue-bound levels)  */
+  LMM_PROF_COUNT = 7
 } lmm_prof_class;
 typedef struct { long long launches; double ms; double work; double bytes; /* algorithmic HBM bytes */ } lmm_prof_entry_t;
 int lmm_profile_begin(int serial);

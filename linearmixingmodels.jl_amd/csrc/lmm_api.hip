@@ -214,7 +214,7 @@ inline int eff_streams() { return (g.prof && g.prof_serial) ? 1 : g.nstreams; }
 struct Dims {
   int n, NC, NR, ld;
   Dims(int n_, int nrider) : n(n_) {
-    NC = rup(std::max(n, 1), 64);
+    NC = rup(std::max(n, 1), 128);      // whole 128-column panels (round 3: the panel / region kernels work on them; the pad is identity)
     NR = rup(NC + std::max(nrider, 0), 64);
     ld = NR;
     if ((ld % 512) == 0) ld += 16;   // keep column starts off the same HBM channel / L2 set
@@ -327,7 +327,9 @@ void potrf_rec_panel(const Batch& B, const BatchPtr& W2, const BatchInfo& flags,
   if (Nc >= 128) {
     // + the leaf's 2 * 128^3 / 3 flops, run by one workgroup of this launch
     {
-      ProfScope ps(LMM_PROF_UPDATE, nb * (2.0 * h * outs + 2.0 * 128.0 * 128.0 * 128.0 / 3.0), st, NR - r0, Nc, h, nb * (16.0 * outs + 8.0 * Mr * h));
+      // K >= 1024: potrf_node_kernel<2> (+ gemm16h_kernel for a ragged last 64 rows) -- the dominant kernel; below: potrf_node_kernel<1>
+      ProfScope ps(h >= 1024 ? LMM_PROF_UPDATE : LMM_PROF_UPDATE_SHORT, nb * (2.0 * h * outs + 2.0 * 128.0 * 128.0 * 128.0 / 3.0), st, NR - r0, Nc, h,
+                   nb * (16.0 * outs + 8.0 * Mr * h));
       launch_update_leaf(B.A, B.W, W2, B.info, ld, NR, j0, h, Nc, n_real, B.nb, st);
     }
     potrf_rec_panel(B, W2, flags, ld, NR, r0, Nc, n_real, st, true);

@@ -75,6 +75,7 @@ struct RegionArgs {
   BatchPtr A, W, W2;
   BatchInfo info, flags;  // flags: P * R readiness words + 1 abort word per matrix (zeroed once per factorisation)
   int ld, M, c0, P, R, n_real, nb, epoch, first_done;
+  int ntasks;             // workgroups per matrix (trace layout)
   long long* trace;       // optional (LMM_REGION_TRACE=1, tools/region_trace.py): start / end wall-clock ticks of every workgroup
 };
 #define LMM_REGION_MAX_PANELS 8

@@ -2437,12 +2437,15 @@ __device__ __forceinline__ void potrf_region_walker(const RegionArgs& a, double*
     img_load(X, a.W.p[b] + (size_t)((a.c0 + 64) / 64) * 4096, 64);     // W_1
     region_publish(wk, a.epoch, 1);            // W_0, L[1, 0]; wk = 2 (W_1 AND L[2, 1]) follows from block 2 below, as always
   }
+  long long* tr2 = a.trace ? a.trace + 2 * (size_t)a.ntasks * a.nb + 64 * (size_t)b : nullptr;      // per-block stamps (debug)
   for (int r = r0; r < Q; ++r) {
     const size_t grow = (size_t)a.c0 + 64 * (size_t)r;
     const double* src = nullptr;
+    if (tr2 && t == 0) tr2[r] = wall_clock64();
     if (r > 0) {
       const size_t gcol = grow - 64;
       if (r >= 2) region_wait_ge(upd + r, a.epoch, r - 1, abort_word, info);     // tiles (r, r-1), (r, r) updated through block r - 2
+      if (tr2 && t == 0) tr2[16 + r] = wall_clock64();
       // the diagonal tile (row j, column i) in the lanes that will hold its update D[i][j]
       double dt[2][2][4];
       const double* Ct = Am + grow * a.ld + grow;
@@ -2463,8 +2466,10 @@ __device__ __forceinline__ void potrf_region_walker(const RegionArgs& a, double*
     }
     __syncthreads();                                                     // the image (r > 0) is complete, Y is free
     unsigned long long bad = 0ull;
+    if (tr2 && t == 0) tr2[32 + r] = wall_clock64();
     if (w == 0) bad = diag64m_wave<double>(Am, grow * a.ld + grow, a.ld, Y, Y + 64 * DIAG_SP, X, l, src);      // L[r, r] -> global, W_r -> X
     __syncthreads();
+    if (tr2 && t == 0) tr2[48 + r] = wall_clock64();
     region_store_W(a, b, X, grow, (r & 1) != 0);
     if (t == 0) { const int i = diag_info_of(bad, (int)grow, a.n_real); if (i) atomicCAS(info, 0, i); }
   }
@@ -3618,19 +3623,25 @@ void launch_region(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2, con
   static int trace_env = -1;
   if (trace_env < 0) { const char* e = getenv("LMM_REGION_TRACE"); trace_env = e ? atoi(e) : 0; }
   long long* tr = nullptr;
-  if (trace_env) { if (hipMalloc((void**)&tr, (size_t)tasks * nb * 2 * sizeof(long long)) != hipSuccess) tr = nullptr; }
-  a.trace = tr;
+  if (trace_env) { if (hipMalloc((void**)&tr, ((size_t)tasks * nb * 2 + 64 * (size_t)nb) * sizeof(long long)) != hipSuccess) tr = nullptr; }
+  a.trace = tr; a.ntasks = (int)tasks;
   if (occ == 1) hipLaunchKernelGGL(potrf_region_kernel<1>, dim3((unsigned)(tasks * nb)), dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
   else hipLaunchKernelGGL(potrf_region_kernel<2>, dim3((unsigned)(tasks * nb)), dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
   if (tr) {
     (void)hipStreamSynchronize(st);
-    std::vector<long long> h((size_t)tasks * nb * 2);
+    std::vector<long long> h((size_t)tasks * nb * 2 + 64 * (size_t)nb);
     (void)hipMemcpy(h.data(), tr, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
     long long t0 = h[0];
-    for (size_t i = 0; i < h.size(); i += 2) if (h[i] < t0) t0 = h[i];
+    for (size_t i = 0; i < (size_t)tasks * nb * 2; i += 2) if (h[i] < t0) t0 = h[i];
     fprintf(stderr, "[region-trace] c0=%d P=%d R=%d nb=%d occ=%d\n", c0, P, R, nb, occ);
     for (long long i = 0; i < tasks * nb; ++i)
       fprintf(stderr, "[region-trace] wg=%lld b=%lld idx=%lld start_us=%.2f end_us=%.2f\n", i, i % nb, i / nb, (h[2 * i] - t0) / 100.0, (h[2 * i + 1] - t0) / 100.0);
+    {                                                             // matrix 0's walker: per block [arrive, flag seen, diag start, diag end]
+      const long long* w0 = h.data() + (size_t)tasks * nb * 2;
+      for (int r = first_done ? 2 : 0; r < 2 * P; ++r)
+        fprintf(stderr, "[region-walker] r=%d arrive=%.2f flag=%.2f diag0=%.2f diag1=%.2f\n", r, (w0[r] - t0) / 100.0, r ? (w0[16 + r] - t0) / 100.0 : 0.0,
+                (w0[32 + r] - t0) / 100.0, (w0[48 + r] - t0) / 100.0);
+    }
     (void)hipFree(tr);
   }
 }

@@ -7,6 +7,16 @@ import csv, json, sys, collections
 # the library (lmm_api.hip potrf_rec) is one gemm16p_kernel<DEPTH> launch plus, for a ragged last 64 rows, one gemm16h_kernel launch:
 # bytes of both, divided by the gemm16p launches (the count bench.py's roofline.launches uses).
 def aggregate_update(out):
+    # round 3: the dominant kernel is potrf_node_kernel<2> (K >= 1024 updates + the next panel's leaf) plus gemm16h_kernel<true> on the
+    # ragged last 64 rows of the same update: bytes of both per potrf_node_kernel<2> launch (= bench.py's roofline.launches)
+    node = [k for k in out if isinstance(out[k], dict) and k.startswith("potrf_node_kernel<2>")]
+    if node:
+        parts = node + [k for k in out if isinstance(out[k], dict) and k.startswith("gemm16h_kernel<true>")]
+        n = sum(out[k]["launches"] for k in node)
+        agg = {f: sum(out[k][f] * out[k]["launches"] for k in parts) / n
+               for f in ("fetch_bytes_per_launch_x2", "write_bytes_per_launch", "bytes_per_launch")}
+        out["update_kernel"] = dict(agg, launches=n, kernel=" + ".join(parts))
+        return
     wide = [k for k in out if isinstance(out[k], dict) and k.startswith("gemm16p_kernel")]
     if not wide:
         wide = [k for k in out if isinstance(out[k], dict) and k.startswith("gemm44_kernel<128, false")]
@@ -35,4 +45,4 @@ for k in f:
     out[k] = {"launches": f[k][0], "fetch_bytes_per_launch_x2": fb, "write_bytes_per_launch": wb, "bytes_per_launch": fb + wb}
 aggregate_update(out)
 json.dump(out, open(sys.argv[4], "w"), indent=1)
-print(json.dumps({k: v for k, v in out.items() if "gemm" in k or "gram" in k or k == "update_kernel"}, indent=1))
+print(json.dumps({k: v for k, v in out.items() if "gemm" in k or "gram" in k or "potrf" in k or "leaf" in k or k == "update_kernel"}, indent=1))

@@ -4,7 +4,7 @@ import collections
 import re
 import sys
 
-CLS = {0: "gram", 1: "update(+leaf)", 2: "update_narrow", 3: "trsm/bulk", 4: "diag/leaf", 5: "region"}
+CLS = {0: "gram", 1: "update(+leaf)", 2: "update_narrow", 3: "trsm/bulk", 4: "diag/leaf", 5: "region", 6: "update_short"}
 acc = collections.OrderedDict()
 for line in open(sys.argv[1]):
     m = re.match(r"\[prof\] cls=(\d+) M=(\d+) N=(\d+) K=(\d+) ms=([\d.]+) tflops=([\d.]+)", line)
