@@ -173,10 +173,21 @@ def get_projection_dtype() -> str:
     return ["native", "bf16", "bf16x2"][load().lmm_get_projection_dtype()]
 
 
+def wait_stream(stream) -> None:
+    """Order the library's streams behind everything queued so far on `stream` (a torch.cuda.Stream, or any object with a
+    `cuda_stream` handle; None = the legacy default stream): lmm_stream_wait_caller.  Call it before handing over a device tensor
+    that was produced on a stream OTHER than torch's current one -- order_after_torch() below only looks at the current stream."""
+    ensure_init()
+    h = None if stream is None else getattr(stream, "cuda_stream", stream)
+    check(load().lmm_stream_wait_caller(C.c_void_p(h)))
+
+
 def order_after_torch() -> None:
     """The library runs on its own non-blocking HIP streams; torch produces (and recycles) device tensors asynchronously on ITS
     current stream.  Before a device pointer crosses the ABI, make the library's streams wait for everything torch has queued
-    (lmm_stream_wait_caller: one event record + one stream wait, no host stall).  Skipped when torch's stream is already idle."""
+    (lmm_stream_wait_caller: one event record + one stream wait, no host stall).  Skipped when torch's CURRENT stream is already
+    idle; a tensor produced on another stream (torch.cuda.stream(s) blocks, side streams of a data loader) must be named by
+    the caller: lmm_amd.wait_stream(s)."""
     import torch
     st = torch.cuda.current_stream()
     if st.query():

@@ -181,9 +181,9 @@ class _PostHandle:
 
     def __init__(self, ptr: C.c_void_p, l0: int, l1: int, dense: bool = False, train=None, latent: bool = False, parent=None):
         self.ptr, self.l0, self.l1, self.dense = ptr, l0, l1, dense      # dense: coupled (mn) x (mn) state of a dense-H ILMM
-        # (x, sigma2, y) the posterior was built from (references, no copies): the gradient of the predictive logpdf is a total
-        # derivative through the posterior and needs them; None after sequential conditioning
-        self.train = train
+        # the conditioning batches [(x, sigma2, y), ...] the posterior was built from (references, no copies): the gradient of the
+        # predictive logpdf is a total derivative through the posterior and needs them (one entry per posterior(...) call)
+        self.train = train if (train is None or isinstance(train, list)) else [train]
         self.latent = latent          # dense only: this handle's H is I_m (it IS the latent PosteriorGP{IndependentMOGP})
         self._parent = parent         # a latent view keeps the handle whose device state it shares alive
         self._view = None
@@ -277,6 +277,38 @@ def unpack(fx: FiniteGP):
     if fx.x.out_dim != f.H.shape[0]:
         raise RuntimeError("out dim of x != out dim of f.")
     return f.f, f.H, fx.sigma2, fx.x.x
+
+
+def _merged_train(train, p: int):
+    """The conditioning batches of a (sequentially conditioned) posterior as ONE batch: posterior(posterior(f(x1, s2), y1)(x2, s2), y2)
+    is the posterior given ([x1 x2], [y1; y2]) when the batches carry the same noise variance, which is the case the gradient entry
+    points serve (two noise blocks: training, test).  Returns (x_all, s2, y_all, sizes); y is by-outputs, so the batches interleave
+    per output."""
+    if train is None:
+        raise NotImplementedError("this posterior does not carry its training data (built outside posterior(fx, y))")
+    if len(train) == 1:
+        x0, s20, y0 = train[0]
+        return x0, s20, y0, [x0.n]
+    s2s = {float(t[1]) for t in train}
+    if len(s2s) != 1:
+        raise NotImplementedError("gradient of the predictive logpdf after sequential conditioning with DIFFERENT noise variances per "
+                                  "batch is not built (equal variances are: the batches merge into one)")
+    xs = [np.asarray(t[0].x.cpu() if L._is_torch(t[0].x) else t[0].x, dtype=np.float64) for t in train]
+    ys = [np.asarray(t[2].cpu() if L._is_torch(t[2]) else t[2], dtype=np.float64).reshape(p, -1) for t in train]
+    x_all = np.concatenate(xs, axis=-1)
+    y_all = np.concatenate(ys, axis=1).reshape(-1)
+    return MOInputIsotopicByOutputs(x_all, p), s2s.pop(), y_all, [t[0].n for t in train]
+
+
+def _split_train_grad(gy, sizes, p: int):
+    """d/dy of the merged batch back into one by-outputs vector per conditioning batch."""
+    if len(sizes) == 1:
+        return gy
+    g = np.asarray(gy.cpu() if L._is_torch(gy) else gy).reshape(p, -1)
+    out, o = [], 0
+    for nb in sizes:
+        out.append(np.ascontiguousarray(g[:, o:o + nb]).reshape(-1)); o += nb
+    return out
 
 
 def _H_args(H):
@@ -398,16 +430,14 @@ def logpdf_and_gradient(fx: FiniteGP, y, with_regulariser: bool = True) -> dict:
         gy, gH = _alloc_like(y if L._is_torch(y) else x.x, n * p), np.empty(p * m)
         gg = (L.GpGradT * m)()
         if post is not None:          # reference test/ilmm.jl:32: gradient(logpdf, pi, y_test) on the dense-H posterior
-            if post.train is None:
-                raise NotImplementedError("gradient of the predictive logpdf after sequential conditioning is not built")
-            x0, s20, y0 = post.train
+            x0, s20, y0, sizes = _merged_train(post.train, p)
             gs2t = C.c_double()
             gy0 = _alloc_like(y0 if L._is_torch(y0) else x0.x, x0.n * p)
             L.check(lib.lmm_ilmm_post_logpdf_grad(x0.carr().ptr, x0.dim, x0.n, L.Arr(y0).ptr, x.carr().ptr, n, L.Arr(y).ptr, p, Ha.ptr, m,
                                                   C.c_double(s20), C.c_double(s2), L.gps_array([g.desc() for g in f.f.fs]), None,
                                                   C.byref(val), L.Arr(gy0, True).ptr, L.Arr(gy, True).ptr, C.byref(gs2t), C.byref(gs2),
                                                   L.Arr(gH, True).ptr, gg))
-            return {"value": val.value, "y": gy, "y_train": gy0, "sigma2": gs2.value, "sigma2_train": gs2t.value,
+            return {"value": val.value, "y": gy, "y_train": _split_train_grad(gy0, sizes, p), "sigma2": gs2.value, "sigma2_train": gs2t.value,
                     "H": gH.reshape(m, p).T.copy(),
                     "gps": [{"variance": gg[l].variance, "lengthscale": gg[l].lengthscale, "mean": gg[l].mean} for l in range(m)]}
         L.check(lib.lmm_ilmm_logpdf_grad(x.carr().ptr, x.dim, n, L.Arr(y).ptr, p, Ha.ptr, m, C.c_double(s2),
@@ -434,15 +464,13 @@ def logpdf_and_gradient(fx: FiniteGP, y, with_regulariser: bool = True) -> dict:
                                           L.gps_array(descs), shard[0], shard[1], int(with_regulariser), C.byref(val),
                                           L.Arr(gy, True).ptr, C.byref(gs2), L.Arr(gS, True).ptr, L.Arr(gU, True).ptr, gg))
     else:
-        if post.train is None:
-            raise NotImplementedError("gradient of the predictive logpdf after sequential conditioning is not built")
-        x0, s20, y0 = post.train
+        x0, s20, y0, sizes = _merged_train(post.train, p)
         gy0 = _alloc_like(y0 if L._is_torch(y0) else x0.x, x0.n * p)
         L.check(lib.lmm_oilmm_post_logpdf_grad(x0.carr().ptr, x0.dim, x0.n, L.Arr(y0).ptr, x.carr().ptr, n, L.Arr(y).ptr, p, Ua.ptr,
                                                Sa.ptr, m, C.c_double(s20), C.c_double(s2), L.gps_array(descs), shard[0], shard[1],
                                                int(with_regulariser), C.byref(val), L.Arr(gy0, True).ptr, L.Arr(gy, True).ptr,
                                                C.byref(gs2t), C.byref(gs2), L.Arr(gS, True).ptr, L.Arr(gU, True).ptr, gg))
-        out.update(y_train=gy0, sigma2_train=gs2t.value)
+        out.update(y_train=_split_train_grad(gy0, sizes, p), sigma2_train=gs2t.value)
     out.update({"value": val.value, "y": gy, "sigma2": gs2.value,
                 "gps": [{"variance": gg[l].variance, "lengthscale": gg[l].lengthscale, "mean": gg[l].mean} for l in range(m)]})
     if not mogp:
@@ -493,6 +521,11 @@ def _post_logpdf(post: _PostHandle, descs, U, S, x, s2, ya, with_reg) -> float:
     return out.value
 
 
+def _more_train(post: "_PostHandle", x, s2, y):
+    """Conditioning batches of posterior(po(x, s2), y): those of `po` plus this one (None if `po` does not know its own)."""
+    return None if post.train is None else post.train + [(x, s2, y)]
+
+
 def posterior(fx: FiniteGP, y):
     """posterior(fx, y): reference src/oilmm.jl:116-134 (returns ILMM(independent_mogp(posteriors), H) -- again
     an OILMM with the same H) and src/independent_mogp.jl:119-126."""
@@ -513,7 +546,7 @@ def posterior(fx: FiniteGP, y):
             Ui, Si = L.Arr(L.colmajor(np.eye(m))), L.Arr(np.ones(m))
             L.check(lib.lmm_post_condition(f._post.ptr, Ui.ptr, Si.ptr, m, m, C.c_double(s2), xa.ptr, x.dim, x.n, ya.ptr,
                                            C.byref(handle)))
-            return IndependentMOGP(f.fs, _PostHandle(handle, 0, m))
+            return IndependentMOGP(f.fs, _PostHandle(handle, 0, m, train=_more_train(f._post, x, s2, y)))
         gps = L.gps_array([g.desc() for g in f.fs])
         L.check(lib.lmm_mogp_posterior_create(xa.ptr, x.dim, x.n, ya.ptr, m, C.c_double(s2), gps, 0, m, C.byref(handle)))
         return IndependentMOGP(f.fs, _PostHandle(handle, 0, m, train=(x, s2, y)))
@@ -523,10 +556,10 @@ def posterior(fx: FiniteGP, y):
     if f.f._post is not None:          # sequential conditioning of a posterior OILMM (same H: reference src/oilmm.jl:133)
         if not f.is_oilmm:         # dense-H posterior: both projected data sets condition the prior (reference src/ilmm.jl:184-198)
             L.check(lib.lmm_ilmm_post_condition(f.f._post.ptr, C.c_double(s2), xa.ptr, x.dim, x.n, ya.ptr, None, C.byref(handle)))
-            return ILMM(IndependentMOGP(f.f.fs, _PostHandle(handle, l0, l1, dense=True)), f.H, shard=f.shard)
+            return ILMM(IndependentMOGP(f.f.fs, _PostHandle(handle, l0, l1, dense=True, train=_more_train(f.f._post, x, s2, y))), f.H, shard=f.shard)
         L.check(lib.lmm_post_condition(f.f._post.ptr, Ua.ptr, Sa.ptr, p, m, C.c_double(s2), xa.ptr, x.dim, x.n, ya.ptr,
                                        C.byref(handle)))
-        return ILMM(IndependentMOGP(f.f.fs, _PostHandle(handle, l0, l1)), f.H, shard=f.shard)
+        return ILMM(IndependentMOGP(f.f.fs, _PostHandle(handle, l0, l1, train=_more_train(f.f._post, x, s2, y))), f.H, shard=f.shard)
     gps = L.gps_array([g.desc() for g in f.f.fs])
     if f.is_oilmm:
         L.check(lib.lmm_oilmm_posterior_create(xa.ptr, x.dim, x.n, ya.ptr, p, Ua.ptr, Sa.ptr, m, C.c_double(s2), gps, l0,

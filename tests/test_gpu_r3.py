@@ -408,3 +408,64 @@ def test_panel_path_reports_the_failing_pivot(lmm):
     rc = lmm.load().lmm_dev_potrf(C.c_void_p(A.data_ptr()), n, n, ld, C.c_void_p(W.data_ptr()), n, C.c_void_p(info.data_ptr()))
     assert rc == 0
     assert int(info.item()) == 301
+
+
+# ---------------------------------------------------------------------------------------------------
+# (f) gradient of the predictive logpdf after SEQUENTIAL conditioning (equal noise per batch: the batches merge), and
+#     device inputs produced on a side stream named through lmm_amd.wait_stream
+# ---------------------------------------------------------------------------------------------------
+def test_gradient_after_sequential_conditioning(lmm):
+    """Zygote differentiates logpdf(posterior(posterior(f(x1, s2), y1)(x2, s2), y2)(xs, s2s), ys) in the reference (src/oilmm.jl:116-134
+    composed twice).  With equal noise on the batches the mirror merges them; value and TOTAL derivatives against central finite
+    differences of the oracle's two-step conditioning, incl. d/dy of EACH batch.  Different variances per batch: refused."""
+    rng = np.random.default_rng(81)
+    n1, n2, ns, p, m = 40, 33, 11, 4, 3
+    x1, x2, xs = np.sort(rng.uniform(0, 8, n1)), np.sort(rng.uniform(0, 8, n2)), np.sort(rng.uniform(0, 8, ns))
+    gps = _gps3(rng)
+    U, S, _ = np.linalg.svd(rng.uniform(size=(p, m)), full_matrices=False)
+    y1, y2, ys = rng.standard_normal(n1 * p), rng.standard_normal(n2 * p), rng.standard_normal(ns * p)
+    s2, s2s = 0.3, 0.2
+
+    def F(gps=gps, s2=s2, s2s=s2s, y1=y1, y2=y2, ys=ys):
+        return O.oilmm_logpdf(O.oilmm_posterior(O.oilmm_posterior(gps, U, S, x1, s2, y1), U, S, x2, s2, y2), U, S, xs, s2s, ys)
+
+    f = lmm.ILMM(_model(lmm, gps), lmm.Orthogonal(U, S))
+    po2 = lmm.posterior(lmm.posterior(f(lmm.MOInputIsotopicByOutputs(x1, p), s2), y1)(lmm.MOInputIsotopicByOutputs(x2, p), s2), y2)
+    fxs = po2(lmm.MOInputIsotopicByOutputs(xs, p), s2s)
+    G = lmm.logpdf_and_gradient(fxs, ys)
+    assert G["value"] == pytest.approx(F(), rel=1e-8)
+    assert G["value"] == pytest.approx(lmm.logpdf(fxs, ys), rel=1e-8)
+    assert G["sigma2"] == pytest.approx(_fd(lambda t: F(s2s=s2s + t)), rel=2e-5, abs=1e-6)
+    assert G["sigma2_train"] == pytest.approx(_fd(lambda t: F(s2=s2 + t)), rel=2e-5, abs=1e-6)
+    assert isinstance(G["y_train"], list) and [len(g) for g in G["y_train"]] == [n1 * p, n2 * p]
+    for k in [0, n1 + 7, n1 * p - 1]:
+        e = np.zeros(n1 * p); e[k] = 1.0
+        assert G["y_train"][0][k] == pytest.approx(_fd(lambda t: F(y1=y1 + t * e)), rel=2e-5, abs=1e-6)
+    for k in [3, 2 * n2 + 5]:
+        e = np.zeros(n2 * p); e[k] = 1.0
+        assert G["y_train"][1][k] == pytest.approx(_fd(lambda t: F(y2=y2 + t * e)), rel=2e-5, abs=1e-6)
+    _check_gps_grad(G, F, gps, [2], 2e-5, 1e-6)
+    po_mixed = lmm.posterior(lmm.posterior(f(lmm.MOInputIsotopicByOutputs(x1, p), 0.1), y1)(lmm.MOInputIsotopicByOutputs(x2, p), 0.3), y2)
+    with pytest.raises(NotImplementedError):
+        lmm.logpdf_and_gradient(po_mixed(lmm.MOInputIsotopicByOutputs(xs, p), s2s), ys)
+
+
+def test_inputs_from_a_side_stream(lmm):
+    """A device tensor produced on a stream that is NOT torch's current stream: the caller names it (lmm_amd.wait_stream ->
+    lmm_stream_wait_caller), and the library's streams order themselves behind it."""
+    import torch
+    P = O.synthetic_problem(3, 5, 700, "matern52", True, s2=0.1, seed=3)
+    f = lmm.ILMM(_model(lmm, P["gps"]), lmm.Orthogonal(P["U"], P["S"]))
+    ref = O.oilmm_logpdf(P["gps"], P["U"], P["S"], P["x"], 0.1, P["y"])
+    side = torch.cuda.Stream()
+    yh = torch.from_numpy(P["y"]).pin_memory()
+    big = torch.randn(1 << 24, device="cuda", dtype=torch.float64)
+    with torch.cuda.stream(side):
+        for _ in range(20):
+            big = big * 1.0000001                          # keep the side stream busy ahead of the copy
+        yd = yh.to("cuda", non_blocking=True)
+        xd = torch.from_numpy(P["x"]).to("cuda", non_blocking=True)
+    lmm.wait_stream(side)
+    got = lmm.logpdf(f(lmm.MOInputIsotopicByOutputs(xd, 5), 0.1), yd)
+    side.synchronize()
+    assert got == pytest.approx(ref, rel=1e-9)
