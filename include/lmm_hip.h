@@ -82,8 +82,12 @@ int lmm_release_cached_memory(void);      /* return the caching device-memory po
  * LMM_F32: the MATRICES -- latent Grams, Cholesky factors, inverse diagonal blocks, cross-solve blocks -- are Float32 and the
  *   trailing updates / TRSMs run on v_mfma_f32_32x32x2_f32 (2x the FP64 matrix rate, half the factor memory); vectors at the
  *   boundary (x, y, normals, outputs), the kernel evaluation, the 64x64 diagonal-block factorisation and all reductions stay
- *   Float64.  Served: OILMM / IndependentMOGP logpdf, posterior, marginals, rand, posterior logpdf, sequential conditioning and
- *   the decoupled dense-H logpdf; the dense (mn)x(mn) ILMM paths, gradients and full covariances return LMM_ERR_UNSUPPORTED.
+ *   Float64.  Served: OILMM / IndependentMOGP logpdf, posterior, marginals, rand, posterior logpdf, sequential conditioning, the
+ *   decoupled dense-H logpdf and (round 3) the OILMM / IndependentMOGP logpdf gradients, prior and predictive
+ *   (lmm_oilmm_logpdf_grad, lmm_oilmm_post_logpdf_grad: Float32 factor, triangular inverse and K^-1 on v_mfma_f32, every reduction
+ *   Float64; tolerance at sigma2 = 0.1, n ~ 10^3: d/dy, d/dU within 1e-4 of their largest component, d/dsigma2 rtol 1e-4, d/dS and
+ *   kernel parameters rtol 2e-3 + 1e-2 absolute -- tests/test_gpu_f32.py); the dense (mn)x(mn) ILMM paths, their gradients and
+ *   full covariances return LMM_ERR_UNSUPPORTED.
  *   Jitters stay explicit arguments: the reference's 1e-18 / 1e-12 defaults are below Float32 resolution, so prior sampling
  *   needs a caller-chosen jitter (>= ~1e-5 x kernel variance).  A posterior handle remembers the dtype it was built in. */
 typedef enum { LMM_F64 = 0, LMM_F32 = 1 } lmm_dtype;

@@ -1056,12 +1056,13 @@ int oilmm_grad_core(const double* xd, int d, int N, int nsplit, const double* yd
     }
   Dims D(n, 1);
   int nb_per = 1, nslots = 1;
-  batch_plan(std::max(ms, 1), &nb_per, &nslots, 2.0 * (double)D.elems() * sizeof(double));     // factor + inverse-factor matrices
+  batch_plan(std::max(ms, 1), &nb_per, &nslots, 2.0 * mat_bytes((double)D.elems()));     // factor + inverse-factor matrices
   std::vector<std::vector<Buf<double>>> Am(nslots), Wm(nslots), Rm(nslots);
   std::vector<Buf<double>> part;
   for (int s = 0; s < nslots; ++s) {
     for (int j = 0; j < nb_per; ++j) {
-      Am[s].emplace_back(D.elems()); Wm[s].emplace_back((size_t)(D.NC / 64) * 4096); Rm[s].emplace_back((size_t)D.ld * D.NC);
+      Am[s].emplace_back(mat_count(D.elems())); Wm[s].emplace_back(mat_count((size_t)(D.NC / 64) * 4096));
+      Rm[s].emplace_back(mat_count((size_t)D.ld * D.NC));
     }
     part.emplace_back((size_t)grad_partials(n));
   }
@@ -1235,7 +1236,8 @@ int lmm_oilmm_logpdf_grad(const double* x, int d, int n, const double* y, int p,
   std::lock_guard<std::mutex> lk(g_mu);
   REQUIRE_INIT();
   LMM_TRY
-  REQUIRE_F64("the OILMM gradient");
+  // fp32 compute mode (round 3): Float32 factor, triangular inverse and K^-1 = L^-T L^-1 (all on v_mfma_f32), Float64 reductions;
+  // stated tolerance against the Float64 gradient: include/lmm_hip.h
   if (!x || !y || !U || !S || !out_logpdf || d <= 0 || n <= 0 || p <= 0 || m <= 0) return fail(LMM_ERR_ARG, "bad arguments");
   if (m > p) return fail(LMM_ERR_DIM, "out dim of x != out dim of f.");
   if (latent_begin < 0 || latent_end > m || latent_begin > latent_end) return fail(LMM_ERR_ARG, "bad latent shard");
@@ -1267,7 +1269,7 @@ int lmm_oilmm_post_logpdf_grad(const double* x, int d, int n, const double* y, c
   std::lock_guard<std::mutex> lk(g_mu);
   REQUIRE_INIT();
   LMM_TRY
-  REQUIRE_F64("the predictive-logpdf gradient");
+  // (the same core with two noise blocks: served in the fp32 compute mode too)
   if (!x || !y || !xs || !ys || !U || !S || !out_logpdf || d <= 0 || n <= 0 || ns <= 0 || p <= 0 || m <= 0)
     return fail(LMM_ERR_ARG, "bad arguments");
   if (m > p) return fail(LMM_ERR_DIM, "out dim of x != out dim of f.");

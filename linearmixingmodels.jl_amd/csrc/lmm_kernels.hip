@@ -3250,10 +3250,11 @@ __global__ void vec_axpby_kernel(const double* a, double sa, const double* b, do
 }
 
 // R = I on an nc x nc block (ld), zero elsewhere: the riders whose triangular solve gives L^-T.
-__global__ void set_identity_kernel(double* __restrict__ R, int ld, int nc) {
+template <typename TS>
+__global__ void set_identity_kernel(void* __restrict__ R, int ld, int nc) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y;
-  if (i < nc) R[(size_t)j * ld + i] = (i == j) ? 1.0 : 0.0;
+  if (i < nc) MatIO<TS>::st1(R, (size_t)j * ld + i, (i == j) ? 1.0 : 0.0);
 }
 
 // d kappa / d lengthscale at scaled distance r (r2 = r^2):  SE v e^{-r2/2} r2 / ell;  Matern32 v s^2 e^{-s} / ell;
@@ -3273,7 +3274,8 @@ __device__ __forceinline__ double dkappa_dell(int kind, double var, double inv_l
 //   partial[NG*tile + 7]      = sum_{i>j in tile} (alpha_i alpha_j - Kinv_ij) K_ij            (variance, when Kinv is a block of a larger inverse)
 // The split at nsplit serves the predictive logpdf (joint of training and test points, each block with its own noise).
 #define LMM_NG 8
-__global__ __launch_bounds__(256) void grad_reduce_kernel(const double* __restrict__ Kinv, int ld, int n, int nsplit,
+template <typename TS>      // storage type of the inverse Kinv (a MATRIX: Float32 in the fp32 compute mode); all sums in Float64
+__global__ __launch_bounds__(256) void grad_reduce_kernel(const void* __restrict__ Kinv, int ld, int n, int nsplit,
                                                           const double* __restrict__ alpha, const double* __restrict__ delta,
                                                           const double* __restrict__ x, int d, LatentDev g, int nt,
                                                           double* __restrict__ partial) {
@@ -3292,7 +3294,7 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const double* __restri
         double r, r2;
         if (d == 1) { r = fabs(x[i0] - x[j]) * g.inv_ls; r2 = r * r; }
         else { r2 = scaled_dist2(x + (size_t)i0 * d, x + (size_t)j * d, d, g.inv_ls); r = sqrt(r2); }
-        const double w = ai * alpha[j] - Kinv[(size_t)j * ld + i0];
+        const double w = ai * alpha[j] - MatIO<TS>::ld1(Kinv, (size_t)j * ld + i0);
         acc = __builtin_fma(w, dkappa_dell(g.kind, g.var, g.inv_ls, r, r2), acc);
         acck = __builtin_fma(w, kappa(g.kind, g.var, r, r2), acck);
       }
@@ -3303,7 +3305,7 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const double* __restri
   const double tk = block_sum_256(acck, sh);
   double tra = 0.0, aaa = 0.0, trb = 0.0, aab = 0.0, ad = 0.0, sa = 0.0;
   if (ti == tj && t < 64 && i0 < n) {
-    const double ai = alpha[i0], kii = Kinv[(size_t)i0 * ld + i0];
+    const double ai = alpha[i0], kii = MatIO<TS>::ld1(Kinv, (size_t)i0 * ld + i0);
     if (i0 < nsplit) { tra = kii; aaa = ai * ai; } else { trb = kii; aab = ai * ai; }
     ad = ai * delta[i0]; sa = ai;
   }
@@ -3762,8 +3764,10 @@ void launch_syrk_upper_set(const BatchPtr& C, int ldc, const BatchPtr& X, int ld
   const int MT = (N + 127) / 128, NT = (N + 127) / 128;
   long long T = 0;
   for (int tj = 0; tj < NT; ++tj) T += MT - tj;
-  hipLaunchKernelGGL((gemm44_kernel<128, true>), dim3((int)T, nb), dim3(256), 0, st, C, (size_t)0, ldc, X, (size_t)0, ldx, X, (size_t)0, ldx,
-                     N, N, N, 1, MT, (int)T, 1, 1);
+  if (g_f32) hipLaunchKernelGGL((gemm32_kernel<128, true>), dim3((int)T, nb), dim3(256), 0, st, C, (size_t)0, ldc, X, (size_t)0, ldx, X, (size_t)0, ldx,
+                                N, N, N, 1, MT, (int)T, 1, 1);
+  else hipLaunchKernelGGL((gemm44_kernel<128, true>), dim3((int)T, nb), dim3(256), 0, st, C, (size_t)0, ldc, X, (size_t)0, ldx, X, (size_t)0, ldx,
+                          N, N, N, 1, MT, (int)T, 1, 1);
 }
 void launch_syrk_upper_set(double* C, int ldc, const double* X, int ldx, int N, hipStream_t st) {
   BatchPtr c{}, a{};
@@ -3893,7 +3897,7 @@ void launch_trmv_lower(const double* L, int ld, int n, const double* z, double m
 }
 
 void launch_set_identity(double* R, int ld, int nc, hipStream_t st) {
-  hipLaunchKernelGGL(set_identity_kernel, dim3((nc + 255) / 256, nc), dim3(256), 0, st, R, ld, nc);
+  LMM_TS_LAUNCH((set_identity_kernel<TS>), dim3((nc + 255) / 256, nc), dim3(256), 0, st, (void*)R, ld, nc);
 }
 
 int grad_partials(int n) { const int nt = (n + 63) / 64; return LMM_NG * nt * nt; }
@@ -3903,7 +3907,7 @@ int grad_partials(int n) { const int nt = (n + 63) / 64; return LMM_NG * nt * nt
 void launch_grad_reduce(const double* Kinv, int ld, int n, int nsplit, const double* alpha, const double* delta, const double* x, int d,
                         LatentDev g, double* partial, double* out7, hipStream_t st) {
   const int nt = (n + 63) / 64;
-  hipLaunchKernelGGL(grad_reduce_kernel, dim3(nt, nt), dim3(256), 0, st, Kinv, ld, n, nsplit, alpha, delta, x, d, g, nt, partial);
+  LMM_TS_LAUNCH((grad_reduce_kernel<TS>), dim3(nt, nt), dim3(256), 0, st, (const void*)Kinv, ld, n, nsplit, alpha, delta, x, d, g, nt, partial);
   hipLaunchKernelGGL(grad_finish_kernel, dim3(1), dim3(256), 0, st, partial, nt, out7);
 }
 

@@ -176,3 +176,50 @@ def test_f32_c4_share_full_size(lmm32):
     np.testing.assert_allclose(ml[:ns], m64, rtol=RTOL32, atol=RTOL32)
     np.testing.assert_allclose(vl[:ns], v64, rtol=10 * RTOL32)
     assert lp32 == pytest.approx(lp64, rel=RTOL32)
+
+
+def test_f32_oilmm_logpdf_gradient(lmm32):
+    """Round 3: value and gradient of logpdf(fx::FiniteGP{<:OILMM}, y) in the fp32 compute mode (Float32 factor, triangular inverse
+    and K^-1 = L^-T L^-1 on v_mfma_f32; every reduction in Float64) against the Float64 oracle's analytic gradient -- the OILMM
+    training loop is where fp32 pays.  STATED TOLERANCE (sigma2 = 0.1, unit-scale kernels, n ~ 10^3; include/lmm_hip.h): value rtol
+    2e-4; d/dy and d/dU within 1e-4 of their largest component; d/dsigma2 rtol 1e-4; d/dS and the kernel parameters rtol 2e-3 + 1e-2
+    absolute (differences tr(K^-1 dK) - a' dK a of O(n) terms).  Observed on the box: 1e-5 / 1e-6 / 4e-7 / 1e-5 ... 7e-4.  Also the
+    predictive logpdf's gradient (two noise blocks through the same core) against the Float64 HIP path."""
+    lmm = lmm32
+    rng = np.random.default_rng(17)
+    n, p, m = 900, 5, 3
+    x = np.sort(rng.uniform(0, 30, n))
+    gps = [{"kind": k, "variance": float(rng.uniform(0.7, 1.5)), "lengthscale": float(rng.uniform(0.7, 1.5)), "mean": float(rng.normal())}
+           for k in ["se", "matern32", "matern52"]]
+    U, S, _ = np.linalg.svd(rng.uniform(size=(p, m)), full_matrices=False)
+    S = np.linspace(2, 1, m)
+    y = rng.standard_normal(n * p)
+    fx = lmm.ILMM(_model(lmm, gps), lmm.Orthogonal(U, S))(lmm.MOInputIsotopicByOutputs(x, p), 0.1)
+    G = lmm.logpdf_and_gradient(fx, y)
+    R = O.oilmm_logpdf_grad(gps, U, S, x, 0.1, y)
+    assert G["value"] == pytest.approx(R["value"], rel=RTOL32)
+    np.testing.assert_allclose(G["y"], R["y"], rtol=0, atol=1e-4 * np.abs(R["y"]).max())
+    assert G["sigma2"] == pytest.approx(R["sigma2"], rel=1e-4)
+    np.testing.assert_allclose(G["S"], R["S"], rtol=2e-3, atol=1e-2)
+    np.testing.assert_allclose(G["U"], R["U"], rtol=0, atol=1e-4 * np.abs(R["U"]).max())
+    for l in range(m):
+        for key in ("variance", "lengthscale", "mean"):
+            assert G["gps"][l][key] == pytest.approx(R["gps"][l][key], rel=2e-3, abs=1e-2), (l, key)
+    # the same answers as the Float64 HIP path, at that tolerance
+    lmm.set_compute_dtype("f64")
+    G64 = lmm.logpdf_and_gradient(fx, y)
+    lmm.set_compute_dtype("f32")
+    np.testing.assert_allclose(G["y"], G64["y"], rtol=0, atol=1e-4 * np.abs(G64["y"]).max())
+    # predictive logpdf gradient (posterior built in fp32, two noise blocks)
+    xs = np.sort(rng.uniform(0, 30, 150)); ys = rng.standard_normal(150 * p)
+    fxs = lmm.posterior(fx, y)(lmm.MOInputIsotopicByOutputs(xs, p), 0.2)
+    Gp = lmm.logpdf_and_gradient(fxs, ys)
+    lmm.set_compute_dtype("f64")
+    fxs64 = lmm.posterior(fx, y)(lmm.MOInputIsotopicByOutputs(xs, p), 0.2)
+    Gp64 = lmm.logpdf_and_gradient(fxs64, ys)
+    lmm.set_compute_dtype("f32")
+    assert Gp["value"] == pytest.approx(Gp64["value"], rel=5e-4)
+    np.testing.assert_allclose(Gp["y"], Gp64["y"], rtol=0, atol=5e-3 * np.abs(Gp64["y"]).max())
+    assert Gp["sigma2"] == pytest.approx(Gp64["sigma2"], rel=2e-2, abs=2e-2)
+    print("f32 gradient errors:", {k: (float(np.max(np.abs(np.asarray(G[k]) - np.asarray(R[k])))), float(np.max(np.abs(np.asarray(R[k]))))) for k in ("y", "S", "U")},
+          "sigma2", G["sigma2"], R["sigma2"], "gps", [(G["gps"][l], R["gps"][l]) for l in range(m)])
