@@ -334,6 +334,14 @@ def main():
                     "flops_per_launch": up["work"] / up["launches"],
                     "algorithmic_bytes_per_launch": up["bytes"] / up["launches"],
                     "mode": f"serial-stream instrumented pass over {nprof} latent(s)"}
+        rg = prof.get("region")
+        if roof is None and rg and rg["launches"] and rg["ms"] > 0:
+            # small matrices (NC <= 1024): the whole factorisation is ONE potrf_region_kernel launch per batch -- the dominant kernel there
+            ach = rg["work"] / (rg["ms"] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "potrf_region_kernel (whole blocked Cholesky of a batch in one dataflow launch: walker + helpers + row streams; latency-bound at these sizes)",
+                    "achieved": round(ach, 4), "peak": peak_tf, "unit": "TFLOP/s", "frac": round(ach / peak_tf, 5), "traffic": None,
+                    "launches": rg["launches"], "avg_launch_ms": round(rg["ms"] / rg["launches"], 4), "flops_per_launch": rg["work"] / rg["launches"],
+                    "mode": f"serial-stream instrumented pass over {nprof} latent(s)"}
         us = prof.get("update_short")
         if us and us["launches"] and us["ms"] > 0:
             extra["roofline_update_short"] = {"bound": "mfma", "kernel": "potrf_node_kernel<1> (the same fused update + leaf, K < 1024: epilogue- and latency-bound levels)",

@@ -292,6 +292,12 @@ void potrf_rec(const Batch& B, int ld, int NR, int j0, int w, int n_real, hipStr
 // also runs the leaf of the panel that follows it (launch_update_leaf), so that per 128 columns the stream sees two launches
 // (update + leaf, bulk) instead of six.  first_done: the diagonal block of the first panel of [j0, j0 + w) is already factored.
 // Widths that are not multiples of 128 (NC = 64 mod 128) end in the round-2 path for their last 64 columns.
+// Staggering of concurrent batches (latent_lmls): same-shaped batches on concurrent streams march through the recursion in
+// lock-step, so their latency-bound phases (panels, K < 1024 updates) coincide and hide nothing behind each other.  The batch that
+// goes first records g_stagger_ev right after its first K >= 1024 update is enqueued; the next batch's stream waits for it, so that
+// its panel phases fall into the other batch's long updates.
+static hipEvent_t g_stagger_ev = nullptr;
+static bool g_stagger_armed = false, g_stagger_recorded = false;
 static int g_region_whole = 1;          // LMM_REGION_ALL=1: also as the base case of the recursion for larger matrices (measured: no gain)
 static int g_region_cols = -1;          // widest block column potrf_region_kernel takes in one launch (LMM_REGION=<columns>, up to 1024; default 0: off)
 void potrf_rec_panel(const Batch& B, const BatchPtr& W2, const BatchInfo& flags, int ld, int NR, int j0, int w, int n_real, hipStream_t st,
@@ -331,6 +337,7 @@ void potrf_rec_panel(const Batch& B, const BatchPtr& W2, const BatchInfo& flags,
       ProfScope ps(h >= 1024 ? LMM_PROF_UPDATE : LMM_PROF_UPDATE_SHORT, nb * (2.0 * h * outs + 2.0 * 128.0 * 128.0 * 128.0 / 3.0), st, NR - r0, Nc, h,
                    nb * (16.0 * outs + 8.0 * Mr * h));
       launch_update_leaf(B.A, B.W, W2, B.info, ld, NR, j0, h, Nc, n_real, B.nb, st);
+      if (g_stagger_armed && !g_stagger_recorded && h >= 1024) { HIPCHK(hipEventRecord(g_stagger_ev, st)); g_stagger_recorded = true; }
     }
     potrf_rec_panel(B, W2, flags, ld, NR, r0, Nc, n_real, st, true);
   } else {
@@ -686,9 +693,18 @@ int latent_lmls(const double* xd, int d, int n, const lmm_gp_t* gps, const doubl
       ga[j] = a;
       B.add(s.A[j].p, s.W[j].p, info.p + k);
     }
+    if (bi > 0 && g_stagger_recorded) HIPCHK(hipStreamWaitEvent(s.st, g_stagger_ev, 0));      // start behind the previous batch's first long update
     launch_gram_batch(ga, nb, s.st);       // one launch per run of equal kernel kinds (blockIdx.z = latent)
     }
+    {
+      static int stagger = -1;
+      if (stagger < 0) { const char* e = getenv("LMM_STAGGER"); stagger = e ? atoi(e) : 0; }      // default off: measured no gain (C2: 686 vs 682 ms)
+      g_stagger_armed = stagger && nslots > 1 && !(g.prof && g.prof_serial);
+      g_stagger_recorded = false;
+      if (g_stagger_armed && !g_stagger_ev) HIPCHK(hipEventCreateWithFlags(&g_stagger_ev, hipEventDisableTiming));
+    }
     potrf_batch(B, D.ld, D.NR, D.NC, n, s.st);
+    g_stagger_armed = false;
     launch_lml_reduce(B.A, nb, D.ld, n, D.NC, nrhs, out.p + (size_t)k0 * nrhs, s.st);
   }
   join_slots(nslots);
