@@ -43,6 +43,8 @@ struct Ctx {
   char* pin = nullptr;
   size_t pin_cap = 0, pin_off = 0;
   std::vector<void*> scratch;          // device blocks that live until the NEXT API call starts (call_scratch)
+  int* region_flags = nullptr;         // dependency flags of potrf_region_kernel: [stream][matrix][region_flag_ints], zeroed ONCE (lmm_init)
+                                       // -- every launch tags its flags with a fresh epoch, so they never need resetting
   std::multimap<size_t, void*> pool;   // cached device blocks (size -> ptr)
   std::map<void*, size_t> live;
   std::string err;
@@ -365,10 +367,16 @@ void potrf_batch(const Batch& B, int ld, int NR, int NC, int n_real, hipStream_t
   // path); larger matrices take the panel recursion throughout (as their base case the region kernel measured no faster than the
   // panel launches: DESIGN.md).  LMM_REGION_ALL=1 enables it there too, LMM_REGION=0 disables it.
   const bool region_here = g_region_cols > 0 && (!g_region_whole || (NC <= g_region_cols && (NC % 128) == 0));
-  if (region_here) {                       // dependency flags of the region launches: zeroed once, then told apart by launch epoch
-    const size_t fi = (region_flag_ints(NR) + 1) / 2 * 2;
-    int* fl = reinterpret_cast<int*>(call_scratch(fi / 2 * B.nb));
-    HIPCHK(hipMemsetAsync(fl, 0, fi * sizeof(int) * B.nb, st));
+  if (region_here) {                       // dependency flags of the region launches: this stream's slice of the persistent, once-zeroed
+    int si = -1;                           // array (launches are told apart by epoch); an unknown stream gets a zeroed scratch
+    for (int s = 0; s < kMaxStreams; ++s) if (g.streams[s] == st) si = s;
+    const size_t fi = region_flag_ints(NR);
+    int* fl;
+    if (si >= 0 && g.region_flags) fl = g.region_flags + (size_t)si * LMM_MAX_BATCH * fi;
+    else {
+      fl = reinterpret_cast<int*>(call_scratch((fi * B.nb + 1) / 2));
+      HIPCHK(hipMemsetAsync(fl, 0, fi * sizeof(int) * B.nb, st));
+    }
     for (int j = 0; j < B.nb; ++j) flags.p[j] = fl + fi * j;
   }
   potrf_rec_panel(B, W2, flags, ld, NR, 0, NC, n_real, st, false);
@@ -494,9 +502,11 @@ void join_slots(int count) {       // main stream waits for every slot stream
 
 int check_info(const std::vector<int>& info, int latent_begin) {
   for (size_t k = 0; k < info.size(); ++k) {
-    if (info[k] == LMM_INFO_SYNC_TIMEOUT)
+    if (info[k] == LMM_INFO_SYNC_TIMEOUT) {
+      if (g.region_flags) (void)hipMemset(g.region_flags, 0, region_flag_ints(0) * (size_t)LMM_MAX_BATCH * kMaxStreams * sizeof(int));     // lower the abort words
       return fail(LMM_ERR_HIP, "potrf_region_kernel: a dependency wait timed out (latent %d); the grid was drained, results are invalid",
                   latent_begin + (int)k);
+    }
     if (info[k] != 0) {
       g.err_latent = latent_begin + (int)k;
       g.err_info = info[k];
@@ -666,8 +676,10 @@ int latent_lmls(const double* xd, int d, int n, const lmm_gp_t* gps, const doubl
   batch_plan(ms, &nb_per, &nslots, mat_bytes((double)D.elems()));
   std::vector<Slot> slots;
   make_slots(slots, nslots, nb_per, D.elems(), D.NC);
-  Buf<double> out((size_t)ms * nrhs);
-  Buf<int> info(ms);
+  // results: [ms * nrhs doubles | ms pivot-info ints] in ONE buffer, so that one copy brings both back
+  const size_t nout = (size_t)ms * nrhs;
+  Buf<double> out(nout + ((size_t)ms + 1) / 2);
+  struct { int* p; } info{reinterpret_cast<int*>(out.p + nout)};
   HIPCHK(hipMemsetAsync(info.p, 0, ms * sizeof(int), g.streams[0]));
   fork_slots(nslots);
   int bi = 0;
@@ -709,13 +721,14 @@ int latent_lmls(const double* xd, int d, int n, const lmm_gp_t* gps, const doubl
   }
   join_slots(nslots);
   std::vector<int> hinfo(ms);
-  double* plml = static_cast<double*>(pin_take((size_t)ms * nrhs * sizeof(double)));
-  int* pinfo = static_cast<int*>(pin_take((size_t)ms * sizeof(int)));
-  HIPCHK(hipMemcpyAsync(plml ? plml : lml.data(), out.p, (size_t)ms * nrhs * sizeof(double), hipMemcpyDeviceToHost, g.streams[0]));
-  HIPCHK(hipMemcpyAsync(pinfo ? pinfo : hinfo.data(), info.p, ms * sizeof(int), hipMemcpyDeviceToHost, g.streams[0]));
+  const size_t nbytes = (nout + ((size_t)ms + 1) / 2) * sizeof(double);
+  std::vector<double> pageable;
+  char* pk = static_cast<char*>(pin_take(nbytes));
+  if (!pk) { pageable.resize(nbytes / sizeof(double)); pk = reinterpret_cast<char*>(pageable.data()); }
+  HIPCHK(hipMemcpyAsync(pk, out.p, nbytes, hipMemcpyDeviceToHost, g.streams[0]));
   HIPCHK(hipStreamSynchronize(g.streams[0]));
-  if (plml) std::memcpy(lml.data(), plml, (size_t)ms * nrhs * sizeof(double));
-  if (pinfo) std::memcpy(hinfo.data(), pinfo, (size_t)ms * sizeof(int));
+  std::memcpy(lml.data(), pk, nout * sizeof(double));
+  std::memcpy(hinfo.data(), pk + nout * sizeof(double), (size_t)ms * sizeof(int));
   return check_info(hinfo, l0);
 }
 
@@ -798,6 +811,12 @@ int lmm_init(int device) {
   HIPCHK(hipEventCreateWithFlags(&g.ev_main, hipEventDisableTiming));
   g.pin_cap = 1u << 20;
   if (hipHostMalloc((void**)&g.pin, g.pin_cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); g.pin = nullptr; g.pin_cap = 0; }
+  {
+    const size_t fi = region_flag_ints(0) * (size_t)LMM_MAX_BATCH * kMaxStreams;
+    HIPCHK(hipMalloc((void**)&g.region_flags, fi * sizeof(int)));
+    HIPCHK(hipMemset(g.region_flags, 0, fi * sizeof(int)));
+    region_flags_register(g.region_flags, fi);
+  }
   g.device = device;
   g.init = true;
   return LMM_OK;
@@ -811,6 +830,7 @@ int lmm_shutdown(void) {
   if (g.comm) { (void)ncclCommDestroy(g.comm); g.comm = nullptr; g.comm_world = 0; }
   if (g.ev_caller) { (void)hipEventDestroy(g.ev_caller); g.ev_caller = nullptr; }
   release_call_scratch();
+  if (g.region_flags) { (void)hipFree(g.region_flags); g.region_flags = nullptr; region_flags_register(nullptr, 0); }
   for (auto& kv : g.pool) (void)hipFree(kv.second);
   g.pool.clear();
   for (int s = 0; s < kMaxStreams; ++s) { (void)hipStreamDestroy(g.streams[s]); (void)hipEventDestroy(g.ev_slot[s]); }
@@ -2571,7 +2591,7 @@ struct XsSlots {
   std::vector<std::vector<Buf<double>>> B, WB, mu, rid, R;
   std::vector<Buf<double>> part;
   XsSlots(const lmm_post* P, int ms, int ns, const Dims& Ds) {
-    nsr = rup(ns, 64);
+    nsr = Ds.NC;                     // the Schur complement reads Ds.NC rows of R (rows beyond ns are zero)
     ldr = nsr; if ((ldr % 512) == 0) ldr += 16;
     batch_plan(std::max(ms, 1), &nb_per, &nslots, mat_bytes((double)Ds.elems() + (P ? (double)ldr * P->NC : 0.0)));
     B.resize(nslots); WB.resize(nslots); mu.resize(nslots); rid.resize(nslots); R.resize(nslots);
@@ -2628,7 +2648,7 @@ extern "C" int lmm_lmm_mean_and_cov(const lmm_post_t* post, const lmm_gp_t* gps,
   DevOut mo(mean_out, (size_t)ns * p), co(cov_out, (size_t)ns * p * ns * p);
   Buf<double> ml((size_t)ns * std::max(ms, 1));
   Dims Ds(ns, 0);
-  const int nsr = rup(ns, 64);
+  const int nsr = Ds.NC;           // the Schur complement reads Ds.NC rows of R
   int ldr = nsr; if ((ldr % 512) == 0) ldr += 16;
   const int CH = LMM_MAX_BATCH;
   std::vector<Buf<double>> Cm;

@@ -1941,44 +1941,61 @@ __global__ __launch_bounds__(256, 2) void gemm16h_kernel(BatchPtr Cb, size_t gof
 // (A[i][k] = As[i sai + k sak], R[k][j] = Rs[k srk + j srj]); emit(u, v, r, row, col, value) receives every entry once, (u, v, r)
 // being compile-time after unrolling (so that callers can keep per-entry registers).
 // acc += A R over K = 64 nblk (operand pointers advance with sak / srk per k), in chunks of 32 k: the 32 operand values a lane needs
-// for a chunk are loaded (independent loads -- the operands may sit in global memory) while the 32 MFMAs of the previous chunk run.
+// for a chunk are loaded (independent loads -- the operands may sit in global memory) while the 32 MFMAs of earlier chunks run.
+// DEEP: two chunks in flight ahead of the one being multiplied (three register sets; for the one-workgroup-per-CU build, which has
+// the registers: a global load takes ~2 us, a chunk's MFMAs 0.85 us); else one.
+struct MM64Chunk { double fa[8][2], fr[8][2]; };
+__device__ __forceinline__ void mm64_load(MM64Chunk& b, const double* pa, size_t sai, size_t sak, const double* pr, size_t srk, size_t srj) {
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) b.fa[ks][u] = pa[16 * u * sai + 4 * ks * sak];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) b.fr[ks][v] = pr[4 * ks * srk + 16 * v * srj];
+  }
+}
+__device__ __forceinline__ void mm64_mul(d4 (&acc)[2][2], const MM64Chunk& b) {
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int v = 0; v < 2; ++v) acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(b.fa[ks][u], b.fr[ks][v], acc[u][v], 0, 0, 0);
+}
+template <bool DEEP = false>
 __device__ __forceinline__ void wg_mm64_core(d4 (&acc)[2][2], const double* As, size_t sai, size_t sak, const double* Rs, size_t srk, size_t srj,
                                              int w, int l, int nblk = 1) {
   const int c = l & 15, g = l >> 4, wi = 32 * (w & 1), wj = 32 * (w >> 1);
   const double* pa = As + (wi + c) * sai + g * sak;
   const double* pr = Rs + g * srk + (wj + c) * srj;
-  double fa[8][2], fr[8][2];
-#pragma unroll
-  for (int ks = 0; ks < 8; ++ks) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u) fa[ks][u] = pa[16 * u * sai + 4 * ks * sak];
-#pragma unroll
-    for (int v = 0; v < 2; ++v) fr[ks][v] = pr[4 * ks * srk + 16 * v * srj];
-  }
   const int nch = 2 * nblk;
-  for (int ch = 0; ch < nch; ++ch) {
-    double fa2[8][2], fr2[8][2];
-    if (ch + 1 < nch) {
-      pa += 32 * sak; pr += 32 * srk;
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) fa2[ks][u] = pa[16 * u * sai + 4 * ks * sak];
-#pragma unroll
-        for (int v = 0; v < 2; ++v) fr2[ks][v] = pr[4 * ks * srk + 16 * v * srj];
+  const size_t da = 32 * sak, dr = 32 * srk;
+  if (DEEP && nch > 2) {
+    MM64Chunk b0, b1, b2;
+    mm64_load(b0, pa, sai, sak, pr, srk, srj);
+    mm64_load(b1, pa + da, sai, sak, pr + dr, srk, srj);
+    for (int ch = 0; ch < nch; ch += 3) {
+      if (ch + 2 < nch) mm64_load(b2, pa + (ch + 2) * da, sai, sak, pr + (ch + 2) * dr, srk, srj);
+      mm64_mul(acc, b0);
+      if (ch + 1 < nch) {
+        if (ch + 3 < nch) mm64_load(b0, pa + (ch + 3) * da, sai, sak, pr + (ch + 3) * dr, srk, srj);
+        mm64_mul(acc, b1);
+      }
+      if (ch + 2 < nch) {
+        if (ch + 4 < nch) mm64_load(b1, pa + (ch + 4) * da, sai, sak, pr + (ch + 4) * dr, srk, srj);
+        mm64_mul(acc, b2);
       }
     }
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks)
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int v = 0; v < 2; ++v) acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ks][u], fr[ks][v], acc[u][v], 0, 0, 0);
+    return;
+  }
+  MM64Chunk b0, b1;
+  mm64_load(b0, pa, sai, sak, pr, srk, srj);
+  for (int ch = 0; ch < nch; ch += 2) {
+    if (ch + 1 < nch) mm64_load(b1, pa + (ch + 1) * da, sai, sak, pr + (ch + 1) * dr, srk, srj);
+    mm64_mul(acc, b0);
     if (ch + 1 < nch) {
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) { fa[ks][u] = fa2[ks][u]; fr[ks][u] = fr2[ks][u]; }
+      if (ch + 2 < nch) mm64_load(b0, pa + (ch + 2) * da, sai, sak, pr + (ch + 2) * dr, srk, srj);
+      mm64_mul(acc, b1);
     }
   }
 }
@@ -2483,6 +2500,7 @@ __device__ __forceinline__ void potrf_region_walker(const RegionArgs& a, double*
 // and once c = r - 2 is done:  A[r, r-1] -= pa,  A[r, r] -= pd  (their only read-modify-write);  publish upd[r] = r - 1.
 // The walker's request "tiles (r, r-1), (r, r) updated through block r - 2" thus costs, after W_{r-2} arrives, one solve, two 64^3
 // products in registers and one write -- about the time the walker spends in diag64m of block r - 1.
+template <bool DEEP>
 __device__ __forceinline__ void potrf_region_helper(const RegionArgs& a, double* __restrict__ lds, double* __restrict__ Am, int b, int r) {
   constexpr int LS = DIAG_LS;
   int* fl = a.flags.p[b];
@@ -2508,7 +2526,7 @@ __device__ __forceinline__ void potrf_region_helper(const RegionArgs& a, double*
         if (c >= 2) region_wait_ge(trs + c, a.epoch, c - 1, abort_word, info);
         region_wait_ge(wk, a.epoch, c, abort_word, info);
         // (tile update)' = L[c, 0:c] L[r, 0:c]'   (A[i][k'] = L[c][i][k']: (1, ld); R[k'][j] = L[r][j][k']: (ld, 1)), K = 64 c
-        wg_mm64_core(acc, Am + col0 + gcol, 1, a.ld, Am + col0 + grow, a.ld, 1, w, l, c);
+        wg_mm64_core<DEEP>(acc, Am + col0 + gcol, 1, a.ld, Am + col0 + grow, a.ld, 1, w, l, c);
       }
       const double* Ct = Am + gcol * a.ld + grow;
       __syncthreads();                                                   // the previous column's readers of Y are done
@@ -2633,7 +2651,7 @@ __global__ __launch_bounds__(256, OCC) void potrf_region_kernel(RegionArgs a) {
   const int Q = 2 * a.P;
   if (a.trace && threadIdx.x == 0) a.trace[2 * blockIdx.x] = wall_clock64();
   if (idx == 0) potrf_region_walker(a, node_lds, Am, b);
-  else if (idx < Q) potrf_region_helper(a, node_lds, Am, b, idx);
+  else if (idx < Q) potrf_region_helper<false>(a, node_lds, Am, b, idx);      // <true> (two chunks ahead) spills even at one workgroup per CU
   else potrf_region_row(a, node_lds, Am, b, a.P + idx - Q);
   if (a.trace && threadIdx.x == 0) a.trace[2 * blockIdx.x + 1] = wall_clock64();
 }
@@ -3605,6 +3623,9 @@ void launch_update_leaf(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2
 
 size_t region_flag_ints(int) { return REGION_FLAG_INTS; }
 static int g_region_epoch = 0;
+static int* g_region_flags_base = nullptr;       // the persistent flag array of the context (lmm_init), for the wrap-around clear
+static size_t g_region_flags_ints = 0;
+void region_flags_register(int* base, size_t ints) { g_region_flags_base = base; g_region_flags_ints = ints; }
 void launch_region(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2, const BatchInfo& info, const BatchInfo& flags, int ld, int NR,
                    int c0, int width, int n_real, int nb, bool first_done, hipStream_t st) {
   const int P = width / 128, M = NR - c0, R = (M + 127) / 128;
@@ -3612,7 +3633,10 @@ void launch_region(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2, con
   node_lds_attr();
   RegionArgs a{};
   a.A = A; a.W = W; a.W2 = W2; a.info = info; a.flags = flags; a.ld = ld; a.M = M; a.c0 = c0; a.P = P; a.R = R; a.n_real = n_real; a.nb = nb;
-  if (++g_region_epoch >= (1 << 26)) g_region_epoch = 1;
+  if (++g_region_epoch >= (1 << 26)) {     // the tags wrap: clear every flag word ever handed out, so that no stale tag can match again
+    g_region_epoch = 1;
+    if (g_region_flags_base) { (void)hipDeviceSynchronize(); (void)hipMemset(g_region_flags_base, 0, g_region_flags_ints * sizeof(int)); }
+  }
   a.epoch = g_region_epoch; a.first_done = first_done ? 1 : 0;
   const long long tasks = 2LL * P + (R - P);       // the square's 64-row blocks + one task per 128-row tile below it
   // LMM_REGION_OCC=1 / 2 forces a build; default: one workgroup per CU while the whole launch is resident that way, else two

@@ -121,10 +121,12 @@ def test_f32_mode_boundaries(lmm32):
     xin = lmm.MOInputIsotopicByOutputs(P["x"], 5)
     post32 = lmm.posterior(f(xin, 0.1), P["y"])
     v32 = lmm.logpdf(f(xin, 0.1), P["y"])
-    with pytest.raises(NotImplementedError):
-        lmm.logpdf_and_gradient(f(xin, 0.1), P["y"])
+    g32 = lmm.logpdf_and_gradient(f(xin, 0.1), P["y"])            # round 3: served in fp32 (values: test_f32_oilmm_logpdf_gradient)
+    assert g32["value"] == pytest.approx(v32, rel=1e-6)
     with pytest.raises(NotImplementedError):
         lmm.mean_and_cov(f(lmm.MOInputIsotopicByOutputs(P["x"][:8], 5), 0.1))
+    with pytest.raises(NotImplementedError):                       # the dense (mn) x (mn) paths stay Float64-only
+        lmm.logpdf_and_gradient(lmm.ILMM(_model(lmm, P["gps"]), np.abs(P["U"]) + 0.1)(xin, 0.1), P["y"])
     lmm.set_compute_dtype("f64")
     v64 = lmm.logpdf(f(xin, 0.1), P["y"])
     ref = O.oilmm_logpdf(P["gps"], P["U"], P["S"], P["x"], 0.1, P["y"])
