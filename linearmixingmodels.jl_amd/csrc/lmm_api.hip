@@ -42,6 +42,7 @@ struct Ctx {
   // pinned memory are truly asynchronous, pageable ones stall the calling thread until the stream has drained
   char* pin = nullptr;
   size_t pin_cap = 0, pin_off = 0;
+  char* pin_dev = nullptr;           // the arena as the device addresses it (hipHostGetDevicePointer); nullptr: not mapped
   std::vector<void*> scratch;          // device blocks that live until the NEXT API call starts (call_scratch)
   int* region_flags = nullptr;         // dependency flags of potrf_region_kernel: [stream][matrix][region_flag_ints], zeroed ONCE (lmm_init)
                                        // -- every launch tags its flags with a fresh epoch, so they never need resetting
@@ -96,6 +97,13 @@ void* pin_take(size_t bytes) {
   return p;
 }
 
+// device-side alias of a pointer into the pinned arena (kernels write small results straight into host memory: no copy back)
+template <typename T>
+T* pin_dev(T* host) {
+  if (host == nullptr || g.pin_dev == nullptr) return nullptr;
+  return reinterpret_cast<T*>(g.pin_dev + (reinterpret_cast<char*>(host) - g.pin));
+}
+
 void* dev_alloc(size_t bytes) {
   if (bytes == 0) bytes = 256;
   bytes = (bytes + 255) & ~size_t(255);
@@ -142,13 +150,14 @@ template <typename T>
 struct Buf {   // RAII device buffer from the caching pool
   T* p = nullptr;
   size_t n = 0;
+  bool own = true;       // false: p is borrowed (a device alias into the pinned arena), not returned to the pool
   Buf() = default;
   explicit Buf(size_t count) : p(static_cast<T*>(dev_alloc(count * sizeof(T)))), n(count) {}
   Buf(const Buf&) = delete;
   Buf& operator=(const Buf&) = delete;
-  Buf(Buf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
-  Buf& operator=(Buf&& o) noexcept { if (this != &o) { dev_free(p); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
-  ~Buf() { dev_free(p); }
+  Buf(Buf&& o) noexcept : p(o.p), n(o.n), own(o.own) { o.p = nullptr; o.n = 0; }
+  Buf& operator=(Buf&& o) noexcept { if (this != &o) { if (own) dev_free(p); p = o.p; n = o.n; own = o.own; o.p = nullptr; o.n = 0; } return *this; }
+  ~Buf() { if (own) dev_free(p); }
 };
 
 bool is_device_ptr(const void* p) {
@@ -302,15 +311,17 @@ static hipEvent_t g_stagger_ev = nullptr;
 static bool g_stagger_armed = false, g_stagger_recorded = false;
 static int g_region_whole = 1;          // LMM_REGION_ALL=1: also as the base case of the recursion for larger matrices (measured: no gain)
 static int g_region_cols = -1;          // widest block column potrf_region_kernel takes in one launch (LMM_REGION=<columns>, up to 1024; default 0: off)
-void potrf_rec_panel(const Batch& B, const BatchPtr& W2, const BatchInfo& flags, int ld, int NR, int j0, int w, int n_real, hipStream_t st,
-                     bool first_done) {
+// bulk_done (implies first_done): the rows below that block are solved as well (the update launch that factored it ran them too).
+struct NodeFlags { int* p = nullptr; int stride = 0; int min_k = 0; int rows_real = -1; };      // rows_real: rows that hold data (-1: all NR)
+void potrf_rec_panel(const Batch& B, const BatchPtr& W2, const BatchInfo& flags, const NodeFlags& nfl, int ld, int NR, int j0, int w, int n_real,
+                     hipStream_t st, bool first_done, bool bulk_done = false) {
   const double nb = B.nb;
   if (g_region_cols > 0 && w <= g_region_cols && w >= 128 && (w % 128) == 0 && flags.p[0] != nullptr) {
     // the whole block column as ONE dataflow launch (lmm_kernels.hip K2d): leaves, bulk products and all updates inside it
     const double Mr = NR - j0, Wd = w;
     const double fl = Mr * Wd * Wd - 2.0 * Wd * Wd * Wd / 3.0;           // flops of factoring an Mr x Wd tall panel: Mr Wd^2 - 2 Wd^3 / 3
     ProfScope ps(LMM_PROF_REGION, nb * fl, st, NR - j0, w, w);
-    launch_region(B.A, B.W, W2, B.info, flags, ld, NR, j0, w, n_real, B.nb, first_done, st);
+    launch_region(B.A, B.W, W2, B.info, flags, ld, NR, j0, w, n_real, B.nb, first_done, st, nfl.rows_real);
     return;
   }
   if (w == 128) {
@@ -319,7 +330,7 @@ void potrf_rec_panel(const Batch& B, const BatchPtr& W2, const BatchInfo& flags,
       launch_leaf128(B.A, (size_t)j0 * ld + j0, ld, B.W, (size_t)(j0 / 64) * 4096, W2, (size_t)(j0 / 128) * 16384, j0, n_real, B.info, B.nb, st);
     }
     const int M = NR - (j0 + 128);
-    if (M > 0) {
+    if (M > 0 && !bulk_done) {
       ProfScope ps(LMM_PROF_TRSM, nb * (double)M * 128.0 * 128.0, st, M, 128, 128);       // triangular solve: M * 128^2 flops
       launch_panel_bulk(B.A, W2, ld, NR, j0, B.nb, st);
     }
@@ -327,21 +338,25 @@ void potrf_rec_panel(const Batch& B, const BatchPtr& W2, const BatchInfo& flags,
   }
   if (w <= 64) { potrf_rec(B, ld, NR, j0, w, n_real, st); return; }          // a trailing 64-column leaf (never pre-factored)
   const int h = split(w);
-  potrf_rec_panel(B, W2, flags, ld, NR, j0, h, n_real, st, first_done);
+  potrf_rec_panel(B, W2, flags, nfl, ld, NR, j0, h, n_real, st, first_done, bulk_done);
   const int r0 = j0 + h, Nc = w - h;
   const double Mr = NR - r0;
   const double outs = (double)Nc * (Nc + 1.0) / 2.0 + (Mr - Nc) * Nc;
   const size_t offA = (size_t)j0 * ld + r0;
   if (Nc >= 128) {
     // + the leaf's 2 * 128^3 / 3 flops, run by one workgroup of this launch
+    bool fused;
     {
-      // K >= 1024: potrf_node_kernel<2> (+ gemm16h_kernel for a ragged last 64 rows) -- the dominant kernel; below: potrf_node_kernel<1>
-      ProfScope ps(h >= 1024 ? LMM_PROF_UPDATE : LMM_PROF_UPDATE_SHORT, nb * (2.0 * h * outs + 2.0 * 128.0 * 128.0 * 128.0 / 3.0), st, NR - r0, Nc, h,
-                   nb * (16.0 * outs + 8.0 * Mr * h));
-      launch_update_leaf(B.A, B.W, W2, B.info, ld, NR, j0, h, Nc, n_real, B.nb, st);
+      // K >= 1024: potrf_node_kernel<2> (+ gemm16h_kernel for a ragged last 64 rows) -- the dominant kernel; below: potrf_node_kernel<1>.
+      // With the bulk rows of the next panel in the same launch (nfl.p): + their Mb * 128^2 flops and 16 B per entry
+      const double Mb = (nfl.p && h >= nfl.min_k) ? std::max(0, NR - (r0 + 128)) : 0;
+      ProfScope ps(h >= 1024 ? LMM_PROF_UPDATE : LMM_PROF_UPDATE_SHORT,
+                   nb * (2.0 * h * outs + 2.0 * 128.0 * 128.0 * 128.0 / 3.0 + Mb * 128.0 * 128.0), st, NR - r0, Nc, h,
+                   nb * (16.0 * outs + 8.0 * Mr * h + 16.0 * Mb * 128.0));
+      fused = launch_update_leaf(B.A, B.W, W2, B.info, ld, NR, j0, h, Nc, n_real, B.nb, st, h >= nfl.min_k ? nfl.p : nullptr, nfl.stride);
       if (g_stagger_armed && !g_stagger_recorded && h >= 1024) { HIPCHK(hipEventRecord(g_stagger_ev, st)); g_stagger_recorded = true; }
     }
-    potrf_rec_panel(B, W2, flags, ld, NR, r0, Nc, n_real, st, true);
+    potrf_rec_panel(B, W2, flags, nfl, ld, NR, r0, Nc, n_real, st, true, fused);
   } else {
     {
       ProfScope ps(LMM_PROF_UPDATE_NARROW, nb * 2.0 * h * outs, st, NR - r0, Nc, h, nb * (16.0 * outs + 8.0 * Mr * h));
@@ -353,7 +368,7 @@ void potrf_rec_panel(const Batch& B, const BatchPtr& W2, const BatchInfo& flags,
 
 // Entry point of the factorisation of a batch: columns [0, NC) of every matrix.  Float64 batches take the 128-column panel path
 // (LMM_PANEL128=0: the round-2 path); its W2 scratch -- one 128 x 128 inverse per panel and matrix -- lives until the API call ends.
-void potrf_batch(const Batch& B, int ld, int NR, int NC, int n_real, hipStream_t st) {
+void potrf_batch(const Batch& B, int ld, int NR, int NC, int n_real, hipStream_t st, int rows_real = -1) {
   static int panel128 = -1;
   if (panel128 < 0) { const char* e = getenv("LMM_PANEL128"); panel128 = e ? (atoi(e) != 0) : 1; }
   if (g_f32 || !panel128 || NC < 128 || (ld & 1)) { potrf_rec(B, ld, NR, 0, NC, n_real, st); return; }
@@ -379,7 +394,22 @@ void potrf_batch(const Batch& B, int ld, int NR, int NC, int n_real, hipStream_t
     }
     for (int j = 0; j < B.nb; ++j) flags.p[j] = fl + fi * j;
   }
-  potrf_rec_panel(B, W2, flags, ld, NR, 0, NC, n_real, st, false);
+  // LMM_FUSE_BULK (default 1): the bulk rows of a panel ride in the update launch that factors its diagonal block (NODE_FUSE), behind
+  // per-call flags zeroed here; not when the region kernel serves as the base case (it solves the first panel's rows itself).
+  static int fuse_bulk = -1;
+  if (fuse_bulk < 0) { const char* e = getenv("LMM_FUSE_BULK"); fuse_bulk = e ? (atoi(e) != 0) : 1; }
+  static int fuse_min_k = -1;
+  if (fuse_min_k < 0) { const char* e = getenv("LMM_FUSE_BULK_MINK"); fuse_min_k = e ? atoi(e) : 512; }
+  NodeFlags nfl;
+  nfl.min_k = fuse_min_k;
+  nfl.rows_real = rows_real;
+  if (fuse_bulk && !region_here && NC > 128) {
+    nfl.stride = (int)node_flag_ints(NR);
+    const size_t ints = (size_t)nfl.stride * B.nb;
+    nfl.p = reinterpret_cast<int*>(call_scratch((ints + 1) / 2));
+    HIPCHK(hipMemsetAsync(nfl.p, 0, ints * sizeof(int), st));
+  }
+  potrf_rec_panel(B, W2, flags, nfl, ld, NR, 0, NC, n_real, st, false);
 }
 
 void potrf_rec(double* A, int ld, int NR, int j0, int w, double* W, int n_real, int* info, hipStream_t st) {
@@ -629,10 +659,17 @@ int project_dense(const double* H, int p, int m, double s2, double jitter, std::
 struct Uploaded {   // small host arrays staged on the device
   Buf<double> buf;
   Uploaded() = default;
-  Uploaded(const std::vector<double>& v, hipStream_t st) : buf(v.size()) {
-    const void* src = v.data();
-    if (void* pp = pin_take(v.size() * sizeof(double))) { std::memcpy(pp, v.data(), v.size() * sizeof(double)); src = pp; }
-    HIPCHK(hipMemcpyAsync(buf.p, src, v.size() * sizeof(double), hipMemcpyHostToDevice, st));
+  // direct_small: up to 256 values that kernels only READ (a few times, as uniform loads) are left in the pinned arena and read
+  // from there through its device mapping -- one copy operation less per call, which is ~8 % of a C0-sized evaluation
+  Uploaded(const std::vector<double>& v, hipStream_t st, bool direct_small = false) {
+    void* pp = pin_take(v.size() * sizeof(double));
+    if (pp) std::memcpy(pp, v.data(), v.size() * sizeof(double));
+    if (direct_small && pp && v.size() <= 256 && g.pin_dev) {
+      buf.p = pin_dev(static_cast<double*>(pp)); buf.n = v.size(); buf.own = false;
+      return;
+    }
+    buf = Buf<double>(v.size());
+    HIPCHK(hipMemcpyAsync(buf.p, pp ? pp : (const void*)v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice, st));
   }
 };
 
@@ -676,11 +713,17 @@ int latent_lmls(const double* xd, int d, int n, const lmm_gp_t* gps, const doubl
   batch_plan(ms, &nb_per, &nslots, mat_bytes((double)D.elems()));
   std::vector<Slot> slots;
   make_slots(slots, nslots, nb_per, D.elems(), D.NC);
-  // results: [ms * nrhs doubles | ms pivot-info ints] in ONE buffer, so that one copy brings both back
+  // results: [ms * nrhs doubles | ms pivot-info ints] in ONE buffer.  When the pinned arena is mapped into the device, lml_reduce
+  // writes both straight into host memory (pk) and nothing is copied back; else one copy brings both back.  The pivot-info words
+  // the kernels work on are zeroed by each latent's Gram launch (no memset).
   const size_t nout = (size_t)ms * nrhs;
+  const size_t nbytes = (nout + ((size_t)ms + 1) / 2) * sizeof(double);
   Buf<double> out(nout + ((size_t)ms + 1) / 2);
   struct { int* p; } info{reinterpret_cast<int*>(out.p + nout)};
-  HIPCHK(hipMemsetAsync(info.p, 0, ms * sizeof(int), g.streams[0]));
+  std::vector<double> pageable;
+  char* pk = static_cast<char*>(pin_take(nbytes));
+  char* pk_dev = pin_dev(pk);
+  if (!pk) { pageable.resize(nbytes / sizeof(double)); pk = reinterpret_cast<char*>(pageable.data()); }
   fork_slots(nslots);
   int bi = 0;
   for (int k0 = 0; k0 < ms; k0 += nb_per, ++bi) {
@@ -702,6 +745,7 @@ int latent_lmls(const double* xd, int d, int n, const lmm_gp_t* gps, const doubl
       a.diag_vec = noisevec ? noisevec + (size_t)k * n : nullptr;      // per-point noise of latent k (device, n values)
       a.rider = delta + (size_t)k * nrhs * n; a.rider_ld = n; a.nrider = nrhs; a.xs = nullptr; a.ns = 0;
       a.rider_sub = rider_sub ? rider_sub[l0 + k] : 0.0;
+      a.info_zero = info.p + k;
       ga[j] = a;
       B.add(s.A[j].p, s.W[j].p, info.p + k);
     }
@@ -715,17 +759,15 @@ int latent_lmls(const double* xd, int d, int n, const lmm_gp_t* gps, const doubl
       g_stagger_recorded = false;
       if (g_stagger_armed && !g_stagger_ev) HIPCHK(hipEventCreateWithFlags(&g_stagger_ev, hipEventDisableTiming));
     }
-    potrf_batch(B, D.ld, D.NR, D.NC, n, s.st);
+    potrf_batch(B, D.ld, D.NR, D.NC, n, s.st, D.NC + nrhs);      // the rider rows NC + nrhs .. NR - 1 are zero padding
     g_stagger_armed = false;
-    launch_lml_reduce(B.A, nb, D.ld, n, D.NC, nrhs, out.p + (size_t)k0 * nrhs, s.st);
+    if (pk_dev) launch_lml_reduce(B.A, nb, D.ld, n, D.NC, nrhs, reinterpret_cast<double*>(pk_dev) + (size_t)k0 * nrhs, s.st, &B.info,
+                                  reinterpret_cast<int*>(pk_dev + nout * sizeof(double)) + k0);
+    else launch_lml_reduce(B.A, nb, D.ld, n, D.NC, nrhs, out.p + (size_t)k0 * nrhs, s.st);
   }
   join_slots(nslots);
   std::vector<int> hinfo(ms);
-  const size_t nbytes = (nout + ((size_t)ms + 1) / 2) * sizeof(double);
-  std::vector<double> pageable;
-  char* pk = static_cast<char*>(pin_take(nbytes));
-  if (!pk) { pageable.resize(nbytes / sizeof(double)); pk = reinterpret_cast<char*>(pageable.data()); }
-  HIPCHK(hipMemcpyAsync(pk, out.p, nbytes, hipMemcpyDeviceToHost, g.streams[0]));
+  if (!pk_dev) HIPCHK(hipMemcpyAsync(pk, out.p, nbytes, hipMemcpyDeviceToHost, g.streams[0]));
   HIPCHK(hipStreamSynchronize(g.streams[0]));
   std::memcpy(lml.data(), pk, nout * sizeof(double));
   std::memcpy(hinfo.data(), pk + nout * sizeof(double), (size_t)ms * sizeof(int));
@@ -811,6 +853,14 @@ int lmm_init(int device) {
   HIPCHK(hipEventCreateWithFlags(&g.ev_main, hipEventDisableTiming));
   g.pin_cap = 1u << 20;
   if (hipHostMalloc((void**)&g.pin, g.pin_cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); g.pin = nullptr; g.pin_cap = 0; }
+  g.pin_dev = nullptr;
+  {
+    static int direct = -1;            // LMM_DIRECT_RESULTS=0: results come back by hipMemcpy (the round-2 path)
+    if (direct < 0) { const char* e = getenv("LMM_DIRECT_RESULTS"); direct = e ? (atoi(e) != 0) : 1; }
+    void* dp = nullptr;
+    if (direct && g.pin && hipHostGetDevicePointer(&dp, g.pin, 0) == hipSuccess) g.pin_dev = static_cast<char*>(dp);
+    else (void)hipGetLastError();
+  }
   {
     const size_t fi = region_flag_ints(0) * (size_t)LMM_MAX_BATCH * kMaxStreams;
     HIPCHK(hipMalloc((void**)&g.region_flags, fi * sizeof(int)));
@@ -835,7 +885,7 @@ int lmm_shutdown(void) {
   g.pool.clear();
   for (int s = 0; s < kMaxStreams; ++s) { (void)hipStreamDestroy(g.streams[s]); (void)hipEventDestroy(g.ev_slot[s]); }
   (void)hipEventDestroy(g.ev_main);
-  if (g.pin) { (void)hipHostFree(g.pin); g.pin = nullptr; g.pin_cap = 0; }
+  if (g.pin) { (void)hipHostFree(g.pin); g.pin = nullptr; g.pin_cap = 0; g.pin_dev = nullptr; }
   g.init = false;
   return LMM_OK;
 }
@@ -1022,14 +1072,15 @@ int lmm_oilmm_logpdf(const double* x, int d, int n, const double* y, int p, cons
     // subtract the latent mean inside the Gram kernel, the per-latent right-hand sides delta_l = (T y)_l - mean_l
     std::vector<double> pack(T);
     pack.insert(pack.end(), H.begin(), H.end());
-    Uploaded THd(pack, st0);
+    Uploaded THd(pack, st0, true);
     const double* Tdev = THd.buf.p;
     const double* Hdev = THd.buf.p + (size_t)m * p;
     Buf<double> Ty((size_t)n * m), resid_dev(1), partial(tall_skinny_partials(n, p));
     project_on_device(yd.p, n, p, Tdev, m, 0, m, nullptr, Ty.p, st0);
     // reference src/oilmm.jl:112: sum(abs2, (I - U U') Y)  ==  |Y - H T Y|_F^2 since H T = U U'
-    residual_on_device(yd.p, n, p, Ty.p, m, Hdev, partial.p, resid_dev.p, st0);
-    HIPCHK(hipMemcpyAsync(resid, resid_dev.p, sizeof(double), hipMemcpyDeviceToHost, st0));    // read after latent_lmls' sync
+    double* resid_direct = (resid != &resid_pageable) ? pin_dev(resid) : nullptr;      // the reduction writes into host memory
+    residual_on_device(yd.p, n, p, Ty.p, m, Hdev, partial.p, resid_direct ? resid_direct : resid_dev.p, st0);
+    if (!resid_direct) HIPCHK(hipMemcpyAsync(resid, resid_dev.p, sizeof(double), hipMemcpyDeviceToHost, st0));    // read after latent_lmls' sync
     if (int rc = latent_lmls(xd.p, d, n, gps, ST.data(), l0, l1, Ty.p + (size_t)l0 * n, lml, 1, nullptr, means.data())) return rc;
   } else {
     Uploaded Td(T, st0), meansd(means, st0);

@@ -26,6 +26,8 @@ struct GramArgs {
   const double* rider; int rider_ld, nrider;   // rows ncols + r  <- rider[r*rider_ld + j] - rider_sub
   double rider_sub;                            // constant subtracted from the rider rows (latent mean: delta = T y - mean)
   const double* xs; int ns;                    // rows ncols + r  <- kappa(xs_r, x_j)
+  int* info_zero;                              // optional: the matrix's pivot-info word, zeroed by the launch (saves a memset per call)
+  int cpw;                                     // column tiles per workgroup (set by the launcher: 4, or 1 when the grid would be small)
 };
 
 // The same assembly for up to LMM_MAX_BATCH same-shaped matrices in ONE launch (blockIdx.z = matrix): everything in `base`
@@ -37,6 +39,7 @@ struct GramBatchArgs {
   const double* diag_vec[LMM_MAX_BATCH];
   const double* rider[LMM_MAX_BATCH];
   double rider_sub[LMM_MAX_BATCH];
+  int* info_zero[LMM_MAX_BATCH];
 };
 
 struct DenseArgs {
@@ -68,13 +71,19 @@ struct NodeArgs {
   int MT, nb;             // 128-row tiles of the region; matrices in the batch
   int rest_items, full_items, splitk;     // work items of the column tiles 1.. (gemm_work_item's enumeration and split-K tail)
   int full_items_last, splitk_last;       // the same for the LAST matrix of the batch, which carries the launch's tail
-  int mode;               // NODE_UPDATE | NODE_LEAF, or NODE_BULK
+  int mode;               // NODE_UPDATE | NODE_LEAF [| NODE_FUSE], or NODE_BULK
+  // NODE_FUSE: the bulk rows of the panel this launch's leaf factors run as the LAST work items of the same launch, behind
+  // device-side flags (nflags: per matrix [0] abort word, [1] leaf done, [2 + ti] column-0 tile ti updated; values epoch * 32 + 1)
+  int* nflags; int nf_stride, epoch;
+  int Mb, MTb, bulk0;     // rows / 128-row tiles the bulk items cover (a ragged last 64 rows included); index of the first bulk item
+  long long* trace;       // optional (LMM_NODE_TRACE=<K>, tools/node_trace.py): start / end wall-clock ticks + CU id of every workgroup
 };
 // Arguments of potrf_region_kernel (lmm_kernels.hip K2d): the columns [c0, c0 + 128 P) of every matrix of the batch, rows c0 .. c0 + M - 1.
 struct RegionArgs {
   BatchPtr A, W, W2;
   BatchInfo info, flags;  // flags: P * R readiness words + 1 abort word per matrix (zeroed once per factorisation)
   int ld, M, c0, P, R, n_real, nb, epoch, first_done;
+  int M_real;             // rows c0 .. c0 + M_real - 1 hold data, the rest of the M rows is zero padding (rider rows are padded to 64)
   int ntasks;             // workgroups per matrix (trace layout)
   long long* trace;       // optional (LMM_REGION_TRACE=1, tools/region_trace.py): start / end wall-clock ticks of every workgroup
 };
@@ -83,15 +92,17 @@ struct RegionArgs {
 void region_flags_register(int* base, size_t ints);     // the context's persistent flag array (cleared when the launch epoch wraps)
 size_t region_flag_ints(int NR);          // ints per matrix that the flags of any region of a matrix with NR rows need
 void launch_region(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2, const BatchInfo& info, const BatchInfo& flags, int ld, int NR,
-                   int c0, int width, int n_real, int nb, bool first_done, hipStream_t st);
+                   int c0, int width, int n_real, int nb, bool first_done, hipStream_t st, int rows_real = -1);
 // plain trailing update (no leaf) through the node kernel: C -= A B' for the region at j0 + h
 void launch_leaf128(const BatchPtr& A, size_t offD, int ld, const BatchPtr& W, size_t offW, const BatchPtr& W2, size_t offW2,
                     int gcol0, int n_real, const BatchInfo& info, int nb, hipStream_t st);
 // bulk rows of the panel at column r0 (its diagonal block factored, its inverse in W2): X = P Dinv' in place
 void launch_panel_bulk(const BatchPtr& A, const BatchPtr& W2, int ld, int NR, int r0, int nb, hipStream_t st);
 // C -= A B' for the region at r0 = j0 + h (N columns, multiple of 128) + leaf128 on its top-left block
-void launch_update_leaf(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2, const BatchInfo& info, int ld, int NR, int j0, int h,
-                        int N, int n_real, int nb, hipStream_t st);
+// nflags != nullptr: also the bulk rows of that panel, in the same launch (NODE_FUSE); returns true when it did
+bool launch_update_leaf(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2, const BatchInfo& info, int ld, int NR, int j0, int h,
+                        int N, int n_real, int nb, hipStream_t st, int* nflags = nullptr, int nf_stride = 0);
+size_t node_flag_ints(int NR);            // ints per matrix of the NODE_FUSE flags of a matrix with NR rows
 void launch_diag64(const BatchPtr& A, size_t offA, int ld, const BatchPtr& W, size_t offW, int gcol0, int n_real,
                    const BatchInfo& info, int nb, hipStream_t st);
 void launch_gemm_nt(const BatchPtr& C, size_t offC, int ldc, const BatchPtr& A, size_t offA, int lda, const BatchPtr& B,
@@ -99,7 +110,10 @@ void launch_gemm_nt(const BatchPtr& C, size_t offC, int ldc, const BatchPtr& A, 
 void launch_gemm_nt(double* C, int ldc, const double* A, int lda, const double* B, int ldb, int M, int N, int K,
                     int lower, bool set, hipStream_t st);
 void launch_lml_reduce(const double* A, int ld, int n, int rider_row0, int nrhs, double* out, hipStream_t st);
-void launch_lml_reduce(const BatchPtr& A, int nb, int ld, int n, int rider_row0, int nrhs, double* out, hipStream_t st);   // out[b*nrhs + r]
+// out[b*nrhs + r]; info_out != nullptr: also info_out[b] = *info.p[b] (out / info_out may be device-mapped pinned host memory: the
+// results then need no copy back)
+void launch_lml_reduce(const BatchPtr& A, int nb, int ld, int n, int rider_row0, int nrhs, double* out, hipStream_t st,
+                       const BatchInfo* info = nullptr, int* info_out = nullptr);
 void launch_extract_row(const double* A, int ld, int row, int n, double* out, hipStream_t st);
 void launch_extract_rows(const BatchPtr& A, int nb, int ld, int row, int n, int nfill, const BatchPtr& o1, const BatchPtr& o2,
                          hipStream_t st);

@@ -292,8 +292,8 @@ __device__ __forceinline__ void gram_body(const GramArgs& a) {
       if (rows_ok) { E0 = exp_any(u0); F0 = exp_any(-u0); E1 = exp_any(u1); F1 = exp_any(-u1); }
     }
   }
-  for (int c4 = 0; c4 < 4; ++c4) {
-    const int tj = sy * 4 + c4;
+  for (int c4 = 0; c4 < a.cpw; ++c4) {
+    const int tj = sy * a.cpw + c4;
     if (tj * 64 >= a.ncols) break;
     if (!a.full && ti < tj) break;                          // lower tiles only
     const bool cols_in = (tj * 64 + 63 < a.n);
@@ -391,13 +391,17 @@ __device__ __forceinline__ void gram_body(const GramArgs& a) {
 }
 
 template <int KIND, bool ND, typename TS>
-__global__ __launch_bounds__(256) void gram_kernel(GramArgs a) { gram_body<KIND, ND, TS>(a); }
+__global__ __launch_bounds__(256) void gram_kernel(GramArgs a) {
+  if (a.info_zero && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *a.info_zero = 0;
+  gram_body<KIND, ND, TS>(a);
+}
 
 template <int KIND, bool ND, typename TS>
 __global__ __launch_bounds__(256) void gram_batch_kernel(GramBatchArgs b) {
   GramArgs a = b.base;
   const int z = blockIdx.z;
   a.A = b.A[z]; a.var = b.var[z]; a.inv_ls = b.inv_ls[z]; a.diag_add = b.diag_add[z]; a.diag_vec = b.diag_vec[z]; a.rider = b.rider[z]; a.rider_sub = b.rider_sub[z];
+  if (b.info_zero[z] && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *b.info_zero[z] = 0;
   gram_body<KIND, ND, TS>(a);
 }
 
@@ -2034,6 +2038,51 @@ __device__ __forceinline__ void wg_mm64(const double* __restrict__ As, int sai, 
       for (int r = 0; r < 4; ++r) emit(u, v, r, wi + 16 * u + 4 * r + g, wj + 16 * v + c, acc[u][v][r]);
 }
 
+// ---- flags of a region launch (per matrix, ints; every value is epoch * 32 + count, so words left by earlier launches never match):
+//   [0] abort word (plain 0 / 1)      [1] wk: blocks the WALKER has finished -- count r means W_0 .. W_{r-1} and L[c, c-1], c <= r, are final
+//   [2 + r]  trs[r]:  64-column blocks of square row r that its HELPER has solved (count k + 1: L[r, 0 .. k] final), r >= 2
+//   [18 + r] upd[r]:  steps whose updates helper r has applied to its two rightmost tiles (r, r-1), (r, r) -- what the walker waits for
+//   [34 + j] dinv[j]: the 128 x 128 inverse of panel j is in the W2 scratch (count 0)
+// A wait spins on thread 0 (bounded: 1 s of the 100 MHz wall clock, or until another workgroup raised the abort word -- the grid
+// always drains), then an agent-scope acquire fence makes the producer's data visible to the whole workgroup.
+#define REGION_FLAG_INTS (34 + LMM_REGION_MAX_PANELS)
+// SLEEP: s_sleep argument between polls (64 clocks each).  1 on the region kernel's chain (a handful of pollers, every 30 ns counts); the
+// hundreds of bulk workgroups of a fused node launch poll the same few words and use 16 (~0.5 us), or they slow the leaf they wait for.
+template <int SLEEP = 1>
+__device__ __forceinline__ void region_wait_ge(const int* f, int epoch, int need, int* abort_word, int* info) {
+  if (threadIdx.x == 0) {
+    const long long t0 = wall_clock64();
+    int polls = 0;
+    for (;;) {
+      const int v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((v >> 5) == epoch && (v & 31) >= need) break;
+      __builtin_amdgcn_s_sleep(SLEEP);
+      if ((++polls & 63) == 0) {
+        if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+        if (wall_clock64() - t0 > 100000000LL) {
+          __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          atomicCAS(info, 0, LMM_INFO_SYNC_TIMEOUT);               // surfaces through the host's check of the pivot info word
+          break;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+// Publishing.  An agent-scope release fence writes back EVERY dirty line of the XCD's L2 -- including the megabytes the row streams
+// of the same launch keep producing -- and costs 4-13 us under load (tools/fence_probe, profiles/r03), twice per 64-column block of
+// the chain.  So everything the square publishes (L blocks, inverse blocks, the pair tiles) is stored WRITE-THROUGH (ST_PUB: agent-
+// scope relaxed atomic stores, `global_store ... sc1`), and publishing only waits for those stores to be acknowledged
+// (s_waitcnt vmcnt(0)) before the flag goes out.  Consumers still take an agent-scope ACQUIRE fence after seeing the flag (an L2
+// invalidate: 0.03-1.4 us), so their ordinary loads fetch the written-through data.
+#define ST_PUB(PTR, VAL) __hip_atomic_store((PTR), (VAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+__device__ __forceinline__ void region_publish(int* f, int epoch, int count) {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // every thread: its write-through stores are acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(f, epoch * 32 + count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // LDS of the node kernel: the update's staging (2 x 2 x 16 x 144 doubles = 73 728 bytes, as gemm16p_kernel) >= the leaf's two 64 x 64
 // images X, Y (2 x 64 x 68 doubles); the diagonal-block work areas Sp / Wt live inside whichever image is dead in that phase.
 constexpr int LEAF_LDS_DOUBLES = 4 * 16 * 144;
@@ -2041,6 +2090,8 @@ static_assert(2 * 64 * DIAG_LS <= LEAF_LDS_DOUBLES && 64 * DIAG_SP + 256 <= 64 *
 // lds: LEAF_LDS_DOUBLES doubles.  A: the matrix (double), offD: element offset of the diagonal block; W: 64 x 64 inverse blocks
 // (offW: block of the first 64 columns; the second follows at + 4096); W2p: this panel's 128 x 128 inverse (column-major, ld 128).
 // All 256 threads of the workgroup call it; it starts and ends with everything in LDS free for reuse.
+// PUB: the panel inverse is stored write-through (ST_PUB), for consumers in the SAME launch (NODE_FUSE bulk items).
+template <bool PUB = false>
 __device__ __forceinline__ void leaf128_dev(double* __restrict__ lds, double* __restrict__ A, size_t offD, int ld,
                                             double* __restrict__ W, size_t offW, double* __restrict__ W2p, int gcol0, int n_real,
                                             int* __restrict__ info) {
@@ -2064,8 +2115,8 @@ __device__ __forceinline__ void leaf128_dev(double* __restrict__ lds, double* __
     const int e = t + 256 * i, row = e & 63, col = e >> 6;
     const double v = X[col * LS + row];
     W[offW + (size_t)col * 64 + row] = v;
-    W2p[(size_t)col * 128 + row] = v;
-    W2p[(size_t)(64 + col) * 128 + row] = 0.0;
+    if (PUB) { ST_PUB(&W2p[(size_t)col * 128 + row], v); ST_PUB(&W2p[(size_t)(64 + col) * 128 + row], 0.0); }
+    else { W2p[(size_t)col * 128 + row] = v; W2p[(size_t)(64 + col) * 128 + row] = 0.0; }
   }
   // B: L21 = A21 W11'   (A[i][k] = Y[k][i]; R[k][j] = W11[j][k] = X[k][j])
   double l21[2][2][4];
@@ -2123,10 +2174,12 @@ __device__ __forceinline__ void leaf128_dev(double* __restrict__ lds, double* __
     const int e = t + 256 * i, row = e & 63, col = e >> 6;
     const double v = Y[col * LS + row];
     W[offW + 4096 + (size_t)col * 64 + row] = v;
-    W2p[(size_t)(64 + col) * 128 + 64 + row] = v;
+    if (PUB) ST_PUB(&W2p[(size_t)(64 + col) * 128 + 64 + row], v); else W2p[(size_t)(64 + col) * 128 + 64 + row] = v;
   }
   // D: W21 = -W22 T   (A[i][k] = W22[i][k] = Y[k][i]; R[k][j] = T[k][j] = X[j][k])
-  wg_mm64(Y, 1, LS, X, 1, LS, w, l, [&](int, int, int, int row, int col, double x) { W2p[(size_t)col * 128 + 64 + row] = -x; });
+  wg_mm64(Y, 1, LS, X, 1, LS, w, l, [&](int, int, int, int row, int col, double x) {
+    if (PUB) ST_PUB(&W2p[(size_t)col * 128 + 64 + row], -x); else W2p[(size_t)col * 128 + 64 + row] = -x;
+  });
   if (t == 0) {
     int i = diag_info_of(bad1, gcol0, n_real);
     if (i == 0) i = diag_info_of(bad2, gcol0 + 64, n_real);
@@ -2138,6 +2191,7 @@ __device__ __forceinline__ void leaf128_dev(double* __restrict__ lds, double* __
 #define NODE_UPDATE 1
 #define NODE_LEAF 2
 #define NODE_BULK 4
+#define NODE_FUSE 8
 __global__ __launch_bounds__(256) void leaf128_kernel(BatchPtr Ab, size_t offD, int ld, BatchPtr Wb, size_t offW, BatchPtr W2b, size_t offW2,
                                                       int gcol0, int n_real, BatchInfo infob) {
   extern __shared__ __attribute__((aligned(16))) double node_lds[];
@@ -2159,13 +2213,20 @@ __global__ __launch_bounds__(256, 2) void potrf_node_kernel(NodeArgs a) {
   //     tiles keeps the matrix-after-matrix order of gemm16p_kernel (interleaving the matrices of a batch instead measured 2-3 %
   //     slower on the K >= 2048 levels: sixteen operand panels of 0.5 GB compete for the caches instead of one).
   //   bulk mode: matrix by matrix, row tiles 1 .. MT-1.
+  //   NODE_FUSE (update mode): after all of the above, the bulk tiles of the panel whose diagonal block this launch's leaf factors
+  //     (row tile by row tile, item = bulk0 + (ti - 1) nb + b).  Bulk tile (b, ti) waits for the leaf of matrix b and for column-0
+  //     tile (b, ti) of this launch -- workgroups dispatched before it, which wait for nothing: no deadlock however few are resident.
+  //     Their results reach it write-through (ST_PUB) + flag, as in the region kernel.
   int part = 0, nparts = 1, tj = 0, ti = 0, bidx = 0;
-  bool bulk = false;
+  bool bulk = false, col0 = false;
+  const bool fuse = (a.mode & NODE_FUSE) != 0;
+  if (a.trace && threadIdx.x == 0) a.trace[4 * (size_t)blockIdx.x] = wall_clock64();
   {
     const int item = blockIdx.x;
     if (a.mode & NODE_UPDATE) {
       const int n0 = a.nb * a.MT;
-      if (item < n0) { ti = item / a.nb; bidx = item - ti * a.nb; }
+      if (item < n0) { ti = item / a.nb; bidx = item - ti * a.nb; col0 = true; }
+      else if (fuse && item >= a.bulk0) { bulk = true; const int q = item - a.bulk0; ti = q / a.nb; bidx = q - ti * a.nb; ti += 1; }
       else {
         const int q = item - n0;
         bidx = q / a.rest_items;
@@ -2179,7 +2240,12 @@ __global__ __launch_bounds__(256, 2) void potrf_node_kernel(NodeArgs a) {
   }
   double* Am = a.A.p[bidx];
   const int r0 = a.j0 + a.h;
-  const int M = a.M;
+  const int M = bulk ? a.Mb : a.M;
+  int* nf = fuse ? a.nflags + (size_t)bidx * a.nf_stride : nullptr;
+  if (bulk && fuse) {
+    region_wait_ge<16>(nf + 1, a.epoch, 1, nf, a.info.p[bidx]);                          // the panel inverse
+    if (ti < a.MT) region_wait_ge<16>(nf + 2 + ti, a.epoch, 1, nf, a.info.p[bidx]);      // this tile's rows of the panel, updated
+  }
   double* C = Am + (size_t)r0 * a.ld + r0;
   const double* A = bulk ? C : Am + (size_t)a.j0 * a.ld + r0;
   const double* B = bulk ? a.W2.p[bidx] + (size_t)(r0 / 128) * 16384 : A;
@@ -2273,10 +2339,17 @@ __global__ __launch_bounds__(256, 2) void potrf_node_kernel(NodeArgs a) {
         for (int u = 0; u < 4; ++u)
 #pragma unroll
           for (int r = 0; r < 4; ++r) cv[u][r] = cpv[(size_t)(4 * r) * ldc + 16 * u];
+        if (fuse && col0) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+          for (int u = 0; u < 4; ++u)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) cpv[(size_t)(4 * r) * ldc + 16 * u] = cv[u][r] - acc[v][u][r];
+            for (int r = 0; r < 4; ++r) ST_PUB(cpv + (size_t)(4 * r) * ldc + 16 * u, cv[u][r] - acc[v][u][r]);
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cpv[(size_t)(4 * r) * ldc + 16 * u] = cv[u][r] - acc[v][u][r];
+        }
       } else {
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -2285,10 +2358,24 @@ __global__ __launch_bounds__(256, 2) void potrf_node_kernel(NodeArgs a) {
       }
     }
   }
+  if (a.trace && threadIdx.x == 0) {
+    unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    a.trace[4 * (size_t)blockIdx.x + 1] = wall_clock64();
+    a.trace[4 * (size_t)blockIdx.x + 2] = ((long long)(xcc & 15) << 32) | hw;
+    a.trace[4 * (size_t)blockIdx.x + 3] = ((long long)bidx << 48) | ((long long)(bulk ? 3 : (col0 ? 0 : (nparts > 1 ? 2 : 1))) << 40) | ((long long)ti << 20) | (long long)(tj << 8) | part;
+  }
+  if (fuse && col0 && ti >= 1) region_publish(nf + 2 + ti, a.epoch, 1);        // uniform over the workgroup
   if ((a.mode & NODE_LEAF) && !bulk && ti == 0 && tj == 0) {       // uniform over the workgroup
     __syncthreads();                                               // the tile's stores are issued; the staging LDS is free
-    leaf128_dev(node_lds, Am, (size_t)r0 * a.ld + r0, a.ld, a.W.p[bidx], (size_t)(r0 / 64) * 4096,
-                a.W2.p[bidx] + (size_t)(r0 / 128) * 16384, r0, a.n_real, a.info.p[bidx]);
+    if (fuse) {
+      leaf128_dev<true>(node_lds, Am, (size_t)r0 * a.ld + r0, a.ld, a.W.p[bidx], (size_t)(r0 / 64) * 4096,
+                        a.W2.p[bidx] + (size_t)(r0 / 128) * 16384, r0, a.n_real, a.info.p[bidx]);
+      region_publish(nf + 1, a.epoch, 1);
+    } else {
+      leaf128_dev(node_lds, Am, (size_t)r0 * a.ld + r0, a.ld, a.W.p[bidx], (size_t)(r0 / 64) * 4096,
+                  a.W2.p[bidx] + (size_t)(r0 / 128) * 16384, r0, a.n_real, a.info.p[bidx]);
+    }
   }
 }
 
@@ -2351,48 +2438,6 @@ __device__ __forceinline__ void pipe128_accumulate(d4 (&acc)[4][4], double* __re
     const int kn = (kt + 2 < nk) ? kt + 2 : nk - 1;
     LMM_TILE_BODY(ra, rb, kn)
   }
-}
-
-// ---- flags of a region launch (per matrix, ints; every value is epoch * 32 + count, so words left by earlier launches never match):
-//   [0] abort word (plain 0 / 1)      [1] wk: blocks the WALKER has finished -- count r means W_0 .. W_{r-1} and L[c, c-1], c <= r, are final
-//   [2 + r]  trs[r]:  64-column blocks of square row r that its HELPER has solved (count k + 1: L[r, 0 .. k] final), r >= 2
-//   [18 + r] upd[r]:  steps whose updates helper r has applied to its two rightmost tiles (r, r-1), (r, r) -- what the walker waits for
-//   [34 + j] dinv[j]: the 128 x 128 inverse of panel j is in the W2 scratch (count 0)
-// A wait spins on thread 0 (bounded: 1 s of the 100 MHz wall clock, or until another workgroup raised the abort word -- the grid
-// always drains), then an agent-scope acquire fence makes the producer's data visible to the whole workgroup.
-#define REGION_FLAG_INTS (34 + LMM_REGION_MAX_PANELS)
-__device__ __forceinline__ void region_wait_ge(const int* f, int epoch, int need, int* abort_word, int* info) {
-  if (threadIdx.x == 0) {
-    const long long t0 = wall_clock64();
-    int polls = 0;
-    for (;;) {
-      const int v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((v >> 5) == epoch && (v & 31) >= need) break;
-      __builtin_amdgcn_s_sleep(1);
-      if ((++polls & 63) == 0) {
-        if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-        if (wall_clock64() - t0 > 100000000LL) {
-          __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          atomicCAS(info, 0, LMM_INFO_SYNC_TIMEOUT);               // surfaces through the host's check of the pivot info word
-          break;
-        }
-      }
-    }
-  }
-  __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-}
-// Publishing.  An agent-scope release fence writes back EVERY dirty line of the XCD's L2 -- including the megabytes the row streams
-// of the same launch keep producing -- and costs 4-13 us under load (tools/fence_probe, profiles/r03), twice per 64-column block of
-// the chain.  So everything the square publishes (L blocks, inverse blocks, the pair tiles) is stored WRITE-THROUGH (ST_PUB: agent-
-// scope relaxed atomic stores, `global_store ... sc1`), and publishing only waits for those stores to be acknowledged
-// (s_waitcnt vmcnt(0)) before the flag goes out.  Consumers still take an agent-scope ACQUIRE fence after seeing the flag (an L2
-// invalidate: 0.03-1.4 us), so their ordinary loads fetch the written-through data.
-#define ST_PUB(PTR, VAL) __hip_atomic_store((PTR), (VAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-__device__ __forceinline__ void region_publish(int* f, int epoch, int count) {
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // every thread: its write-through stores are acknowledged
-  __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_store(f, epoch * 32 + count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // 64 x 64 block G (column-major, leading dimension ldg) -> LDS image img[col * DIAG_LS + row]; all 256 threads, 512-byte row runs
@@ -2459,6 +2504,16 @@ __device__ __forceinline__ void potrf_region_walker(const RegionArgs& a, double*
     const size_t grow = (size_t)a.c0 + 64 * (size_t)r;
     const double* src = nullptr;
     if (tr2 && t == 0) tr2[r] = wall_clock64();
+    if (r > 0 && (int)grow >= a.n_real) {
+      // A block of padding columns only (the width is rounded up to 128: n = 552 -> 640): the assembly left L[r, :] = [0 .. 0 I]
+      // there, which IS the factor, and W_r = I.  Nothing to wait for and nothing to compute -- a whole step of the chain less.
+      __syncthreads();                                                   // readers of X / Y of the previous block are done
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { const int e = t + 256 * i, row = e & 63, col = e >> 6; X[col * LS + row] = row == col ? 1.0 : 0.0; }
+      region_publish(wk, a.epoch, r);                                    // W_{r-1} is stored; L[r, r-1] = 0 has been final all along
+      region_store_W(a, b, X, grow, (r & 1) != 0);                       // (region_publish's barrier completed the image)
+      continue;
+    }
     if (r > 0) {
       const size_t gcol = grow - 64;
       if (r >= 2) region_wait_ge(upd + r, a.epoch, r - 1, abort_word, info);     // tiles (r, r-1), (r, r) updated through block r - 2
@@ -2638,6 +2693,123 @@ __device__ __forceinline__ void potrf_region_row(const RegionArgs& a, double* __
   }
 }
 
+// THIN row task: a row tile with at most 16 real rows -- the rider rows of a logpdf (ONE projected observation vector per latent,
+// zero-padded to 64 rows).  The full-tile stream above multiplies 128 x 128 tiles whatever the row count and, alone on its CU, runs
+// ~60 us per panel behind the square at P = 5 (notebook shape: walker done at 200 us, row stream at 306).  Here the 16 rows are ONE
+// MFMA row block: products are formed transposed, c' (128 panel columns x 16 rows), wave w owning panel columns 32 w .. 32 w + 31,
+//   c' = C[i, j]' - X[j, 0:128 j] X[i, 0:128 j]'     operands straight from global memory (32-k chunks, one chunk prefetched), as soon
+//                                                    as the square's rows of each earlier panel p are final (progressive waits);
+//   X[i, j]' = Dinv_j c'                             c' through LDS (16 KB): the D layout of a 16x16x4 product IS the B-operand layout
+//                                                    of the next one (register s of lane (g, c) = row 4 s + g), so nothing is transposed;
+//                                                    Dinv is lower triangular: wave w stops at k = 32 (w + 1).
+// Rows 16 .. of the tile are padding (zeros before and after).  Nothing is published: nobody reads a row stream inside the launch.
+__device__ __forceinline__ void region_wait3(const int* f1, int n1, const int* f2, int n2, const int* f3, int n3, int epoch, int* abort_word, int* info) {
+  if (threadIdx.x == 0) {
+    const long long t0 = wall_clock64();
+    int polls = 0;
+    for (;;) {
+      const int v1 = __hip_atomic_load(f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int v2 = f2 ? __hip_atomic_load(f2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch * 32 + 31;
+      const int v3 = f3 ? __hip_atomic_load(f3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch * 32 + 31;
+      if ((v1 >> 5) == epoch && (v1 & 31) >= n1 && (v2 >> 5) == epoch && (v2 & 31) >= n2 && (v3 >> 5) == epoch && (v3 & 31) >= n3) break;
+      __builtin_amdgcn_s_sleep(1);
+      if ((++polls & 63) == 0) {
+        if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+        if (wall_clock64() - t0 > 100000000LL) {
+          __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          atomicCAS(info, 0, LMM_INFO_SYNC_TIMEOUT);
+          break;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+struct ThinChunk { double fb[8], fa[8][2]; };
+__device__ __forceinline__ void potrf_region_row_thin(const RegionArgs& a, double* __restrict__ lds, double* __restrict__ Am, int b, int ti) {
+  int* abort_word = a.flags.p[b];
+  int* wk = abort_word + 1; int* trs = abort_word + 2; int* dinv = abort_word + 34;
+  int* info = a.info.p[b];
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int l15 = lane & 15, lk = lane >> 4;
+  const size_t row_i = (size_t)a.c0 + 128 * (size_t)ti;
+  double* cT = lds;                                      // c'[k][row]: 128 x 16 doubles
+  for (int tj = 0; tj < a.P; ++tj) {
+    const size_t row_j = (size_t)a.c0 + 128 * (size_t)tj;
+    const size_t jw = row_j + 32 * (size_t)w;            // this wave's panel columns = rows jw .. jw + 31 of the square
+    d4 acc[2];
+    acc[0] = acc[1] = (d4){0.0, 0.0, 0.0, 0.0};
+    const int R = 2 * tj;
+    for (int p = 0; p < tj; ++p) {
+      // square rows R, R + 1 final in the columns of panel p (64-column blocks 2p, 2p + 1): helpers' blocks; the walker's
+      // subdiagonal block L[R, R - 1] when 2p + 1 = R - 1
+      if (p < tj - 1) region_wait3(trs + R, 2 * p + 2, trs + R + 1, 2 * p + 2, nullptr, 0, a.epoch, abort_word, info);
+      else region_wait3(trs + R + 1, 2 * p + 2, wk, R, R >= 2 ? trs + R : nullptr, R - 1, a.epoch, abort_word, info);
+      auto load_chunk = [&](ThinChunk& ch, int k0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const size_t kc = ((size_t)a.c0 + k0 + 4 * q + lk) * a.ld;
+          ch.fb[q] = Am[kc + row_i + l15];
+          ch.fa[q][0] = Am[kc + jw + l15];
+          ch.fa[q][1] = Am[kc + jw + 16 + l15];
+        }
+      };
+      auto mul_chunk = [&](const ThinChunk& ch) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ch.fa[q][0], ch.fb[q], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ch.fa[q][1], ch.fb[q], acc[1], 0, 0, 0);
+        }
+      };
+      ThinChunk c0_, c1_;
+      load_chunk(c0_, 128 * p);
+      load_chunk(c1_, 128 * p + 32);
+      mul_chunk(c0_);
+      load_chunk(c0_, 128 * p + 64);
+      mul_chunk(c1_);
+      load_chunk(c1_, 128 * p + 96);
+      mul_chunk(c0_);
+      mul_chunk(c1_);
+    }
+    // c' = C' - acc  ->  LDS   (lane (g, c), register r of block v: panel column 32 w + 16 v + 4 r + g, tile row c)
+    __syncthreads();                                     // the previous panel's readers of cT are done
+#pragma unroll
+    for (int v = 0; v < 2; ++v)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int col = 32 * w + 16 * v + 4 * r + lk;
+        cT[col * 16 + l15] = Am[(row_j + col) * a.ld + row_i + l15] - acc[v][r];
+      }
+    region_wait_ge(dinv + tj, a.epoch, 0, abort_word, info);                          // Dinv_j (its barrier completes cT)
+    const double* Dv = a.W2.p[b] + (size_t)(row_j / 128) * 16384;                      // Dinv[out][k] = Dv[k * 128 + out]
+    d4 xo[2];
+    xo[0] = xo[1] = (d4){0.0, 0.0, 0.0, 0.0};
+    const int nch = w + 1;                               // 32-k chunks: k < 32 (w + 1) (lower triangular)
+    for (int ch = 0; ch < nch; ++ch) {
+      double fa[8][2], fb[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int k = 32 * ch + 4 * q + lk;
+        fa[q][0] = Dv[(size_t)k * 128 + 32 * w + l15];
+        fa[q][1] = Dv[(size_t)k * 128 + 32 * w + 16 + l15];
+        fb[q] = cT[k * 16 + l15];
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        xo[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[q][0], fb[q], xo[0], 0, 0, 0);
+        xo[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[q][1], fb[q], xo[1], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < 2; ++v)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Am[(row_j + 32 * w + 16 * v + 4 * r + lk) * a.ld + row_i + l15] = xo[v][r];
+    __syncthreads();                                     // X[i, j] is in memory for this workgroup's own later passes
+  }
+}
+
 // 1-D grid in dispatch order (matrices interleaved): the walkers, the helpers of square rows 1 .. 2P-1, then the row streams.
 // Deadlock freedom: helper r waits only for the walker and for helpers of rows above it, a row stream only for the square -- all
 // dispatched before it.  The walker is the one workgroup that waits for a LATER one (helper r, at block r); but by then it has
@@ -2652,7 +2824,12 @@ __global__ __launch_bounds__(256, OCC) void potrf_region_kernel(RegionArgs a) {
   if (a.trace && threadIdx.x == 0) a.trace[2 * blockIdx.x] = wall_clock64();
   if (idx == 0) potrf_region_walker(a, node_lds, Am, b);
   else if (idx < Q) potrf_region_helper<false>(a, node_lds, Am, b, idx);      // <true> (two chunks ahead) spills even at one workgroup per CU
-  else potrf_region_row(a, node_lds, Am, b, a.P + idx - Q);
+  else {
+    const int ti = a.P + idx - Q;
+    const int real = a.M_real - 128 * ti;                // rows of this tile that hold data (the rest is zero padding, before and after)
+    if (real > 16) potrf_region_row(a, node_lds, Am, b, ti);
+    else if (real > 0) potrf_region_row_thin(a, node_lds, Am, b, ti);
+  }
   if (a.trace && threadIdx.x == 0) a.trace[2 * blockIdx.x + 1] = wall_clock64();
 }
 
@@ -2845,8 +3022,9 @@ __global__ __launch_bounds__(256, SCHED == 1 ? 1 : 2) void gemm32_kernel(BatchPt
 // One workgroup per matrix of the batch (blockIdx.x); matrix b writes out[b * nrhs + r].
 template <typename TS>
 __global__ __launch_bounds__(256) void lml_reduce_kernel(BatchPtr Ab, int ld, int n,
-                                                         int rider_row0, int nrhs, double* __restrict__ out) {
+                                                         int rider_row0, int nrhs, double* __restrict__ out, BatchInfo infob, int* __restrict__ info_out) {
   const void* __restrict__ A = Ab.p[blockIdx.x];
+  if (info_out && threadIdx.x == 0) info_out[blockIdx.x] = *infob.p[blockIdx.x];
   out += (size_t)blockIdx.x * nrhs;
   __shared__ double sh[4];
   double sl = 0.0;
@@ -3027,21 +3205,38 @@ __global__ __launch_bounds__(64 * NW) void tall_skinny_kernel(const double* __re
   // each walking 150 dependent loads took 114 us of a 570-us evaluation).
   __shared__ double red[NW - 1][CH][64];
   __shared__ double sh[4];
-  const int lane = threadIdx.x & 63, ks = threadIdx.x >> 6;
+  // ks is wave-uniform: as an SGPR it makes every Mx address scalar, so the CH coefficients of a k-step arrive by scalar loads (one
+  // s_load per k-step) instead of CH vector loads of 64 identical addresses -- the kernel was bound by the vector-memory issue rate
+  // of the few CUs it runs on (notebook shape: 9 loads per k-step, 8 of them these: 45 us)
+  const int lane = threadIdx.x & 63, ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = blockIdx.x * 64 + lane;
   const int c0 = blockIdx.y * CH;
   double acc[CH];
 #pragma unroll
   for (int c = 0; c < CH; ++c) acc[c] = 0.0;
   if (i < n) {
-#pragma unroll 8
-    for (int k = ks; k < K; k += NW) {
-      const double v = In[(size_t)k * ldi + i];
+    // UB k-steps per batch with ALL their loads issued before the first FMA (UB + UB * CH independent loads in flight): left to the
+    // compiler's unrolling, every k-step waited for its own loads -- 38 dependent round trips of ~1.2 us for the notebook shape
+    // (45 us of a 515-us evaluation).  16 waves per workgroup leave 128 registers per lane: UB = 4 there.
+    constexpr int UB = NW >= 16 ? 4 : 8;
+    int cc[CH];
 #pragma unroll
-      for (int c = 0; c < CH; ++c) {
-        const int cc = (c0 + c < C) ? (c0 + c) : (C - 1);
-        acc[c] = __builtin_fma(Mx[(size_t)k * ldm + cc], v, acc[c]);
+    for (int c = 0; c < CH; ++c) cc[c] = (c0 + c < C) ? (c0 + c) : (C - 1);
+    for (int k0 = ks; k0 < K; k0 += UB * NW) {
+      double v[UB], mx[UB][CH];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int k = k0 + u * NW;
+        const int kk = k < K ? k : K - 1;
+        v[u] = In[(size_t)kk * ldi + i];
+        if (k >= K) v[u] = 0.0;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) mx[u][c] = Mx[(size_t)kk * ldm + cc[c]];
       }
+#pragma unroll
+      for (int u = 0; u < UB; ++u)
+#pragma unroll
+        for (int c = 0; c < CH; ++c) acc[c] = __builtin_fma(mx[u][c], v[u], acc[c]);
     }
   }
   if (ks > 0) {
@@ -3468,8 +3663,15 @@ int g_f32 = 0;
     else { using TS = double; hipLaunchKernelGGL(KERNEL_T, __VA_ARGS__); }             \
   } while (0)
 
-void launch_gram(const GramArgs& a, hipStream_t st) {
-  dim3 grid(a.nrows / 64 - a.row_tile0, (a.ncols / 64 + 3) / 4);
+// Column tiles per workgroup: 4 (a strip's row data and row exponentials are reused across them), or 1 when that grid would leave
+// most of the device idle (small matrices: C0's 22-us Gram was 15 workgroups walking up to four tiles each).
+static int gram_cpw(int row_tiles, int col_tiles, int nmat) {
+  return (long long)row_tiles * ((col_tiles + 3) / 4) * nmat < 2048 ? 1 : 4;
+}
+void launch_gram(const GramArgs& a0, hipStream_t st) {
+  GramArgs a = a0;
+  a.cpw = gram_cpw(a.nrows / 64 - a.row_tile0, a.ncols / 64, 1);
+  dim3 grid(a.nrows / 64 - a.row_tile0, (a.ncols / 64 + a.cpw - 1) / a.cpw);
   const bool nd = (a.d > 1 && a.d <= 8);
 #define LMM_GRAM_LAUNCH(K)                                                                          \
   do {                                                                                              \
@@ -3493,10 +3695,11 @@ void launch_gram_batch(const GramArgs* args, int nb, hipStream_t st) {
     for (int j = j0; j < j1; ++j) {
       const GramArgs& a = args[j];
       b.A[j - j0] = a.A; b.var[j - j0] = a.var; b.inv_ls[j - j0] = a.inv_ls; b.diag_add[j - j0] = a.diag_add;
-      b.diag_vec[j - j0] = a.diag_vec; b.rider[j - j0] = a.rider; b.rider_sub[j - j0] = a.rider_sub;
+      b.diag_vec[j - j0] = a.diag_vec; b.rider[j - j0] = a.rider; b.rider_sub[j - j0] = a.rider_sub; b.info_zero[j - j0] = a.info_zero;
     }
+    b.base.cpw = gram_cpw(b.base.nrows / 64 - b.base.row_tile0, b.base.ncols / 64, j1 - j0);
     const GramArgs& a = b.base;
-    dim3 grid(a.nrows / 64 - a.row_tile0, (a.ncols / 64 + 3) / 4, j1 - j0);
+    dim3 grid(a.nrows / 64 - a.row_tile0, (a.ncols / 64 + a.cpw - 1) / a.cpw, j1 - j0);
     const bool nd = (a.d > 1 && a.d <= 8);
 #define LMM_GRAM_LAUNCH(K)                                                                          \
     do {                                                                                            \
@@ -3566,20 +3769,44 @@ void launch_panel_bulk(const BatchPtr& A, const BatchPtr& W2, int ld, int NR, in
   if (MT <= 1 || nb <= 0) return;
   node_lds_attr();
   NodeArgs a{};
-  a.A = A; a.W2 = W2; a.ld = ld; a.M = M; a.j0 = r0; a.h = 0; a.N = 128; a.MT = MT; a.nb = nb; a.mode = NODE_BULK;
+  a.A = A; a.W2 = W2; a.ld = ld; a.M = M; a.Mb = M; a.j0 = r0; a.h = 0; a.N = 128; a.MT = MT; a.MTb = MT; a.nb = nb; a.mode = NODE_BULK;
   hipLaunchKernelGGL(potrf_node_kernel<1>, dim3((unsigned)nb * (MT - 1)), dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
 }
-void launch_update_leaf(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2, const BatchInfo& info, int ld, int NR, int j0, int h,
-                        int N, int n_real, int nb, hipStream_t st) {
+static int g_region_epoch = 0;
+static int* g_region_flags_base = nullptr;       // the persistent flag array of the context (lmm_init), for the wrap-around clear
+static size_t g_region_flags_ints = 0;
+void region_flags_register(int* base, size_t ints) { g_region_flags_base = base; g_region_flags_ints = ints; }
+// Every flag-carrying launch (region, fused node) takes a fresh tag.  When the tags wrap, every persistent flag word is cleared, so that
+// no stale tag can match again (the per-call NODE_FUSE flags are zeroed at the start of their factorisation anyway).
+static int next_flag_epoch() {
+  if (++g_region_epoch >= (1 << 26)) {
+    g_region_epoch = 1;
+    if (g_region_flags_base) { (void)hipDeviceSynchronize(); (void)hipMemset(g_region_flags_base, 0, g_region_flags_ints * sizeof(int)); }
+  }
+  return g_region_epoch;
+}
+size_t node_flag_ints(int NR) { return (size_t)(2 + (NR + 127) / 128 + 1); }
+bool launch_update_leaf(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2, const BatchInfo& info, int ld, int NR, int j0, int h,
+                        int N, int n_real, int nb, hipStream_t st, int* nflags, int nf_stride) {
   const int r0 = j0 + h, NT = (N + 127) / 128;     // N may end in a 64-column half tile
-  if (nb <= 0 || N <= 0 || h <= 0) return;
+  if (nb <= 0 || N <= 0 || h <= 0) return false;
   node_lds_attr();
   // ragged last row tile (the rider rows make the row count an odd multiple of 64): on the long products the node kernel takes the
   // full 128-row tiles and gemm16h_kernel the last 64 rows, as in launch_gemm_nt (two idle waves for a whole tile time otherwise)
   int M = NR - r0;
   const bool strip = (M % 128) == 64 && M - 64 >= N && (N % 128) == 0 && h >= 1024;
+  const int Mfull = M;
   if (strip) M -= 64;
   const int MT = (M + 127) / 128;
+  const int MTb = (Mfull + 127) / 128;
+  // the ragged rows first when the bulk tiles ride along: they cover those rows too (the two launches touch disjoint entries)
+  const bool fuse = nflags != nullptr && N >= 128 && MTb > 1;
+  auto launch_strip = [&]() {
+    const size_t offA = (size_t)j0 * ld + r0 + (size_t)M;
+    hipLaunchKernelGGL((gemm16h_kernel<true>), dim3(N / 128, nb), dim3(256), 0, st, A, (size_t)r0 * ld + r0 + (size_t)M, ld, A, offA, ld,
+                       A, (size_t)j0 * ld + r0, ld, N, h, 0);
+  };
+  if (strip && fuse) launch_strip();
   static int cus = 0;
   if (cus == 0) { int dev = 0; cus = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); }
   long long T = 0;                                            // tiles of the column tiles 1 .. NT-1 (lower trapezoid)
@@ -3592,16 +3819,29 @@ void launch_update_leaf(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2
   const int cap = 2 * cus, nk = h / 16;
   static int deterministic = -1;
   if (deterministic < 0) { const char* e = getenv("LMM_DETERMINISTIC"); deterministic = (e && atoi(e) != 0) ? 1 : 0; }
+  static int tail_policy = -1;
+  if (tail_policy < 0) { const char* e = getenv("LMM_TAIL_POLICY"); tail_policy = e ? atoi(e) : 0; }      // 1 measured no better
   int full_a = (int)T, split_a = 1, full_l = (int)T, split_l = 1;
   if (!deterministic && T > 0 && nk >= 8) {
     const long long all = (long long)nb * T + (long long)nb * MT;
     if (all <= cap / 2) {
       int sk = (int)(cap / all); if (sk > nk / 4) sk = nk / 4; if (sk < 1) sk = 1;
       if (sk > 1) { full_a = full_l = 0; split_a = split_l = sk; }
-    } else {
+    } else if (tail_policy == 0) {          // (b): always the last cap / s tiles
       int sk = nk >= 16 ? 4 : 2;
       long long tail = cap / sk; if (tail > T) tail = T;
       full_l = (int)(T - tail); split_l = sk;
+    } else {
+      // LMM_TAIL_POLICY=1 (kept for A/B; not faster): were equal tiles to stay in lock-step, the launch would run in rounds of cap
+      // tiles and the last, partial round (x = all mod cap tiles) would cost a whole tile time: split exactly those x tiles,
+      // s = cap / x ways.  The per-workgroup trace (tools/node_trace.py) shows the tiles do NOT stay in lock-step -- of the two
+      // workgroups of a CU the older one gets the matrix pipe (150 us against 280 us in the first round at K = 1024) -- and the slots are
+      // 94-96 % busy either way.
+      long long x = all % cap;
+      if (x > T) x = T;
+      int skmax = nk / 4; if (skmax > 8) skmax = 8;
+      int sk = x > 0 ? (int)(cap / x) : 1; if (sk > skmax) sk = skmax;
+      if (sk >= 2) { full_l = (int)(T - x); split_l = sk; }
     }
   }
   NodeArgs a{};
@@ -3611,33 +3851,53 @@ void launch_update_leaf(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2
   const int rest_last = full_l + (int)(T - full_l) * split_l;
   if (a.rest_items < 1) a.rest_items = 1;          // divisor in the kernel's item decode (no item reaches it when T = 0)
   a.mode = NODE_UPDATE | NODE_LEAF;
-  const dim3 grid((unsigned)(nb * MT + (T > 0 ? (long long)(nb - 1) * a.rest_items + rest_last : 0)));
+  long long items = nb * MT + (T > 0 ? (long long)(nb - 1) * a.rest_items + rest_last : 0);
+  a.Mb = Mfull; a.MTb = MTb; a.bulk0 = (int)items;
+  if (fuse) {
+    a.mode |= NODE_FUSE; a.nflags = nflags; a.nf_stride = nf_stride; a.epoch = next_flag_epoch();
+    items += (long long)nb * (MTb - 1);
+  }
+  const dim3 grid((unsigned)items);
+  // LMM_NODE_TRACE=<K>: per-workgroup start / end ticks (100 MHz), CU and work item of every update launch with this K, to stderr (a
+  // debugging aid for tools/node_trace.py: it synchronises the stream after the launch)
+  static int trace_k = -1;
+  if (trace_k < 0) { const char* e = getenv("LMM_NODE_TRACE"); trace_k = e ? atoi(e) : 0; }
+  long long* tr = nullptr;
+  static int trace_skip = -1, trace_left = 0;        // LMM_NODE_TRACE_SKIP / _COUNT: launches of that K to pass over first (warm-up) / to record (16)
+  if (trace_skip < 0) { const char* e = getenv("LMM_NODE_TRACE_SKIP"); trace_skip = e ? atoi(e) : 0; const char* c = getenv("LMM_NODE_TRACE_COUNT"); trace_left = c ? atoi(c) : 16; }
+  if (trace_k == h && trace_skip > 0) --trace_skip;
+  else if (trace_k == h && trace_left > 0) { --trace_left; if (hipMalloc((void**)&tr, (size_t)items * 4 * sizeof(long long)) != hipSuccess) tr = nullptr; }
+  a.trace = tr;
   if (h >= 1024) hipLaunchKernelGGL(potrf_node_kernel<2>, grid, dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
   else hipLaunchKernelGGL(potrf_node_kernel<1>, grid, dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
-  if (strip) {
-    const size_t offA = (size_t)j0 * ld + r0 + (size_t)M;
-    hipLaunchKernelGGL((gemm16h_kernel<true>), dim3(N / 128, nb), dim3(256), 0, st, A, (size_t)r0 * ld + r0 + (size_t)M, ld, A, offA, ld,
-                       A, (size_t)j0 * ld + r0, ld, N, h, 0);
+  if (tr) {
+    (void)hipStreamSynchronize(st);
+    std::vector<long long> hh((size_t)items * 4);
+    (void)hipMemcpy(hh.data(), tr, hh.size() * sizeof(long long), hipMemcpyDeviceToHost);
+    long long t0 = hh[0];
+    for (long long i = 0; i < items; ++i) if (hh[4 * i] < t0) t0 = hh[4 * i];
+    fprintf(stderr, "[node-trace] launch M=%d N=%d K=%d nb=%d MT=%d items=%lld full_l=%d split_l=%d fuse=%d\n", M, N, h, nb, MT, items, full_l, split_l, fuse ? 1 : 0);
+    for (long long i = 0; i < items; ++i) {
+      const long long w3 = hh[4 * i + 3], w2 = hh[4 * i + 2];
+      fprintf(stderr, "[node-trace] wg=%lld b=%lld kind=%lld ti=%lld tj=%lld part=%lld xcc=%lld hw=%lld start_us=%.2f end_us=%.2f\n", i, w3 >> 48, (w3 >> 40) & 255,
+              (w3 >> 20) & 0xfffff, (w3 >> 8) & 0xfff, w3 & 255, w2 >> 32, w2 & 0xffffffffLL, (hh[4 * i] - t0) / 100.0, (hh[4 * i + 1] - t0) / 100.0);
+    }
+    (void)hipFree(tr);
   }
+  if (strip && !fuse) launch_strip();
+  return fuse;
 }
 
 size_t region_flag_ints(int) { return REGION_FLAG_INTS; }
-static int g_region_epoch = 0;
-static int* g_region_flags_base = nullptr;       // the persistent flag array of the context (lmm_init), for the wrap-around clear
-static size_t g_region_flags_ints = 0;
-void region_flags_register(int* base, size_t ints) { g_region_flags_base = base; g_region_flags_ints = ints; }
 void launch_region(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2, const BatchInfo& info, const BatchInfo& flags, int ld, int NR,
-                   int c0, int width, int n_real, int nb, bool first_done, hipStream_t st) {
+                   int c0, int width, int n_real, int nb, bool first_done, hipStream_t st, int rows_real) {
   const int P = width / 128, M = NR - c0, R = (M + 127) / 128;
   if (nb <= 0 || P <= 0) return;
   node_lds_attr();
   RegionArgs a{};
   a.A = A; a.W = W; a.W2 = W2; a.info = info; a.flags = flags; a.ld = ld; a.M = M; a.c0 = c0; a.P = P; a.R = R; a.n_real = n_real; a.nb = nb;
-  if (++g_region_epoch >= (1 << 26)) {     // the tags wrap: clear every flag word ever handed out, so that no stale tag can match again
-    g_region_epoch = 1;
-    if (g_region_flags_base) { (void)hipDeviceSynchronize(); (void)hipMemset(g_region_flags_base, 0, g_region_flags_ints * sizeof(int)); }
-  }
-  a.epoch = g_region_epoch; a.first_done = first_done ? 1 : 0;
+  a.epoch = next_flag_epoch(); a.first_done = first_done ? 1 : 0;
+  a.M_real = (rows_real >= 0 && rows_real <= NR) ? rows_real - c0 : M;
   const long long tasks = 2LL * P + (R - P);       // the square's 64-row blocks + one task per 128-row tile below it
   // LMM_REGION_OCC=1 / 2 forces a build; default: one workgroup per CU while the whole launch is resident that way, else two
   static int occ_env = -1, cus = 0;
@@ -3806,8 +4066,11 @@ void launch_gemm_nt(double* C, int ldc, const double* A, int lda, const double* 
   launch_gemm_nt(c, 0, ldc, a, 0, lda, b, 0, ldb, M, N, K, lower, set, 1, st);
 }
 
-void launch_lml_reduce(const BatchPtr& A, int nb, int ld, int n, int rider_row0, int nrhs, double* out, hipStream_t st) {
-  LMM_TS_LAUNCH((lml_reduce_kernel<TS>), dim3(nb), dim3(256), 0, st, A, ld, n, rider_row0, nrhs, out);
+void launch_lml_reduce(const BatchPtr& A, int nb, int ld, int n, int rider_row0, int nrhs, double* out, hipStream_t st,
+                       const BatchInfo* info, int* info_out) {
+  BatchInfo ib{};
+  if (info && info_out) ib = *info; else info_out = nullptr;
+  LMM_TS_LAUNCH((lml_reduce_kernel<TS>), dim3(nb), dim3(256), 0, st, A, ld, n, rider_row0, nrhs, out, ib, info_out);
 }
 void launch_lml_reduce(const double* A, int ld, int n, int rider_row0, int nrhs, double* out, hipStream_t st) {
   BatchPtr b{};

@@ -92,8 +92,11 @@ class Orthogonal:
     """reference src/orthogonal_matrix.jl:11-34: H = U * sqrt(S); validates U'U ~ I."""
 
     def __init__(self, U, S, validate_fields: bool = True):
-        self.U = np.asarray(U, dtype=np.float64)
-        self.S = np.asarray(S, dtype=np.float64).reshape(-1)      # the Diagonal's diag
+        # U is held column-major (what Julia holds and the C ABI takes): a row-major argument is copied once, here, and the ABI then
+        # reads H.U's own buffer on every call (in-place edits of H.U are seen; edits of a row-major original are not)
+        self.U = np.asfortranarray(np.asarray(U, dtype=np.float64))
+        self.S = np.ascontiguousarray(np.asarray(S, dtype=np.float64).reshape(-1))      # the Diagonal's diag
+        self._args = None                                         # (U object, S object, column-major image of U): see abi_args()
         if self.U.ndim != 2 or self.U.shape[1] != self.S.shape[0]:
             raise ValueError("U must be p x m and S of length m")
         if validate_fields:
@@ -103,6 +106,19 @@ class Orthogonal:
     @property
     def shape(self) -> Tuple[int, int]:
         return self.U.shape
+
+    def abi_args(self):
+        """(U column-major, S) as the C ABI takes them.  A U that is already column-major (Fortran order, what Julia holds) goes over
+        as it is, with no copy and therefore always current; a row-major U is re-imaged per call."""
+        U, S = self.U, self.S
+        a = self._args
+        if a is not None and a[0] is U and a[1] is S:
+            return a[2], a[3]
+        Uc = L.colmajor(U)
+        Ua, Sa = L.Arr(Uc), L.Arr(S)
+        if Uc.base is U or Uc is U:                  # a view of the live buffer: safe to keep (in-place edits of U stay visible)
+            self._args = (U, S, Ua, Sa)
+        return Ua, Sa
 
     def collect(self) -> np.ndarray:
         """reference src/orthogonal_matrix.jl:27-30 (materialised H)."""
@@ -314,7 +330,8 @@ def _split_train_grad(gy, sizes, p: int):
 def _H_args(H):
     """(U or dense-H pointer, S pointer or None, p, m) for the C ABI."""
     if isinstance(H, Orthogonal):
-        return L.Arr(L.colmajor(H.U)), L.Arr(H.S), H.U.shape[0], H.U.shape[1]
+        Ua, Sa = H.abi_args()
+        return Ua, Sa, H.U.shape[0], H.U.shape[1]
     return L.Arr(L.colmajor(H)), None, H.shape[0], H.shape[1]
 
 

@@ -40,6 +40,7 @@ def test_f32_gemm_and_potrf_building_blocks(lmm32):
         At = torch.randn(K, lda, generator=g, device="cuda", dtype=torch.float32)
         Bt = torch.randn(K, ldb, generator=g, device="cuda", dtype=torch.float32)
         C0 = Ct.clone()
+        torch.cuda.synchronize()      # raw pointers cross the ABI: torch's asynchronous producers of these tensors must be done
         rc = lib.lmm_dev_gemm_nt_sub(C.c_void_p(Ct.data_ptr()), ldc, C.c_void_p(At.data_ptr()), lda, C.c_void_p(Bt.data_ptr()), ldb, M, N, K, lower)
         assert rc == 0, lib.lmm_last_error_string()
         ref = C0[:, :M].double() - (Bt[:, :N].double().T @ At[:, :M].double())          # [col][row]
@@ -64,6 +65,7 @@ def test_f32_gemm_and_potrf_building_blocks(lmm32):
         Ad = torch.from_numpy(buf).cuda()
         W = torch.zeros((n // 64) * 4096, dtype=torch.float32, device="cuda")
         info = torch.zeros(1, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()      # raw pointers cross the ABI: torch's asynchronous producers of these tensors must be done
         assert lib.lmm_dev_potrf(C.c_void_p(Ad.data_ptr()), ld, n, ld, C.c_void_p(W.data_ptr()), n, C.c_void_p(info.data_ptr())) == 0
         assert int(info.item()) == 0
         out = Ad.cpu().numpy().astype(np.float64)

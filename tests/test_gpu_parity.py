@@ -55,6 +55,7 @@ def test_mfma_gemm_nt_sub(lmm):
         At = torch.randn(K, lda, generator=g, device="cuda", dtype=torch.float64)
         Bt = torch.randn(K, ldb, generator=g, device="cuda", dtype=torch.float64)
         C0 = Ct.clone()
+        torch.cuda.synchronize()      # raw pointers cross the ABI: torch's asynchronous producers of these tensors must be done
         rc = lib.lmm_dev_gemm_nt_sub(C.c_void_p(Ct.data_ptr()), ldc, C.c_void_p(At.data_ptr()), lda,
                                      C.c_void_p(Bt.data_ptr()), ldb, M, N, K, lower)
         assert rc == 0, lib.lmm_last_error_string()
@@ -89,6 +90,7 @@ def test_potrf_vs_lapack(lmm, n, riders):
     A[:, :NR] = torch.from_numpy(full.T.copy()).cuda()
     W = torch.zeros(NC // 64 * 4096, dtype=torch.float64, device="cuda")
     info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()      # raw pointers cross the ABI: torch's asynchronous producers of these tensors must be done
     rc = lib.lmm_dev_potrf(C.c_void_p(A.data_ptr()), NR, NC, ld, C.c_void_p(W.data_ptr()), n, C.c_void_p(info.data_ptr()))
     assert rc == 0, lib.lmm_last_error_string()
     assert int(info.item()) == 0
@@ -115,6 +117,7 @@ def test_potrf_reports_not_pd(lmm):
     A = torch.from_numpy(M.copy()).cuda()
     W = torch.zeros(2 * 4096, dtype=torch.float64, device="cuda")
     info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()      # raw pointers cross the ABI: torch's asynchronous producers of these tensors must be done
     assert lib.lmm_dev_potrf(C.c_void_p(A.data_ptr()), n, n, n, C.c_void_p(W.data_ptr()), n, C.c_void_p(info.data_ptr())) == 0
     assert int(info.item()) == 71          # LAPACK-style 1-based failing pivot
 
@@ -134,6 +137,7 @@ def test_gram_vs_oracle(lmm, kind, d):
     xd = torch.from_numpy(np.ascontiguousarray(x.T if d > 1 else x)).cuda()
     from lmm_amd import _lib as L
     garr = L.gps_array([gp])
+    torch.cuda.synchronize()      # raw pointers cross the ABI: torch's asynchronous producers of these tensors must be done
     assert lib.lmm_dev_gram(C.c_void_p(A.data_ptr()), ld, NR, NC, C.c_void_p(xd.data_ptr()), d, n, garr, C.c_double(0.25)) == 0
     got = A.T.cpu().numpy()
     ref = O.kernelmatrix(gp, x) + 0.25 * np.eye(n)

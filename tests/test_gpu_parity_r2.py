@@ -65,6 +65,7 @@ def test_hip_gram_and_potrf_vs_notebook_literals(lmm):
     A = torch.full((n, ld), float("nan"), dtype=torch.float64, device="cuda")        # column-major: A[col][row]
     xd = torch.from_numpy(x).cuda()
     gp = L.gps_array([{"kind": "matern52", "variance": 1.0, "lengthscale": 1.0, "mean": 0.0}])
+    torch.cuda.synchronize()      # raw pointers cross the ABI: torch's asynchronous producers of these tensors must be done
     assert lib.lmm_dev_gram(C.c_void_p(A.data_ptr()), ld, n, n, C.c_void_p(xd.data_ptr()), 1, n, gp, C.c_double(noise)) == 0
     K = A.cpu().numpy()                                          # K[col, row]
     assert K[0, 1] == pytest.approx(g["K_21"], rel=1e-13)
@@ -72,6 +73,7 @@ def test_hip_gram_and_potrf_vs_notebook_literals(lmm):
     assert K[0, n - 2] == pytest.approx(g["K_nm1_1_at_20_minus_spacing"], rel=1e-12)
     W = torch.zeros((n // 64) * 4096, dtype=torch.float64, device="cuda")
     info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()      # raw pointers cross the ABI: torch's asynchronous producers of these tensors must be done
     assert lib.lmm_dev_potrf(C.c_void_p(A.data_ptr()), n, n, ld, C.c_void_p(W.data_ptr()), n, C.c_void_p(info.data_ptr())) == 0
     assert int(info.item()) == 0
     Lf = A.cpu().numpy()                                         # Lf[col, row] = L[row, col];  U = L'
@@ -490,7 +492,12 @@ def test_update_kernel_variants_agree():
     for name, env in [("default", {}), ("round2_path", r2), ("m16_0", dict(r2, LMM_GEMM_M16="0")), ("m16_1", dict(r2, LMM_GEMM_M16="1")),
                       ("flags", dict(r2, LMM_GEMM_M16="0", LMM_GEMM_FLAGS="1")),
                       ("diag_form1", dict(r2, LMM_DIAG_FORM="1")), ("diag_form2", dict(r2, LMM_DIAG_FORM="2")), ("full_tiles", dict(r2, LMM_HALF_TILES="0")),
-                      ("no_ragged_split", dict(r2, LMM_RAGGED_SPLIT="0")), ("deterministic", {"LMM_DETERMINISTIC": "1"})]:
+                      ("no_ragged_split", dict(r2, LMM_RAGGED_SPLIT="0")), ("deterministic", {"LMM_DETERMINISTIC": "1"}),
+                      # round 3, panel path: bulk rows as separate launches / riding in EVERY update launch (default: K >= 512), the
+                      # round-aligned split-K tail, the dataflow kernel as the base case of the recursion
+                      ("no_fused_bulk", {"LMM_FUSE_BULK": "0"}), ("fused_bulk_all", {"LMM_FUSE_BULK_MINK": "128"}),
+                      ("fused_bulk_deterministic", {"LMM_FUSE_BULK_MINK": "128", "LMM_DETERMINISTIC": "1"}),
+                      ("tail_policy1", {"LMM_TAIL_POLICY": "1"}), ("region_base", {"LMM_REGION_ALL": "1", "LMM_REGION": "512"})]:
         out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr[-2000:]
         vals[name] = json.loads(out.stdout.strip().splitlines()[-1])

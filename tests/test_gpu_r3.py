@@ -125,6 +125,7 @@ def _gram(lmm, gp, x, d, n, diag=0.25):
     ld = NR + 16
     A = torch.full((NC, ld), float("nan"), dtype=torch.float64, device="cuda")
     xd = torch.from_numpy(np.ascontiguousarray(x.T if d > 1 else x)).cuda()
+    torch.cuda.synchronize()      # raw pointers cross the ABI: torch's asynchronous producers of these tensors must be done
     rc = lmm.load().lmm_dev_gram(C.c_void_p(A.data_ptr()), ld, NR, NC, C.c_void_p(xd.data_ptr()), d, n, L.gps_array([gp]), C.c_double(diag))
     assert rc == 0, lmm.load().lmm_last_error_string()
     return A.T.cpu().numpy()[:NR]
@@ -376,6 +377,7 @@ def test_panel_factorisation_vs_lapack(lmm, n, nrider):
     W = torch.full((NC // 64, 64, 64), float("nan"), dtype=torch.float64, device="cuda")
     info = torch.zeros(1, dtype=torch.int32, device="cuda")
     lib = lmm.load()
+    torch.cuda.synchronize()      # raw pointers cross the ABI: torch's asynchronous producers of these tensors must be done
     rc = lib.lmm_dev_potrf(C.c_void_p(A.data_ptr()), NR, NC, ld, C.c_void_p(W.data_ptr()), n, C.c_void_p(info.data_ptr()))
     assert rc == 0, lib.lmm_last_error_string()
     assert int(info.item()) == 0
@@ -405,6 +407,7 @@ def test_panel_path_reports_the_failing_pivot(lmm):
     A[:, :n] = torch.from_numpy(np.ascontiguousarray(np.tril(K).T)).cuda()
     W = torch.zeros((n // 64, 64, 64), dtype=torch.float64, device="cuda")
     info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()      # raw pointers cross the ABI: torch's asynchronous producers of these tensors must be done
     rc = lmm.load().lmm_dev_potrf(C.c_void_p(A.data_ptr()), n, n, ld, C.c_void_p(W.data_ptr()), n, C.c_void_p(info.data_ptr()))
     assert rc == 0
     assert int(info.item()) == 301
@@ -469,3 +472,32 @@ def test_inputs_from_a_side_stream(lmm):
     got = lmm.logpdf(f(lmm.MOInputIsotopicByOutputs(xd, 5), 0.1), yd)
     side.synchronize()
     assert got == pytest.approx(ref, rel=1e-9)
+
+
+# ---------------------------------------------------------------------------------------------------
+# (h) widths whose last 64-column block is padding only (the factor width is rounded up to 128 columns; potrf_region_kernel's walker
+#     passes over such a block: L = [0 .. 0 I], W = I): logpdf, and the posterior verbs that go on to use the stored factor and
+#     inverse blocks, against the oracle
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,kind,d", [(130, "matern52", 1), (320, "se", 2), (552, "matern32", 1), (833, "matern52", 1)])
+def test_all_padding_last_block(lmm, n, kind, d):
+    rng = np.random.default_rng(n)
+    m, p, s2 = 3, 4, 0.1
+    x = np.sort(rng.uniform(0, 9, size=n)) if d == 1 else rng.uniform(0, 5, size=(d, n))
+    gps = [{"kind": kind, "variance": 0.7 + 0.3 * l, "lengthscale": 0.8 + 0.2 * l, "mean": 0.1 * l} for l in range(m)]
+    U, _ = np.linalg.qr(rng.standard_normal((p, m)))
+    S = np.linspace(1.5, 0.8, m)
+    y = rng.standard_normal(n * p)
+    fx = lmm.ILMM(_model(lmm, gps), lmm.Orthogonal(U, S))(lmm.MOInputIsotopicByOutputs(x, p), s2)
+    assert lmm.logpdf(fx, y) == pytest.approx(O.oilmm_logpdf(gps, U, S, x, s2, y), rel=1e-9)
+    ns = 70
+    xs = (np.sort(rng.uniform(0, 9, size=ns)) if d == 1 else rng.uniform(0, 5, size=(d, ns)))
+    po = O.oilmm_posterior(gps, U, S, x, s2, y)
+    mo, vo = O.oilmm_mean_var(po, U, S, xs, s2)
+    post = lmm.posterior(fx, y)
+    mu, v = lmm.mean_and_var(post(lmm.MOInputIsotopicByOutputs(xs, p), s2))
+    np.testing.assert_allclose(mu, mo, rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(v, vo, rtol=1e-7)
+    ys = rng.standard_normal(ns * p)
+    assert lmm.logpdf(post(lmm.MOInputIsotopicByOutputs(xs, p), s2), ys) == pytest.approx(
+        O.oilmm_logpdf(po, U, S, xs, s2, ys), rel=1e-8)
