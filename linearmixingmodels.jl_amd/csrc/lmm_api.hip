@@ -312,7 +312,7 @@ static bool g_stagger_armed = false, g_stagger_recorded = false;
 static int g_region_whole = 1;          // LMM_REGION_ALL=1: also as the base case of the recursion for larger matrices (measured: no gain)
 static int g_region_cols = -1;          // widest block column potrf_region_kernel takes in one launch (LMM_REGION=<columns>, up to 1024; default 0: off)
 // bulk_done (implies first_done): the rows below that block are solved as well (the update launch that factored it ran them too).
-struct NodeFlags { int* p = nullptr; int stride = 0; int min_k = 0; int rows_real = -1; };      // rows_real: rows that hold data (-1: all NR)
+struct NodeFlags { int* p = nullptr; int stride = 0; int min_k = 0, max_k = 1 << 30; int rows_real = -1; };      // rows_real: rows that hold data (-1: all NR)
 void potrf_rec_panel(const Batch& B, const BatchPtr& W2, const BatchInfo& flags, const NodeFlags& nfl, int ld, int NR, int j0, int w, int n_real,
                      hipStream_t st, bool first_done, bool bulk_done = false) {
   const double nb = B.nb;
@@ -349,11 +349,11 @@ void potrf_rec_panel(const Batch& B, const BatchPtr& W2, const BatchInfo& flags,
     {
       // K >= 1024: potrf_node_kernel<2> (+ gemm16h_kernel for a ragged last 64 rows) -- the dominant kernel; below: potrf_node_kernel<1>.
       // With the bulk rows of the next panel in the same launch (nfl.p): + their Mb * 128^2 flops and 16 B per entry
-      const double Mb = (nfl.p && h >= nfl.min_k) ? std::max(0, NR - (r0 + 128)) : 0;
+      const double Mb = (nfl.p && h >= nfl.min_k && h <= nfl.max_k) ? std::max(0, NR - (r0 + 128)) : 0;
       ProfScope ps(h >= 1024 ? LMM_PROF_UPDATE : LMM_PROF_UPDATE_SHORT,
                    nb * (2.0 * h * outs + 2.0 * 128.0 * 128.0 * 128.0 / 3.0 + Mb * 128.0 * 128.0), st, NR - r0, Nc, h,
                    nb * (16.0 * outs + 8.0 * Mr * h + 16.0 * Mb * 128.0));
-      fused = launch_update_leaf(B.A, B.W, W2, B.info, ld, NR, j0, h, Nc, n_real, B.nb, st, h >= nfl.min_k ? nfl.p : nullptr, nfl.stride);
+      fused = launch_update_leaf(B.A, B.W, W2, B.info, ld, NR, j0, h, Nc, n_real, B.nb, st, (h >= nfl.min_k && h <= nfl.max_k) ? nfl.p : nullptr, nfl.stride);
       if (g_stagger_armed && !g_stagger_recorded && h >= 1024) { HIPCHK(hipEventRecord(g_stagger_ev, st)); g_stagger_recorded = true; }
     }
     potrf_rec_panel(B, W2, flags, nfl, ld, NR, r0, Nc, n_real, st, true, fused);
@@ -381,7 +381,19 @@ void potrf_batch(const Batch& B, int ld, int NR, int NC, int n_real, hipStream_t
   // Default: the region kernel serves matrices that are ONE region (NC <= 1024: the whole factorisation in one launch, the small-n
   // path); larger matrices take the panel recursion throughout (as their base case the region kernel measured no faster than the
   // panel launches: DESIGN.md).  LMM_REGION_ALL=1 enables it there too, LMM_REGION=0 disables it.
-  const bool region_here = g_region_cols > 0 && (!g_region_whole || (NC <= g_region_cols && (NC % 128) == 0));
+  // Mid sizes with few matrices (round 3, tools/mid_probe.py): while a block column's dataflow launch -- 2 P square tasks + one per
+  // 128-row tile below, per matrix -- is (nearly) resident at once, it beats the panel launches it replaces (8 latents: n = 1536
+  // 1.34 -> 0.99 ms, 2048 1.97 -> 1.59, 3072 3.50 -> 2.96; 4 latents, n = 4096: 4.61 -> 4.00); with more work per launch than that
+  // it does not (16 latents at n >= 2048, n = 8192, the C2 sizes: 1-7 % slower).  LMM_REGION_ALL=1 forces it, =0 (explicit) never.
+  static int region_auto = -1, cus = 0;
+  if (region_auto < 0) { const char* ea = getenv("LMM_REGION_ALL"); region_auto = ea ? 0 : 1; }
+  if (cus == 0) { int dev = 0; cus = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); }
+  bool region_base = !g_region_whole;
+  if (region_auto && g_region_cols >= 1024 && NC > g_region_cols && (NC % 128) == 0) {
+    const long long tasks = 2LL * (g_region_cols / 128) + ((NR + 127) / 128 - g_region_cols / 128);      // of the first (tallest) block column
+    region_base = tasks * B.nb <= (long long)(1.3 * cus);
+  }
+  const bool region_here = g_region_cols > 0 && (region_base || (NC <= g_region_cols && (NC % 128) == 0));
   if (region_here) {                       // dependency flags of the region launches: this stream's slice of the persistent, once-zeroed
     int si = -1;                           // array (launches are told apart by epoch); an unknown stream gets a zeroed scratch
     for (int s = 0; s < kMaxStreams; ++s) if (g.streams[s] == st) si = s;
@@ -398,10 +410,13 @@ void potrf_batch(const Batch& B, int ld, int NR, int NC, int n_real, hipStream_t
   // per-call flags zeroed here; not when the region kernel serves as the base case (it solves the first panel's rows itself).
   static int fuse_bulk = -1;
   if (fuse_bulk < 0) { const char* e = getenv("LMM_FUSE_BULK"); fuse_bulk = e ? (atoi(e) != 0) : 1; }
-  static int fuse_min_k = -1;
-  if (fuse_min_k < 0) { const char* e = getenv("LMM_FUSE_BULK_MINK"); fuse_min_k = e ? atoi(e) : 512; }
+  // ... in the launches with 512 <= K <= 2048 (LMM_FUSE_BULK_MINK / _MAXK): below, the chain update -> leaf -> bulk inside one launch
+  // is no shorter than two launches (K = 128: 115 us against 72 + 34); above, the fused build's 3-4 spilled registers cost the long
+  // launches more (0.3 % of 11-30 ms) than the bulk launch they absorb (33 us)
+  static int fuse_min_k = -1, fuse_max_k = -1;
+  if (fuse_min_k < 0) { const char* e = getenv("LMM_FUSE_BULK_MINK"); fuse_min_k = e ? atoi(e) : 512; const char* x = getenv("LMM_FUSE_BULK_MAXK"); fuse_max_k = x ? atoi(x) : 2048; }
   NodeFlags nfl;
-  nfl.min_k = fuse_min_k;
+  nfl.min_k = fuse_min_k; nfl.max_k = fuse_max_k;
   nfl.rows_real = rows_real;
   if (fuse_bulk && !region_here && NC > 128) {
     nfl.stride = (int)node_flag_ints(NR);
@@ -551,17 +566,30 @@ int check_info(const std::vector<int>& info, int latent_begin) {
 // host-side small dense algebra (m, p <= a few hundred): projections and regulariser scalars
 // ------------------------------------------------------------------------------------------------
 // reference src/oilmm.jl:20-30:  T = sqrt(S) \ U'  (m x p, column-major), SigmaT = sigma2 ./ S
-void project_orthogonal(const double* U, const double* S, int p, int m, double s2, std::vector<double>& T,
-                        std::vector<double>& ST, std::vector<double>& H) {
-  T.assign((size_t)m * p, 0.0); ST.assign(m, 0.0); H.assign((size_t)p * m, 0.0);
+// T, H: caller's buffers (m p doubles each; may be pinned memory), ST: m.  H by contiguous columns, T (the transposed image) in
+// blocks of 16 outputs so that both its reads and its writes stay in a few cache lines: 11 us instead of 90 at p = 600, m = 20
+// (the reference notebook's shape, where this host loop was a fifth of the evaluation); same operations, same results.
+void project_orthogonal_into(const double* U, const double* S, int p, int m, double s2, double* T, double* ST, double* H) {
   for (int l = 0; l < m; ++l) {
     const double rs = std::sqrt(S[l]);
     ST[l] = s2 / S[l];
-    for (int o = 0; o < p; ++o) {
-      T[l + (size_t)o * m] = U[o + (size_t)l * p] / rs;
-      H[o + (size_t)l * p] = U[o + (size_t)l * p] * rs;   // reference src/orthogonal_matrix.jl:27-30
+    const double* u = U + (size_t)l * p;
+    double* h = H + (size_t)l * p;
+    for (int o = 0; o < p; ++o) h[o] = u[o] * rs;          // reference src/orthogonal_matrix.jl:27-30
+  }
+  for (int o0 = 0; o0 < p; o0 += 16) {
+    const int o1 = std::min(p, o0 + 16);
+    for (int l = 0; l < m; ++l) {
+      const double rs = std::sqrt(S[l]);
+      const double* u = U + (size_t)l * p;
+      for (int o = o0; o < o1; ++o) T[l + (size_t)o * m] = u[o] / rs;
     }
   }
+}
+void project_orthogonal(const double* U, const double* S, int p, int m, double s2, std::vector<double>& T,
+                        std::vector<double>& ST, std::vector<double>& H) {
+  T.resize((size_t)m * p); ST.resize(m); H.resize((size_t)p * m);
+  project_orthogonal_into(U, S, p, m, s2, T.data(), ST.data(), H.data());
 }
 
 bool host_cholesky(std::vector<double>& A, int m) {   // lower, in place, column-major
@@ -664,12 +692,18 @@ struct Uploaded {   // small host arrays staged on the device
   Uploaded(const std::vector<double>& v, hipStream_t st, bool direct_small = false) {
     void* pp = pin_take(v.size() * sizeof(double));
     if (pp) std::memcpy(pp, v.data(), v.size() * sizeof(double));
-    if (direct_small && pp && v.size() <= 256 && g.pin_dev) {
-      buf.p = pin_dev(static_cast<double*>(pp)); buf.n = v.size(); buf.own = false;
+    stage(pp ? static_cast<const double*>(pp) : v.data(), pp != nullptr, v.size(), st, direct_small);
+  }
+  // values the caller already wrote into the pinned arena (pin_take)
+  Uploaded(const double* pinned, size_t count, hipStream_t st, bool direct_small) { stage(pinned, true, count, st, direct_small); }
+ private:
+  void stage(const double* src, bool pinned, size_t count, hipStream_t st, bool direct_small) {
+    if (direct_small && pinned && count <= 256 && g.pin_dev) {
+      buf.p = pin_dev(const_cast<double*>(src)); buf.n = count; buf.own = false;
       return;
     }
-    buf = Buf<double>(v.size());
-    HIPCHK(hipMemcpyAsync(buf.p, pp ? pp : (const void*)v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    buf = Buf<double>(count);
+    HIPCHK(hipMemcpyAsync(buf.p, src, count * sizeof(double), hipMemcpyHostToDevice, st));
   }
 };
 
@@ -1057,7 +1091,10 @@ int lmm_oilmm_logpdf(const double* x, int d, int n, const double* y, int p, cons
   if (!(sigma2 > 0.0)) return fail(LMM_ERR_ARG, "sigma2 must be > 0");
   hipStream_t st0 = g.streams[0];
   std::vector<double> T, ST, H;
-  project_orthogonal(U, S, p, m, sigma2, T, ST, H);
+  // [T | H] straight into the pinned arena when the regulariser path (which uploads both as one block) has room there
+  double* packp = with_regulariser ? static_cast<double*>(pin_take(2 * (size_t)m * p * sizeof(double))) : nullptr;
+  if (packp) { ST.resize(m); project_orthogonal_into(U, S, p, m, sigma2, packp, ST.data(), packp + (size_t)m * p); }
+  else project_orthogonal(U, S, p, m, sigma2, T, ST, H);
   DevIn xd(x, (size_t)d * n, st0), yd(y, (size_t)n * p, st0);
   std::vector<double> means(m);
   for (int l = 0; l < m; ++l) means[l] = gps[l].mean;
@@ -1070,9 +1107,9 @@ int lmm_oilmm_logpdf(const double* x, int d, int n, const double* y, int p, cons
   if (with_regulariser) {
     // ONE upload [T | H]; ONE projection T*Y of all m latents serves the regulariser's residual and, through rider rows that
     // subtract the latent mean inside the Gram kernel, the per-latent right-hand sides delta_l = (T y)_l - mean_l
-    std::vector<double> pack(T);
-    pack.insert(pack.end(), H.begin(), H.end());
-    Uploaded THd(pack, st0, true);
+    std::vector<double> pack;
+    if (!packp) { pack = T; pack.insert(pack.end(), H.begin(), H.end()); }
+    Uploaded THd = packp ? Uploaded(packp, 2 * (size_t)m * p, st0, true) : Uploaded(pack, st0, true);
     const double* Tdev = THd.buf.p;
     const double* Hdev = THd.buf.p + (size_t)m * p;
     Buf<double> Ty((size_t)n * m), resid_dev(1), partial(tall_skinny_partials(n, p));

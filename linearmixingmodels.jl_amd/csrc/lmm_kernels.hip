@@ -2198,7 +2198,9 @@ __global__ __launch_bounds__(256) void leaf128_kernel(BatchPtr Ab, size_t offD, 
   leaf128_dev(node_lds, Ab.p[blockIdx.x], offD, ld, Wb.p[blockIdx.x], offW, W2b.p[blockIdx.x] + offW2, gcol0, n_real, infob.p[blockIdx.x]);
 }
 
-template <int DEPTH>
+// FUSE: the NODE_FUSE work items exist (their waits and write-through stores cost the hot loop 3-4 spilled registers: 0.3 % on the
+// K >= 4096 launches, which is why it is a template parameter and the long launches run without it)
+template <int DEPTH, bool FUSE = false>
 __global__ __launch_bounds__(256, 2) void potrf_node_kernel(NodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) double node_lds[];
   constexpr int BM = 128, BN = 128, BK = 16;
@@ -2219,7 +2221,7 @@ __global__ __launch_bounds__(256, 2) void potrf_node_kernel(NodeArgs a) {
   //     Their results reach it write-through (ST_PUB) + flag, as in the region kernel.
   int part = 0, nparts = 1, tj = 0, ti = 0, bidx = 0;
   bool bulk = false, col0 = false;
-  const bool fuse = (a.mode & NODE_FUSE) != 0;
+  constexpr bool fuse = FUSE;
   if (a.trace && threadIdx.x == 0) a.trace[4 * (size_t)blockIdx.x] = wall_clock64();
   {
     const int item = blockIdx.x;
@@ -3755,6 +3757,8 @@ static void node_lds_attr() {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(leaf128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_node_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_node_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_node_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_node_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_region_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_region_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   done = true;
@@ -3868,8 +3872,13 @@ bool launch_update_leaf(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2
   if (trace_k == h && trace_skip > 0) --trace_skip;
   else if (trace_k == h && trace_left > 0) { --trace_left; if (hipMalloc((void**)&tr, (size_t)items * 4 * sizeof(long long)) != hipSuccess) tr = nullptr; }
   a.trace = tr;
-  if (h >= 1024) hipLaunchKernelGGL(potrf_node_kernel<2>, grid, dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
-  else hipLaunchKernelGGL(potrf_node_kernel<1>, grid, dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
+  if (fuse) {
+    if (h >= 1024) hipLaunchKernelGGL((potrf_node_kernel<2, true>), grid, dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
+    else hipLaunchKernelGGL((potrf_node_kernel<1, true>), grid, dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
+  } else {
+    if (h >= 1024) hipLaunchKernelGGL(potrf_node_kernel<2>, grid, dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
+    else hipLaunchKernelGGL(potrf_node_kernel<1>, grid, dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
+  }
   if (tr) {
     (void)hipStreamSynchronize(st);
     std::vector<long long> hh((size_t)items * 4);

@@ -327,6 +327,19 @@ def _split_train_grad(gy, sizes, p: int):
     return out
 
 
+def _gps_arg(mogp):
+    """(descs, lmm_gp_t array) of an IndependentMOGP's latents.  The ctypes array is rebuilt only when a hyperparameter changed (the key
+    is the tuple of current values: building it costs a third of filling the array, which at m = 20 is 25 us of a 380-us call)."""
+    key = tuple((g.kernel.kind, g.kernel.variance, g.kernel.lengthscale, g.mean) for g in mogp.fs)
+    hit = getattr(mogp, "_gps_cache", None)
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
+    descs = [g.desc() for g in mogp.fs]
+    arr = L.gps_array(descs)
+    mogp._gps_cache = (key, descs, arr)
+    return descs, arr
+
+
 def _H_args(H):
     """(U or dense-H pointer, S pointer or None, p, m) for the C ABI."""
     if isinstance(H, Orthogonal):
@@ -397,8 +410,7 @@ def logpdf(fx: FiniteGP, y, with_regulariser: bool = True) -> float:
     unpack(fx)
     if ya.size != x.n * x.out_dim:
         raise ValueError("length(y) != n * out_dim")
-    descs = [g.desc() for g in f.f.fs]
-    gps = L.gps_array(descs)
+    descs, gps = _gps_arg(f.f)
     Ua, Sa, p, m = _H_args(f.H)
     l0, l1 = f.shard
     if f.f._post is not None:

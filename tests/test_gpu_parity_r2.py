@@ -495,8 +495,8 @@ def test_update_kernel_variants_agree():
                       ("no_ragged_split", dict(r2, LMM_RAGGED_SPLIT="0")), ("deterministic", {"LMM_DETERMINISTIC": "1"}),
                       # round 3, panel path: bulk rows as separate launches / riding in EVERY update launch (default: K >= 512), the
                       # round-aligned split-K tail, the dataflow kernel as the base case of the recursion
-                      ("no_fused_bulk", {"LMM_FUSE_BULK": "0"}), ("fused_bulk_all", {"LMM_FUSE_BULK_MINK": "128"}),
-                      ("fused_bulk_deterministic", {"LMM_FUSE_BULK_MINK": "128", "LMM_DETERMINISTIC": "1"}),
+                      ("no_fused_bulk", {"LMM_FUSE_BULK": "0"}), ("fused_bulk_all", {"LMM_FUSE_BULK_MINK": "128", "LMM_FUSE_BULK_MAXK": "65536"}),
+                      ("fused_bulk_deterministic", {"LMM_FUSE_BULK_MINK": "128", "LMM_FUSE_BULK_MAXK": "65536", "LMM_DETERMINISTIC": "1"}),
                       ("tail_policy1", {"LMM_TAIL_POLICY": "1"}), ("region_base", {"LMM_REGION_ALL": "1", "LMM_REGION": "512"})]:
         out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr[-2000:]
