@@ -1217,7 +1217,7 @@ int oilmm_grad_core(const double* xd, int d, int N, int nsplit, const double* yd
       Rb.p[j] = Rm[s][j].p; alb.p[j] = alpha.p + (size_t)k * D.NC;
     }
     launch_gram_batch(ga, nb, st);
-    potrf_batch(B, D.ld, D.NR, D.NC, n, st);
+    potrf_batch(B, D.ld, D.NR, D.NC, n, st, D.NC + 1);        // one rider row (delta); rows NC + 1 .. NR - 1 are zero padding
     launch_lml_reduce(B.A, nb, D.ld, n, D.NC, 1, lmld.p + k0, st);
     for (int j = 0; j < nb; ++j) {
       launch_extract_row(Am[s][j].p, D.ld, D.NC, n, alb.p[j], st);
@@ -2062,7 +2062,7 @@ static int posterior_create_common(const double* xd, int d, int n, const lmm_gp_
         B.add(P->L[k].p, P->W[k].p, info.p + k);
       }
       launch_gram_batch(ga, nb, st);
-      potrf_batch(B, D.ld, D.NR, D.NC, n, st);
+      potrf_batch(B, D.ld, D.NR, D.NC, n, st, D.NC + 1);        // one rider row (delta); rows NC + 1 .. NR - 1 are zero padding
       // alpha = L^-T (L^-1 delta): the rider row is z = L^-1 delta (kept as P->z, zero-padded to NC)
       BatchPtr ab{}, zb{};
       for (int j = 0; j < nb; ++j) { ab.p[j] = P->alpha[k0 + j].p; zb.p[j] = P->z[k0 + j].p; }

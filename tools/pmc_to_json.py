@@ -9,7 +9,8 @@ import csv, json, sys, collections
 def aggregate_update(out):
     # round 3: the dominant kernel is potrf_node_kernel<2> (K >= 1024 updates + the next panel's leaf) plus gemm16h_kernel<true> on the
     # ragged last 64 rows of the same update: bytes of both per potrf_node_kernel<2> launch (= bench.py's roofline.launches)
-    node = [k for k in out if isinstance(out[k], dict) and k.startswith("potrf_node_kernel<2>")]
+    # (its two instantiations: <2, false>, and <2, true> when the next panel's bulk rows ride in the launch)
+    node = [k for k in out if isinstance(out[k], dict) and (k.startswith("potrf_node_kernel<2>") or k.startswith("potrf_node_kernel<2,"))]
     if node:
         parts = node + [k for k in out if isinstance(out[k], dict) and k.startswith("gemm16h_kernel<true>")]
         n = sum(out[k]["launches"] for k in node)
