@@ -324,8 +324,8 @@ def main():
                     traffic = tj.get("update_kernel", {}).get("bytes_per_launch")
             roof = {"bound": "mfma", "kernel": ("gemm32_kernel<128,false> (v_mfma_f32_32x32x2_f32 SYRK/GEMM trailing update)" if args.dtype == "f32"
                                                 else "potrf_node_kernel<2> (v_mfma_f64_16x16x4_f64, VGPR accumulators, software-pipelined SYRK/GEMM trailing update, K >= 1024; "
-                                                     "one workgroup per matrix also factors the next panel's 128 x 128 diagonal block; + gemm16h_kernel<true> "
-                                                     "on a ragged last 64 rows)"),
+                                                     "one workgroup per matrix also factors the next panel's 128 x 128 diagonal block, and at K = 1024, 2048 the "
+                                                     "launch ends with that panel's bulk rows; + gemm16h_kernel<true> on a ragged last 64 rows)"),
                     "achieved": round(ach, 3), "peak": peak_tf, "unit": "TFLOP/s",
                     "frac": round(ach / peak_tf, 4), "traffic": traffic if args.dtype == "f64" else None,
                     "traffic_source": ("profiles/pmc_traffic.json: fabric bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "

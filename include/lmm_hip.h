@@ -20,7 +20,9 @@
  *   - return value: LMM_OK or an lmm_status code; lmm_last_error_string() gives the message,
  *     lmm_last_error_detail() the failing latent and LAPACK-style pivot `info`
  *     (-> Julia `PosDefException(info)`).  Nothing is ever NaN-and-continue.
- *   - calls are blocking; the library never keeps a caller pointer after returning.
+ *   - calls are blocking; the library never keeps a caller pointer after returning.  Scalar results (log-likelihoods, the
+ *     regulariser's residual, pivot info) are written by the kernels straight into a pinned host arena that is mapped into the
+ *     device and read after one stream synchronisation (LMM_DIRECT_RESULTS=0 in the environment: device buffers + hipMemcpy).
  *   - reproducibility: by default the last partial scheduling round of a trailing update is split along K and combined with f64
  *     atomics, so results are reproducible to ~1e-13 relative, NOT bitwise; LMM_DETERMINISTIC=1 (environment) disables the split
  *     and makes every result bitwise reproducible (slower tail of the large updates).
@@ -352,11 +354,13 @@ int lmm_normals(unsigned long long seed, unsigned long long stream, size_t count
  * work = algorithmic flops (MFMA classes) or algorithmic HBM bytes (Gram assembly) summed over launches. */
 typedef enum {
   LMM_PROF_GRAM = 0,          /* gram_batch_kernel: lower-triangular f64 write, bytes                                          */
-  LMM_PROF_UPDATE = 1,        /* potrf_node_kernel<2> (round 3: SYRK/GEMM trailing update with K >= 1024 + the next panel's leaf128 in
-                                 one launch, + gemm16h_kernel<true> for a ragged last 64 rows; LMM_PANEL128=0 / fp32: every wide
+  LMM_PROF_UPDATE = 1,        /* potrf_node_kernel<2, .> (round 3: SYRK/GEMM trailing update with K >= 1024 + the next panel's leaf128 in
+                                 one launch -- at K = 1024, 2048 also that panel's bulk rows --, + gemm16h_kernel<true> for a ragged
+                                 last 64 rows; LMM_PANEL128=0 / fp32: every wide
                                  update: gemm16p_kernel / gemm16h_kernel / gemm32_kernel), flops                                */
   LMM_PROF_UPDATE_NARROW = 2, /* gemm44_kernel<64,false>: 64-column update (round-2 path; trailing 64 columns), flops           */
-  LMM_PROF_TRSM = 3,          /* potrf_node_kernel<1> in bulk mode: panel rows x 128 x 128 inverse (round-2 path:
+  LMM_PROF_TRSM = 3,          /* potrf_node_kernel<1> in bulk mode (the panels whose bulk rows do not ride in an update launch): panel
+                                 rows x 128 x 128 inverse (round-2 path:
                                  gemm44_kernel<64,true>, TRSM by the 64 x 64 inverse block), flops                              */
   LMM_PROF_DIAG = 4,          /* leaf128_kernel (first panel) / diag64m_kernel: diagonal-block factor + inverse, flops          */
   LMM_PROF_REGION = 5,        /* potrf_region_kernel: a block column of <= 8 panels (leaves, bulk products, inner updates) in one
