@@ -312,7 +312,7 @@ static bool g_stagger_armed = false, g_stagger_recorded = false;
 static int g_region_whole = 1;          // LMM_REGION_ALL=1: also as the base case of the recursion for larger matrices (measured: no gain)
 static int g_region_cols = -1;          // widest block column potrf_region_kernel takes in one launch (LMM_REGION=<columns>, up to 1024; default 0: off)
 // bulk_done (implies first_done): the rows below that block are solved as well (the update launch that factored it ran them too).
-struct NodeFlags { int* p = nullptr; int stride = 0; int min_k = 0, max_k = 1 << 30; int rows_real = -1; };      // rows_real: rows that hold data (-1: all NR)
+struct NodeFlags { int* p = nullptr; int stride = 0; int min_k = 0, max_k = 1 << 30; int rows_real = -1; BatchPtr S{}; };   // S: region assistants' scratch      // rows_real: rows that hold data (-1: all NR)
 void potrf_rec_panel(const Batch& B, const BatchPtr& W2, const BatchInfo& flags, const NodeFlags& nfl, int ld, int NR, int j0, int w, int n_real,
                      hipStream_t st, bool first_done, bool bulk_done = false) {
   const double nb = B.nb;
@@ -321,7 +321,7 @@ void potrf_rec_panel(const Batch& B, const BatchPtr& W2, const BatchInfo& flags,
     const double Mr = NR - j0, Wd = w;
     const double fl = Mr * Wd * Wd - 2.0 * Wd * Wd * Wd / 3.0;           // flops of factoring an Mr x Wd tall panel: Mr Wd^2 - 2 Wd^3 / 3
     ProfScope ps(LMM_PROF_REGION, nb * fl, st, NR - j0, w, w);
-    launch_region(B.A, B.W, W2, B.info, flags, ld, NR, j0, w, n_real, B.nb, first_done, st, nfl.rows_real);
+    launch_region(B.A, B.W, W2, B.info, flags, ld, NR, j0, w, n_real, B.nb, first_done, st, nfl.rows_real, &nfl.S);
     return;
   }
   if (w == 128) {
@@ -381,17 +381,18 @@ void potrf_batch(const Batch& B, int ld, int NR, int NC, int n_real, hipStream_t
   // Default: the region kernel serves matrices that are ONE region (NC <= 1024: the whole factorisation in one launch, the small-n
   // path); larger matrices take the panel recursion throughout (as their base case the region kernel measured no faster than the
   // panel launches: DESIGN.md).  LMM_REGION_ALL=1 enables it there too, LMM_REGION=0 disables it.
-  // Mid sizes with few matrices (round 3, tools/mid_probe.py): while a block column's dataflow launch -- 2 P square tasks + one per
-  // 128-row tile below, per matrix -- is (nearly) resident at once, it beats the panel launches it replaces (8 latents: n = 1536
-  // 1.34 -> 0.99 ms, 2048 1.97 -> 1.59, 3072 3.50 -> 2.96; 4 latents, n = 4096: 4.61 -> 4.00); with more work per launch than that
-  // it does not (16 latents at n >= 2048, n = 8192, the C2 sizes: 1-7 % slower).  LMM_REGION_ALL=1 forces it, =0 (explicit) never.
+  // Mid sizes / few matrices (round 3, tools/mid_probe.py): while a block column's dataflow launch -- 2 P square tasks + one per
+  // 128-row tile below, per matrix -- is at most ~2.3 workgroups per CU, it beats the panel launches it replaces (8 latents: n = 1536
+  // 1.34 -> 0.96 ms, 2048 1.97 -> 1.51, 3072 3.50 -> 2.93, 4096 5.80 -> 5.2, 8192 27.1 -> 26.5; 16 x 2048: 2.19 -> 2.01; a rank's
+  // 4-latent share of C2: 94.5 -> 93.9); with more work per launch it does not (16 x 4096: a tie; the two concurrent 16-latent batches
+  // of C2 at N = 1: 696 -> 706 ms).  LMM_REGION_ALL=1 forces it, =0 (explicit) never.
   static int region_auto = -1, cus = 0;
   if (region_auto < 0) { const char* ea = getenv("LMM_REGION_ALL"); region_auto = ea ? 0 : 1; }
   if (cus == 0) { int dev = 0; cus = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); }
   bool region_base = !g_region_whole;
   if (region_auto && g_region_cols >= 1024 && NC > g_region_cols && (NC % 128) == 0) {
     const long long tasks = 2LL * (g_region_cols / 128) + ((NR + 127) / 128 - g_region_cols / 128);      // of the first (tallest) block column
-    region_base = tasks * B.nb <= (long long)(1.3 * cus);
+    region_base = tasks * B.nb <= (long long)(2.3 * cus);
   }
   const bool region_here = g_region_cols > 0 && (region_base || (NC <= g_region_cols && (NC % 128) == 0));
   if (region_here) {                       // dependency flags of the region launches: this stream's slice of the persistent, once-zeroed
@@ -423,6 +424,11 @@ void potrf_batch(const Batch& B, int ld, int NR, int NC, int n_real, hipStream_t
     const size_t ints = (size_t)nfl.stride * B.nb;
     nfl.p = reinterpret_cast<int*>(call_scratch((ints + 1) / 2));
     HIPCHK(hipMemsetAsync(nfl.p, 0, ints * sizeof(int), st));
+  }
+  if (region_here && std::min(NC, g_region_cols) > 64 * LMM_REGION_ASST_MIN_R) {      // block columns with assistant rows: their scratch tiles
+    const size_t per_s = (size_t)LMM_REGION_ASST_TILES * 4096;
+    double* sb = call_scratch(per_s * B.nb);
+    for (int j = 0; j < B.nb; ++j) nfl.S.p[j] = sb + per_s * j;
   }
   potrf_rec_panel(B, W2, flags, nfl, ld, NR, 0, NC, n_real, st, false);
 }

@@ -84,15 +84,20 @@ struct RegionArgs {
   BatchInfo info, flags;  // flags: P * R readiness words + 1 abort word per matrix (zeroed once per factorisation)
   int ld, M, c0, P, R, n_real, nb, epoch, first_done;
   int M_real;             // rows c0 .. c0 + M_real - 1 hold data, the rest of the M rows is zero padding (rider rows are padded to 64)
+  BatchPtr S;             // optional scratch (LMM_REGION_ASST_TILES 64 x 64 tiles per matrix): partial products of the ASSISTANT tasks
+  int na;                 // assistant tasks per matrix (square rows LMM_REGION_ASST_MIN_R .. 2P - 1), 0: none
   int ntasks;             // workgroups per matrix (trace layout)
   long long* trace;       // optional (LMM_REGION_TRACE=1, tools/region_trace.py): start / end wall-clock ticks of every workgroup
 };
 #define LMM_REGION_MAX_PANELS 8
+#define LMM_REGION_ASST_MIN_C 4           // a helper's product for column block c >= this is split with its row's assistant
+#define LMM_REGION_ASST_MIN_R (LMM_REGION_ASST_MIN_C + 2)
+#define LMM_REGION_ASST_TILES ((2 * LMM_REGION_MAX_PANELS - LMM_REGION_ASST_MIN_R) * 16)
 #define LMM_INFO_SYNC_TIMEOUT (-7777)     // pivot-info value a region launch leaves when a dependency wait timed out (never expected)
 void region_flags_register(int* base, size_t ints);     // the context's persistent flag array (cleared when the launch epoch wraps)
 size_t region_flag_ints(int NR);          // ints per matrix that the flags of any region of a matrix with NR rows need
 void launch_region(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2, const BatchInfo& info, const BatchInfo& flags, int ld, int NR,
-                   int c0, int width, int n_real, int nb, bool first_done, hipStream_t st, int rows_real = -1);
+                   int c0, int width, int n_real, int nb, bool first_done, hipStream_t st, int rows_real = -1, const BatchPtr* S = nullptr);
 // plain trailing update (no leaf) through the node kernel: C -= A B' for the region at j0 + h
 void launch_leaf128(const BatchPtr& A, size_t offD, int ld, const BatchPtr& W, size_t offW, const BatchPtr& W2, size_t offW2,
                     int gcol0, int n_real, const BatchInfo& info, int nb, hipStream_t st);

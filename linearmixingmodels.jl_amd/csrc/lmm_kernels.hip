@@ -2045,7 +2045,8 @@ __device__ __forceinline__ void wg_mm64(const double* __restrict__ As, int sai, 
 //   [34 + j] dinv[j]: the 128 x 128 inverse of panel j is in the W2 scratch (count 0)
 // A wait spins on thread 0 (bounded: 1 s of the 100 MHz wall clock, or until another workgroup raised the abort word -- the grid
 // always drains), then an agent-scope acquire fence makes the producer's data visible to the whole workgroup.
-#define REGION_FLAG_INTS (34 + LMM_REGION_MAX_PANELS)
+//   [42 + r] asst[r]: column blocks whose first-half partial product the ASSISTANT of square row r has left in the scratch (count c)
+#define REGION_FLAG_INTS (34 + LMM_REGION_MAX_PANELS + 16)
 // SLEEP: s_sleep argument between polls (64 clocks each).  1 on the region kernel's chain (a handful of pollers, every 30 ns counts); the
 // hundreds of bulk workgroups of a fused node launch poll the same few words and use 16 (~0.5 us), or they slow the leaf they wait for.
 template <int SLEEP = 1>
@@ -2442,6 +2443,30 @@ __device__ __forceinline__ void pipe128_accumulate(d4 (&acc)[4][4], double* __re
   }
 }
 
+// the same for up to three flags at once (one barrier, one fence); f2 / f3 may be nullptr
+__device__ __forceinline__ void region_wait3(const int* f1, int n1, const int* f2, int n2, const int* f3, int n3, int epoch, int* abort_word, int* info) {
+  if (threadIdx.x == 0) {
+    const long long t0 = wall_clock64();
+    int polls = 0;
+    for (;;) {
+      const int v1 = __hip_atomic_load(f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int v2 = f2 ? __hip_atomic_load(f2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch * 32 + 31;
+      const int v3 = f3 ? __hip_atomic_load(f3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch * 32 + 31;
+      if ((v1 >> 5) == epoch && (v1 & 31) >= n1 && (v2 >> 5) == epoch && (v2 & 31) >= n2 && (v3 >> 5) == epoch && (v3 & 31) >= n3) break;
+      __builtin_amdgcn_s_sleep(1);
+      if ((++polls & 63) == 0) {
+        if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+        if (wall_clock64() - t0 > 100000000LL) {
+          __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          atomicCAS(info, 0, LMM_INFO_SYNC_TIMEOUT);
+          break;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
 // 64 x 64 block G (column-major, leading dimension ldg) -> LDS image img[col * DIAG_LS + row]; all 256 threads, 512-byte row runs
 __device__ __forceinline__ void img_load(double* __restrict__ img, const double* __restrict__ G, int ldg) {
   const int t = threadIdx.x;
@@ -2557,7 +2582,7 @@ __device__ __forceinline__ void potrf_region_walker(const RegionArgs& a, double*
 // and once c = r - 2 is done:  A[r, r-1] -= pa,  A[r, r] -= pd  (their only read-modify-write);  publish upd[r] = r - 1.
 // The walker's request "tiles (r, r-1), (r, r) updated through block r - 2" thus costs, after W_{r-2} arrives, one solve, two 64^3
 // products in registers and one write -- about the time the walker spends in diag64m of block r - 1.
-template <bool DEEP>
+template <bool DEEP, bool ASST>
 __device__ __forceinline__ void potrf_region_helper(const RegionArgs& a, double* __restrict__ lds, double* __restrict__ Am, int b, int r) {
   constexpr int LS = DIAG_LS;
   int* fl = a.flags.p[b];
@@ -2582,8 +2607,22 @@ __device__ __forceinline__ void potrf_region_helper(const RegionArgs& a, double*
         // row c final through block c - 1: its helper's blocks (c >= 2) and the walker's subdiagonal block
         if (c >= 2) region_wait_ge(trs + c, a.epoch, c - 1, abort_word, info);
         region_wait_ge(wk, a.epoch, c, abort_word, info);
-        // (tile update)' = L[c, 0:c] L[r, 0:c]'   (A[i][k'] = L[c][i][k']: (1, ld); R[k'][j] = L[r][j][k']: (ld, 1)), K = 64 c
-        wg_mm64_core<DEEP>(acc, Am + col0 + gcol, 1, a.ld, Am + col0 + grow, a.ld, 1, w, l, c);
+        // (tile update)' = L[c, 0:c] L[r, 0:c]'   (A[i][k'] = L[c][i][k']: (1, ld); R[k'][j] = L[r][j][k']: (ld, 1)), K = 64 c.
+        // From column block LMM_REGION_ASST_MIN_C on, this row's ASSISTANT has formed the part over the blocks [0, cs) ahead of time
+        // (its inputs are final several steps earlier); this workgroup multiplies the blocks [cs, c) and adds the assistant's tile.
+        const int cs = (ASST && a.na > 0 && r >= LMM_REGION_ASST_MIN_R && c >= LMM_REGION_ASST_MIN_C) ? c / 2 : 0;
+        const size_t koff = (size_t)cs * 64 * a.ld;
+        wg_mm64_core<DEEP>(acc, Am + col0 + koff + gcol, 1, a.ld, Am + col0 + koff + grow, a.ld, 1, w, l, c - cs);
+        if (ASST && cs > 0) {
+          region_wait_ge(fl + 42 + r, a.epoch, c, abort_word, info);
+          const double* St = a.S.p[b] + ((size_t)(r - LMM_REGION_ASST_MIN_R) * 16 + c) * 4096;
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int v = 0; v < 2; ++v)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) acc[u][v][q] += St[((u * 2 + v) * 4 + q) * 256 + t];
+        }
       }
       const double* Ct = Am + gcol * a.ld + grow;
       __syncthreads();                                                   // the previous column's readers of Y are done
@@ -2625,6 +2664,38 @@ __device__ __forceinline__ void potrf_region_helper(const RegionArgs& a, double*
     region_publish(dinv + (r >> 1), a.epoch, 0);
   } else if (skip && r == 1) {
     region_publish(dinv + 0, a.epoch, 0);                                // the fused leaf left Dinv_0 in the scratch
+  }
+}
+
+// ASSISTANT of square row r >= LMM_REGION_ASST_MIN_R.  A helper's left-looking product for column block c is K = 64 c long at ONE
+// workgroup's rate (2.5 us per 64 k) and cannot start before row c is final through block c - 1; from row 8 on it no longer fits into
+// the walker's 22-us block period, and at 16 blocks the chain ran at the helpers' pace (walker waits of 10-23 us per block,
+// profiles/r03).  The first half of that product, over the blocks [0, c / 2), depends only on blocks that were final c / 2 steps
+// earlier: the assistant forms it ahead of time into a scratch tile (in the helper's own lane layout: element ((u 2 + v) 4 + q) 256 + t,
+// coalesced both ways) and flags it; the helper multiplies the blocks [c / 2, c) and adds the tile.
+__device__ __forceinline__ void potrf_region_assistant(const RegionArgs& a, double* __restrict__ Am, int b, int r) {
+  int* fl = a.flags.p[b];
+  int* abort_word = fl; int* trs = fl + 2; int* asst = fl + 42;
+  int* info = a.info.p[b];
+  const int t = threadIdx.x, l = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const size_t grow = (size_t)a.c0 + 64 * (size_t)r;
+  const size_t col0 = (size_t)a.c0 * a.ld;
+  for (int c = LMM_REGION_ASST_MIN_C; c <= r - 2; ++c) {
+    const int cs = c / 2;
+    const size_t gcol = (size_t)a.c0 + 64 * (size_t)c;
+    region_wait3(trs + c, cs, trs + r, cs, nullptr, 0, a.epoch, abort_word, info);       // L[c, 0:cs], L[r, 0:cs] final
+    d4 acc[2][2];
+    MM64_ZERO(acc);
+    wg_mm64_core(acc, Am + col0 + gcol, 1, a.ld, Am + col0 + grow, a.ld, 1, w, l, cs);
+    double* St = a.S.p[b] + ((size_t)(r - LMM_REGION_ASST_MIN_R) * 16 + c) * 4096;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int v = 0; v < 2; ++v)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ST_PUB(&St[((u * 2 + v) * 4 + q) * 256 + t], acc[u][v][q]);
+    region_publish(asst + r, a.epoch, c);
   }
 }
 
@@ -2705,29 +2776,6 @@ __device__ __forceinline__ void potrf_region_row(const RegionArgs& a, double* __
 //                                                    of the next one (register s of lane (g, c) = row 4 s + g), so nothing is transposed;
 //                                                    Dinv is lower triangular: wave w stops at k = 32 (w + 1).
 // Rows 16 .. of the tile are padding (zeros before and after).  Nothing is published: nobody reads a row stream inside the launch.
-__device__ __forceinline__ void region_wait3(const int* f1, int n1, const int* f2, int n2, const int* f3, int n3, int epoch, int* abort_word, int* info) {
-  if (threadIdx.x == 0) {
-    const long long t0 = wall_clock64();
-    int polls = 0;
-    for (;;) {
-      const int v1 = __hip_atomic_load(f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int v2 = f2 ? __hip_atomic_load(f2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch * 32 + 31;
-      const int v3 = f3 ? __hip_atomic_load(f3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch * 32 + 31;
-      if ((v1 >> 5) == epoch && (v1 & 31) >= n1 && (v2 >> 5) == epoch && (v2 & 31) >= n2 && (v3 >> 5) == epoch && (v3 & 31) >= n3) break;
-      __builtin_amdgcn_s_sleep(1);
-      if ((++polls & 63) == 0) {
-        if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-        if (wall_clock64() - t0 > 100000000LL) {
-          __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          atomicCAS(info, 0, LMM_INFO_SYNC_TIMEOUT);
-          break;
-        }
-      }
-    }
-  }
-  __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-}
 struct ThinChunk { double fb[8], fa[8][2]; };
 __device__ __forceinline__ void potrf_region_row_thin(const RegionArgs& a, double* __restrict__ lds, double* __restrict__ Am, int b, int ti) {
   int* abort_word = a.flags.p[b];
@@ -2825,9 +2873,10 @@ __global__ __launch_bounds__(256, OCC) void potrf_region_kernel(RegionArgs a) {
   const int Q = 2 * a.P;
   if (a.trace && threadIdx.x == 0) a.trace[2 * blockIdx.x] = wall_clock64();
   if (idx == 0) potrf_region_walker(a, node_lds, Am, b);
-  else if (idx < Q) potrf_region_helper<false>(a, node_lds, Am, b, idx);      // <true> (two chunks ahead) spills even at one workgroup per CU
+  else if (idx < Q) potrf_region_helper<false, OCC == 1>(a, node_lds, Am, b, idx);      // DEEP (two chunks ahead) spills even at one workgroup per CU
+  else if (OCC == 1 && idx < Q + a.na) potrf_region_assistant(a, Am, b, LMM_REGION_ASST_MIN_R + idx - Q);   // (the two-per-CU build has no assistants)
   else {
-    const int ti = a.P + idx - Q;
+    const int ti = a.P + idx - Q - a.na;
     const int real = a.M_real - 128 * ti;                // rows of this tile that hold data (the rest is zero padding, before and after)
     if (real > 16) potrf_region_row(a, node_lds, Am, b, ti);
     else if (real > 0) potrf_region_row_thin(a, node_lds, Am, b, ti);
@@ -3899,7 +3948,7 @@ bool launch_update_leaf(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2
 
 size_t region_flag_ints(int) { return REGION_FLAG_INTS; }
 void launch_region(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2, const BatchInfo& info, const BatchInfo& flags, int ld, int NR,
-                   int c0, int width, int n_real, int nb, bool first_done, hipStream_t st, int rows_real) {
+                   int c0, int width, int n_real, int nb, bool first_done, hipStream_t st, int rows_real, const BatchPtr* S) {
   const int P = width / 128, M = NR - c0, R = (M + 127) / 128;
   if (nb <= 0 || P <= 0) return;
   node_lds_attr();
@@ -3907,12 +3956,31 @@ void launch_region(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2, con
   a.A = A; a.W = W; a.W2 = W2; a.info = info; a.flags = flags; a.ld = ld; a.M = M; a.c0 = c0; a.P = P; a.R = R; a.n_real = n_real; a.nb = nb;
   a.epoch = next_flag_epoch(); a.first_done = first_done ? 1 : 0;
   a.M_real = (rows_real >= 0 && rows_real <= NR) ? rows_real - c0 : M;
-  const long long tasks = 2LL * P + (R - P);       // the square's 64-row blocks + one task per 128-row tile below it
-  // LMM_REGION_OCC=1 / 2 forces a build; default: one workgroup per CU while the whole launch is resident that way, else two
-  static int occ_env = -1, cus = 0;
-  if (occ_env < 0) { const char* e = getenv("LMM_REGION_OCC"); occ_env = e ? atoi(e) : 0; }
+  // assistants (LMM_REGION_ASST=0 disables them): one per square row from LMM_REGION_ASST_MIN_R on, when the caller gave scratch
+  static int asst_env = -1;
+  if (asst_env < 0) { const char* e = getenv("LMM_REGION_ASST"); asst_env = e ? (atoi(e) != 0) : 1; }
+  static int cus = 0;
   if (cus == 0) { int dev = 0; cus = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); }
-  const int occ = occ_env ? occ_env : (tasks * nb <= cus ? 1 : 2);
+  a.na = (asst_env && S != nullptr && S->p[0] != nullptr && 2 * P > LMM_REGION_ASST_MIN_R) ? 2 * P - LMM_REGION_ASST_MIN_R : 0;
+  // ... and only while the launch with them still fits one workgroup per CU: pushed into the two-per-CU build (where the walker spills)
+  // they cost more than they bring (8 latents, n = 2048: 1.60 -> 1.87 ms)
+  // Row tiles that take the thin stream (or hold padding only) need not be resident from the start: they wait for the square, never
+  // the square for them, and catch up within a panel's time.  What must fit one workgroup per CU for that build: square + full rows.
+  int full_rows = 0;
+  for (int ti = P; ti < R; ++ti) if (a.M_real - 128 * ti > 16) ++full_rows;
+  // LMM_REGION_OCC=1 / 2 forces a build; default: one workgroup per CU (414 registers per lane, no spills in the walker)
+  static int occ_env = -1;
+  if (occ_env < 0) { const char* e = getenv("LMM_REGION_OCC"); occ_env = e ? atoi(e) : 0; }
+  // (Until late in round 3 the default went to the two-per-CU build whenever the launch did not fit one workgroup per CU.  Measured
+  // again with the thin row stream in place, the one-per-CU build wins at EVERY size: 32 x 1024: 0.82 against 1.05 ms, 8 x 3072: 2.98
+  // against 3.42, 8 x 4096: 5.23 against 5.65, 8 x 8192: 26.5 against 28.6 -- the walker's 432 spilled registers sit on the chain every
+  // other task waits for, while tasks that are dispatched late (helpers of high rows, row streams) are also needed late.)
+  int occ = 1;
+  if ((2LL * P + a.na + full_rows) * nb > cus) a.na = 0;          // assistants only while everything is resident from the start
+  if (occ_env) occ = occ_env;
+  if (occ != 1) a.na = 0;
+  if (a.na > 0) a.S = *S;
+  const long long tasks = 2LL * P + a.na + (R - P);       // the square's 64-row blocks + assistants + one task per 128-row tile below it
   // LMM_REGION_TRACE=1: per-workgroup start / end ticks (100 MHz) of every region launch, printed to stderr (a debugging aid: it
   // synchronises the stream after each launch)
   static int trace_env = -1;

@@ -497,7 +497,11 @@ def test_update_kernel_variants_agree():
                       # round-aligned split-K tail, the dataflow kernel as the base case of the recursion
                       ("no_fused_bulk", {"LMM_FUSE_BULK": "0"}), ("fused_bulk_all", {"LMM_FUSE_BULK_MINK": "128", "LMM_FUSE_BULK_MAXK": "65536"}),
                       ("fused_bulk_deterministic", {"LMM_FUSE_BULK_MINK": "128", "LMM_FUSE_BULK_MAXK": "65536", "LMM_DETERMINISTIC": "1"}),
-                      ("tail_policy1", {"LMM_TAIL_POLICY": "1"}), ("region_base", {"LMM_REGION_ALL": "1", "LMM_REGION": "512"})]:
+                      ("tail_policy1", {"LMM_TAIL_POLICY": "1"}), ("region_base", {"LMM_REGION_ALL": "1", "LMM_REGION": "512"}),
+                      # the default at this size: 1024-column region launches as base case, with assistants; without them; the
+                      # two-per-CU build; the panel recursion instead
+                      ("region_no_assistants", {"LMM_REGION_ASST": "0"}), ("region_occ2", {"LMM_REGION_OCC": "2"}),
+                      ("panel_recursion", {"LMM_REGION_ALL": "0"})]:
         out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr[-2000:]
         vals[name] = json.loads(out.stdout.strip().splitlines()[-1])

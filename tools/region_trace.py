@@ -14,13 +14,15 @@ L = launches[k]
 c0, P, R, nb, occ = L["hdr"]
 print(f"launch {k} of {len(launches)}: c0={c0} P={P} R={R} nb={nb} occ={occ}; {len(L['wg'])} workgroups; end of launch {max(w[3] for w in L['wg']):.1f} us")
 Q = 2 * P
+NA = max(0, Q - 6) if len(L["wg"]) // nb >= 2 * Q - 6 + (R - P) and Q > 6 else 0      # assistant tasks (rows 6 ..) when the launch has them
 for b in range(min(nb, 2)):
     ws = [w for w in L["wg"] if w[0] == b]
     print(f" matrix {b}:")
     for (_, idx, s, e) in ws:
         if idx == 0: print(f"   walker      start {s:8.1f} end {e:8.1f}")
         elif idx < Q: print(f"   helper r={idx:2d} start {s:8.1f} end {e:8.1f}")
-    rows = [w for w in ws if w[1] >= Q]
+        elif idx < Q + NA: print(f"   assist r={idx - Q + 6:2d} start {s:8.1f} end {e:8.1f}")
+    rows = [w for w in ws if w[1] >= Q + NA]
     if rows:
         print(f"   rows: {len(rows)}  start min/max {min(r[2] for r in rows):.1f}/{max(r[2] for r in rows):.1f}  end min/max {min(r[3] for r in rows):.1f}/{max(r[3] for r in rows):.1f}  "
               f"duration mean {sum(r[3] - r[2] for r in rows) / len(rows):.1f}")
