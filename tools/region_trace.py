@@ -20,8 +20,10 @@ for b in range(min(nb, 2)):
     print(f" matrix {b}:")
     for (_, idx, s, e) in ws:
         if idx == 0: print(f"   walker      start {s:8.1f} end {e:8.1f}")
+        elif NA and 6 <= idx < Q + NA:             # (helper r, assistant r) pairs from row 6 on
+            k = idx - 6
+            print(f"   {'helper' if k % 2 == 0 else 'assist'} r={6 + k // 2:2d} start {s:8.1f} end {e:8.1f}")
         elif idx < Q: print(f"   helper r={idx:2d} start {s:8.1f} end {e:8.1f}")
-        elif idx < Q + NA: print(f"   assist r={idx - Q + 6:2d} start {s:8.1f} end {e:8.1f}")
     rows = [w for w in ws if w[1] >= Q + NA]
     if rows:
         print(f"   rows: {len(rows)}  start min/max {min(r[2] for r in rows):.1f}/{max(r[2] for r in rows):.1f}  end min/max {min(r[3] for r in rows):.1f}/{max(r[3] for r in rows):.1f}  "
