@@ -86,7 +86,6 @@ struct RegionArgs {
   int M_real;             // rows c0 .. c0 + M_real - 1 hold data, the rest of the M rows is zero padding (rider rows are padded to 64)
   BatchPtr S;             // optional scratch (LMM_REGION_ASST_TILES 64 x 64 tiles per matrix): partial products of the ASSISTANT tasks
   int na;                 // assistant tasks per matrix (square rows LMM_REGION_ASST_MIN_R .. 2P - 1), 0: none
-  int diag_form;          // walker's diagonal blocks: 1 = two 32-blocks + products on all waves (diag64_2x32), 0 = one-wave diag64m
   int ntasks;             // workgroups per matrix (trace layout)
   long long* trace;       // optional (LMM_REGION_TRACE=1, tools/region_trace.py): start / end wall-clock ticks of every workgroup
 };

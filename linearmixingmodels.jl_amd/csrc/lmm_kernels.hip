@@ -873,15 +873,13 @@ __device__ long long g_diag_ts[8];
 #else
 #define LMM_DIAG_TS(i)
 #endif
-template <int NB = 4>                                                // NB 16-row blocks per side: 4 (a 64 x 64 block) or 2 (32 x 32)
-struct DiagmState {
-  d4 S[NB][NB], V[NB][NB];                                         // [block row][block col], block col <= block row
+struct Diag64mState {
+  d4 S[4][4], V[4][4];                                             // [block row][block col], block col <= block row
   double Ym[2][4], nY[2][4], Z[2][4];                              // operands of step s live in set s & 1 (the lagging MFMAs of step
                                                                    // s are issued inside step s+1, under its VALU chain)
   double e0, e1, e2, e3;                                           // lane-group indicator (row g of the 4x4 inverse)
   unsigned long long badmask;                                      // bit k: pivot k is not > 0 (uniform)
 };
-using Diag64mState = DiagmState<4>;
 // The MFMAs of step T in three groups, by when the NEXT step (pivot block column jn) needs their block:
 //   0: S[jn][jn], 1: S[rb > jn][jn] and V[jn][*]  -- the next panel / the next pivot rows of W: issued at the end of step T
 //   2: everything else                              -- issued inside step T+1, between its LDS reads and its VALU chain, so that the
@@ -889,11 +887,11 @@ using Diag64mState = DiagmState<4>;
 // (f64 MFMAs and f64 VALU instructions of one wave do NOT overlap on gfx950 -- interleaving them one-for-one changed nothing,
 // profiles/r02/diag_ab_*.log -- so the kernel is bound by its instruction count: ~9 MFMAs of 64 cycles and ~60 f64 VALU
 // instructions of 8 cycles per step.)
-template <int T, int GROUP, int NB = 4>
-__device__ __forceinline__ void diag64m_mfmas(DiagmState<NB>& st) {
+template <int T, int GROUP>
+__device__ __forceinline__ void diag64m_mfmas(Diag64mState& st) {
   constexpr int jb = T >> 2, q = T & 3, jn = (T + 1) >> 2, o = T & 1;
 #pragma unroll
-  for (int rb = jb; rb < NB; ++rb) {
+  for (int rb = jb; rb < 4; ++rb) {
     if (rb == jb && q == 3) continue;                              // no rows below the pivots in this block row
 #pragma unroll
     for (int cb = jb; cb <= rb; ++cb) {
@@ -913,8 +911,8 @@ constexpr int DIAG_LS = 68;                                        // column str
 // DIRECT: the finished L entries of a step leave for global memory straight from the registers (four columns x sixteen consecutive
 // rows per store instruction: four 128-byte segments) instead of being collected in the Lo image for a coalesced epilogue --
 // the form leaf128 uses, which has no LDS to spare for Lo.
-template <int s, bool DIRECT = false, typename TS = double, int NB = 4>
-__device__ __forceinline__ void diag64m_step(DiagmState<NB>& st, double* __restrict__ Sp, double* __restrict__ Wt, double* __restrict__ Lo,
+template <int s, bool DIRECT = false, typename TS = double>
+__device__ __forceinline__ void diag64m_step(Diag64mState& st, double* __restrict__ Sp, double* __restrict__ Wt, double* __restrict__ Lo,
                                              int c, int g, void* __restrict__ Ag = nullptr, size_t offAg = 0, int ldg = 0) {
   constexpr int SP = DIAG_SP, LS = DIAG_LS;
   constexpr int J = 4 * s, jb = s >> 2, q = s & 3, o = s & 1;
@@ -922,7 +920,7 @@ __device__ __forceinline__ void diag64m_step(DiagmState<NB>& st, double* __restr
   // one wave: LDS executes its instructions in order, and the compiler keeps may-aliasing LDS accesses in program order
   // the current block column of S and the pivot rows of the W part -> LDS
 #pragma unroll
-  for (int rb = jb; rb < NB; ++rb)
+  for (int rb = jb; rb < 4; ++rb)
 #pragma unroll
     for (int r = 0; r < 4; ++r) Sp[(16 * rb + 4 * r + g) * SP + c] = st.S[rb][jb][r];
 #pragma unroll
@@ -932,9 +930,9 @@ __device__ __forceinline__ void diag64m_step(DiagmState<NB>& st, double* __restr
   const d2 pr1 = *reinterpret_cast<const d2*>(&Sp[(J + 1) * SP + 4 * q]);
   const d2 pr2a = *reinterpret_cast<const d2*>(&Sp[(J + 2) * SP + 4 * q]), pr2b = *reinterpret_cast<const d2*>(&Sp[(J + 2) * SP + 4 * q + 2]);
   const d2 pr3a = *reinterpret_cast<const d2*>(&Sp[(J + 3) * SP + 4 * q]), pr3b = *reinterpret_cast<const d2*>(&Sp[(J + 3) * SP + 4 * q + 2]);
-  d2 bo[NB][2], wo[NB][2];
+  d2 bo[4][2], wo[4][2];
 #pragma unroll
-  for (int rb = jb; rb < NB; ++rb) {
+  for (int rb = jb; rb < 4; ++rb) {
     bo[rb][0] = *reinterpret_cast<const d2*>(&Sp[(16 * rb + c) * SP + 4 * q]);
     bo[rb][1] = *reinterpret_cast<const d2*>(&Sp[(16 * rb + c) * SP + 4 * q + 2]);
   }
@@ -943,7 +941,7 @@ __device__ __forceinline__ void diag64m_step(DiagmState<NB>& st, double* __restr
     wo[cb][0] = *reinterpret_cast<const d2*>(&Wt[(16 * cb + c) * 4]);
     wo[cb][1] = *reinterpret_cast<const d2*>(&Wt[(16 * cb + c) * 4 + 2]);
   }
-  if constexpr (s > 0) diag64m_mfmas<s - 1, 2, NB>(st);                // the previous step's lagging blocks
+  if constexpr (s > 0) diag64m_mfmas<s - 1, 2>(st);                // the previous step's lagging blocks
   auto rsq = [](double x) {          // 1/sqrt(x): v_rsq_f64 + two Newton steps
     double y = __builtin_amdgcn_rsq(x);
     const double h = 0.5 * x;
@@ -965,7 +963,7 @@ __device__ __forceinline__ void diag64m_step(DiagmState<NB>& st, double* __restr
   const double k1 = __builtin_fma(-k2, l21, __builtin_fma(-k3, l31, st.e1)) * r1;
   const double k0 = __builtin_fma(-k1, l10, __builtin_fma(-k2, l20, __builtin_fma(-k3, l30, st.e0))) * r0;
 #pragma unroll
-  for (int rb = jb; rb < NB; ++rb) {
+  for (int rb = jb; rb < 4; ++rb) {
     const double y = __builtin_fma(bo[rb][1].y, k3, __builtin_fma(bo[rb][1].x, k2, __builtin_fma(bo[rb][0].y, k1, bo[rb][0].x * k0)));
     const int row = 16 * rb + c;
     if constexpr (DIRECT) { if (row >= J + g) MatIO<TS>::st1(Ag, offAg + (size_t)(J + g) * ldg + row, y); }
@@ -979,7 +977,7 @@ __device__ __forceinline__ void diag64m_step(DiagmState<NB>& st, double* __restr
 #pragma unroll
   for (int cb = 0; cb <= jb; ++cb) st.V[jb][cb][q] = st.Z[o][cb];  // rows J..J+3 of W = Lp^-1 Wtop, final (the MFMAs of this step
                                                                    // add 0 * Z to them: rows of the pivot block have Ym = 0)
-  diag64m_mfmas<s, 0, NB>(st); diag64m_mfmas<s, 1, NB>(st);                // the blocks the next step reads
+  diag64m_mfmas<s, 0>(st); diag64m_mfmas<s, 1>(st);                // the blocks the next step reads
   __builtin_amdgcn_sched_barrier(0);
   // non-positive (or NaN) pivots: the values are uniform, so any lane's comparison will do
   if (__builtin_amdgcn_ballot_w64(!(d0 > 0.0) | !(d1 > 0.0) | !(d2v > 0.0) | !(d3 > 0.0)) != 0ull) {
@@ -992,12 +990,12 @@ __device__ __forceinline__ void diag64m_steps(Diag64mState& st, double* __restri
                                               int c, int g) {
   if constexpr (s < 16) { diag64m_step<s>(st, Sp, Wt, Lo, c, g); diag64m_steps<s + 1>(st, Sp, Wt, Lo, c, g); }
 }
-template <int s, typename TS, int NB = 4>
-__device__ __forceinline__ void diag64m_steps_direct(DiagmState<NB>& st, double* __restrict__ Sp, double* __restrict__ Wt, int c, int g,
+template <int s, typename TS>
+__device__ __forceinline__ void diag64m_steps_direct(Diag64mState& st, double* __restrict__ Sp, double* __restrict__ Wt, int c, int g,
                                                      void* __restrict__ Ag, size_t offAg, int ldg) {
-  if constexpr (s < 4 * NB) {
-    diag64m_step<s, true, TS, NB>(st, Sp, Wt, nullptr, c, g, Ag, offAg, ldg);
-    diag64m_steps_direct<s + 1, TS, NB>(st, Sp, Wt, c, g, Ag, offAg, ldg);
+  if constexpr (s < 16) {
+    diag64m_step<s, true, TS>(st, Sp, Wt, nullptr, c, g, Ag, offAg, ldg);
+    diag64m_steps_direct<s + 1, TS>(st, Sp, Wt, c, g, Ag, offAg, ldg);
   }
 }
 
@@ -1006,14 +1004,13 @@ __device__ __forceinline__ void diag64m_steps_direct(DiagmState<NB>& st, double*
 // non-positive (or NaN) pivots.  l = lane.  The last step's lagging MFMAs (group 2 of step 15) do not exist: nothing is pending.
 // Wl MAY overlap Sp / Wt (leaf128 does that to stay inside the update kernel's LDS footprint): it is written only after the last step.
 // src != nullptr: the block is taken from the LDS image src[col * DIAG_LS + row] instead of global memory (L still goes to A).
-// NB = 2: the same for a 32 x 32 block (8 steps, 3 + 3 register blocks): a quarter of the one-wave work of NB = 4, see diag64_2x32.
-template <typename TS, int NB = 4>
+template <typename TS>
 __device__ __forceinline__ unsigned long long diag64m_wave(void* __restrict__ A, size_t offA, int ld, double* Sp, double* Wt, double* Wl, int l,
                                                            const double* src = nullptr) {
   const int c = l & 15, g = l >> 4;
-  DiagmState<NB> st;
+  Diag64mState st;
 #pragma unroll
-  for (int rb = 0; rb < NB; ++rb)
+  for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
     for (int cb = 0; cb <= rb; ++cb)
 #pragma unroll
@@ -1024,12 +1021,12 @@ __device__ __forceinline__ unsigned long long diag64m_wave(void* __restrict__ A,
       }
   st.e0 = g == 0 ? 1.0 : 0.0; st.e1 = g == 1 ? 1.0 : 0.0; st.e2 = g == 2 ? 1.0 : 0.0; st.e3 = g == 3 ? 1.0 : 0.0;
   st.badmask = 0ull;
-  diag64m_steps_direct<0, TS, NB>(st, Sp, Wt, c, g, A, offA, ld);
+  diag64m_steps_direct<0, TS>(st, Sp, Wt, c, g, A, offA, ld);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int rb = 0; rb < NB; ++rb)
+  for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-    for (int cb = 0; cb < NB; ++cb)
+    for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) Wl[(16 * cb + c) * DIAG_LS + 16 * rb + 4 * r + g] = cb <= rb ? st.V[rb][cb][r] : 0.0;
   return st.badmask;
@@ -2087,70 +2084,6 @@ __device__ __forceinline__ void region_publish(int* f, int epoch, int count) {
   if (threadIdx.x == 0) __hip_atomic_store(f, epoch * 32 + count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// ---------------------------------------------------------------------------------------------------
-// A 64 x 64 diagonal block as TWO 32 x 32 blocks (round 3).  diag64m_wave<.., 4> is one wave for ~12 us: 16 rank-4 steps, each ~60
-// f64 VALU instructions of pivot algebra + ~9 MFMAs of trailing update + an LDS round trip.  Split 2 x 2, the one-wave part shrinks to
-// two 8-step factorisations with at most 3 + 3 register blocks (~2.7 us each) and the off-diagonal work -- L21 = A21 W11', A22 -= L21 L21',
-// W21 = -W22 L21 W11 -- becomes four 32^3 products on all four waves (8 MFMAs per wave each):
-//   X: LDS image of the block (element (row, col) at X[col LS + row]; the lower triangle is read), which becomes the image of W = L^-1
-//      (zeros above the diagonal);  Y: >= 704 + 2 * 32 * 36 doubles of scratch (work areas of the 32-blocks, images of L21 and T);
-//   L goes to global memory (A, offA, ld).  All 256 threads call it; the caller synchronises before (image complete) and after.
-// ---------------------------------------------------------------------------------------------------
-// D (32 x 32) = A R over K = 32 on four waves (wave w: block (w & 1, w >> 1)), operands in LDS with element strides; emit(row, col, value)
-template <typename Emit>
-__device__ __forceinline__ void wg_mm32(const double* __restrict__ As, int sai, int sak, const double* __restrict__ Rs, int srk, int srj,
-                                        int w, int l, Emit emit) {
-  const int c = l & 15, g = l >> 4, bi = 16 * (w & 1), bj = 16 * (w >> 1);
-  double fa[8], fr[8];
-#pragma unroll
-  for (int ks = 0; ks < 8; ++ks) { fa[ks] = As[(bi + c) * sai + (4 * ks + g) * sak]; fr[ks] = Rs[(4 * ks + g) * srk + (bj + c) * srj]; }
-  d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int ks = 0; ks < 8; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ks], fr[ks], acc, 0, 0, 0);
-#pragma unroll
-  for (int r = 0; r < 4; ++r) emit(bi + 4 * r + g, bj + c, acc[r]);
-}
-constexpr int DIAG_L2 = 36;                                        // column stride of the 32 x 32 images of L21 and T
-template <bool PUBL = false>                                       // PUBL: L21 goes out write-through (the region kernel's walker publishes it)
-__device__ __forceinline__ unsigned long long diag64_2x32(double* __restrict__ A, size_t offA, int ld, double* __restrict__ X, double* __restrict__ Y) {
-  constexpr int LS = DIAG_LS, L2 = DIAG_L2;
-  const int t = threadIdx.x, l = t & 63;
-  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  double* Sp = Y; double* Wt = Y + 32 * DIAG_SP;                   // work areas of the 32-blocks (576 + 128 doubles)
-  double* L21 = Y + 704; double* Tm = L21 + 32 * L2;               // images: element (row, col) at [col L2 + row]
-  unsigned long long bad1 = 0ull, bad2 = 0ull;
-  if (w == 0) bad1 = diag64m_wave<double, 2>(A, offA, ld, Sp, Wt, X, l, X);                       // L11 -> global, W11 -> X[0:32, 0:32]
-  __syncthreads();
-  // L21 = A21 W11'   (A[i][k] = A21[i][k] = X[k LS + 32 + i];  R[k][j] = W11[j][k] = X[k LS + j])
-  wg_mm32(X + 32, 1, LS, X, LS, 1, w, l, [&](int i, int j, double v) {
-    L21[j * L2 + i] = v;
-    if (PUBL) ST_PUB(&A[offA + (size_t)j * ld + 32 + i], v); else A[offA + (size_t)j * ld + 32 + i] = v;
-  });
-  __syncthreads();
-  // A22 -= L21 L21'  (A[i][k] = L21[i][k];  R[k][j] = L21[j][k]), in place in the image
-  wg_mm32(L21, 1, L2, L21, L2, 1, w, l, [&](int i, int j, double v) { X[(32 + j) * LS + 32 + i] -= v; });
-  __syncthreads();
-  if (w == 0) bad2 = diag64m_wave<double, 2>(A, offA + (size_t)32 * ld + 32, ld, Sp, Wt, X + 32 * LS + 32, l, X + 32 * LS + 32);
-  else {                                                            // meanwhile: T = L21 W11 (A[i][k] = L21[i][k];  R[k][j] = W11[k][j] = X[j LS + k])
-    // three waves, four blocks: wave 1 takes two
-    for (int blk = w - 1; blk < 4; blk += 3) {
-      const int c = l & 15, g = l >> 4, bi = 16 * (blk & 1), bj = 16 * (blk >> 1);
-      d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(L21[(4 * ks + g) * L2 + bi + c], X[(bj + c) * LS + 4 * ks + g], acc, 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Tm[(bj + c) * L2 + bi + 4 * r + g] = acc[r];
-    }
-  }
-  __syncthreads();
-  // W21 = -W22 T     (A[i][k] = W22[i][k] = X[(32 + k) LS + 32 + i];  R[k][j] = T[k][j] = Tm[j L2 + k])  -> X[32:64, 0:32]; zeros above
-  wg_mm32(X + 32 * LS + 32, 1, LS, Tm, 1, L2, w, l, [&](int i, int j, double v) { X[j * LS + 32 + i] = -v; });
-#pragma unroll
-  for (int e = t; e < 1024; e += 256) X[(32 + (e >> 5)) * LS + (e & 31)] = 0.0;
-  return bad1 | (bad2 << 32);
-}
-
 // LDS of the node kernel: the update's staging (2 x 2 x 16 x 144 doubles = 73 728 bytes, as gemm16p_kernel) >= the leaf's two 64 x 64
 // images X, Y (2 x 64 x 68 doubles); the diagonal-block work areas Sp / Wt live inside whichever image is dead in that phase.
 constexpr int LEAF_LDS_DOUBLES = 4 * 16 * 144;
@@ -2633,12 +2566,7 @@ __device__ __forceinline__ void potrf_region_walker(const RegionArgs& a, double*
     __syncthreads();                                                     // the image (r > 0) is complete, Y is free
     unsigned long long bad = 0ull;
     if (tr2 && t == 0) tr2[32 + r] = wall_clock64();
-    if (a.diag_form == 0) {
-      if (w == 0) bad = diag64m_wave<double>(Am, grow * a.ld + grow, a.ld, Y, Y + 64 * DIAG_SP, X, l, src);      // L[r, r] -> global, W_r -> X
-    } else {                                                             // two 32-blocks + four 32^3 products on all waves (diag64_2x32)
-      if (src == nullptr) { img_load(X, Am + grow * a.ld + grow, a.ld); __syncthreads(); }
-      bad = diag64_2x32(Am, grow * a.ld + grow, a.ld, X, Y);
-    }
+    if (w == 0) bad = diag64m_wave<double>(Am, grow * a.ld + grow, a.ld, Y, Y + 64 * DIAG_SP, X, l, src);      // L[r, r] -> global, W_r -> X
     __syncthreads();
     if (tr2 && t == 0) tr2[48 + r] = wall_clock64();
     region_store_W(a, b, X, grow, (r & 1) != 0);
@@ -4036,13 +3964,10 @@ void launch_region(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2, con
   RegionArgs a{};
   a.A = A; a.W = W; a.W2 = W2; a.info = info; a.flags = flags; a.ld = ld; a.M = M; a.c0 = c0; a.P = P; a.R = R; a.n_real = n_real; a.nb = nb;
   a.epoch = next_flag_epoch(); a.first_done = first_done ? 1 : 0;
-  static int diag_form = -1;          // LMM_REGION_DIAG=0: the walker's diagonal blocks by the one-wave 64-column kernel (first form)
-  if (diag_form < 0) { const char* e = getenv("LMM_REGION_DIAG"); diag_form = e ? atoi(e) : 1; }
-  a.diag_form = diag_form;
   a.M_real = (rows_real >= 0 && rows_real <= NR) ? rows_real - c0 : M;
   // assistants (LMM_REGION_ASST=0 disables them): one per square row from LMM_REGION_ASST_MIN_R on, when the caller gave scratch
   static int asst_env = -1;
-  if (asst_env < 0) { const char* e = getenv("LMM_REGION_ASST"); asst_env = e ? atoi(e) : 1; }       // 2: also when they are not resident from the start
+  if (asst_env < 0) { const char* e = getenv("LMM_REGION_ASST"); asst_env = e ? atoi(e) : 1; }       // 2: also when they are not resident from the start (measured slower)
   static int cus = 0;
   if (cus == 0) { int dev = 0; cus = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); }
   a.na = (asst_env && S != nullptr && S->p[0] != nullptr && 2 * P > LMM_REGION_ASST_MIN_R) ? 2 * P - LMM_REGION_ASST_MIN_R : 0;
