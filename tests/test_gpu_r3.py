@@ -501,3 +501,19 @@ def test_all_padding_last_block(lmm, n, kind, d):
     ys = rng.standard_normal(ns * p)
     assert lmm.logpdf(post(lmm.MOInputIsotopicByOutputs(xs, p), s2), ys) == pytest.approx(
         O.oilmm_logpdf(po, U, S, xs, s2, ys), rel=1e-8)
+
+
+def test_two_concurrent_batches_with_region_base(lmm):
+    """36 latents at n = 1100 (factor width 1152 > one region): two lock-step batches (32 + 4) on concurrent streams, each taking its own
+    choice of base case for the recursion (the small one: 1024-column dataflow launches with assistants; the large one: by the residency
+    rule) -- the sum over latents must still be the oracle's."""
+    rng = np.random.default_rng(36)
+    n, m, p, s2 = 1100, 36, 40, 0.2
+    x = np.sort(rng.uniform(0, 30, size=n))
+    kinds = ["matern52", "se", "matern32"]
+    gps = [{"kind": kinds[l % 3], "variance": 0.6 + 0.02 * l, "lengthscale": 0.7 + 0.03 * l, "mean": 0.01 * l} for l in range(m)]
+    U, _ = np.linalg.qr(rng.standard_normal((p, m)))
+    S = np.linspace(1.6, 0.7, m)
+    y = rng.standard_normal(n * p)
+    fx = lmm.ILMM(_model(lmm, gps), lmm.Orthogonal(U, S))(lmm.MOInputIsotopicByOutputs(x, p), s2)
+    assert lmm.logpdf(fx, y) == pytest.approx(O.oilmm_logpdf(gps, U, S, x, s2, y), rel=1e-9)
