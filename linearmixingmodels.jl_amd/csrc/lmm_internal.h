@@ -108,6 +108,9 @@ void launch_panel_bulk(const BatchPtr& A, const BatchPtr& W2, int ld, int NR, in
 bool launch_update_leaf(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2, const BatchInfo& info, int ld, int NR, int j0, int h,
                         int N, int n_real, int nb, hipStream_t st, int* nflags = nullptr, int nf_stride = 0);
 size_t node_flag_ints(int NR);            // ints per matrix of the NODE_FUSE flags of a matrix with NR rows
+// lmm_kernels_f32w.hip: fp32 C -= A B' on 256 x 256 tiles (one workgroup per CU); false: not launched (shape / switch), use the 128-tile kernel
+bool launch_gemm32w(const BatchPtr& C, size_t offC, int ldc, const BatchPtr& A, size_t offA, int lda, const BatchPtr& B, size_t offB, int ldb,
+                    int M, int N, int K, int lower, int nb, int cus, bool deterministic, hipStream_t st);
 void launch_diag64(const BatchPtr& A, size_t offA, int ld, const BatchPtr& W, size_t offW, int gcol0, int n_real,
                    const BatchInfo& info, int nb, hipStream_t st);
 void launch_gemm_nt(const BatchPtr& C, size_t offC, int ldc, const BatchPtr& A, size_t offA, int lda, const BatchPtr& B,

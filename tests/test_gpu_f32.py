@@ -75,6 +75,33 @@ def test_f32_gemm_and_potrf_building_blocks(lmm32):
         np.testing.assert_allclose(out[:, n:].T, sla.solve_triangular(L, R.T, lower=True).T, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("M,N,K,lower", [(4096, 4096, 512, 0), (6208, 6144, 320, 1), (8256, 4096, 288, 1)])
+def test_f32_wide_update_256_tiles(lmm32, M, N, K, lower):
+    """The 256 x 256-tile fp32 update (gemm32w_kernel, its own translation unit: AccVGPR accumulators) takes over where its tiles fill
+    the device: full tiles; a ragged last row tile (M = 6208 = 24.25 tiles) with a split-K tail (324 tiles on 256 CUs); the lower
+    trapezoid with a split-K tail -- against torch in Float64."""
+    import torch
+    lib = lmm32.load()
+    g = torch.Generator(device="cuda").manual_seed(M + K)
+    ldc, lda, ldb = M + 16, M + 4, N + 8
+    Ct = torch.randn(N, ldc, generator=g, device="cuda", dtype=torch.float32)
+    At = torch.randn(K, lda, generator=g, device="cuda", dtype=torch.float32)
+    Bt = torch.randn(K, ldb, generator=g, device="cuda", dtype=torch.float32)
+    C0 = Ct.clone()
+    torch.cuda.synchronize()
+    rc = lib.lmm_dev_gemm_nt_sub(C.c_void_p(Ct.data_ptr()), ldc, C.c_void_p(At.data_ptr()), lda, C.c_void_p(Bt.data_ptr()), ldb, M, N, K, lower)
+    assert rc == 0, lib.lmm_last_error_string()
+    ref = C0[:, :M].double() - (Bt[:, :N].double().T @ At[:, :M].double())
+    got = Ct[:, :M].double()
+    if lower:
+        r = torch.arange(M, device="cuda")[None, :]; c = torch.arange(N, device="cuda")[:, None]
+        mask = r >= c
+        assert torch.allclose(got[mask], ref[mask], rtol=1e-4, atol=1e-4 * math.sqrt(K))
+    else:
+        assert torch.allclose(got, ref, rtol=1e-4, atol=1e-4 * math.sqrt(K))
+    assert torch.equal(Ct[:, M:], C0[:, M:])
+
+
 @pytest.mark.parametrize("kind,n,m,p,d", [("matern52", 700, 3, 5, 1), ("se", 1100, 2, 4, 2), ("matern32", 2100, 4, 6, 1)])
 def test_f32_oilmm_logpdf_posterior_marginals_rand_vs_f64_oracle(lmm32, kind, n, m, p, d):
     lmm = lmm32
