@@ -10,25 +10,25 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ---------------------------------------------------------------------------------------------------
 // fp32 wide update on a 256 x 256 block tile (round 3).  gemm32_kernel<128> stops at 0.79 of the 157-TFLOP/s fp32 matrix peak: per
-// MFMA it reads one operand fragment from LDS and stages 1/4 of a float4 from global memory, and two workgroups share a CU.  Here
-// ONE workgroup per CU owns a 256 x 256 tile, each wave a 128 x 128 quarter: 16 accumulator blocks of v_mfma_f32_32x32x2_f32 in the
-// 256 AccVGPRs (for fp32 the AccVGPR form issues at full rate -- unlike f64), 8 fragment reads per 16 MFMAs and half the
-// global bytes per flop.  Same software pipeline as gemm32_kernel (BK = 32 per LDS stage = 16 k-pairs; per k-pair the fragments of
-// the next pair are read and TWO staging instructions ride along: the 16 ds_write_b128 of tile t+1 in the first half, the 16
-// global_load_dwordx4 of tile t+2 in the second; the barrier sits before the last k-pair).  133 120 bytes of dynamic LDS.
+// MFMA it reads one operand fragment from LDS and stages 1/4 of a float4 from global memory.  Here ONE workgroup of EIGHT waves per CU
+// owns a 256 x 256 tile, each wave a 128 x 64 piece (2 x 4 waves): 8 accumulator blocks of v_mfma_f32_32x32x2_f32 in AccVGPRs (for fp32
+// the AccVGPR form issues at full rate -- unlike f64), 6 fragment reads per 8 MFMAs and half the global bytes per flop.
+// Same software pipeline as gemm32_kernel (BK = 32 per LDS stage), in GROUPS of two k-pairs: the fragments of the next group are read
+// and two staging instructions ride along (the 8 ds_write_b128 of tile t+1 in the first half of a stage, the 8 global_load_dwordx4 of
+// tile t+2 in the second), then a burst of 16 MFMAs; the barrier sits before the last group.  133 120 bytes of dynamic LDS.
 // C -= A B' on the lower trapezoid (lower) or the full M x N (rows / columns beyond M / N masked per 32 x 32 block; M, N multiples
 // of 64); split-K parts combine with fp32 atomics.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 1) void gemm32w_kernel(BatchPtr Cb, size_t goffC, int ldc, BatchPtr Ab, size_t goffA, int lda,
+__global__ __launch_bounds__(512, 1) void gemm32w_kernel(BatchPtr Cb, size_t goffC, int ldc, BatchPtr Ab, size_t goffA, int lda,
                                                          BatchPtr Bb, size_t goffB, int ldb, int M, int N, int K, int lower, int MT,
                                                          int full_items, int splitk) {
   extern __shared__ __attribute__((aligned(16))) float w32_lds[];
   float* C = reinterpret_cast<float*>(Cb.p[blockIdx.y]) + goffC;
   const float* A = reinterpret_cast<const float*>(Ab.p[blockIdx.y]) + goffA;
   const float* B = reinterpret_cast<const float*>(Bb.p[blockIdx.y]) + goffB;
-  constexpr int BM = 256, BN = 256, BK = 32, WM = 128, WN = 128, TU = 4, TV = 4;
+  constexpr int BM = 256, BN = 256, BK = 32, WM = 128, WN = 64, TU = 4, TV = 2;       // 8 waves: 2 (rows) x 4 (columns) of 128 x 64
   constexpr int SA = BM + 4, SB = BN + 4;
-  constexpr int NL = 8, KS = 4;                // thread t stages rows 4 (t % 64).. of k-columns t / 64 + 4 q, q < 8, of either operand
+  constexpr int NL = 4, KS = 8;                // thread t stages rows 4 (t % 64).. of k-columns t / 64 + 8 q, q < 4, of either operand
   float (*As)[BK * SA] = reinterpret_cast<float (*)[BK * SA]>(w32_lds);
   float (*Bs)[BK * SB] = reinterpret_cast<float (*)[BK * SB]>(w32_lds + 2 * BK * SA);
   int part = 0, nparts = 1, tj = 0, ti = 0;
@@ -79,11 +79,15 @@ __global__ __launch_bounds__(256, 1) void gemm32w_kernel(BatchPtr Cb, size_t gof
       for (int r = 0; r < 16; ++r) acc[v][u][r] = 0.f;
   const int l31 = lane & 31, lh = lane >> 5;
   const int offA = lh * SA + wr + l31, offB = lh * SB + wc + l31;
-  float fu[2][TU], fv[2][TV];
+  // fragments of TWO k-pairs per set: the loop body is "read the next set (8 ds_read2), 4 staging instructions, then a burst of 32 MFMAs"
+  float fu[2][2][TU], fv[2][2][TV];
 #pragma unroll
-  for (int u = 0; u < TU; ++u) fu[0][u] = As[0][offA + 32 * u];
+  for (int h = 0; h < 2; ++h) {
 #pragma unroll
-  for (int v = 0; v < TV; ++v) fv[0][v] = Bs[0][offB + 32 * v];
+    for (int u = 0; u < TU; ++u) fu[0][h][u] = As[0][offA + 2 * h * SA + 32 * u];
+#pragma unroll
+    for (int v = 0; v < TV; ++v) fv[0][h][v] = Bs[0][offB + 2 * h * SB + 32 * v];
+  }
 
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
@@ -93,46 +97,51 @@ __global__ __launch_bounds__(256, 1) void gemm32w_kernel(BatchPtr Cb, size_t gof
     float* bsn = &Bs[buf ^ 1][0];
     const int kn2 = kc0 + ((kt + 2 < nk) ? kt + 2 : nk - 1);
 #pragma unroll
-    for (int kp = 0; kp < BK / 2; ++kp) {
-      const int cur = kp & 1, nxt = cur ^ 1;
-      if (kp == BK / 2 - 1) __syncthreads();       // every fragment of this buffer has been read; tile t+1 is complete in the other
-      if (kp + 1 < BK / 2) {
-#pragma unroll
-        for (int u = 0; u < TU; ++u) fu[nxt][u] = as[offA + 2 * (kp + 1) * SA + 32 * u];
-#pragma unroll
-        for (int v = 0; v < TV; ++v) fv[nxt][v] = bs[offB + 2 * (kp + 1) * SB + 32 * v];
-      } else {
-#pragma unroll
-        for (int u = 0; u < TU; ++u) fu[nxt][u] = asn[offA + 32 * u];
-#pragma unroll
-        for (int v = 0; v < TV; ++v) fv[nxt][v] = bsn[offB + 32 * v];
-      }
-      // two staging instructions per k-pair: slots 0-7 write A of tile t+1, 8-15 write B, 16-23 load A of tile t+2, 24-31 load B
+    for (int kg = 0; kg < BK / 4; ++kg) {          // groups of two k-pairs
+      const int cur = kg & 1, nxt = cur ^ 1;
+      if (kg == BK / 4 - 1) __syncthreads();       // every fragment of this buffer has been read; tile t+1 is complete in the other
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const int sl = 2 * kp + h;
-        if (sl < 8) *reinterpret_cast<float4*>(&asn[sa0 + KS * sl * SA]) = ra[sl];
-        else if (sl < 16) *reinterpret_cast<float4*>(&bsn[sb0 + KS * (sl - 8) * SB]) = rb[sl - 8];
-        else if (sl < 24) {
-          const int q = sl - 16, k = kn2 * BK + kq + KS * q;
+        if (kg + 1 < BK / 4) {
+#pragma unroll
+          for (int u = 0; u < TU; ++u) fu[nxt][h][u] = as[offA + 2 * (2 * (kg + 1) + h) * SA + 32 * u];
+#pragma unroll
+          for (int v = 0; v < TV; ++v) fv[nxt][h][v] = bs[offB + 2 * (2 * (kg + 1) + h) * SB + 32 * v];
+        } else {
+#pragma unroll
+          for (int u = 0; u < TU; ++u) fu[nxt][h][u] = asn[offA + 2 * h * SA + 32 * u];
+#pragma unroll
+          for (int v = 0; v < TV; ++v) fv[nxt][h][v] = bsn[offB + 2 * h * SB + 32 * v];
+        }
+      }
+      // two staging instructions per group: slots 0-3 write A of tile t+1, 4-7 write B, 8-11 load A of tile t+2, 12-15 load B
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int sl = 2 * kg + h;
+        if (sl < 4) *reinterpret_cast<float4*>(&asn[sa0 + KS * sl * SA]) = ra[sl];
+        else if (sl < 8) *reinterpret_cast<float4*>(&bsn[sb0 + KS * (sl - 4) * SB]) = rb[sl - 4];
+        else if (sl < 12) {
+          const int q = sl - 8, k = kn2 * BK + kq + KS * q;
           ra[q] = *reinterpret_cast<const float4*>(gA + (size_t)(k <= kmax ? k : kmax) * lda);
           if (k > kmax) ra[q] = make_float4(0.f, 0.f, 0.f, 0.f);
         } else {
-          const int q = sl - 24, k = kn2 * BK + kq + KS * q;
+          const int q = sl - 12, k = kn2 * BK + kq + KS * q;
           rb[q] = *reinterpret_cast<const float4*>(gB + (size_t)(k <= kmax ? k : kmax) * ldb);
           if (k > kmax) rb[q] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
-      // (the branch also keeps the 16 MFMAs of a k-pair in a block of their own, behind the pair's LDS reads and staging instructions:
-      // without it the compiler interleaves them its own way and the kernel loses 7 % -- 120 against 129 TFLOP/s)
+      // (the branch also keeps the MFMAs of a group in a block of their own, behind the group's LDS reads and staging instructions:
+      // every instruction that sits between two MFMAs of a wave costs -- see DESIGN.md 4.3)
       if (active) {
 #pragma unroll
-        for (int v = 0; v < TV; ++v)
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-          for (int uu = 0; uu < TU; ++uu) {
-            const int u = (v & 1) ? TU - 1 - uu : uu;
-            acc[v][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[cur][v], fu[cur][u], acc[v][u], 0, 0, 0);
-          }
+          for (int v = 0; v < TV; ++v)
+#pragma unroll
+            for (int uu = 0; uu < TU; ++uu) {
+              const int u = (v & 1) ? TU - 1 - uu : uu;
+              acc[v][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[cur][h][v], fu[cur][h][u], acc[v][u], 0, 0, 0);
+            }
       }
     }
   }
@@ -178,7 +187,7 @@ bool launch_gemm32w(const BatchPtr& C, size_t offC, int ldc, const BatchPtr& A, 
   if (!deterministic && Rw > 0 && Rw <= slw / 2 && nk32 >= 8) { skw = slw / Rw; if (skw > nk32 / 4) skw = nk32 / 4; if (skw < 1) skw = 1; }
   if (skw == 1) fullw = (int)Tw;
   const int itemsw = fullw + (int)(Tw - fullw) * skw;
-  hipLaunchKernelGGL(gemm32w_kernel, dim3(itemsw, nb), dim3(256), lds_bytes, st, C, offC, ldc, A, offA, lda, B, offB, ldb, M, N, K, lower, MTw,
+  hipLaunchKernelGGL(gemm32w_kernel, dim3(itemsw, nb), dim3(512), lds_bytes, st, C, offC, ldc, A, offA, lda, B, offB, ldb, M, N, K, lower, MTw,
                      fullw, skw);
   return true;
 }
