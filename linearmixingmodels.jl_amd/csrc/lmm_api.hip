@@ -309,6 +309,7 @@ void potrf_rec(const Batch& B, int ld, int NR, int j0, int w, int n_real, hipStr
 // its panel phases fall into the other batch's long updates.
 static hipEvent_t g_stagger_ev = nullptr;
 static bool g_stagger_armed = false, g_stagger_recorded = false;
+static int g_slots_in_flight = 1;       // batches that run concurrently on the slot streams (set by fork_slots; read by potrf_batch's base-case rule)
 static int g_region_whole = 1;          // LMM_REGION_ALL=1: also as the base case of the recursion for larger matrices (measured: no gain)
 static int g_region_cols = -1;          // widest block column potrf_region_kernel takes in one launch (LMM_REGION=<columns>, up to 1024; default 0: off)
 // bulk_done (implies first_done): the rows below that block are solved as well (the update launch that factored it ran them too).
@@ -392,7 +393,9 @@ void potrf_batch(const Batch& B, int ld, int NR, int NC, int n_real, hipStream_t
   bool region_base = !g_region_whole;
   if (region_auto && g_region_cols >= 1024 && NC > g_region_cols && (NC % 128) == 0) {
     const long long tasks = 2LL * (g_region_cols / 128) + ((NR + 127) / 128 - g_region_cols / 128);      // of the first (tallest) block column
-    region_base = tasks * B.nb <= (long long)(2.3 * cus);
+    // (concurrent batches count together: configs[3]'s 8-latent batches at n = 8192 fit the rule one by one, but four of them in
+    // flight do not -- 724 -> 748 ms per step with the dataflow base case, the same effect as for C2's two 16-latent batches)
+    region_base = tasks * B.nb * g_slots_in_flight <= (long long)(2.3 * cus);
   }
   const bool region_here = g_region_cols > 0 && (region_base || (NC <= g_region_cols && (NC % 128) == 0));
   if (region_here) {                       // dependency flags of the region launches: this stream's slice of the persistent, once-zeroed
@@ -540,11 +543,13 @@ void make_slots(std::vector<Slot>& slots, int count, int nb_per, size_t a_elems,
 }
 
 void fork_slots(int count) {       // slot streams wait for everything queued on the main stream
+  g_slots_in_flight = count > 1 ? count : 1;
   HIPCHK(hipEventRecord(g.ev_main, g.streams[0]));
   for (int s = 1; s < count; ++s) HIPCHK(hipStreamWaitEvent(g.streams[s], g.ev_main, 0));
 }
 
 void join_slots(int count) {       // main stream waits for every slot stream
+  g_slots_in_flight = 1;
   for (int s = 1; s < count; ++s) {
     HIPCHK(hipEventRecord(g.ev_slot[s], g.streams[s]));
     HIPCHK(hipStreamWaitEvent(g.streams[0], g.ev_slot[s], 0));
