@@ -322,7 +322,7 @@ def main():
                 tj = json.load(open(tpath))
                 if tj.get("workload") == args.workload:
                     traffic = tj.get("update_kernel", {}).get("bytes_per_launch")
-            roof = {"bound": "mfma", "kernel": ("gemm32_kernel<128,false> (v_mfma_f32_32x32x2_f32 SYRK/GEMM trailing update)" if args.dtype == "f32"
+            roof = {"bound": "mfma", "kernel": ("gemm32w_kernel (v_mfma_f32_32x32x2_f32 SYRK/GEMM trailing update on 256 x 256 tiles, AccVGPR accumulators; gemm32_kernel<128> where those do not fill the device)" if args.dtype == "f32"
                                                 else "potrf_node_kernel<2> (v_mfma_f64_16x16x4_f64, VGPR accumulators, software-pipelined SYRK/GEMM trailing update, K >= 1024; "
                                                      "one workgroup per matrix also factors the next panel's 128 x 128 diagonal block, and at K = 1024, 2048 the "
                                                      "launch ends with that panel's bulk rows; + gemm16h_kernel<true> on a ragged last 64 rows)"),
