@@ -517,3 +517,18 @@ def test_two_concurrent_batches_with_region_base(lmm):
     y = rng.standard_normal(n * p)
     fx = lmm.ILMM(_model(lmm, gps), lmm.Orthogonal(U, S))(lmm.MOInputIsotopicByOutputs(x, p), s2)
     assert lmm.logpdf(fx, y) == pytest.approx(O.oilmm_logpdf(gps, U, S, x, s2, y), rel=1e-9)
+
+
+@pytest.mark.parametrize("n,m", [(552, 20), (1024, 8)])
+def test_region_kernel_is_bitwise_reproducible(lmm, n, m):
+    """potrf_region_kernel (walker, helpers, assistants, thin row streams; flags + write-through publishing) uses no atomics on data: a
+    repeated evaluation must return the same bits -- a missed dependency would show as a differing value (tools/stress_region.py runs the
+    long version, profiles/r03/stress_region.txt)."""
+    import torch
+    from lmm_amd import workloads as W
+    P = W.synthetic_problem(m, 2 * m, n, "matern52", True, s2=0.1, seed=n + m)
+    fs = lmm.independent_mogp([lmm.GP(lmm.Matern52Kernel()) for _ in range(m)])
+    fx = lmm.ILMM(fs, lmm.Orthogonal(P["U"], P["S"]))(lmm.MOInputIsotopicByOutputs(torch.from_numpy(P["x"]).cuda(), 2 * m), 0.1)
+    yd = torch.from_numpy(P["y"]).cuda()
+    vals = {lmm.logpdf(fx, yd) for _ in range(60)}
+    assert len(vals) == 1, vals
