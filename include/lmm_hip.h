@@ -88,7 +88,8 @@ int lmm_release_cached_memory(void);      /* return the caching device-memory po
  *   decoupled dense-H logpdf and (round 3) the OILMM / IndependentMOGP logpdf gradients, prior and predictive
  *   (lmm_oilmm_logpdf_grad, lmm_oilmm_post_logpdf_grad: Float32 factor, triangular inverse and K^-1 on v_mfma_f32, every reduction
  *   Float64; tolerance at sigma2 = 0.1, n ~ 10^3: d/dy, d/dU within 1e-4 of their largest component, d/dsigma2 rtol 1e-4, d/dS and
- *   kernel parameters rtol 2e-3 + 1e-2 absolute -- tests/test_gpu_f32.py); the dense (mn)x(mn) ILMM paths, their gradients and
+ *   kernel parameters rtol 2e-3 + 1e-2 absolute -- tests/test_gpu_f32.py) and the dense (mn)x(mn) ILMM logpdf (lmm_ilmm_logpdf[_ex],
+ *   lmm_ilmm_logpdf_multi: Float32 (mn)x(mn) matrix, rtol 2e-4 on the value); the dense-H posterior paths, the dense-H gradients and
  *   full covariances return LMM_ERR_UNSUPPORTED.
  *   Jitters stay explicit arguments: the reference's 1e-18 / 1e-12 defaults are below Float32 resolution, so prior sampling
  *   needs a caller-chosen jitter (>= ~1e-5 x kernel variance).  A posterior handle remembers the dtype it was built in. */

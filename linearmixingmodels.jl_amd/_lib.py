@@ -122,6 +122,19 @@ def _is_torch(a) -> bool:
     return type(a).__module__.startswith("torch")
 
 
+class _OwnedPtr(C.c_void_p):
+    """A void* that keeps the array it points into alive.  Call sites write `lib.f(Arr(a).ptr, ...)`: the temporary Arr dies as soon as
+    `.ptr` has been read, and with it a converted copy it may own (a transposed (d, n) input, a non-contiguous or non-float64 array)
+    -- the C call would then read freed memory.  (Found by tools/stress_alternate.py: gradients of d = 2 problems were occasionally
+    evaluated on recycled memory; a plain c_void_p holds only the integer.)"""
+
+
+def _ptr_of(addr, owner):
+    p = _OwnedPtr(addr)
+    p._owner = owner
+    return p
+
+
 # id(ndarray) -> (ndarray, pointer, size) of the last few host arrays handed over: taking the address of a NumPy buffer through ctypes
 # costs 2-4 us, several times per call, which shows at n = 200 (an evaluation is ~150 us).  The entry keeps the array alive, so an
 # id cannot be reused by another object while it is cached.
@@ -142,7 +155,7 @@ class Arr:
                     raise ValueError("output tensor must be contiguous")
                 a = a.contiguous()
             self.owner = a
-            self.ptr = C.c_void_p(a.data_ptr())
+            self.ptr = _ptr_of(a.data_ptr(), a)
             self.size = a.numel()
             if a.is_cuda:
                 order_after_torch()
@@ -158,7 +171,7 @@ class Arr:
             elif not ok:
                 a = np.ascontiguousarray(a, dtype=np.float64)
             self.owner = a
-            self.ptr = C.c_void_p(a.ctypes.data)
+            self.ptr = _ptr_of(a.ctypes.data, a)
             self.size = a.size
             if ok:
                 if len(_PTRS) >= 64:

@@ -1632,12 +1632,11 @@ int lmm_ilmm_logpdf_ex(const double* x, int d, int n, const double* y, int p, co
     *out = total + regulariser(resid);
     return LMM_OK;
   }
-  REQUIRE_F64("the dense (mn) x (mn) ILMM factorisation");
   project_on_device(yd.p, n, p, Td.buf, m, 0, m, meansd.buf.p, delta.p, st0);
-  // one dense (mn) x (mn) factorisation: reference src/ilmm.jl:160-162
+  // one dense (mn) x (mn) factorisation: reference src/ilmm.jl:160-162 (fp32 compute mode: a Float32 matrix, as the per-latent paths)
   const int N = m * n;
   Dims D(N, 1);
-  Buf<double> A(D.elems()), W((size_t)(D.NC / 64) * 4096), lml_dev(1);
+  Buf<double> A(mat_count(D.elems())), W(mat_count((size_t)(D.NC / 64) * 4096)), lml_dev(1);
   Buf<int> info(1);
   HIPCHK(hipMemsetAsync(info.p, 0, sizeof(int), st0));
   DenseArgs a{};
@@ -1671,7 +1670,6 @@ int lmm_ilmm_logpdf_multi(const double* x, int d, int n, const double* Y, int p,
   std::lock_guard<std::mutex> lk(g_mu);
   REQUIRE_INIT();
   LMM_TRY
-  REQUIRE_F64("the dense (mn) x (mn) ILMM factorisation");
   if (!x || !Y || !H || !out || d <= 0 || n <= 0 || p <= 0 || m <= 0 || ncol <= 0) return fail(LMM_ERR_ARG, "bad arguments");
   if (int rc = check_gps(gps, m)) return rc;
   if (!(sigma2 > 0.0)) return fail(LMM_ERR_ARG, "sigma2 must be > 0");
@@ -1698,7 +1696,7 @@ int lmm_ilmm_logpdf_multi(const double* x, int d, int n, const double* Y, int p,
     project_on_device(yc, n, p, Td.buf, m, 0, m, meansd.buf.p, delta.p + (size_t)c * N, st0);      // rider c: [latent][point]
   }
   Dims D(N, ncol);
-  Buf<double> A(D.elems()), W((size_t)(D.NC / 64) * 4096);
+  Buf<double> A(mat_count(D.elems())), W(mat_count((size_t)(D.NC / 64) * 4096));
   Buf<int> info(1);
   HIPCHK(hipMemsetAsync(info.p, 0, sizeof(int), st0));
   DenseArgs a{};

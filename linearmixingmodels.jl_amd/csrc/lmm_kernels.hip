@@ -408,6 +408,7 @@ __global__ __launch_bounds__(256) void gram_batch_kernel(GramBatchArgs b) {
 // K8: dense ILMM latent covariance  blockdiag(K_1..K_m) + SigmaT (x) I_n  (+ mean-free rider row):
 // element (i, j), i = li*n + ii, j = lj*n + jj  ->  [li == lj] kappa_li(x_ii, x_jj) + [ii == jj] SigmaT[li, lj].
 // Reference: src/ilmm.jl:160 kron(SigmaT, I) + src/independent_mogp.jl:60-63 BlockDiagonal.
+template <typename TS>
 __global__ __launch_bounds__(256) void ilmm_dense_assemble_kernel(DenseArgs a) {
   const int ti = blockIdx.x, tj = blockIdx.y;
   if (ti < tj) return;
@@ -448,7 +449,7 @@ __global__ __launch_bounds__(256) void ilmm_dense_assemble_kernel(DenseArgs a) {
       }
     }
     d2 v; v.x = out[0]; v.y = out[1];
-    *reinterpret_cast<d2*>(a.A + (size_t)j * a.ld + i0) = v;
+    MatIO<TS>::st2(a.A, (size_t)j * a.ld + i0, v);
   }
 }
 
@@ -3751,7 +3752,7 @@ void launch_dense_cov(const double* S, int lds, int ns, int m, const double* Hm,
 
 void launch_dense_assemble(const DenseArgs& a, hipStream_t st) {
   dim3 grid(a.nrows / 64, a.ncols / 64);
-  hipLaunchKernelGGL(ilmm_dense_assemble_kernel, grid, dim3(256), 0, st, a);
+  LMM_TS_LAUNCH((ilmm_dense_assemble_kernel<TS>), grid, dim3(256), 0, st, a);      // fp32 compute mode: Float32 matrix (the dense logpdf paths)
 }
 
 // ---- round 3: 128-column panels (leaf128 / bulk) and the update fused with the next panel's leaf (K2c) ----

@@ -140,6 +140,25 @@ def test_f32_oilmm_logpdf_posterior_marginals_rand_vs_f64_oracle(lmm32, kind, n,
     np.testing.assert_allclose(s0, (O.orthogonal_dense(U, S) @ X).reshape(-1) + math.sqrt(0.1) * eps, rtol=20 * RTOL32, atol=20 * RTOL32)
 
 
+def test_f32_dense_ilmm_logpdf(lmm32):
+    """logpdf of a dense-H ILMM with DIFFERENT latent kernels (the reference's single (mn) x (mn) factorisation, src/ilmm.jl:150-163) and
+    its matrix-Y form in the fp32 compute mode (Float32 (mn) x (mn) matrix, Float64 projections and reductions) against the Float64
+    oracle.  Tolerance: RTOL32 on the value (the quadratic form and the log-determinant are sums over mn Float32 pivots)."""
+    lmm = lmm32
+    rng = np.random.default_rng(8)
+    n, p, m = 180, 5, 3
+    x = np.sort(rng.uniform(0, 8, n))
+    gps = [{"kind": k, "variance": 0.8 + 0.2 * l, "lengthscale": 0.9 + 0.3 * l, "mean": 0.1 * l} for l, k in enumerate(["se", "matern32", "matern52"])]
+    H = rng.standard_normal((p, m))
+    y = rng.standard_normal(n * p)
+    fx = lmm.ILMM(_model(lmm, gps), H)(lmm.MOInputIsotopicByOutputs(x, p), 0.3)
+    ref = O.ilmm_logpdf(gps, H, x, 0.3, y)
+    assert lmm.logpdf(fx, y) == pytest.approx(ref, rel=RTOL32)
+    Y = rng.standard_normal((n * p, 3))
+    got = lmm.logpdf(fx, Y)
+    np.testing.assert_allclose(got, [O.ilmm_logpdf(gps, H, x, 0.3, Y[:, c]) for c in range(3)], rtol=RTOL32)
+
+
 def test_f32_mode_boundaries(lmm32):
     """Handles remember their dtype; unsupported paths say so instead of computing in the wrong precision; switching back to
     Float64 restores the parity mode bit for bit."""

@@ -532,3 +532,25 @@ def test_region_kernel_is_bitwise_reproducible(lmm, n, m):
     yd = torch.from_numpy(P["y"]).cuda()
     vals = {lmm.logpdf(fx, yd) for _ in range(60)}
     assert len(vals) == 1, vals
+
+
+def test_alternating_problems_never_see_recycled_memory(lmm):
+    """Different problems of the same shapes in turn (tools/stress_alternate.py, short form): whatever a recycled host or device buffer
+    still holds from the previous call is wrong for the current one, so a pointer that outlives its array, or a consumer that reads
+    ahead of its producer, changes the value.  (Found that way: the mirror handed the C ABI pointers into temporaries -- the transposed
+    copy of a (d, n) input -- that died before the call; _lib._OwnedPtr keeps them alive.)"""
+    def problem(seed, n, d, p=4, m=3):
+        rng = np.random.default_rng(seed)
+        x = np.sort(rng.uniform(0, 6, n)) if d == 1 else rng.uniform(0, 4, size=(d, n))
+        kinds = [lmm.Matern52Kernel, lmm.SEKernel, lmm.Matern32Kernel]
+        gps = [lmm.GP(float(rng.normal()), kinds[l % 3](float(rng.uniform(0.5, 2.0)), float(rng.uniform(0.5, 2.0)))) for l in range(m)]
+        U, S, _ = np.linalg.svd(rng.uniform(size=(p, m)), full_matrices=False)
+        return lmm.ILMM(lmm.independent_mogp(gps), lmm.Orthogonal(U, S))(lmm.MOInputIsotopicByOutputs(x, p), 0.3), rng.standard_normal(n * p)
+    probs = [problem(17 * i + n, n, d) for i, (n, d) in enumerate([(130, 2), (150, 1), (130, 1), (150, 2)])]
+    ref = [(lmm.logpdf(fx, y), lmm.logpdf_and_gradient(fx, y)["value"]) for fx, y in probs]
+    for fx, y in probs:                 # the two entry points agree to begin with
+        assert lmm.logpdf(fx, y) == pytest.approx(lmm.logpdf_and_gradient(fx, y)["value"], rel=1e-12)
+    for it in range(150):
+        for k, (fx, y) in enumerate(probs):
+            v = lmm.logpdf(fx, y) if it % 2 == 0 else lmm.logpdf_and_gradient(fx, y)["value"]
+            assert v == ref[k][it % 2], (it, k, v, ref[k])
