@@ -104,7 +104,7 @@ int lmm_get_compute_dtype(void);
  *     v_mfma_f32_16x16x32_bf16 with Float32 accumulation; sigma2 is added in Float64.  STATED TOLERANCE: each operand carries a
  *     relative rounding error <= 2^-8 (bfloat16 keeps 8 significant bits), so |M - M_f64| <= 2^-7 * sum_l |H[o,l]| |M_latent[l,s]| (plus Float32 accumulation,
  *     ~m 2^-24) and likewise for V; the latent marginals themselves (Gram, Cholesky, triangular solves) stay in the compute dtype.
- *   LMM_PROJ_BF16X2: the same pipe with each operand split into two bfloat16 terms (hi + lo), three MFMA products: error ~2^-16. */
+ *   LMM_PROJ_BF16X2: the same pipe with each operand split into two bfloat16 terms (hi + lo), three MFMA products: error <= 2^-15 * sum_l |H||M_lat| (the dropped lo*lo term and the rounding of the lo parts are ~2^-16; Float32 accumulation on top). */
 typedef enum { LMM_PROJ_NATIVE = 0, LMM_PROJ_BF16 = 1, LMM_PROJ_BF16X2 = 2 } lmm_proj_dtype;
 int lmm_set_projection_dtype(int dtype);
 int lmm_get_projection_dtype(void);
@@ -338,6 +338,15 @@ int lmm_lmm_rand_multi(const lmm_post_t* post, const lmm_gp_t* gps,
  * rows >= ncols ride along (become A21 * L11^-T).  nrows, ncols multiples of 64.  Winv: ncols/64 dense
  * 64x64 inverse diagonal blocks (scratch / output).  info: device int (0 = ok, k = pivot k failed). */
 int lmm_dev_potrf(double* A, int nrows, int ncols, int ld, double* Winv, int n_real, int* info_dev);
+/* Host-only (no GPU needed): the status the library derives from `count` pivot-info words of a batch -- LMM_OK; LMM_ERR_NOT_PD for
+ * the first non-zero word (lmm_last_error_detail: latent_begin + index, pivot; reference: `cholesky` throwing PosDefException inside
+ * src/oilmm.jl:90 / AbstractGPs logpdf); LMM_ERR_HIP when ANY word carries -7777, the marker potrf_region_kernel leaves when one of
+ * its bounded dependency waits timed out (never expected; results are then undefined and must not be read as a PosDefException). */
+int lmm_dev_check_info(const int* info, int count, int latent_begin);
+/* Test hook of the allocation-extent guard (lmm_api.hip guard_extent: every Gram / triangular-solve / Schur-complement / factorisation
+ * launch site checks the rows x cols (ld) block it touches against the pooled allocation the pointer lies in and returns LMM_ERR_ARG
+ * instead of launching): applies it to a fresh pooled block of alloc_bytes, a block of Float64 elements. */
+int lmm_dev_extent_check(size_t alloc_bytes, size_t rows, size_t ld, size_t cols);
 /* C[MxN] -= A[MxK] * B[NxK]^T (column-major, device). lower != 0: only tiles on/below the diagonal. */
 int lmm_dev_gemm_nt_sub(double* C, int ldc, const double* A, int lda, const double* B, int ldb,
                         int M, int N, int K, int lower);

@@ -24,7 +24,7 @@ SYMBOLS = [
     "lmm_oilmm_posterior_create", "lmm_mogp_posterior_create", "lmm_post_condition", "lmm_ilmm_posterior_create", "lmm_post_destroy", "lmm_ilmm_post_latent_view", "lmm_ilmm_post_mean_and_var", "lmm_ilmm_post_mean_and_cov", "lmm_ilmm_post_condition", "lmm_ilmm_post_logpdf", "lmm_ilmm_post_rand",
     "lmm_latent_marginals", "lmm_oilmm_mean_and_var", "lmm_lmm_mean_and_cov", "lmm_oilmm_post_logpdf", "lmm_lmm_rand", "lmm_lmm_rand_multi", "lmm_normals",
     "lmm_profile_begin", "lmm_profile_end",
-    "lmm_dev_potrf", "lmm_dev_gemm_nt_sub", "lmm_dev_gram", "lmm_dev_mfma_f64_peak",
+    "lmm_dev_potrf", "lmm_dev_check_info", "lmm_dev_extent_check", "lmm_dev_gemm_nt_sub", "lmm_dev_gram", "lmm_dev_mfma_f64_peak",
 ]
 
 
@@ -135,10 +135,14 @@ def _ptr_of(addr, owner):
     return p
 
 
-# id(ndarray) -> (ndarray, pointer, size) of the last few host arrays handed over: taking the address of a NumPy buffer through ctypes
-# costs 2-4 us, several times per call, which shows at n = 200 (an evaluation is ~150 us).  The entry keeps the array alive, so an
-# id cannot be reused by another object while it is cached.
+# id(ndarray) -> (ndarray, pointer, size) of the last few SMALL read-only host arrays handed over (model matrices, inputs of the
+# reference's regime): taking the address of a NumPy buffer through ctypes costs 2-4 us, several times per call, which shows at
+# n = 200 (an evaluation is ~140 us).  The entry keeps the array alive, so an id cannot be reused by another object while it is
+# cached; it is only trusted while the array still has the size it was cached with (an in-place ndarray.resize, the one way a live
+# array's buffer moves, changes it).  Outputs, temporaries of conversions and anything above _PTRS_MAX_ELEMS are never inserted, so
+# the cache cannot pin large buffers the caller has dropped.
 _PTRS: dict = {}
+_PTRS_MAX_ELEMS = 1 << 16
 
 
 class Arr:
@@ -160,8 +164,8 @@ class Arr:
             if a.is_cuda:
                 order_after_torch()
         else:
-            hit = _PTRS.get(id(a))
-            if hit is not None and hit[0] is a:         # the same ndarray object as before: its buffer address cannot have changed
+            hit = None if writable else _PTRS.get(id(a))
+            if hit is not None and hit[0] is a and a.size == hit[2]:      # the same, un-resized ndarray object as before
                 self.owner, self.ptr, self.size = hit
                 return
             ok = type(a) is np.ndarray and a.dtype == np.float64 and a.flags.c_contiguous
@@ -173,7 +177,7 @@ class Arr:
             self.owner = a
             self.ptr = _ptr_of(a.ctypes.data, a)
             self.size = a.size
-            if ok:
+            if ok and not writable and a.size <= _PTRS_MAX_ELEMS:
                 if len(_PTRS) >= 64:
                     _PTRS.clear()
                 _PTRS[id(a)] = (a, self.ptr, self.size)

@@ -202,6 +202,55 @@ inline size_t mat_count(size_t elems) { return g_f32 ? (elems + 1) / 2 : elems; 
 inline double mat_bytes(double elems) { return elems * (g_f32 ? 4.0 : 8.0); }
 #define REQUIRE_F64(what) if (g_f32) return fail(LMM_ERR_UNSUPPORTED, what " is not built for the fp32 compute mode (lmm_set_compute_dtype)")
 
+// ---- allocation-extent guard -------------------------------------------------------------------------------------------------
+// Every launch below that reads or writes a rows x cols block (leading dimension ld) of a POOLED buffer is preceded by this check of
+// the block against the allocation the pointer lies in: a mismatch between two roundings of the same size (round 3: cross-solve
+// blocks kept rup(n*, 64) rows while the Schur complement read rup(n*, 128) of them -- an out-of-bounds device read at n* = 9 that a
+// later run hid) becomes LMM_ERR_ARG before anything is launched, instead of a fault.  Pointers outside the pool (caller memory)
+// are not checked.  matrix: the block is in the compute dtype (Float32 elements in the fp32 mode), else Float64.
+void guard_extent(const void* p, size_t rows, size_t ld, size_t cols, bool matrix, const char* what) {
+  if (p == nullptr || rows == 0 || cols == 0) return;
+  auto it = g.live.upper_bound(const_cast<void*>(p));
+  if (it == g.live.begin()) return;
+  --it;
+  const char* b0 = static_cast<const char*>(it->first);
+  const char* b1 = b0 + it->second;
+  const char* q = static_cast<const char*>(p);
+  if (q >= b1) return;                                   // not inside a pooled block
+  const size_t eb = (matrix && g_f32) ? 4 : 8;
+  const size_t need = ((cols - 1) * ld + rows) * eb;
+  if (rows > ld || q + need > b1)
+    throw fail(LMM_ERR_ARG, "internal extent check failed: %s touches %zu x %zu (ld %zu) = %zu bytes at offset %zu of a %zu-byte allocation",
+               what, rows, cols, ld, need, (size_t)(q - b0), it->second);
+}
+void guard_gram(const GramArgs& a, const char* what) { guard_extent(a.A, (size_t)a.nrows, (size_t)a.ld, (size_t)a.ncols, true, what); }
+void gram_g(const GramArgs& a, hipStream_t st, const char* what = "Gram assembly") { guard_gram(a, what); launch_gram(a, st); }
+void gram_batch_g(const GramArgs* ga, int nb, hipStream_t st, const char* what = "Gram assembly") {
+  for (int j = 0; j < nb; ++j) guard_gram(ga[j], what);
+  launch_gram_batch(ga, nb, st);
+}
+// C (M x N, ldc) -= A (M x K, lda) B (N x K, ldb)'
+void gemm_nt_g(double* C, int ldc, const double* A, int lda, const double* B, int ldb, int M, int N, int K, int lower, bool set,
+               hipStream_t st, const char* what) {
+  guard_extent(C, M, ldc, N, true, what); guard_extent(A, M, lda, K, true, what); guard_extent(B, N, ldb, K, true, what);
+  launch_gemm_nt(C, ldc, A, lda, B, ldb, M, N, K, lower, set, st);
+}
+void gemm_nt_g(const BatchPtr& C, size_t offC, int ldc, const BatchPtr& A, size_t offA, int lda, const BatchPtr& B, size_t offB, int ldb,
+               int M, int N, int K, int lower, bool set, int nb, hipStream_t st, const char* what) {
+  const size_t eb = g_f32 ? 4 : 8;
+  for (int j = 0; j < nb; ++j) {
+    guard_extent(reinterpret_cast<const char*>(C.p[j]) + offC * eb, M, ldc, N, true, what);
+    guard_extent(reinterpret_cast<const char*>(A.p[j]) + offA * eb, M, lda, K, true, what);
+    guard_extent(reinterpret_cast<const char*>(B.p[j]) + offB * eb, N, ldb, K, true, what);
+  }
+  launch_gemm_nt(C, offC, ldc, A, offA, lda, B, offB, ldb, M, N, K, lower, set, nb, st);
+}
+void rider_stats_g(const double* R, int ld, int nr, int nk, const double* z, double mu, double base, double* partial,
+                   double* mean_out, double* var_out, hipStream_t st) {
+  if (R) guard_extent(R, nr, ld, nk, true, "rider statistics (R)");
+  launch_rider_stats(R, ld, nr, nk, z, mu, base, partial, mean_out, var_out, st);
+}
+
 // Brackets one launch with events when profiling is on (lmm_profile_begin); otherwise just launches.
 struct ProfScope {
   bool on; hipStream_t st; size_t idx;
@@ -370,6 +419,10 @@ void potrf_rec_panel(const Batch& B, const BatchPtr& W2, const BatchInfo& flags,
 // Entry point of the factorisation of a batch: columns [0, NC) of every matrix.  Float64 batches take the 128-column panel path
 // (LMM_PANEL128=0: the round-2 path); its W2 scratch -- one 128 x 128 inverse per panel and matrix -- lives until the API call ends.
 void potrf_batch(const Batch& B, int ld, int NR, int NC, int n_real, hipStream_t st, int rows_real = -1) {
+  for (int j = 0; j < B.nb; ++j) {
+    guard_extent(B.A.p[j], NR, ld, NC, true, "factorisation (factor matrix)");
+    guard_extent(B.W.p[j], 64, 64, (size_t)(NC / 64) * 64, true, "factorisation (inverse diagonal blocks)");
+  }
   static int panel128 = -1;
   if (panel128 < 0) { const char* e = getenv("LMM_PANEL128"); panel128 = e ? (atoi(e) != 0) : 1; }
   if (g_f32 || !panel128 || NC < 128 || (ld & 1)) { potrf_rec(B, ld, NR, 0, NC, n_real, st); return; }
@@ -446,7 +499,12 @@ void potrf_rec(double* A, int ld, int NR, int j0, int w, double* W, int n_real, 
 // tri: R starts as the identity and becomes the upper triangular L^-T; rows below the current column block are still
 // zero and are skipped (~n^3/3 flops instead of n^3 for a rectangular solve).
 void trsm_rec(double* R, int ldr, int nr, const double* L, int ld, const double* W, int j0, int w, hipStream_t st,
-              bool tri = false) {
+              bool tri = false, bool top = true) {
+  if (top) {          // rows / columns this solve touches against the allocations (checked once, not per recursion level)
+    guard_extent(R, nr, ldr, (size_t)j0 + w, true, "triangular solve (R)");
+    guard_extent(L, (size_t)j0 + w, ld, (size_t)j0 + w, true, "triangular solve (L)");
+    guard_extent(W, 64, 64, (size_t)((j0 + w) / 64) * 64, true, "triangular solve (inverse blocks)");
+  }
   if (w <= 64) {
     const int rows = tri ? std::min(nr, j0 + 64) : nr;
     double* pan = R + (size_t)j0 * ldr;
@@ -454,28 +512,34 @@ void trsm_rec(double* R, int ldr, int nr, const double* L, int ld, const double*
     return;
   }
   const int h = split(w);
-  trsm_rec(R, ldr, nr, L, ld, W, j0, h, st, tri);
+  trsm_rec(R, ldr, nr, L, ld, W, j0, h, st, tri, false);
   // tri: the left block R[:, j0:j0+h] is upper triangular (zero below row j0+h), so only rows < j0+h contribute
   const int rows = tri ? std::min(nr, j0 + h) : nr;
   launch_gemm_nt(R + (size_t)(j0 + h) * ldr, ldr, R + (size_t)j0 * ldr, ldr, L + (size_t)j0 * ld + (j0 + h), ld,
                  rows, w - h, h, 0, false, st);
-  trsm_rec(R, ldr, nr, L, ld, W, j0 + h, w - h, st, tri);
+  trsm_rec(R, ldr, nr, L, ld, W, j0 + h, w - h, st, tri, false);
 }
 
 // The same solve for a batch of (R_j, L_j, W_j) of identical shapes in lock-step launches (blockIdx.y = matrix).
 void trsm_rec(const BatchPtr& R, int ldr, int nr, const BatchPtr& L, int ld, const BatchPtr& W, int nb, int j0, int w,
-              hipStream_t st, bool tri = false) {
+              hipStream_t st, bool tri = false, bool top = true) {
+  if (top)
+    for (int j = 0; j < nb; ++j) {
+      guard_extent(R.p[j], nr, ldr, (size_t)j0 + w, true, "batched triangular solve (R)");
+      guard_extent(L.p[j], (size_t)j0 + w, ld, (size_t)j0 + w, true, "batched triangular solve (L)");
+      guard_extent(W.p[j], 64, 64, (size_t)((j0 + w) / 64) * 64, true, "batched triangular solve (inverse blocks)");
+    }
   if (w <= 64) {
     const int rows = tri ? std::min(nr, j0 + 64) : nr;
     launch_gemm_nt(R, (size_t)j0 * ldr, ldr, R, (size_t)j0 * ldr, ldr, W, (size_t)(j0 / 64) * 4096, 64, rows, 64, 64, 0, true, nb, st);
     return;
   }
   const int h = split(w);
-  trsm_rec(R, ldr, nr, L, ld, W, nb, j0, h, st, tri);
+  trsm_rec(R, ldr, nr, L, ld, W, nb, j0, h, st, tri, false);
   const int rows = tri ? std::min(nr, j0 + h) : nr;
   launch_gemm_nt(R, (size_t)(j0 + h) * ldr, ldr, R, (size_t)j0 * ldr, ldr, L, (size_t)j0 * ld + (j0 + h), ld, rows, w - h, h, 0, false,
                  nb, st);
-  trsm_rec(R, ldr, nr, L, ld, W, nb, j0 + h, w - h, st, tri);
+  trsm_rec(R, ldr, nr, L, ld, W, nb, j0 + h, w - h, st, tri, false);
 }
 
 // alpha (in place over z = L^-1 delta) <- L^-T z for one factor matrix
@@ -556,22 +620,25 @@ void join_slots(int count) {       // main stream waits for every slot stream
   }
 }
 
-int check_info(const std::vector<int>& info, int latent_begin) {
-  for (size_t k = 0; k < info.size(); ++k) {
-    if (info[k] == LMM_INFO_SYNC_TIMEOUT) {
-      if (g.region_flags) (void)hipMemset(g.region_flags, 0, region_flag_ints(0) * (size_t)LMM_MAX_BATCH * kMaxStreams * sizeof(int));     // lower the abort words
+// Pivot-info words of a batch -> status.  A dependency-wait timeout of potrf_region_kernel (LMM_INFO_SYNC_TIMEOUT in ANY word) outranks
+// a PosDefException in an earlier latent: it means the launch was drained with results undefined, which must never be reported as a
+// property of the caller's matrix.  (The abort words the kernel raised are epoch-tagged, so they need no reset: a later launch never
+// matches them.)
+int check_info(const int* info, size_t count, int latent_begin) {
+  for (size_t k = 0; k < count; ++k)
+    if (info[k] == LMM_INFO_SYNC_TIMEOUT)
       return fail(LMM_ERR_HIP, "potrf_region_kernel: a dependency wait timed out (latent %d); the grid was drained, results are invalid",
                   latent_begin + (int)k);
-    }
+  for (size_t k = 0; k < count; ++k)
     if (info[k] != 0) {
       g.err_latent = latent_begin + (int)k;
       g.err_info = info[k];
       return fail(LMM_ERR_NOT_PD, "PosDefException: matrix is not positive definite; Cholesky factorization failed "
                                   "(latent %d, pivot %d)", g.err_latent, g.err_info);
     }
-  }
   return LMM_OK;
 }
+int check_info(const std::vector<int>& info, int latent_begin) { return check_info(info.data(), info.size(), latent_begin); }
 
 // ------------------------------------------------------------------------------------------------
 // host-side small dense algebra (m, p <= a few hundred): projections and regulariser scalars
@@ -795,7 +862,7 @@ int latent_lmls(const double* xd, int d, int n, const lmm_gp_t* gps, const doubl
       B.add(s.A[j].p, s.W[j].p, info.p + k);
     }
     if (bi > 0 && g_stagger_recorded) HIPCHK(hipStreamWaitEvent(s.st, g_stagger_ev, 0));      // start behind the previous batch's first long update
-    launch_gram_batch(ga, nb, s.st);       // one launch per run of equal kernel kinds (blockIdx.z = latent)
+    gram_batch_g(ga, nb, s.st);       // one launch per run of equal kernel kinds (blockIdx.z = latent)
     }
     {
       static int stagger = -1;
@@ -1227,7 +1294,7 @@ int oilmm_grad_core(const double* xd, int d, int N, int nsplit, const double* yd
       B.add(Am[s][j].p, Wm[s][j].p, info.p + k);
       Rb.p[j] = Rm[s][j].p; alb.p[j] = alpha.p + (size_t)k * D.NC;
     }
-    launch_gram_batch(ga, nb, st);
+    gram_batch_g(ga, nb, st);
     potrf_batch(B, D.ld, D.NR, D.NC, n, st, D.NC + 1);        // one rider row (delta); rows NC + 1 .. NR - 1 are zero padding
     launch_lml_reduce(B.A, nb, D.ld, n, D.NC, 1, lmld.p + k0, st);
     for (int j = 0; j < nb; ++j) {
@@ -2070,7 +2137,7 @@ static int posterior_create_common(const double* xd, int d, int n, const lmm_gp_
         ga[j] = a;
         B.add(P->L[k].p, P->W[k].p, info.p + k);
       }
-      launch_gram_batch(ga, nb, st);
+      gram_batch_g(ga, nb, st);
       potrf_batch(B, D.ld, D.NR, D.NC, n, st, D.NC + 1);        // one rider row (delta); rows NC + 1 .. NR - 1 are zero padding
       // alpha = L^-T (L^-1 delta): the rider row is z = L^-1 delta (kept as P->z, zero-padded to NC)
       BatchPtr ab{}, zb{};
@@ -2337,7 +2404,7 @@ static void dense_post_cov_factor(const lmm_post* P, const double* xsd, int d, i
   launch_dense_assemble(a, st);
   launch_dense_cross(R, ldr, Ds.NC, P->NC, xsd, ns, D->x.p, P->n, d, m, D->latd.p, st);
   trsm_rec(R, ldr, Ds.NC, D->L[0].p, P->ld, D->W[0].p, 0, P->NC, st);
-  launch_gemm_nt(A, Ds.ld, R, ldr, R, ldr, Ds.NC, Ds.NC, P->NC, 1, false, st);
+  gemm_nt_g(A, Ds.ld, R, ldr, R, ldr, Ds.NC, Ds.NC, P->NC, 1, false, st, "Schur complement (dense-H posterior covariance)");
   if (factor) potrf_rec(A, Ds.ld, Ds.NR, 0, Ds.NC, WA, m * ns, info, st);
 }
 
@@ -2520,7 +2587,7 @@ static GramArgs cross_gram_args(const lmm_post* P, const lmm_gp_t& gp, const dou
 }
 static void cross_gram(const lmm_post* P, const lmm_gp_t& gp, const double* xsd, int d, int ns, double* Rk, int ldr, int nsr,
                        hipStream_t st) {
-  launch_gram(cross_gram_args(P, gp, xsd, d, ns, Rk, ldr, nsr), st);
+  gram_g(cross_gram_args(P, gp, xsd, d, ns, Rk, ldr, nsr), st);
 }
 
 // Latent marginals (mean, var) of latents [l0, l1) at xs into device arrays (ns per latent).
@@ -2533,7 +2600,7 @@ static int latent_marginals_dev(const lmm_post* P, const lmm_gp_t* gps_shard, in
     for (int k = 0; k < ms; ++k) {
       LatentDev gd = to_dev(gps_shard[k]);
       // prior: constant mean, variance kappa(0)
-      launch_rider_stats(nullptr, 0, ns, 0, nullptr, gd.mean, gps_shard[k].variance, nullptr, mean_lat + (size_t)k * ns,
+      rider_stats_g(nullptr, 0, ns, 0, nullptr, gd.mean, gps_shard[k].variance, nullptr, mean_lat + (size_t)k * ns,
                          var_lat + (size_t)k * ns, g.streams[0]);
     }
     return LMM_OK;
@@ -2561,13 +2628,13 @@ static int latent_marginals_dev(const lmm_post* P, const lmm_gp_t* gps_shard, in
       ga[j] = cross_gram_args(P, P->gps[P->l0 + k], xsd, d, ns, R[s][j].p, ldr, nsr);
       Rb.p[j] = R[s][j].p; Lb.p[j] = P->L[k].p; Wb.p[j] = P->W[k].p;
     }
-    launch_gram_batch(ga, nb, st);
+    gram_batch_g(ga, nb, st);
     trsm_rec(Rb, ldr, nsr, Lb, P->ld, Wb, nb, 0, P->NC, st);       // R_j <- K(x*, x) L_j^-T for the whole batch
     for (int j = 0; j < nb; ++j) {
       const int k = k0 + j;
       const lmm_gp_t& gp = P->gps[P->l0 + k];
       // mean = mu + K(x*,x) alpha = mu + R' (L^-1 delta);  var = kappa(0) - colsumsq(R)   (one pass over R)
-      launch_rider_stats(R[s][j].p, ldr, ns, P->n, P->z[k].p, gp.mean, gp.variance, part[s].p, mean_lat + (size_t)k * ns,
+      rider_stats_g(R[s][j].p, ldr, ns, P->n, P->z[k].p, gp.mean, gp.variance, part[s].p, mean_lat + (size_t)k * ns,
                          var_lat + (size_t)k * ns, st);
     }
   }
@@ -2669,15 +2736,15 @@ static GramArgs cov_args(const lmm_gp_t& gp, const double* xsd, int d, int ns, d
 }
 static void cov_at_xs(const lmm_post* P, const lmm_gp_t& gp, const double* xsd, int d, int ns, double diag_add,
                       const double* rider_vec, const Dims& Ds, double* B, const double* Rk, int ldr, hipStream_t st) {
-  launch_gram(cov_args(gp, xsd, d, ns, diag_add, rider_vec, Ds, B), st);
+  gram_g(cov_args(gp, xsd, d, ns, diag_add, rider_vec, Ds, B), st);
   // Schur complement on the leading NCs x NCs block (rows of R beyond ns are zero)
-  if (P != nullptr) launch_gemm_nt(B, Ds.ld, Rk, ldr, Rk, ldr, Ds.NC, Ds.NC, P->NC, 1, false, st);
+  if (P != nullptr) gemm_nt_g(B, Ds.ld, Rk, ldr, Rk, ldr, Ds.NC, Ds.NC, P->NC, 1, false, st, "Schur complement (posterior covariance at xs)");
 }
 // The same for the nb latents of a batch: one Gram launch per run of equal kinds, ONE batched Schur-complement GEMM.
 static void cov_at_xs_batch(const lmm_post* P, const GramArgs* ga, int nb, const Dims& Ds, const BatchPtr& Bb, const BatchPtr& Rb,
                             int ldr, hipStream_t st) {
-  launch_gram_batch(ga, nb, st);
-  if (P != nullptr) launch_gemm_nt(Bb, 0, Ds.ld, Rb, 0, ldr, Rb, 0, ldr, Ds.NC, Ds.NC, P->NC, 1, false, nb, st);
+  gram_batch_g(ga, nb, st);
+  if (P != nullptr) gemm_nt_g(Bb, 0, Ds.ld, Rb, 0, ldr, Rb, 0, ldr, Ds.NC, Ds.NC, P->NC, 1, false, nb, st, "batched Schur complement (posterior covariance at xs)");
 }
 
 // Working buffers of the batched "covariance at xs" loops (rand, posterior logpdf): per stream slot nb_per factor matrices
@@ -2709,10 +2776,10 @@ struct XsSlots {
       ga[j] = cross_gram_args(P, P->gps[P->l0 + k0 + j], xsd, d, ns, R[s][j].p, ldr, nsr);
       Rb.p[j] = R[s][j].p; Lb.p[j] = P->L[k0 + j].p; Wb.p[j] = P->W[k0 + j].p;
     }
-    launch_gram_batch(ga, nb, st);
+    gram_batch_g(ga, nb, st);
     trsm_rec(Rb, ldr, nsr, Lb, P->ld, Wb, nb, 0, P->NC, st);
     for (int j = 0; j < nb; ++j)
-      launch_rider_stats(R[s][j].p, ldr, ns, P->n, P->z[k0 + j].p, P->gps[P->l0 + k0 + j].mean, 0.0, part[s].p, mu[s][j].p, nullptr, st);
+      rider_stats_g(R[s][j].p, ldr, ns, P->n, P->z[k0 + j].p, P->gps[P->l0 + k0 + j].mean, 0.0, part[s].p, mu[s][j].p, nullptr, st);
   }
 };
 
@@ -2763,7 +2830,7 @@ extern "C" int lmm_lmm_mean_and_cov(const lmm_post_t* post, const lmm_gp_t* gps,
       const int k = k0 + j;
       const lmm_gp_t& gp = P ? P->gps[l0 + k] : gps[l0 + k];
       if (P) cross_solve(P, k, gp, xsd.p, d, ns, R.p, ldr, nsr, st0);
-      launch_rider_stats(P ? R.p : nullptr, ldr, ns, P ? P->n : 0, P ? P->z[k].p : nullptr, gp.mean, 0.0, part.p,
+      rider_stats_g(P ? R.p : nullptr, ldr, ns, P ? P->n : 0, P ? P->z[k].p : nullptr, gp.mean, 0.0, part.p,
                          ml.p + (size_t)k * ns, nullptr, st0);
       cov_at_xs(P, gp, xsd.p, d, ns, 0.0, nullptr, Ds, Cm[j].p, R.p, ldr, st0);
       cl.p[j] = Cm[j].p;
@@ -2967,9 +3034,34 @@ int lmm_dev_potrf(double* A, int nrows, int ncols, int ld, double* Winv, int n_r
   if (!A || !Winv || !info_dev || nrows % 64 || ncols % 64 || nrows < ncols || ld < nrows || (ld & 1))
     return fail(LMM_ERR_ARG, "bad arguments");
   potrf_rec(A, ld, nrows, 0, ncols, Winv, n_real, info_dev, g.streams[0]);
+  int hinfo = 0;
+  HIPCHK(hipMemcpyAsync(&hinfo, info_dev, sizeof(int), hipMemcpyDeviceToHost, g.streams[0]));
   HIPCHK(hipStreamSynchronize(g.streams[0]));
+  // a dependency-wait timeout is an error of the launch (LMM_ERR_HIP); a non-positive pivot stays in *info_dev for the caller, as before
+  if (hinfo == LMM_INFO_SYNC_TIMEOUT) return check_info(&hinfo, 1, 0);
   return LMM_OK;
   LMM_CATCH
+}
+
+// The allocation-extent guard on a freshly pooled block of alloc_bytes: LMM_OK when a rows x cols block of doubles with leading
+// dimension ld fits, LMM_ERR_ARG (and nothing launched) when it does not.  Exists so that the guard itself has a test.
+int lmm_dev_extent_check(size_t alloc_bytes, size_t rows, size_t ld, size_t cols) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  REQUIRE_INIT();
+  LMM_TRY
+  Buf<double> blk((alloc_bytes + 7) / 8);
+  guard_extent(blk.p, rows, ld, cols, false, "lmm_dev_extent_check");
+  return LMM_OK;
+  LMM_CATCH
+}
+
+// Host-only (no GPU, no lmm_init needed): the status the library derives from `count` pivot-info words -- LMM_OK, LMM_ERR_NOT_PD
+// (first non-zero word; lmm_last_error_detail gives latent_begin + index and the pivot) or LMM_ERR_HIP when ANY word carries the
+// region kernel's dependency-timeout marker (-7777), whichever position it is in.  Exists so that this translation has a test.
+int lmm_dev_check_info(const int* info, int count, int latent_begin) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!info || count < 0) return fail(LMM_ERR_ARG, "bad arguments");
+  return check_info(info, (size_t)count, latent_begin);
 }
 
 int lmm_dev_gemm_nt_sub(double* C, int ldc, const double* A, int lda, const double* B, int ldb, int M, int N, int K,
@@ -2998,7 +3090,7 @@ int lmm_dev_gram(double* A, int ld, int nrows, int ncols, const double* x, int d
   GramArgs a{};
   a.A = A; a.ld = ld; a.nrows = nrows; a.ncols = ncols; a.x = x; a.d = d; a.n = n;
   a.kind = gp->kind; a.var = gp->variance; a.inv_ls = 1.0 / gp->lengthscale; a.diag_add = diag_add; a.pad_diag = 1.0;
-  launch_gram(a, g.streams[0]);
+  gram_g(a, g.streams[0]);
   HIPCHK(hipStreamSynchronize(g.streams[0]));
   return LMM_OK;
   LMM_CATCH

@@ -93,6 +93,10 @@ struct RegionArgs {
 #define LMM_REGION_ASST_MIN_C 4           // a helper's product for column block c >= this is split with its row's assistant
 #define LMM_REGION_ASST_MIN_R (LMM_REGION_ASST_MIN_C + 2)
 #define LMM_REGION_ASST_TILES ((2 * LMM_REGION_MAX_PANELS - LMM_REGION_ASST_MIN_R) * 16)
+// Bound of every dependency spin of the dataflow kernels, in ticks of the 100 MHz wall clock (4 s).  The deadlock argument (a workgroup
+// only waits for workgroups dispatched before it, the walker excepted) covers one launch on an otherwise free device; kernels of other
+// streams holding CUs or a serialising profiler can delay the one later-dispatched workgroup a walker waits for, hence seconds, not ms.
+#define LMM_REGION_SPIN_TICKS 400000000LL
 #define LMM_INFO_SYNC_TIMEOUT (-7777)     // pivot-info value a region launch leaves when a dependency wait timed out (never expected)
 void region_flags_register(int* base, size_t ints);     // the context's persistent flag array (cleared when the launch epoch wraps)
 size_t region_flag_ints(int NR);          // ints per matrix that the flags of any region of a matrix with NR rows need

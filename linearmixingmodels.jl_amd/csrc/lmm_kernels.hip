@@ -1988,16 +1988,22 @@ __device__ __forceinline__ void wg_mm64(const double* __restrict__ As, int sai, 
 }
 
 // ---- flags of a region launch (per matrix, ints; every value is epoch * 32 + count, so words left by earlier launches never match):
-//   [0] abort word (plain 0 / 1)      [1] wk: blocks the WALKER has finished -- count r means W_0 .. W_{r-1} and L[c, c-1], c <= r, are final
+//   [0] abort word (epoch * 32 + 1 when raised)      [1] wk: blocks the WALKER has finished -- count r means W_0 .. W_{r-1} and L[c, c-1], c <= r, are final
 //   [2 + r]  trs[r]:  64-column blocks of square row r that its HELPER has solved (count k + 1: L[r, 0 .. k] final), r >= 2
 //   [18 + r] upd[r]:  steps whose updates helper r has applied to its two rightmost tiles (r, r-1), (r, r) -- what the walker waits for
 //   [34 + j] dinv[j]: the 128 x 128 inverse of panel j is in the W2 scratch (count 0)
-// A wait spins on thread 0 (bounded: 1 s of the 100 MHz wall clock, or until another workgroup raised the abort word -- the grid
+// A wait spins on thread 0 (bounded: LMM_REGION_SPIN_TICKS = 4 s of the 100 MHz wall clock, or until another workgroup raised the abort word -- the grid
 // always drains), then an agent-scope acquire fence makes the producer's data visible to the whole workgroup.
 //   [42 + r] asst[r]: column blocks whose first-half partial product the ASSISTANT of square row r has left in the scratch (count c)
 #define REGION_FLAG_INTS (34 + LMM_REGION_MAX_PANELS + 16)
 // SLEEP: s_sleep argument between polls (64 clocks each).  1 on the region kernel's chain (a handful of pollers, every 30 ns counts); the
 // hundreds of bulk workgroups of a fused node launch poll the same few words and use 16 (~0.5 us), or they slow the leaf they wait for.
+// The abort word is epoch-tagged like every other flag (epoch * 32 + 1): a word raised by an EARLIER launch on the same slice of the
+// persistent flag array never matches, so a timeout in one launch cannot make a later launch leave its waits early.
+__device__ __forceinline__ bool region_aborted(const int* abort_word, int epoch) {
+  const int v = __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return (v >> 5) == epoch && (v & 31) != 0;
+}
 template <int SLEEP = 1>
 __device__ __forceinline__ void region_wait_ge(const int* f, int epoch, int need, int* abort_word, int* info) {
   if (threadIdx.x == 0) {
@@ -2008,9 +2014,9 @@ __device__ __forceinline__ void region_wait_ge(const int* f, int epoch, int need
       if ((v >> 5) == epoch && (v & 31) >= need) break;
       __builtin_amdgcn_s_sleep(SLEEP);
       if ((++polls & 63) == 0) {
-        if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-        if (wall_clock64() - t0 > 100000000LL) {
-          __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (region_aborted(abort_word, epoch)) break;
+        if (wall_clock64() - t0 > LMM_REGION_SPIN_TICKS) {
+          __hip_atomic_store(abort_word, epoch * 32 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           atomicCAS(info, 0, LMM_INFO_SYNC_TIMEOUT);               // surfaces through the host's check of the pivot info word
           break;
         }
@@ -2347,7 +2353,7 @@ __global__ __launch_bounds__(256, 2) void potrf_node_kernel(NodeArgs a) {
 //   interleaved.  Every dependency of a task -- (i, p), (j, p) for p < j and (j, j) -- lies on an earlier wavefront, so a waiting
 //   workgroup only ever waits for workgroups dispatched before it (already resident or finished): no deadlock however many are
 //   resident; and the critical path leaf(j) -> X[j+1, j] -> tile (j+1, j+1) -> leaf(j+1) is at the FRONT of each wavefront.
-//   Every spin is bounded (1 s): on a timeout the abort word is raised, all spinners leave, the grid drains and the host reports it.
+//   Every spin is bounded (4 s): on a timeout the abort word is raised, all spinners leave, the grid drains and the host reports it.
 // ---------------------------------------------------------------------------------------------------
 // acc += A (128 rows x 128 k-columns, from row pointer A, leading dimension lda; rows >= rows_a are clamped) * B' (likewise), through
 // the LDS staging buffers `lds` (4 x 16 x 144 doubles) with gemm16p_kernel's one-tile-ahead pipeline.  All 256 threads.
@@ -2404,9 +2410,9 @@ __device__ __forceinline__ void region_wait3(const int* f1, int n1, const int* f
       if ((v1 >> 5) == epoch && (v1 & 31) >= n1 && (v2 >> 5) == epoch && (v2 & 31) >= n2 && (v3 >> 5) == epoch && (v3 & 31) >= n3) break;
       __builtin_amdgcn_s_sleep(1);
       if ((++polls & 63) == 0) {
-        if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-        if (wall_clock64() - t0 > 100000000LL) {
-          __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (region_aborted(abort_word, epoch)) break;
+        if (wall_clock64() - t0 > LMM_REGION_SPIN_TICKS) {
+          __hip_atomic_store(abort_word, epoch * 32 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           atomicCAS(info, 0, LMM_INFO_SYNC_TIMEOUT);
           break;
         }

@@ -13,6 +13,7 @@ through the C ABI).
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 import math
 from typing import List, Optional, Sequence, Tuple
 
@@ -201,7 +202,10 @@ class _PostHandle:
         # predictive logpdf is a total derivative through the posterior and needs them (one entry per posterior(...) call)
         self.train = train if (train is None or isinstance(train, list)) else [train]
         self.latent = latent          # dense only: this handle's H is I_m (it IS the latent PosteriorGP{IndependentMOGP})
-        self._parent = parent         # a latent view keeps the handle whose device state it shares alive
+        # A latent view does NOT reference its parent: the C side keeps the shared device state alive until the last of the two handles
+        # is destroyed (either order), and a back-reference would make parent <-> view a cycle of objects with __del__, whose device
+        # memory only the cyclic collector would free.
+        self._parent = weakref.ref(parent) if parent is not None else None
         self._view = None
 
     def latent_view(self) -> "_PostHandle":
@@ -305,6 +309,9 @@ def _merged_train(train, p: int):
     if len(train) == 1:
         x0, s20, y0 = train[0]
         return x0, s20, y0, [x0.n]
+    if any(np.ndim(t[1]) > 0 for t in train):
+        raise NotImplementedError("gradient of the predictive logpdf after sequential conditioning with a per-point (Diagonal) noise is not "
+                                  "built (scalar noise variances, equal per batch, are)")
     s2s = {float(t[1]) for t in train}
     if len(s2s) != 1:
         raise NotImplementedError("gradient of the predictive logpdf after sequential conditioning with DIFFERENT noise variances per "
@@ -441,6 +448,9 @@ def logpdf_and_gradient(fx: FiniteGP, y, with_regulariser: bool = True) -> dict:
       posterior dense-H ILMM        : as the posterior OILMM below with "H" in place of "S", "U" (test/ilmm.jl:32)
       posterior OILMM / MOGP        : fx = posterior(f(x, s2), y0)(xs, s2s); TOTAL derivatives of the predictive logpdf through the
                                       posterior: {"value", "y" (= d/d ys), "y_train", "sigma2" (= d/d s2s), "sigma2_train", "S", "U", "gps"}
+                                      After sequential conditioning (equal noise variance per batch) "y_train" is a LIST with one
+                                      by-outputs vector per conditioning batch, while "sigma2_train" stays ONE number: the derivative
+                                      with respect to the variance the batches share (= the sum of the per-batch derivatives).
     Partial sums over the latent shard."""
     L.ensure_init()
     lib = L.load()

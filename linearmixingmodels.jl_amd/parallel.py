@@ -95,11 +95,17 @@ def select_collective(backend: str, world: int, init_fn: Optional[Callable] = No
         got = init_fn()
         if got != world:
             raise RuntimeError(f"ABI communicator has {got} ranks, expected {world}")
-        probe_fn(world)
     except Exception as e:          # noqa: BLE001 -- any failure means "fall back", the reason is reported
         err = f"{type(e).__name__}: {e}"
+    # Agree on the INIT outcome before anybody enters the probe collective: a rank whose init raised would otherwise skip the probe
+    # while the others block inside an RCCL all-reduce that can never complete.
     if agree_fn(err is None):
-        return True, ABI_COLLECTIVE
+        try:
+            probe_fn(world)
+        except Exception as e:      # noqa: BLE001
+            err = f"{type(e).__name__}: {e}"
+        if agree_fn(err is None):
+            return True, ABI_COLLECTIVE
     try:
         destroy_fn()
     except Exception:               # noqa: BLE001

@@ -140,7 +140,7 @@ def test_select_collective_branches():
     assert PP.select_collective("nccl", 1) == (False, None)
     assert PP.select_collective("gloo", 2) == (False, "torch.distributed/gloo")
     assert PP.select_collective("nccl", 2, ok_init, ok_probe, agree, destroy) == (True, PP.ABI_COLLECTIVE)
-    assert calls == ["init", ("probe", 2), ("agree", True)]
+    assert calls == ["init", ("agree", True), ("probe", 2), ("agree", True)]      # the init outcome is agreed BEFORE the probe collective
     # the communicator comes up with the wrong size
     calls.clear()
     use, desc = PP.select_collective("nccl", 4, ok_init, ok_probe, agree, destroy)
@@ -150,8 +150,14 @@ def test_select_collective_branches():
     def bad_init():
         raise lmm_amd.LMMError("ncclCommInitRank failed: unhandled system error")
 
+    calls.clear()
     use, desc = PP.select_collective("nccl", 2, bad_init, ok_probe, agree, destroy)
     assert not use and desc.startswith("torch.distributed/nccl (ABI RCCL failed: LMMError: ncclCommInitRank failed")
+    assert ("probe", 2) not in calls          # a rank whose init failed never enters the probe all-reduce ...
+    # ... and neither does a rank whose own init succeeded when ANOTHER rank's did not (it would block in RCCL for ever)
+    calls.clear()
+    use, desc = PP.select_collective("nccl", 2, ok_init, ok_probe, lambda ok: (calls.append(("agree", ok)), False)[1], destroy)
+    assert not use and ("probe", 2) not in calls and "on another rank" in desc
     # the first collective fails
 
     def bad_probe(world):
@@ -171,3 +177,31 @@ def test_bench_uses_select_collective():
     src = open(os.path.join(root, "bench.py")).read()
     assert "select_collective(backend, world)" in src and "comm_init_from_torch" not in src
     assert '"per_rank": per_rank' in src and "rccl_ranks" in src
+
+
+def test_check_info_translation_and_ordering():
+    """lmm_dev_check_info (host only): the pivot-info words of a batch -> status.  A dependency-wait timeout marker of
+    potrf_region_kernel (-7777) in ANY position outranks a PosDefException of an earlier latent and becomes LMM_ERR_HIP; a
+    non-zero pivot alone is LMM_ERR_NOT_PD with latent and pivot in lmm_last_error_detail; all zeros is LMM_OK."""
+    import ctypes as C
+    import lmm_amd
+    from lmm_amd import _lib as L
+    lib = lmm_amd.load()
+
+    def status(words, begin=0):
+        arr = (C.c_int * len(words))(*words)
+        return lib.lmm_dev_check_info(arr, len(words), begin)
+
+    assert status([0, 0, 0]) == L.LMM_OK
+    assert status([0, 17, 0, 3], begin=4) == L.LMM_ERR_NOT_PD
+    lat, info = C.c_int(), C.c_int()
+    lib.lmm_last_error_detail(C.byref(lat), C.byref(info))
+    assert (lat.value, info.value) == (5, 17)
+    assert status([-7777]) == L.LMM_ERR_HIP
+    assert b"timed out" in lib.lmm_last_error_string()
+    assert status([9, 0, -7777, 0]) == L.LMM_ERR_HIP            # the timeout is not masked by the earlier non-PD pivot
+    assert b"latent 2" in lib.lmm_last_error_string()
+    with pytest.raises(lmm_amd.LMMError):
+        L.check(status([0, -7777]))
+    with pytest.raises(lmm_amd.PosDefException):
+        L.check(status([0, 2]))
