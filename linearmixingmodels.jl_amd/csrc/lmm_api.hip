@@ -223,7 +223,11 @@ void guard_extent(const void* p, size_t rows, size_t ld, size_t cols, bool matri
     throw fail(LMM_ERR_ARG, "internal extent check failed: %s touches %zu x %zu (ld %zu) = %zu bytes at offset %zu of a %zu-byte allocation",
                what, rows, cols, ld, need, (size_t)(q - b0), it->second);
 }
-void guard_gram(const GramArgs& a, const char* what) { guard_extent(a.A, (size_t)a.nrows, (size_t)a.ld, (size_t)a.ncols, true, what); }
+// (a launch covers the matrix rows [64 row_tile0, nrows), stored from buffer row 64 row_tile0 - row_shift on: buffer rows < nrows - row_shift)
+void guard_gram(const GramArgs& a, const char* what) {
+  if (64 * a.row_tile0 < a.row_shift) throw fail(LMM_ERR_ARG, "internal extent check failed: %s starts above its buffer (row tile %d, shift %d)", what, a.row_tile0, a.row_shift);
+  guard_extent(a.A, (size_t)(a.nrows - a.row_shift), (size_t)a.ld, (size_t)a.ncols, true, what);
+}
 void gram_g(const GramArgs& a, hipStream_t st, const char* what = "Gram assembly") { guard_gram(a, what); launch_gram(a, st); }
 void gram_batch_g(const GramArgs* ga, int nb, hipStream_t st, const char* what = "Gram assembly") {
   for (int j = 0; j < nb; ++j) guard_gram(ga[j], what);

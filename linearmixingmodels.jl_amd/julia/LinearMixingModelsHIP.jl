@@ -16,7 +16,7 @@
 #     logpdf(fx, y); po = posterior(fx, y); marginals(po(xs, σ²)); rand(rng, fx); Zygote.gradient(logpdf, fx, y)
 module LinearMixingModelsHIP
 
-using AbstractGPs, KernelFunctions, LinearAlgebra, Random, FillArrays, ChainRulesCore
+using AbstractGPs, KernelFunctions, LinearAlgebra, Random, FillArrays, ChainRulesCore, Distributions
 using LinearMixingModels
 using LinearMixingModels: ILMM, IndependentMOGP, Orthogonal, unpack, noise_var
 
@@ -386,6 +386,85 @@ end
 AbstractGPs.rand(rng::AbstractRNG, ft::ByOutputsFill{HIPMOGP}) = vec(_rand_mogp(rng, ft, 1))
 AbstractGPs.rand(rng::AbstractRNG, ft::ByOutputsFill{HIPMOGP}, N::Int) = _rand_mogp(rng, ft, N)
 
+# reference src/ilmm.jl:95-106 and src/independent_mogp.jl:102-113: `rand!(rng, fx, y)` (what AbstractGPs.TestUtils reaches through
+# Distributions) fills y with one sample (vector, or one column) or N samples (N columns) -- the draws come from the methods above, so the
+# normals are consumed in the reference's order
+function Distributions._rand!(rng::AbstractRNG, fx::Union{HIPLMMFinite,ByOutputsFill{HIPMOGP}}, y::AbstractVecOrMat{<:Real})
+    N = size(y, 2)
+    if N == 1
+        y .= AbstractGPs.rand(rng, fx)
+    else
+        y .= AbstractGPs.rand(rng, fx, N)
+    end
+end
+
+# ---- MOInputIsotopicByFeatures (reference src/independent_mogp.jl:128-229) --------------------------------------------------------
+# The reference serves by-features inputs of an IndependentMOGP by re-ordering to by-outputs, calling the by-outputs method and
+# permuting the result back (indices_which_reorder_*, :135-147).  Same here: the by-outputs methods above do the work, the
+# permutation of the length-(n p) vectors is the library's (lmm_reorder: to_outputs = 1 is `v[indices_which_reorder_features_to_outputs]`,
+# 0 the inverse), and the (n p) x (n p) covariance is permuted on the host with the reference's own index vectors.
+const ByFeatures{F} = FiniteGP{<:F,<:MOInputIsotopicByFeatures,<:Diagonal{<:Real}}
+const ByFeaturesFill{F} = FiniteGP{<:F,<:MOInputIsotopicByFeatures,<:Diagonal{<:Real,<:Fill}}
+function _reorder(v::AbstractVector{<:Real}, n::Integer, p::Integer, to_outputs::Bool)
+    vin = Vector{Float64}(v); out = Vector{Float64}(undef, n * p)
+    GC.@preserve vin out check(ccall((:lmm_reorder, liblmm), Cint, (Ptr{Cdouble}, Cint, Cint, Cint, Ptr{Cdouble}),
+        vin, n, p, to_outputs ? 1 : 0, out))
+    return out
+end
+_nx(x::MOInputIsotopicByFeatures) = length(x.x)
+_by_outputs(x::MOInputIsotopicByFeatures) = MOInputIsotopicByOutputs(x.x, x.out_dim)                      # src/independent_mogp.jl:149
+_by_outputs(Σy::Diagonal{<:Real,<:Fill}, x::MOInputIsotopicByFeatures) = Σy                                # :155
+_by_outputs(Σy::Diagonal{<:Real}, x::MOInputIsotopicByFeatures) = Diagonal(_reorder(Σy.diag, _nx(x), x.out_dim, true))   # :151-153
+_by_outputs(ft::ByFeatures{HIPMOGP}) = FiniteGP(ft.f, _by_outputs(ft.x), _by_outputs(ft.Σy, ft.x))        # :157-159
+_to_features(v::AbstractVector{<:Real}, x::MOInputIsotopicByFeatures) = _reorder(v, _nx(x), x.out_dim, false)
+
+# src/independent_mogp.jl:222-229 (any Diagonal noise: a Fill stays a Fill, a general diagonal is permuted with the data)
+AbstractGPs.logpdf(ft::ByFeatures{HIPMOGP}, y::AbstractVector{<:Real}) =
+    logpdf(_by_outputs(ft), _reorder(y, _nx(ft.x), ft.x.out_dim, true))
+# src/independent_mogp.jl:217-220: the by-outputs sample, permuted (the normals are drawn latent by latent, as in the reference)
+AbstractGPs.rand(rng::AbstractRNG, ft::ByFeaturesFill{HIPMOGP}) = _to_features(rand(rng, _by_outputs(ft)), ft.x)
+function AbstractGPs.rand(rng::AbstractRNG, ft::ByFeaturesFill{HIPMOGP}, N::Int)
+    return reduce(hcat, [rand(rng, ft) for _ in 1:N])
+end
+# src/independent_mogp.jl:165-175 (mean, var) on the finite GP: by-outputs marginals, permuted
+function AbstractGPs.mean_and_var(ft::ByFeaturesFill{HIPMOGP})
+    M, V = mean_and_var(_by_outputs(ft))
+    return _to_features(M, ft.x), _to_features(V, ft.x)
+end
+AbstractGPs.mean(ft::ByFeaturesFill{HIPMOGP}) = mean_and_var(ft)[1]
+AbstractGPs.var(ft::ByFeaturesFill{HIPMOGP}) = mean_and_var(ft)[2]
+# src/independent_mogp.jl:177-182: C_by_outputs[idx, idx] (block-diagonal latent covariances + Σy, lmm_lmm_mean_and_cov with U = I)
+function AbstractGPs.mean_and_cov(ft::ByOutputsFill{HIPMOGP})
+    X = _xmat(ft.x.x); d, ns = size(X); m = length(ft.f.fs); σ² = noise_var(ft.Σy)
+    U = Matrix{Float64}(I, m, m)
+    gps = isposterior(ft.f) ? LmmGp[] : _gps(ft.f.fs)
+    M = Vector{Float64}(undef, ns * m); Cm = Matrix{Float64}(undef, ns * m, ns * m)
+    jit = Ref(LmmJitters(1e-9, 0.0, 0.0))                   # cov(f, x) + Σy of a bare MOGP: no latent jitter (src/independent_mogp.jl:60-63)
+    GC.@preserve X U gps M Cm check(ccall((:lmm_lmm_mean_and_cov, liblmm), Cint,
+        (Ptr{Cvoid}, Ptr{LmmGp}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Cint, Cint, Cdouble, Cint, Ptr{Cdouble}, Cint, Cint,
+         Ref{LmmJitters}, Ptr{Cdouble}, Ptr{Cdouble}),
+        ft.f.handle, isposterior(ft.f) ? Ptr{LmmGp}(C_NULL) : pointer(gps), U, Ptr{Cdouble}(C_NULL), m, m, 0, m, σ², 1, X, d, ns, jit, M, Cm))
+    return M, Cm
+end
+AbstractGPs.cov(ft::ByOutputsFill{HIPMOGP}) = mean_and_cov(ft)[2]
+function AbstractGPs.mean_and_cov(ft::ByFeaturesFill{HIPMOGP})
+    M, Cm = mean_and_cov(_by_outputs(ft))
+    idx = LinearMixingModels.indices_which_reorder_outputs_to_features(_by_outputs(ft.x))
+    return _to_features(M, ft.x), Cm[idx, idx]
+end
+AbstractGPs.cov(ft::ByFeaturesFill{HIPMOGP}) = mean_and_cov(ft)[2]
+# conditioning on by-features data: reorder, then the by-outputs posterior (the reference reaches the same through reorder_by_outputs)
+AbstractGPs.posterior(ft::ByFeaturesFill{HIPMOGP}, y::AbstractVector{<:Real}) =
+    posterior(_by_outputs(ft), _reorder(y, _nx(ft.x), ft.x.out_dim, true))
+function Distributions._rand!(rng::AbstractRNG, ft::ByFeaturesFill{HIPMOGP}, y::AbstractVecOrMat{<:Real})
+    N = size(y, 2)
+    if N == 1
+        y .= AbstractGPs.rand(rng, ft)
+    else
+        y .= AbstractGPs.rand(rng, ft, N)
+    end
+end
+
 # ---- gradients: ChainRulesCore.rrule around the ccall --------------------------------------------------------------------
 # The reference's tests take Zygote.gradient(logpdf, fx, y) on prior and posterior models (test/oilmm.jl:31-32,
 # test/ilmm.jl:31-32, test/independent_mogp.jl:65-66).  A ccall is opaque to Zygote, so the pullbacks come from the library
@@ -509,7 +588,7 @@ end
 # compute dtype of the per-latent matrices: :f64 (parity mode) | :f32 (BASELINE configs[4])
 set_compute_dtype(d::Symbol) = check(ccall((:lmm_set_compute_dtype, liblmm), Cint, (Cint,), d === :f32 ? 1 : 0))
 # dtype of the H unprojection of predictive marginals (reference src/oilmm.jl:69-72): :native | :bf16 (BASELINE configs[3]:
-# v_mfma_f32_16x16x32_bf16, tolerance 2^-7 Σ_l |H||M_lat|) | :bf16x2 (hi + lo split, ~2^-15)
+# v_mfma_f32_16x16x32_bf16, tolerance 2^-7 Σ_l |H||M_lat|) | :bf16x2 (hi + lo split, <= 2^-15 Σ_l |H||M_lat|, include/lmm_hip.h)
 set_projection_dtype(d::Symbol) =
     check(ccall((:lmm_set_projection_dtype, liblmm), Cint, (Cint,), d === :bf16 ? 1 : (d === :bf16x2 ? 2 : 0)))
 

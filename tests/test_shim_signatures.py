@@ -1,0 +1,130 @@
+"""The Julia shim (linearmixingmodels.jl_amd/julia/LinearMixingModelsHIP.jl) cannot be executed here (no Julia in the image or on the
+GPU box), so its `ccall`s are checked statically: every `ccall((:sym, liblmm), Ret, (ArgTypes...), args...)` must name a symbol that
+include/lmm_hip.h declares, with the same arity, return type and -- argument by argument -- a Julia type that is ABI-compatible with
+the C parameter type; and it must pass exactly as many values as it declares types."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHIM = os.path.join(ROOT, "linearmixingmodels.jl_amd", "julia", "LinearMixingModelsHIP.jl")
+HEADER = os.path.join(ROOT, "include", "lmm_hip.h")
+
+# C parameter type (normalised: no `const`, no parameter name) -> the Julia ccall types that are ABI-compatible with it
+COMPAT = {
+    "int": {"Cint"},
+    "double": {"Cdouble"},
+    "size_t": {"Csize_t"},
+    "unsigned long long": {"Culonglong", "UInt64"},
+    "double*": {"Ptr{Cdouble}", "Ref{Cdouble}"},
+    "int*": {"Ptr{Cint}", "Ref{Cint}"},
+    "void*": {"Ptr{Cvoid}", "Ptr{UInt8}"},
+    "lmm_gp_t*": {"Ptr{LmmGp}"},
+    "lmm_gp_grad_t*": {"Ptr{LmmGpGrad}"},
+    "lmm_jitters_t*": {"Ptr{LmmJitters}", "Ref{LmmJitters}"},
+    "lmm_post_t*": {"Ptr{Cvoid}"},
+    "lmm_post_t**": {"Ref{Ptr{Cvoid}}", "Ptr{Ptr{Cvoid}}"},
+    "lmm_prof_entry_t*": {"Ptr{LmmProfEntry}"},
+}
+RET = {"int": "Cint", "const char*": "Cstring"}
+
+
+def _split_top(s):
+    """Split on commas that are not nested in (), {} or []."""
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "({[":
+            depth += 1
+        elif ch in ")}]":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip()); cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+def header_prototypes():
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    protos = {}
+    for ret, name, args in re.findall(r"\b(int|const char\s*\*)\s+(lmm_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", src):
+        params = []
+        args = " ".join(args.split())
+        if args not in ("void", ""):
+            for a in _split_top(args):
+                a = re.sub(r"/\*.*?\*/", "", a)
+                a = re.sub(r"\bconst\b", "", a).strip()
+                stars = a.count("*")
+                a = a.replace("*", " ")
+                toks = a.split()
+                # the last token is the parameter name unless the type is a bare builtin without a name
+                base = " ".join(toks[:-1]) if len(toks) > 1 else toks[0]
+                params.append(base + "*" * stars)
+        protos[name] = (" ".join(ret.split()).replace(" *", "*"), params)
+    return protos
+
+
+def shim_ccalls():
+    src = open(SHIM).read()
+    src = re.sub(r"#[^\n]*", "", src)                       # comments
+    calls = []
+    for mt in re.finditer(r"ccall\(\(:(lmm_[a-z0-9_]+),\s*liblmm\),", src):
+        i = mt.end()
+        depth, j = 1, i
+        while depth:                                         # to the matching ')' of ccall(
+            ch = src[j]
+            depth += ch == "("
+            depth -= ch == ")"
+            j += 1
+        parts = _split_top(src[i:j - 1])
+        ret, types = parts[0], parts[1]
+        assert types.startswith("(") and types.endswith(")"), (mt.group(1), types)
+        tlist = _split_top(types[1:-1])
+        calls.append((mt.group(1), ret, tlist, parts[2:], src[:mt.start()].count("\n") + 1))
+    return calls
+
+
+def test_every_shim_ccall_matches_the_header():
+    protos = header_prototypes()
+    assert len(protos) >= 50 and "lmm_oilmm_logpdf" in protos and "lmm_last_error_string" in protos
+    calls = shim_ccalls()
+    assert len(calls) >= 40
+    errors = []
+    for sym, ret, types, values, line in calls:
+        if sym not in protos:
+            errors.append(f"line ~{line}: {sym} is not declared in include/lmm_hip.h"); continue
+        cret, cparams = protos[sym]
+        if RET[cret] != ret:
+            errors.append(f"line ~{line}: {sym} returns {cret}, shim says {ret}")
+        if len(types) != len(cparams):
+            errors.append(f"line ~{line}: {sym} takes {len(cparams)} parameters, shim declares {len(types)}"); continue
+        if len(values) != len(types):
+            errors.append(f"line ~{line}: {sym}: {len(types)} argument types but {len(values)} values")
+        for k, (ct, jt) in enumerate(zip(cparams, types)):
+            if ct not in COMPAT:
+                errors.append(f"line ~{line}: {sym} parameter {k}: C type {ct!r} has no Julia mapping in this test")
+            elif jt not in COMPAT[ct]:
+                errors.append(f"line ~{line}: {sym} parameter {k}: C {ct} vs Julia {jt}")
+    assert not errors, "\n".join(errors)
+
+
+def test_shim_covers_the_reference_method_families():
+    """The reference's AbstractGPs method families on ILMM / IndependentMOGP FiniteGPs (src/ilmm.jl, src/oilmm.jl,
+    src/independent_mogp.jl) each have a shim method that reaches the library: by-outputs verbs, the MOInputIsotopicByFeatures
+    family (src/independent_mogp.jl:128-229) through lmm_reorder, and Distributions._rand! (src/ilmm.jl:95-106,
+    src/independent_mogp.jl:102-113)."""
+    src = open(SHIM).read()
+    used = {c[0] for c in shim_ccalls()}
+    for sym in ["lmm_oilmm_logpdf", "lmm_ilmm_logpdf", "lmm_mogp_logpdf", "lmm_mogp_logpdf_diag", "lmm_oilmm_posterior_create",
+                "lmm_mogp_posterior_create", "lmm_ilmm_posterior_create", "lmm_post_condition", "lmm_ilmm_post_condition",
+                "lmm_oilmm_mean_and_var", "lmm_ilmm_post_mean_and_var", "lmm_latent_marginals", "lmm_lmm_mean_and_cov",
+                "lmm_ilmm_post_mean_and_cov", "lmm_lmm_rand_multi", "lmm_ilmm_post_rand", "lmm_oilmm_logpdf_grad",
+                "lmm_oilmm_post_logpdf_grad", "lmm_ilmm_logpdf_grad", "lmm_ilmm_post_logpdf_grad", "lmm_reorder",
+                "lmm_ilmm_post_latent_view", "lmm_post_destroy"]:
+        assert sym in used, sym
+    assert "Distributions._rand!" in src
+    for verb in ["logpdf", "rand", "mean", "var", "cov", "posterior"]:
+        assert re.search(r"AbstractGPs\.%s\([^)]*ByFeatures" % verb, src), verb
