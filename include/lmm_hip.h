@@ -376,11 +376,7 @@ typedef enum {
   LMM_PROF_REGION = 5,        /* potrf_region_kernel: a block column of <= 8 panels (leaves, bulk products, inner updates) in one
                                  dataflow launch, flops                                                                         */
   LMM_PROF_UPDATE_SHORT = 6,  /* potrf_node_kernel<1>: the same fused update + leaf for K < 1024 (latency- and epilogue-bound levels)  */
-  LMM_PROF_ROWS = 7,          /* potrf_rows_kernel (round 4): the rows below a block column's square, left-looking solve in one launch;
-                                 flops M w^2, bytes: the block column's rows read and written once                                  */
-  LMM_PROF_UPDATE_SQ = 8,     /* gemm16p_kernel on the tiles of the NEXT block column's square (the part of a K >= 1024 trailing update
-                                 that the look-ahead issues first, on the auxiliary stream), flops                                  */
-  LMM_PROF_COUNT = 9
+  LMM_PROF_COUNT = 7
 } lmm_prof_class;
 typedef struct { long long launches; double ms; double work; double bytes; /* algorithmic HBM bytes */ } lmm_prof_entry_t;
 int lmm_profile_begin(int serial);

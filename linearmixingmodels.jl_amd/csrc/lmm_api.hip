@@ -59,7 +59,6 @@ struct Ctx {
   struct ProfRec { int cls; double work, bytes; hipEvent_t e0, e1; int M, N, K, count; };
   std::vector<ProfRec> prof_recs;
   std::vector<hipEvent_t> ev_pool;
-  std::vector<hipEvent_t> bc_events[kMaxStreams];   // block-column look-ahead: hand-off events of slot stream s (created on demand, reused across calls)
 };
 Ctx g;
 std::mutex g_mu;
@@ -387,7 +386,7 @@ void potrf_rec_panel(const Batch& B, const BatchPtr& W2, const BatchInfo& flags,
     const int M = NR - (j0 + 128);
     if (M > 0 && !bulk_done) {
       const double Mreal = (nfl.rows_real >= 0 ? std::min(NR, nfl.rows_real) : NR) - (j0 + 128);
-      ProfScope ps(LMM_PROF_TRSM, nb * Mreal * 128.0 * 128.0, st, M, 128, 128);       // triangular solve: M * 128^2 flops
+      ProfScope ps(LMM_PROF_TRSM, nb * Mreal * 128.0 * 128.0, st, M, 128, 128);       // triangular solve: (real rows) * 128^2 flops
       launch_panel_bulk(B.A, W2, ld, NR, j0, B.nb, st);
     }
     return;
@@ -423,82 +422,6 @@ void potrf_rec_panel(const Batch& B, const BatchPtr& W2, const BatchInfo& flags,
   }
 }
 
-// Round 4: BLOCK COLUMNS WITH LOOK-AHEAD.  The panel recursion above leaves, below its K = 1024 level, 15 launches per 1024 columns whose
-// products run at 15-52 TFLOP/s (K = 128 .. 512: every trailing tile re-read and re-written once per level, the leaf of every panel
-// exposed) -- 10 % of the flops in 13-14 % of the time, and at few matrices per launch the chain of leaves IS the time.  Here the
-// matrix is cut into block columns of W = 1024 columns (the last one may be narrower) and block column t is
-//     square(t)  rows = columns [1024 t, 1024 t + w):  the panel recursion (or, for few matrices, potrf_region_kernel) on those w rows only
-//     rows(t)    everything below the square: potrf_rows_kernel, ONE launch, no dependency inside it
-// and between block columns the trailing updates of the recursion's K >= 1024 levels, in binary-counter order: after block column
-// t - 1 the columns [1024 t, 1024 t + h), h = 1024 lowbit(t), receive the product with the h columns before them -- every block column
-// has then seen all columns to its left when its turn comes (the intervals [t - lowbit(t), t) along the chain t, t - lowbit(t), ...
-// partition [0, t)), for any number of block columns.  The update is issued in parts: the tiles of the NEXT square first, on the
-// auxiliary stream, which goes on to factor that square while the main stream runs the rest of the update: the latency-bound chain
-// of a square (0.4-1 ms) sits beside 1-70 ms of MFMA-bound work instead of between two launches.
-//     main stream:  rows(t-1) | ev ->         update rest (rectangle below the next square, trapezoid right of it) | <- ev | rows(t) ...
-//     aux stream :            -> | update of square(t)'s tiles, square(t) | ->
-// Serial instrumented pass (lmm_profile_begin(serial = 1)): everything on the main stream, so that per-launch durations are clean.
-static inline int lowbit(int t) { return t & -t; }
-void potrf_blockcols(const Batch& B, const BatchPtr& W2, const BatchInfo& flags_main, const BatchInfo& flags_aux, const NodeFlags& nfl, int ld,
-                     int NR, int NC, int n_real, hipStream_t st, hipStream_t aux, std::vector<hipEvent_t>* evs) {
-  constexpr int Wb = 1024;
-  const int nbc = (NC + Wb - 1) / Wb;
-  const double nb = B.nb;
-  const int rr = nfl.rows_real >= 0 ? std::min(NR, nfl.rows_real) : NR;       // rows that hold data
-  const bool two = aux != st && evs != nullptr;
-  size_t evi = 0;
-  auto next_event = [&]() -> hipEvent_t {
-    if (evi == evs->size()) { hipEvent_t e; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); evs->push_back(e); }
-    return (*evs)[evi++];
-  };
-  NodeFlags nsq = nfl; nsq.rows_real = -1;                                    // a square has no rows below it
-  auto square = [&](int r0, int wsq, hipStream_t s, const BatchInfo& fl) {
-    potrf_rec_panel(B, W2, fl, nsq, ld, r0 + wsq, r0, wsq, n_real, s, false);
-  };
-  square(0, std::min(Wb, NC), st, flags_main);
-  hipEvent_t ev_sq = nullptr;
-  for (int k = 0; k < nbc; ++k) {
-    const int r0 = k * Wb, wsq = std::min(Wb, NC - r0);
-    if (k > 0 && two) HIPCHK(hipStreamWaitEvent(st, ev_sq, 0));                 // square(k) is factored
-    {
-      const double Mreal = rr - (r0 + wsq);
-      if (NR - (r0 + wsq) > 0) {
-        // triangular solve of the rows below the square: Mreal w^2 flops; bytes: the block column's rows read and written once
-        ProfScope ps(LMM_PROF_ROWS, nb * Mreal * (double)wsq * wsq, st, NR - (r0 + wsq), wsq, wsq, nb * 16.0 * Mreal * wsq);
-        launch_rows(B.A, W2, ld, NR, r0, wsq, B.nb, st);
-      }
-    }
-    if (k + 1 == nbc) break;
-    const int t = k + 1, r1 = t * Wb, w1 = std::min(Wb, NC - r1), h = lowbit(t) * Wb, j0 = r1 - h, Ncu = std::min(h, NC - r1);
-    const size_t offB1 = (size_t)j0 * ld + r1;
-    hipStream_t s1 = two ? aux : st;
-    if (two) { hipEvent_t e = next_event(); HIPCHK(hipEventRecord(e, st)); HIPCHK(hipStreamWaitEvent(aux, e, 0)); }
-    {
-      const double outs = (double)w1 * (w1 + 1.0) / 2.0;
-      ProfScope ps(LMM_PROF_UPDATE_SQ, nb * 2.0 * h * outs, s1, w1, w1, h, nb * (16.0 * outs + 8.0 * (double)w1 * h));
-      launch_gemm_nt(B.A, (size_t)r1 * ld + r1, ld, B.A, offB1, ld, B.A, offB1, ld, w1, w1, h, 1, false, B.nb, s1);
-    }
-    square(r1, w1, s1, two ? flags_aux : flags_main);
-    if (two) { ev_sq = next_event(); HIPCHK(hipEventRecord(ev_sq, aux)); }
-    const int Mrest = NR - (r1 + w1);
-    if (Mrest > 0) {
-      const double Mreal = rr - (r1 + w1);
-      const size_t offA2 = (size_t)j0 * ld + (r1 + w1);
-      {
-        // rectangle below the next square (its w1 columns, all rows below it)
-        ProfScope ps(LMM_PROF_UPDATE, nb * 2.0 * h * Mreal * w1, st, Mrest, w1, h, nb * (16.0 * Mreal * w1 + 8.0 * (Mreal + w1) * h));
-        launch_gemm_nt(B.A, (size_t)r1 * ld + (r1 + w1), ld, B.A, offA2, ld, B.A, offB1, ld, Mrest, w1, h, 0, false, B.nb, st);
-      }
-      if (Ncu > w1) {
-        const int Nb = Ncu - w1;
-        const double outs = (double)Nb * (Nb + 1.0) / 2.0 + (Mreal - Nb) * Nb;
-        ProfScope ps(LMM_PROF_UPDATE, nb * 2.0 * h * outs, st, Mrest, Nb, h, nb * (16.0 * outs + 8.0 * Mreal * h));
-        launch_gemm_nt(B.A, (size_t)(r1 + w1) * ld + (r1 + w1), ld, B.A, offA2, ld, B.A, offA2, ld, Mrest, Nb, h, 1, false, B.nb, st);
-      }
-    }
-  }
-}
-
 // Entry point of the factorisation of a batch: columns [0, NC) of every matrix.  Float64 batches take the 128-column panel path
 // (LMM_PANEL128=0: the round-2 path); its W2 scratch -- one 128 x 128 inverse per panel and matrix -- lives until the API call ends.
 void potrf_batch(const Batch& B, int ld, int NR, int NC, int n_real, hipStream_t st, int rows_real = -1) {
@@ -514,72 +437,18 @@ void potrf_batch(const Batch& B, int ld, int NR, int NC, int n_real, hipStream_t
   double* w2 = call_scratch(per * B.nb);
   BatchPtr W2{};
   for (int j = 0; j < B.nb; ++j) W2.p[j] = w2 + per * j;
-  static int cus = 0;
-  if (cus == 0) { int dev = 0; cus = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); }
-  int si = -1;
-  for (int s = 0; s < kMaxStreams; ++s) if (g.streams[s] == st) si = s;
-  // dependency flags of the region launches on stream s: that stream's slice of the persistent, once-zeroed array (launches are told
-  // apart by epoch); an unknown stream gets a zeroed scratch
-  auto region_flags_of = [&](int sidx, hipStream_t s) {
-    BatchInfo f{};
-    const size_t fi = region_flag_ints(NR);
-    int* fl;
-    if (sidx >= 0 && g.region_flags) fl = g.region_flags + (size_t)sidx * LMM_MAX_BATCH * fi;
-    else {
-      fl = reinterpret_cast<int*>(call_scratch((fi * B.nb + 1) / 2));
-      HIPCHK(hipMemsetAsync(fl, 0, fi * sizeof(int) * B.nb, s));
-    }
-    for (int j = 0; j < B.nb; ++j) f.p[j] = fl + fi * j;
-    return f;
-  };
-  // LMM_FUSE_BULK (default 1): the bulk rows of a panel ride in the update launch that factors its diagonal block (NODE_FUSE), behind
-  // per-call flags zeroed here, in the launches with 512 <= K <= 2048 (LMM_FUSE_BULK_MINK / _MAXK): below, the chain update -> leaf ->
-  // bulk inside one launch is no shorter than two launches (K = 128: 115 us against 72 + 34); above, the fused build's 3-4 spilled
-  // registers cost the long launches more (0.3 % of 11-30 ms) than the bulk launch they absorb (33 us)
-  static int fuse_bulk = -1, fuse_min_k = -1, fuse_max_k = -1;
-  if (fuse_bulk < 0) { const char* e = getenv("LMM_FUSE_BULK"); fuse_bulk = e ? (atoi(e) != 0) : 1; }
-  if (fuse_min_k < 0) { const char* e = getenv("LMM_FUSE_BULK_MINK"); fuse_min_k = e ? atoi(e) : 512; const char* x = getenv("LMM_FUSE_BULK_MAXK"); fuse_max_k = x ? atoi(x) : 2048; }
-  NodeFlags nfl;
-  nfl.min_k = fuse_min_k; nfl.max_k = fuse_max_k;
-  nfl.rows_real = rows_real;
-  auto node_fuse_flags = [&]() {
-    nfl.stride = (int)node_flag_ints(NR);
-    const size_t ints = (size_t)nfl.stride * B.nb;
-    nfl.p = reinterpret_cast<int*>(call_scratch((ints + 1) / 2));
-    HIPCHK(hipMemsetAsync(nfl.p, 0, ints * sizeof(int), st));
-  };
-  auto assistant_scratch = [&]() {
-    const size_t per_s = (size_t)LMM_REGION_ASST_TILES * 4096;
-    double* sb = call_scratch(per_s * B.nb);
-    for (int j = 0; j < B.nb; ++j) nfl.S.p[j] = sb + per_s * j;
-  };
-
-  // Round 4: block columns with look-ahead (potrf_blockcols) for every matrix wider than one region.  LMM_BLOCKCOL=0: the round-3
-  // recursion (below).  The squares go to potrf_region_kernel while its walker + helpers + assistants of all matrices are a minority of
-  // the CUs (they hold a CU each at one workgroup per CU), else to the panel recursion restricted to the square's rows (small launches
-  // that share the device with the update on the other stream); LMM_BLOCKCOL_SQ=region|panel forces one.
-  static int blockcol = -1, sq_force = -1;
-  if (blockcol < 0) { const char* e = getenv("LMM_BLOCKCOL"); blockcol = e ? atoi(e) : 1; }
-  if (sq_force < 0) { const char* e = getenv("LMM_BLOCKCOL_SQ"); sq_force = !e ? 0 : (e[0] == 'r' ? 1 : 2); }
-  if (blockcol && NC > 1024 && (NC % 128) == 0) {
-    const int sq_tasks = 2 * LMM_REGION_MAX_PANELS + (2 * LMM_REGION_MAX_PANELS - LMM_REGION_ASST_MIN_R);
-    const bool sq_region = g_region_cols >= 1024 && (sq_force ? sq_force == 1 : (long long)sq_tasks * B.nb * g_slots_in_flight <= cus / 2);
-    const bool overlap = blockcol != 2 && !(g.prof && g.prof_serial) && si >= 0 && si + 8 < kMaxStreams;     // LMM_BLOCKCOL=2: no second stream
-    hipStream_t aux = overlap ? g.streams[si + 8] : st;
-    BatchInfo fm{}, fa{};
-    if (sq_region) { fm = region_flags_of(si, st); fa = overlap ? region_flags_of(si + 8, aux) : fm; assistant_scratch(); }
-    else if (fuse_bulk) node_fuse_flags();
-    potrf_blockcols(B, W2, fm, fa, nfl, ld, NR, NC, n_real, st, aux, overlap ? &g.bc_events[si] : nullptr);
-    return;
-  }
-
   BatchInfo flags{};
   // Default: the region kernel serves matrices that are ONE region (NC <= 1024: the whole factorisation in one launch, the small-n
-  // path).  LMM_BLOCKCOL=0 keeps the round-3 rules for wider ones: the panel recursion throughout, or, for mid sizes / few matrices
-  // (tools/mid_probe.py), the region kernel as its base case while a block column's dataflow launch -- 2 P square tasks + one per
-  // 128-row tile below, per matrix -- is at most ~2.3 workgroups per CU (LMM_REGION_ALL=1 forces it, =0 never).
-  static int region_auto = -1;
+  // path); larger matrices take the panel recursion throughout (as their base case the region kernel measured no faster than the
+  // panel launches: DESIGN.md).  LMM_REGION_ALL=1 enables it there too, LMM_REGION=0 disables it.
+  // Mid sizes / few matrices (round 3, tools/mid_probe.py): while a block column's dataflow launch -- 2 P square tasks + one per
+  // 128-row tile below, per matrix -- is at most ~2.3 workgroups per CU, it beats the panel launches it replaces (8 latents: n = 1536
+  // 1.34 -> 0.96 ms, 2048 1.97 -> 1.51, 3072 3.50 -> 2.93, 4096 5.80 -> 5.2, 8192 27.1 -> 26.5; 16 x 2048: 2.19 -> 2.01; a rank's
+  // 4-latent share of C2: 94.5 -> 93.9); with more work per launch it does not (16 x 4096: a tie; the two concurrent 16-latent batches
+  // of C2 at N = 1: 696 -> 706 ms).  LMM_REGION_ALL=1 forces it, =0 (explicit) never.
+  static int region_auto = -1, cus = 0;
   if (region_auto < 0) { const char* ea = getenv("LMM_REGION_ALL"); region_auto = ea ? 0 : 1; }
+  if (cus == 0) { int dev = 0; cus = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); }
   bool region_base = !g_region_whole;
   if (region_auto && g_region_cols >= 1024 && NC > g_region_cols && (NC % 128) == 0) {
     const long long tasks = 2LL * (g_region_cols / 128) + ((NR + 127) / 128 - g_region_cols / 128);      // of the first (tallest) block column
@@ -588,9 +457,41 @@ void potrf_batch(const Batch& B, int ld, int NR, int NC, int n_real, hipStream_t
     region_base = tasks * B.nb * g_slots_in_flight <= (long long)(2.3 * cus);
   }
   const bool region_here = g_region_cols > 0 && (region_base || (NC <= g_region_cols && (NC % 128) == 0));
-  if (region_here) flags = region_flags_of(si, st);
-  if (fuse_bulk && !region_here && NC > 128) node_fuse_flags();      // not when the region kernel serves as the base case (it solves the first panel's rows itself)
-  if (region_here && std::min(NC, g_region_cols) > 64 * LMM_REGION_ASST_MIN_R) assistant_scratch();      // block columns with assistant rows: their scratch tiles
+  if (region_here) {                       // dependency flags of the region launches: this stream's slice of the persistent, once-zeroed
+    int si = -1;                           // array (launches are told apart by epoch); an unknown stream gets a zeroed scratch
+    for (int s = 0; s < kMaxStreams; ++s) if (g.streams[s] == st) si = s;
+    const size_t fi = region_flag_ints(NR);
+    int* fl;
+    if (si >= 0 && g.region_flags) fl = g.region_flags + (size_t)si * LMM_MAX_BATCH * fi;
+    else {
+      fl = reinterpret_cast<int*>(call_scratch((fi * B.nb + 1) / 2));
+      HIPCHK(hipMemsetAsync(fl, 0, fi * sizeof(int) * B.nb, st));
+    }
+    for (int j = 0; j < B.nb; ++j) flags.p[j] = fl + fi * j;
+  }
+  // LMM_FUSE_BULK (default 1): the bulk rows of a panel ride in the update launch that factors its diagonal block (NODE_FUSE), behind
+  // per-call flags zeroed here; not when the region kernel serves as the base case (it solves the first panel's rows itself).
+  static int fuse_bulk = -1;
+  if (fuse_bulk < 0) { const char* e = getenv("LMM_FUSE_BULK"); fuse_bulk = e ? (atoi(e) != 0) : 1; }
+  // ... in the launches with 512 <= K <= 2048 (LMM_FUSE_BULK_MINK / _MAXK): below, the chain update -> leaf -> bulk inside one launch
+  // is no shorter than two launches (K = 128: 115 us against 72 + 34); above, the fused build's 3-4 spilled registers cost the long
+  // launches more (0.3 % of 11-30 ms) than the bulk launch they absorb (33 us)
+  static int fuse_min_k = -1, fuse_max_k = -1;
+  if (fuse_min_k < 0) { const char* e = getenv("LMM_FUSE_BULK_MINK"); fuse_min_k = e ? atoi(e) : 512; const char* x = getenv("LMM_FUSE_BULK_MAXK"); fuse_max_k = x ? atoi(x) : 2048; }
+  NodeFlags nfl;
+  nfl.min_k = fuse_min_k; nfl.max_k = fuse_max_k;
+  nfl.rows_real = rows_real;
+  if (fuse_bulk && !region_here && NC > 128) {
+    nfl.stride = (int)node_flag_ints(NR);
+    const size_t ints = (size_t)nfl.stride * B.nb;
+    nfl.p = reinterpret_cast<int*>(call_scratch((ints + 1) / 2));
+    HIPCHK(hipMemsetAsync(nfl.p, 0, ints * sizeof(int), st));
+  }
+  if (region_here && std::min(NC, g_region_cols) > 64 * LMM_REGION_ASST_MIN_R) {      // block columns with assistant rows: their scratch tiles
+    const size_t per_s = (size_t)LMM_REGION_ASST_TILES * 4096;
+    double* sb = call_scratch(per_s * B.nb);
+    for (int j = 0; j < B.nb; ++j) nfl.S.p[j] = sb + per_s * j;
+  }
   potrf_rec_panel(B, W2, flags, nfl, ld, NR, 0, NC, n_real, st, false);
 }
 

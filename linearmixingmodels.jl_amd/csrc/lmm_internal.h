@@ -102,9 +102,6 @@ void region_flags_register(int* base, size_t ints);     // the context's persist
 size_t region_flag_ints(int NR);          // ints per matrix that the flags of any region of a matrix with NR rows need
 void launch_region(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2, const BatchInfo& info, const BatchInfo& flags, int ld, int NR,
                    int c0, int width, int n_real, int nb, bool first_done, hipStream_t st, int rows_real = -1, const BatchPtr* S = nullptr);
-// potrf_rows_kernel (lmm_kernels.hip K2e): the rows [c0 + width, NR) of the block column [c0, c0 + width), whose square is factored and whose
-// panel inverses are in W2 -- left-looking solve, one workgroup per 128-row tile, no dependencies inside the launch
-void launch_rows(const BatchPtr& A, const BatchPtr& W2, int ld, int NR, int c0, int width, int nb, hipStream_t st);
 // plain trailing update (no leaf) through the node kernel: C -= A B' for the region at j0 + h
 void launch_leaf128(const BatchPtr& A, size_t offD, int ld, const BatchPtr& W, size_t offW, const BatchPtr& W2, size_t offW2,
                     int gcol0, int n_real, const BatchInfo& info, int nb, hipStream_t st);

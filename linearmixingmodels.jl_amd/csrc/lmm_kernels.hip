@@ -2860,81 +2860,6 @@ __global__ __launch_bounds__(256, OCC) void potrf_region_kernel(RegionArgs a) {
   if (a.trace && threadIdx.x == 0) a.trace[2 * blockIdx.x + 1] = wall_clock64();
 }
 
-// ---------------------------------------------------------------------------------------------------
-// K2e (round 4): the ROWS of a block column, alone -- potrf_rows_kernel.
-// Block-column factorisation with look-ahead (lmm_api.hip potrf_blockcols): the W = 128 P columns [c0, c0 + W) of every matrix, whose
-// diagonal SQUARE (rows c0 .. c0 + W - 1) has already been factored -- on a second stream, beside the previous trailing update -- with
-// its panel inverses Dinv_j in the W2 scratch.  What is left is, for every 128-row tile i below the square (rider rows included), the
-// left-looking solve of potrf_region_row without a single wait:
-//     column j = 0 .. P-1:  acc = X[i, 0:j] L[j, 0:j]'   (ONE pass over K = 128 j: the tile's own earlier outputs times the square's rows)
-//                           C[i, j] -= acc;   X[i, j] = C[i, j] Dinv_j'   (one K = 128 pass, in place)
-// Each tile of the block column is read and written ONCE per panel (the recursion's K = 128 .. 512 update launches and its bulk launches
-// re-read and re-wrote the trailing tiles once per level: four passes over the same rows, HBM-bound at 16 matrices per launch), all
-// products run on the pipelined 16x16x4 loop at two workgroups per CU, and nothing in the launch is latency-bound: no leaf, no flag.
-// Grid: 1-D, matrix fastest (consecutive workgroups -- dealt round-robin over the XCDs -- spread a matrix's square over few L2s), row
-// tile by row tile from the top: the tiles of the NEXT square's rows finish first.
-// ---------------------------------------------------------------------------------------------------
-struct RowsArgs {
-  BatchPtr A, W2;
-  int ld, c0, P, M, nb;      // M: rows below the square (from row c0 + 128 P), a multiple of 64
-};
-__global__ __launch_bounds__(256, 2) void potrf_rows_kernel(RowsArgs a) {
-  extern __shared__ __attribute__((aligned(16))) double node_lds[];
-  const int b = blockIdx.x % a.nb, ti = blockIdx.x / a.nb;
-  double* Am = a.A.p[b];
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const int wr = (w & 1) * 64, wc = (w >> 1) * 64;
-  const int l15 = lane & 15, lk = lane >> 4;
-  const int rows_i = min(128, a.M - 128 * ti);
-  const size_t row_i = (size_t)a.c0 + 128 * (size_t)a.P + 128 * (size_t)ti;
-  const size_t col0 = (size_t)a.c0 * a.ld;
-  const bool active = wr < rows_i;
-  for (int tj = 0; tj < a.P; ++tj) {
-    const size_t row_j = (size_t)a.c0 + 128 * (size_t)tj;
-    double* C = Am + row_j * a.ld + row_i;
-    d4 acc[4][4];
-    if (tj > 0) {
-#pragma unroll
-      for (int v = 0; v < 4; ++v)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc[v][u] = (d4){0.0, 0.0, 0.0, 0.0};
-      pipe128_accumulate(acc, node_lds, Am + col0 + row_i, a.ld, rows_i, Am + col0 + row_j, a.ld, 128, 8 * tj);
-      if (active) {
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          double* cpv = C + (size_t)(wc + 16 * v + lk) * a.ld + wr + l15;
-          double cv[4][4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) cv[u][r] = cpv[(size_t)(4 * r) * a.ld + 16 * u];
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) cpv[(size_t)(4 * r) * a.ld + 16 * u] = cv[u][r] - acc[v][u][r];
-        }
-      }
-      __syncthreads();                                             // C[i, j] is in memory (this workgroup reads it back as an operand)
-    }
-#pragma unroll
-    for (int v = 0; v < 4; ++v)
-#pragma unroll
-      for (int u = 0; u < 4; ++u) acc[v][u] = (d4){0.0, 0.0, 0.0, 0.0};
-    pipe128_accumulate(acc, node_lds, C, a.ld, rows_i, a.W2.p[b] + (size_t)(row_j / 128) * 16384, 128, 128);
-    if (active) {
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        double* cpv = C + (size_t)(wc + 16 * v + lk) * a.ld + wr + l15;
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) cpv[(size_t)(4 * r) * a.ld + 16 * u] = acc[v][u][r];
-      }
-    }
-    __syncthreads();                                               // X[i, j] is in memory for this workgroup's own later passes
-  }
-}
-
 #undef LMM_MFMA16H_ALL
 #undef LMM_TILE_BODY
 #undef LMM_MFMA16_ALL
@@ -3861,7 +3786,6 @@ static void node_lds_attr() {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_node_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_region_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_region_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   done = true;
 }
 void launch_leaf128(const BatchPtr& A, size_t offD, int ld, const BatchPtr& W, size_t offW, const BatchPtr& W2, size_t offW2,
@@ -3996,17 +3920,6 @@ bool launch_update_leaf(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2
   }
   if (strip && !fuse) launch_strip();
   return fuse;
-}
-
-// rows [c0 + width, NR) of the block column [c0, c0 + width) of every matrix (square factored, panel inverses in W2): see K2e
-void launch_rows(const BatchPtr& A, const BatchPtr& W2, int ld, int NR, int c0, int width, int nb, hipStream_t st) {
-  const int P = width / 128, M = NR - (c0 + width);
-  if (nb <= 0 || P <= 0 || M <= 0) return;
-  node_lds_attr();
-  RowsArgs a{};
-  a.A = A; a.W2 = W2; a.ld = ld; a.c0 = c0; a.P = P; a.M = M; a.nb = nb;
-  const int MT = (M + 127) / 128;
-  hipLaunchKernelGGL(potrf_rows_kernel, dim3((unsigned)MT * nb), dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
 }
 
 size_t region_flag_ints(int) { return REGION_FLAG_INTS; }
