@@ -295,7 +295,7 @@ def main():
     peak_tf = FP32_MFMA_PEAK_TFLOPS if args.dtype == "f32" else FP64_MFMA_PEAK_TFLOPS
     prof = None
     nprof = min(16, shard[1] - shard[0]) if orth else m     # one production-sized batch of latents (LMM_BATCH default 16)
-    if (rank == 0 or world > 1) and not args.no_roofline and not predictive and nprof > 0:
+    if (rank == 0 or world > 1) and not args.no_roofline and nprof > 0:
         # Instrumented pass: one more evaluation of one batch of this rank's latents with every launch of the hot kernels
         # bracketed by HIP events on its stream; the batch runs on ONE stream so that an event pair times its kernel alone (the
         # timed region above runs several batches on concurrent streams).  Rank 0's pass is the roofline leg (DESIGN.md
@@ -305,6 +305,8 @@ def main():
         L.check(lib.lmm_profile_begin(1))
         if sampling:
             lmm_amd.rand(lmm_amd.DeviceNormals(99), fprof, jitters=jit_rand, add_noise=False)
+        elif predictive:
+            lmm_amd.mean_and_var(lmm_amd.posterior(fprof, yd)(xs_in, s2))      # posterior + marginals of one batch, one stream
         else:
             lmm_amd.logpdf(fprof, yd, False)
         ent = (L.ProfEntryT * len(L.PROF_CLASSES))()
@@ -314,7 +316,28 @@ def main():
     if rank == 0 and prof is not None:
         lib = lmm_amd.load()
         up = prof["update"]
-        if up["launches"] and up["ms"] > 0:
+        sv = prof.get("solve")
+        if predictive and sv and sv["launches"] and sv["ms"] > 0:
+            # configs[3]: per latent n^3/3 flops of factorisation against n* n^2 of the cross-solve R = K(x*, x) L^-T -- the block
+            # updates of that triangular solve (trsm_rec) are the dominant kernel class of the posterior-predictive step
+            ach = sv["work"] / (sv["ms"] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "gemm16p_kernel<DEPTH> (v_mfma_f64_16x16x4_f64, VGPR accumulators, software-pipelined) as the block updates "
+                                               "R[:, c1] -= R[:, c0] L[c1, c0]' of the triangular solve K(x*, x) L^-T (trsm_rec: K = 64 .. n/2; + gemm16h_kernel on ragged rows)",
+                    "achieved": round(ach, 3), "peak": peak_tf, "unit": "TFLOP/s", "frac": round(ach / peak_tf, 4), "traffic": None,
+                    "launches": sv["launches"], "avg_launch_ms": round(sv["ms"] / sv["launches"], 4),
+                    "flops_per_launch": sv["work"] / sv["launches"], "algorithmic_bytes_per_launch": sv["bytes"] / sv["launches"],
+                    "mode": f"serial-stream instrumented pass over {nprof} latent(s): posterior + marginals"}
+            if up["launches"] and up["ms"] > 0:
+                extra["roofline_factor_update"] = {"bound": "mfma", "kernel": "potrf_node_kernel<2> (the K >= 1024 trailing updates of the n x n factorisations)",
+                                                   "achieved": round(up["work"] / (up["ms"] * 1e-3) / 1e12, 3), "peak": peak_tf, "unit": "TFLOP/s",
+                                                   "frac": round(up["work"] / (up["ms"] * 1e-3) / 1e12 / peak_tf, 4), "launches": up["launches"]}
+            stp = prof.get("strip")
+            if stp and stp["launches"] and stp["ms"] > 0:
+                gbs = stp["bytes"] / (stp["ms"] * 1e-3) / 1e9
+                extra["roofline_strip"] = {"bound": "hbm", "kernel": "strip_reduce_kernel (posterior mean and variance from one read of R)",
+                                           "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                           "launches": stp["launches"]}
+        elif up["launches"] and up["ms"] > 0:
             ach = up["work"] / (up["ms"] * 1e-3) / 1e12
             traffic = None       # HBM-side bytes per launch from the committed rocprofv3 --pmc passes (separate runs)
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")

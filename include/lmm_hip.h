@@ -376,7 +376,12 @@ typedef enum {
   LMM_PROF_REGION = 5,        /* potrf_region_kernel: a block column of <= 8 panels (leaves, bulk products, inner updates) in one
                                  dataflow launch, flops                                                                         */
   LMM_PROF_UPDATE_SHORT = 6,  /* potrf_node_kernel<1>: the same fused update + leaf for K < 1024 (latency- and epilogue-bound levels)  */
-  LMM_PROF_COUNT = 7
+  LMM_PROF_SOLVE = 7,         /* gemm16p_kernel inside the triangular solves R <- R L^-T against a stored factor (cross-Gram rows of the
+                                 predictive paths, L^-T of the gradient paths): the K = 64 .. n/2 block updates, flops 2 rows cols K;
+                                 the dominant class of BASELINE configs[3] (n* n^2 of its n^3/3 + n* n^2 flops per latent)            */
+  LMM_PROF_SOLVE_LEAF = 8,    /* gemm44_kernel<64,true>: the 64-column solves by the stored inverse diagonal blocks, flops rows 64^2    */
+  LMM_PROF_STRIP = 9,         /* strip_reduce_kernel + strip_finish_kernel: posterior marginals from one read of R (HBM read), bytes   */
+  LMM_PROF_COUNT = 10
 } lmm_prof_class;
 typedef struct { long long launches; double ms; double work; double bytes; /* algorithmic HBM bytes */ } lmm_prof_entry_t;
 int lmm_profile_begin(int serial);

@@ -44,7 +44,7 @@ class ProfEntryT(C.Structure):
     _fields_ = [("launches", C.c_longlong), ("ms", C.c_double), ("work", C.c_double), ("bytes", C.c_double)]
 
 
-PROF_CLASSES = ["gram", "update", "update_narrow", "trsm", "diag", "region", "update_short"]
+PROF_CLASSES = ["gram", "update", "update_narrow", "trsm", "diag", "region", "update_short", "solve", "solve_leaf", "strip"]
 
 
 class PosDefException(ArithmeticError):

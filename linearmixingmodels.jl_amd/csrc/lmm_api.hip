@@ -514,6 +514,7 @@ void trsm_rec(double* R, int ldr, int nr, const double* L, int ld, const double*
   if (w <= 64) {
     const int rows = tri ? std::min(nr, j0 + 64) : nr;
     double* pan = R + (size_t)j0 * ldr;
+    ProfScope ps(LMM_PROF_SOLVE_LEAF, (double)rows * 64.0 * 64.0, st, rows, 64, 64);
     launch_gemm_nt(pan, ldr, pan, ldr, W + (size_t)(j0 / 64) * 4096, 64, rows, 64, 64, 0, true, st);
     return;
   }
@@ -521,8 +522,12 @@ void trsm_rec(double* R, int ldr, int nr, const double* L, int ld, const double*
   trsm_rec(R, ldr, nr, L, ld, W, j0, h, st, tri, false);
   // tri: the left block R[:, j0:j0+h] is upper triangular (zero below row j0+h), so only rows < j0+h contribute
   const int rows = tri ? std::min(nr, j0 + h) : nr;
-  launch_gemm_nt(R + (size_t)(j0 + h) * ldr, ldr, R + (size_t)j0 * ldr, ldr, L + (size_t)j0 * ld + (j0 + h), ld,
-                 rows, w - h, h, 0, false, st);
+  {
+    const double r = rows, c = w - h, k = h;
+    ProfScope ps(LMM_PROF_SOLVE, 2.0 * r * c * k, st, rows, w - h, h, 16.0 * r * c + 8.0 * r * k + 8.0 * c * k);
+    launch_gemm_nt(R + (size_t)(j0 + h) * ldr, ldr, R + (size_t)j0 * ldr, ldr, L + (size_t)j0 * ld + (j0 + h), ld,
+                   rows, w - h, h, 0, false, st);
+  }
   trsm_rec(R, ldr, nr, L, ld, W, j0 + h, w - h, st, tri, false);
 }
 
@@ -537,14 +542,21 @@ void trsm_rec(const BatchPtr& R, int ldr, int nr, const BatchPtr& L, int ld, con
     }
   if (w <= 64) {
     const int rows = tri ? std::min(nr, j0 + 64) : nr;
+    ProfScope ps(LMM_PROF_SOLVE_LEAF, (double)nb * rows * 64.0 * 64.0, st, rows, 64, 64);       // 64-column solve by the inverse block: rows * 64^2 flops
     launch_gemm_nt(R, (size_t)j0 * ldr, ldr, R, (size_t)j0 * ldr, ldr, W, (size_t)(j0 / 64) * 4096, 64, rows, 64, 64, 0, true, nb, st);
     return;
   }
   const int h = split(w);
   trsm_rec(R, ldr, nr, L, ld, W, nb, j0, h, st, tri, false);
   const int rows = tri ? std::min(nr, j0 + h) : nr;
-  launch_gemm_nt(R, (size_t)(j0 + h) * ldr, ldr, R, (size_t)j0 * ldr, ldr, L, (size_t)j0 * ld + (j0 + h), ld, rows, w - h, h, 0, false,
-                 nb, st);
+  {
+    // R[:, j0+h : j0+w] -= R[:, j0 : j0+h] L[j0+h : j0+w, j0 : j0+h]': 2 rows (w - h) h flops; bytes: the target block read + written,
+    // both operand blocks read once
+    const double r = rows, c = w - h, k = h;
+    ProfScope ps(LMM_PROF_SOLVE, (double)nb * 2.0 * r * c * k, st, rows, w - h, h, (double)nb * (16.0 * r * c + 8.0 * r * k + 8.0 * c * k));
+    launch_gemm_nt(R, (size_t)(j0 + h) * ldr, ldr, R, (size_t)j0 * ldr, ldr, L, (size_t)j0 * ld + (j0 + h), ld, rows, w - h, h, 0, false,
+                   nb, st);
+  }
   trsm_rec(R, ldr, nr, L, ld, W, nb, j0 + h, w - h, st, tri, false);
 }
 
@@ -2143,7 +2155,11 @@ static int posterior_create_common(const double* xd, int d, int n, const lmm_gp_
         ga[j] = a;
         B.add(P->L[k].p, P->W[k].p, info.p + k);
       }
-      gram_batch_g(ga, nb, st);
+      {
+        const double gb = (double)n * ((double)n + 1.0) / 2.0 * 8.0;
+        ProfScope ps(LMM_PROF_GRAM, nb * gb, st, 0, 0, 0, nb * gb, nb);
+        gram_batch_g(ga, nb, st);
+      }
       potrf_batch(B, D.ld, D.NR, D.NC, n, st, D.NC + 1);        // one rider row (delta); rows NC + 1 .. NR - 1 are zero padding
       // alpha = L^-T (L^-1 delta): the rider row is z = L^-1 delta (kept as P->z, zero-padded to NC)
       BatchPtr ab{}, zb{};
@@ -2634,12 +2650,18 @@ static int latent_marginals_dev(const lmm_post* P, const lmm_gp_t* gps_shard, in
       ga[j] = cross_gram_args(P, P->gps[P->l0 + k], xsd, d, ns, R[s][j].p, ldr, nsr);
       Rb.p[j] = R[s][j].p; Lb.p[j] = P->L[k].p; Wb.p[j] = P->W[k].p;
     }
-    gram_batch_g(ga, nb, st);
+    {
+      const double gb = (double)ns * P->n * 8.0;                   // cross-Gram K(x*, x): a full n* x n rectangle written once
+      ProfScope ps(LMM_PROF_GRAM, nb * gb, st, 0, 0, 0, nb * gb, nb);
+      gram_batch_g(ga, nb, st);
+    }
     trsm_rec(Rb, ldr, nsr, Lb, P->ld, Wb, nb, 0, P->NC, st);       // R_j <- K(x*, x) L_j^-T for the whole batch
     for (int j = 0; j < nb; ++j) {
       const int k = k0 + j;
       const lmm_gp_t& gp = P->gps[P->l0 + k];
       // mean = mu + K(x*,x) alpha = mu + R' (L^-1 delta);  var = kappa(0) - colsumsq(R)   (one pass over R)
+      const double rb = (double)ns * P->n * 8.0;                   // R read once
+      ProfScope ps(LMM_PROF_STRIP, rb, st, ns, P->n, 0, rb);
       rider_stats_g(R[s][j].p, ldr, ns, P->n, P->z[k].p, gp.mean, gp.variance, part[s].p, mean_lat + (size_t)k * ns,
                          var_lat + (size_t)k * ns, st);
     }
