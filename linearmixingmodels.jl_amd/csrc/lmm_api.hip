@@ -356,12 +356,6 @@ void potrf_rec(const Batch& B, int ld, int NR, int j0, int w, int n_real, hipStr
 // also runs the leaf of the panel that follows it (launch_update_leaf), so that per 128 columns the stream sees two launches
 // (update + leaf, bulk) instead of six.  first_done: the diagonal block of the first panel of [j0, j0 + w) is already factored.
 // Widths that are not multiples of 128 (NC = 64 mod 128) end in the round-2 path for their last 64 columns.
-// Staggering of concurrent batches (latent_lmls): same-shaped batches on concurrent streams march through the recursion in
-// lock-step, so their latency-bound phases (panels, K < 1024 updates) coincide and hide nothing behind each other.  The batch that
-// goes first records g_stagger_ev right after its first K >= 1024 update is enqueued; the next batch's stream waits for it, so that
-// its panel phases fall into the other batch's long updates.
-static hipEvent_t g_stagger_ev = nullptr;
-static bool g_stagger_armed = false, g_stagger_recorded = false;
 static int g_slots_in_flight = 1;       // batches that run concurrently on the slot streams (set by fork_slots; read by potrf_batch's base-case rule)
 static int g_region_whole = 1;          // LMM_REGION_ALL=1: also as the base case of the recursion for larger matrices (measured: no gain)
 static int g_region_cols = -1;          // widest block column potrf_region_kernel takes in one launch (LMM_REGION=<columns>, up to 1024; default 0: off)
@@ -410,7 +404,6 @@ void potrf_rec_panel(const Batch& B, const BatchPtr& W2, const BatchInfo& flags,
                    nb * (2.0 * h * outs + 2.0 * 128.0 * 128.0 * 128.0 / 3.0 + Mb * 128.0 * 128.0), st, NR - r0, Nc, h,
                    nb * (16.0 * outs + 8.0 * Mr * h + 16.0 * Mb * 128.0));
       fused = launch_update_leaf(B.A, B.W, W2, B.info, ld, NR, j0, h, Nc, n_real, B.nb, st, (h >= nfl.min_k && h <= nfl.max_k) ? nfl.p : nullptr, nfl.stride);
-      if (g_stagger_armed && !g_stagger_recorded && h >= 1024) { HIPCHK(hipEventRecord(g_stagger_ev, st)); g_stagger_recorded = true; }
     }
     potrf_rec_panel(B, W2, flags, nfl, ld, NR, r0, Nc, n_real, st, true, fused);
   } else {
@@ -476,8 +469,7 @@ void potrf_batch(const Batch& B, int ld, int NR, int NC, int n_real, hipStream_t
   // ... in the launches with 512 <= K <= 2048 (LMM_FUSE_BULK_MINK / _MAXK): below, the chain update -> leaf -> bulk inside one launch
   // is no shorter than two launches (K = 128: 115 us against 72 + 34); above, the fused build's 3-4 spilled registers cost the long
   // launches more (0.3 % of 11-30 ms) than the bulk launch they absorb (33 us)
-  static int fuse_min_k = -1, fuse_max_k = -1;
-  if (fuse_min_k < 0) { const char* e = getenv("LMM_FUSE_BULK_MINK"); fuse_min_k = e ? atoi(e) : 512; const char* x = getenv("LMM_FUSE_BULK_MAXK"); fuse_max_k = x ? atoi(x) : 2048; }
+  constexpr int fuse_min_k = 512, fuse_max_k = 2048;
   NodeFlags nfl;
   nfl.min_k = fuse_min_k; nfl.max_k = fuse_max_k;
   nfl.rows_real = rows_real;
@@ -573,21 +565,14 @@ void backsolve1(const double* L, int ld, const double* W, int nblk, double* z, h
 void batch_plan(int ms, int* nb_per, int* nstreams_used, double bytes_per_latent = 0.0) {
   static int bmax = -1;
   if (bmax < 0) { const char* e = getenv("LMM_BATCH"); bmax = e ? atoi(e) : 16; if (bmax < 1) bmax = 1; if (bmax > LMM_MAX_BATCH) bmax = LMM_MAX_BATCH; }   // round 2: 16 (C2: 690 vs 696 ms at 8)
-  // Batches kept in flight for small shards: factor matrices up to n = 8192 do best as ONE lock-step batch (fewer, fuller
-  // launches: n = 2048, m = 8: 2.82 -> 2.51 ms); larger ones as two batches on two streams, so one batch's leaf chain hides
-  // behind the other's updates (C2 share of 4 latents: 108 vs 110 ms).  LMM_MIN_BATCHES overrides.
-  static int minb_env = -2;
-  if (minb_env == -2) { const char* e = getenv("LMM_MIN_BATCHES"); minb_env = e ? std::max(1, atoi(e)) : -1; }
-  // Round 2: with the software-pipelined update kernel one fuller lock-step batch beats two smaller ones on two streams at every
-  // size (C2 share of 4 latents: 99.5 ms as one batch, 102.3 as 2 x 2, 105.4 as 4 x 1; gpurun r2n_shard_batches.log), so the
-  // default is ONE batch per `bmax` latents; concurrent streams still carry the batches of larger shards.
-  const int minb = minb_env > 0 ? minb_env : 1;
+  // ONE lock-step batch per `bmax` latents (with the software-pipelined update kernel a fuller batch beats two smaller ones on two
+  // streams at every size: C2 share of 4 latents 99.5 ms as one batch, 102.3 as 2 x 2, 105.4 as 4 x 1, round 2); concurrent streams
+  // carry the batches of larger shards.
   // small factor matrices (n <= ~2000) are latency-bound end to end: one lock-step batch of up to LMM_MAX_BATCH latents costs the
   // same leaf chain as a batch of 8 (reference notebook shape, 20 latents: 3 batches of 8/8/4 -> one of 20)
-  static int bsmall = -1;
-  if (bsmall < 0) { const char* e = getenv("LMM_BATCH_SMALL"); bsmall = e ? std::max(1, std::min(LMM_MAX_BATCH, atoi(e))) : LMM_MAX_BATCH; }
+  constexpr int bsmall = LMM_MAX_BATCH;
   const int bcap = (bytes_per_latent > 0.0 && bytes_per_latent <= 4e7) ? std::max(bmax, bsmall) : bmax;
-  int b = std::min(bcap, std::max(1, ms / minb));
+  int b = std::min(bcap, std::max(1, ms));
   if (g.prof && g.prof_serial) b = std::min(bcap, ms);  // instrumented pass: production-sized batches on ONE stream
   int nbatches = (ms + b - 1) / b;
   int ns = std::max(1, std::min(nbatches, eff_streams()));
@@ -879,18 +864,9 @@ int latent_lmls(const double* xd, int d, int n, const lmm_gp_t* gps, const doubl
       ga[j] = a;
       B.add(s.A[j].p, s.W[j].p, info.p + k);
     }
-    if (bi > 0 && g_stagger_recorded) HIPCHK(hipStreamWaitEvent(s.st, g_stagger_ev, 0));      // start behind the previous batch's first long update
     gram_batch_g(ga, nb, s.st);       // one launch per run of equal kernel kinds (blockIdx.z = latent)
     }
-    {
-      static int stagger = -1;
-      if (stagger < 0) { const char* e = getenv("LMM_STAGGER"); stagger = e ? atoi(e) : 0; }      // default off: measured no gain (C2: 686 vs 682 ms)
-      g_stagger_armed = stagger && nslots > 1 && !(g.prof && g.prof_serial);
-      g_stagger_recorded = false;
-      if (g_stagger_armed && !g_stagger_ev) HIPCHK(hipEventCreateWithFlags(&g_stagger_ev, hipEventDisableTiming));
-    }
     potrf_batch(B, D.ld, D.NR, D.NC, n, s.st, D.NC + nrhs);      // the rider rows NC + nrhs .. NR - 1 are zero padding
-    g_stagger_armed = false;
     if (pk_dev) launch_lml_reduce(B.A, nb, D.ld, n, D.NC, nrhs, reinterpret_cast<double*>(pk_dev) + (size_t)k0 * nrhs, s.st, &B.info,
                                   reinterpret_cast<int*>(pk_dev + nout * sizeof(double)) + k0);
     else launch_lml_reduce(B.A, nb, D.ld, n, D.NC, nrhs, out.p + (size_t)k0 * nrhs, s.st);

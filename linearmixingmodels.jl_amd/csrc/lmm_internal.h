@@ -76,7 +76,6 @@ struct NodeArgs {
   // device-side flags (nflags: per matrix [0] abort word, [1] leaf done, [2 + ti] column-0 tile ti updated; values epoch * 32 + 1)
   int* nflags; int nf_stride, epoch;
   int Mb, MTb, bulk0;     // rows / 128-row tiles the bulk items cover (a ragged last 64 rows included); index of the first bulk item
-  long long* trace;       // optional (LMM_NODE_TRACE=<K>, tools/node_trace.py): start / end wall-clock ticks + CU id of every workgroup
 };
 // Arguments of potrf_region_kernel (lmm_kernels.hip K2d): the columns [c0, c0 + 128 P) of every matrix of the batch, rows c0 .. c0 + M - 1.
 struct RegionArgs {

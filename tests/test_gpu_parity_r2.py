@@ -477,31 +477,24 @@ def test_dense_ilmm_matrix_y_logpdf(lmm):
 
 
 def test_update_kernel_variants_agree():
-    """The round-1 update kernels stay selectable (LMM_GEMM_M16=0: v_mfma_f64_4x4x4; 1: 16x16x4 in the round-1 loop; LMM_GEMM_FLAGS=1:
-    LDS-flag synchronised 4x4x4), and so do the earlier diagonal-block kernels (LMM_DIAG_FORM=1: 256-thread register blocks, 2: owner-only
-    pivot work; default 3: one wave, MFMA rank-4 steps); each must give the default kernels' logpdf."""
+    """The factorisation paths that remain selectable -- the 128-column panel recursion with and without the bulk rows riding in the
+    update launches, the dataflow region kernel as its base case (with / without assistants, one or two workgroups per CU), the round-2
+    64-column path (LMM_PANEL128=0: diag64m + solve by inverse + gemm16p updates) and the split-free deterministic sums -- must all
+    give the default path's logpdf.  (The round-1/2 kernel variants that used to be switched here -- 4x4x4 update, LDS-flag loop,
+    256-thread diagonal blocks -- left the library in round 4: tools/retired_kernels.hip.)"""
     import subprocess, sys, json
     code = ("import sys, json; sys.path.insert(0, %r); import numpy as np, lmm_amd; "
             "from lmm_amd.workloads import synthetic_problem as sp; lmm_amd.init(0); P = sp(3, 5, 1500, 'matern52', True, seed=2); "
             "f = lmm_amd.ILMM(lmm_amd.independent_mogp([lmm_amd.GP(lmm_amd.Matern52Kernel()) for _ in range(3)]), lmm_amd.Orthogonal(P['U'], P['S'])); "
             "print(json.dumps(lmm_amd.logpdf(f(lmm_amd.MOInputIsotopicByOutputs(P['x'], 5), 0.1), P['y'])))") % os.path.dirname(HERE)
     vals = {}
-    # round 3: the default factorisation takes the 128-column panel path (potrf_node_kernel / leaf128); LMM_PANEL128=0 is the
-    # round-2 path, which the older kernel switches act on
-    r2 = {"LMM_PANEL128": "0"}
-    for name, env in [("default", {}), ("round2_path", r2), ("m16_0", dict(r2, LMM_GEMM_M16="0")), ("m16_1", dict(r2, LMM_GEMM_M16="1")),
-                      ("flags", dict(r2, LMM_GEMM_M16="0", LMM_GEMM_FLAGS="1")),
-                      ("diag_form1", dict(r2, LMM_DIAG_FORM="1")), ("diag_form2", dict(r2, LMM_DIAG_FORM="2")), ("full_tiles", dict(r2, LMM_HALF_TILES="0")),
-                      ("no_ragged_split", dict(r2, LMM_RAGGED_SPLIT="0")), ("deterministic", {"LMM_DETERMINISTIC": "1"}),
-                      # round 3, panel path: bulk rows as separate launches / riding in EVERY update launch (default: K >= 512), the
-                      # round-aligned split-K tail, the dataflow kernel as the base case of the recursion
-                      ("no_fused_bulk", {"LMM_FUSE_BULK": "0"}), ("fused_bulk_all", {"LMM_FUSE_BULK_MINK": "128", "LMM_FUSE_BULK_MAXK": "65536"}),
-                      ("fused_bulk_deterministic", {"LMM_FUSE_BULK_MINK": "128", "LMM_FUSE_BULK_MAXK": "65536", "LMM_DETERMINISTIC": "1"}),
-                      ("tail_policy1", {"LMM_TAIL_POLICY": "1"}), ("region_base", {"LMM_REGION_ALL": "1", "LMM_REGION": "512"}),
+    for name, env in [("default", {}), ("round2_path", {"LMM_PANEL128": "0"}), ("deterministic", {"LMM_DETERMINISTIC": "1"}),
+                      ("round2_deterministic", {"LMM_PANEL128": "0", "LMM_DETERMINISTIC": "1"}),
+                      ("no_fused_bulk", {"LMM_FUSE_BULK": "0"}), ("region_base_512", {"LMM_REGION_ALL": "1", "LMM_REGION": "512"}),
                       # the default at this size: 1024-column region launches as base case, with assistants; without them; the
                       # two-per-CU build; the panel recursion instead
                       ("region_no_assistants", {"LMM_REGION_ASST": "0"}), ("region_occ2", {"LMM_REGION_OCC": "2"}),
-                      ("panel_recursion", {"LMM_REGION_ALL": "0"})]:
+                      ("panel_recursion", {"LMM_REGION_ALL": "0"}), ("panel_recursion_deterministic", {"LMM_REGION_ALL": "0", "LMM_DETERMINISTIC": "1"})]:
         out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr[-2000:]
         vals[name] = json.loads(out.stdout.strip().splitlines()[-1])
