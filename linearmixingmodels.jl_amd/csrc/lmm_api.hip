@@ -496,33 +496,6 @@ void potrf_rec(double* A, int ld, int NR, int j0, int w, double* W, int n_real, 
 // R (nr x NC, ldr) <- R * L^-T for an already factored L (ld) with inverse diagonal blocks W.
 // tri: R starts as the identity and becomes the upper triangular L^-T; rows below the current column block are still
 // zero and are skipped (~n^3/3 flops instead of n^3 for a rectangular solve).
-void trsm_rec(double* R, int ldr, int nr, const double* L, int ld, const double* W, int j0, int w, hipStream_t st,
-              bool tri = false, bool top = true) {
-  if (top) {          // rows / columns this solve touches against the allocations (checked once, not per recursion level)
-    guard_extent(R, nr, ldr, (size_t)j0 + w, true, "triangular solve (R)");
-    guard_extent(L, (size_t)j0 + w, ld, (size_t)j0 + w, true, "triangular solve (L)");
-    guard_extent(W, 64, 64, (size_t)((j0 + w) / 64) * 64, true, "triangular solve (inverse blocks)");
-  }
-  if (w <= 64) {
-    const int rows = tri ? std::min(nr, j0 + 64) : nr;
-    double* pan = R + (size_t)j0 * ldr;
-    ProfScope ps(LMM_PROF_SOLVE_LEAF, (double)rows * 64.0 * 64.0, st, rows, 64, 64);
-    launch_gemm_nt(pan, ldr, pan, ldr, W + (size_t)(j0 / 64) * 4096, 64, rows, 64, 64, 0, true, st);
-    return;
-  }
-  const int h = split(w);
-  trsm_rec(R, ldr, nr, L, ld, W, j0, h, st, tri, false);
-  // tri: the left block R[:, j0:j0+h] is upper triangular (zero below row j0+h), so only rows < j0+h contribute
-  const int rows = tri ? std::min(nr, j0 + h) : nr;
-  {
-    const double r = rows, c = w - h, k = h;
-    ProfScope ps(LMM_PROF_SOLVE, 2.0 * r * c * k, st, rows, w - h, h, 16.0 * r * c + 8.0 * r * k + 8.0 * c * k);
-    launch_gemm_nt(R + (size_t)(j0 + h) * ldr, ldr, R + (size_t)j0 * ldr, ldr, L + (size_t)j0 * ld + (j0 + h), ld,
-                   rows, w - h, h, 0, false, st);
-  }
-  trsm_rec(R, ldr, nr, L, ld, W, j0 + h, w - h, st, tri, false);
-}
-
 // The same solve for a batch of (R_j, L_j, W_j) of identical shapes in lock-step launches (blockIdx.y = matrix).
 void trsm_rec(const BatchPtr& R, int ldr, int nr, const BatchPtr& L, int ld, const BatchPtr& W, int nb, int j0, int w,
               hipStream_t st, bool tri = false, bool top = true) {
@@ -550,6 +523,14 @@ void trsm_rec(const BatchPtr& R, int ldr, int nr, const BatchPtr& L, int ld, con
                    nb, st);
   }
   trsm_rec(R, ldr, nr, L, ld, W, nb, j0 + h, w - h, st, tri, false);
+}
+
+// One matrix: the batch of one (element offsets are applied inside the kernels in units of the storage type, so the solve is
+// correct in the fp32 compute mode too -- pointer arithmetic on the opaque double* would not be)
+void trsm_rec(double* R, int ldr, int nr, const double* L, int ld, const double* W, int j0, int w, hipStream_t st, bool tri = false) {
+  BatchPtr Rb{}, Lb{}, Wb{};
+  Rb.p[0] = R; Lb.p[0] = const_cast<double*>(L); Wb.p[0] = const_cast<double*>(W);
+  trsm_rec(Rb, ldr, nr, Lb, ld, Wb, 1, j0, w, st, tri);
 }
 
 // alpha (in place over z = L^-1 delta) <- L^-T z for one factor matrix
@@ -2253,7 +2234,7 @@ static int dense_posterior_build(const double* xd, int d, int n, const double* H
   Dims D(N, 1);
   lmm_post* P = new lmm_post();
   try {
-    P->kind = 1; P->n = n; P->d = d; P->l0 = 0; P->l1 = m; P->m = m; P->p = p;
+    P->kind = 1; P->f32 = g_f32; P->n = n; P->d = d; P->l0 = 0; P->l1 = m; P->m = m; P->p = p;
     P->NC = D.NC; P->NR = D.NR; P->ld = D.ld;
     P->gps.assign(gps, gps + m);
     P->H.assign(H, H + (size_t)p * m);
@@ -2267,9 +2248,10 @@ static int dense_posterior_build(const double* xd, int d, int n, const double* H
     Uploaded STd(sigs, st0);
     Buf<int> idxd(n);
     HIPCHK(hipMemcpyAsync(idxd.p, sigidx.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, st0));
-    P->L.emplace_back(D.elems());
-    P->W.emplace_back((size_t)(D.NC / 64) * 4096);
+    P->L.emplace_back(mat_count(D.elems()));
+    P->W.emplace_back(mat_count((size_t)(D.NC / 64) * 4096));
     P->alpha.emplace_back((size_t)D.NC);
+    P->z.emplace_back((size_t)D.NC);          // z = L^-1 delta (the rider row): the fp32 mode's means are mu + R' z, not mu + K(x*, x) alpha
     Buf<int> info(1);
     HIPCHK(hipMemsetAsync(info.p, 0, sizeof(int), st0));
     DenseArgs a{};
@@ -2279,6 +2261,7 @@ static int dense_posterior_build(const double* xd, int d, int n, const double* H
     potrf_rec(P->L[0].p, D.ld, D.NR, 0, D.NC, P->W[0].p, N, info.p, st0);
     HIPCHK(hipMemsetAsync(P->alpha[0].p, 0, (size_t)D.NC * sizeof(double), st0));
     launch_extract_row(P->L[0].p, D.ld, D.NC, N, P->alpha[0].p, st0);
+    HIPCHK(hipMemcpyAsync(P->z[0].p, P->alpha[0].p, (size_t)D.NC * sizeof(double), hipMemcpyDeviceToDevice, st0));
     backsolve1(P->L[0].p, D.ld, P->W[0].p, D.NC / 64, P->alpha[0].p, st0);
     int hinfo = 0;
     HIPCHK(hipMemcpyAsync(&hinfo, info.p, sizeof(int), hipMemcpyDeviceToHost, st0));
@@ -2296,7 +2279,6 @@ int lmm_ilmm_posterior_create(const double* x, int d, int n, const double* y, in
   std::lock_guard<std::mutex> lk(g_mu);
   REQUIRE_INIT();
   LMM_TRY
-  REQUIRE_F64("the dense-H ILMM posterior");
   if (!x || !y || !H || !out || d <= 0 || n <= 0 || p <= 0 || m <= 0) return fail(LMM_ERR_ARG, "bad arguments");
   if (int rc = check_gps(gps, m)) return rc;
   if (!jit) jit = &kDefaultJit;
@@ -2322,7 +2304,7 @@ int lmm_ilmm_post_condition(const lmm_post_t* post, double sigma2, const double*
   std::lock_guard<std::mutex> lk(g_mu);
   REQUIRE_INIT();
   LMM_TRY
-  REQUIRE_F64("the dense-H ILMM posterior");
+  if (post && post->f32 != g_f32) return fail(LMM_ERR_ARG, "posterior handle was built in the other compute dtype (lmm_set_compute_dtype)");
   if (!post || !x2 || !y2 || !out || d <= 0 || n2 <= 0) return fail(LMM_ERR_ARG, "bad arguments");
   const lmm_post* P = post;
   if (P->kind != 1) return fail(LMM_ERR_ARG, "not a dense-H ILMM posterior");
@@ -2354,12 +2336,15 @@ int lmm_ilmm_post_condition(const lmm_post_t* post, double sigma2, const double*
   LMM_CATCH
 }
 
+static void dense_post_cross(const lmm_post* P, const double* xsd, int d, int ns, int nr, double* R, int ldr, hipStream_t st);
+static void dense_post_means(const lmm_post* P, const double* xsd, int d, int ns, const double* R, int ldr, double* ml, hipStream_t st);
+
 int lmm_ilmm_post_mean_and_var(const lmm_post_t* post, double sigma2, const double* xs, int d, int ns,
                                const lmm_jitters_t* jit, double* mean_out, double* var_out) {
   std::lock_guard<std::mutex> lk(g_mu);
   REQUIRE_INIT();
   LMM_TRY
-  REQUIRE_F64("the dense-H ILMM posterior");
+  if (post && post->f32 != g_f32) return fail(LMM_ERR_ARG, "posterior handle was built in the other compute dtype (lmm_set_compute_dtype)");
   if (!post || !xs || !mean_out || !var_out || d <= 0 || ns <= 0) return fail(LMM_ERR_ARG, "bad arguments");
   const lmm_post* P = post;
   if (P->kind != 1) return fail(LMM_ERR_ARG, "not a dense-H ILMM posterior");
@@ -2371,14 +2356,11 @@ int lmm_ilmm_post_mean_and_var(const lmm_post_t* post, double sigma2, const doub
   DevIn xsd(xs, (size_t)d * ns, st0);
   Uploaded Hd(P->H, st0);
   Buf<double> ml((size_t)ns * m);
-  Buf<double> pm_part(post_mean_partial_elems(ns, n));
-  for (int l = 0; l < m; ++l)
-    launch_post_mean(xsd.p, ns, D->x.p, n, d, D->alpha[0].p + (size_t)l * n, to_dev(P->gps[l]), pm_part.p, ml.p + (size_t)l * ns, st0);
   const int nr = rup(m * ns, 64);
   int ldr = nr; if ((ldr % 512) == 0) ldr += 16;
-  Buf<double> R((size_t)ldr * P->NC);
-  launch_dense_cross(R.p, ldr, nr, P->NC, xsd.p, ns, D->x.p, n, d, m, D->latd.p, st0);
-  trsm_rec(R.p, ldr, nr, D->L[0].p, P->ld, D->W[0].p, 0, P->NC, st0);
+  Buf<double> R(mat_count((size_t)ldr * P->NC));
+  dense_post_cross(P, xsd.p, d, ns, nr, R.p, ldr, st0);
+  dense_post_means(P, xsd.p, d, ns, R.p, ldr, ml.p, st0);
   DevOut mo(mean_out, (size_t)ns * p), vo(var_out, (size_t)ns * p);
   launch_mix(ml.p, ns, m, Hd.buf.p, p, 1, 0.0, 0.0, nullptr, 0.0, mo.p, st0);
   Buf<double> dv_part(dense_var_partial_elems(ns, p, N));
@@ -2389,19 +2371,45 @@ int lmm_ilmm_post_mean_and_var(const lmm_post_t* post, double sigma2, const doub
   LMM_CATCH
 }
 
-// Dense-H posterior: latent joint covariance at xs as a factor matrix,  blockdiag(K_l(xs,xs)) + SigAdd (x) I_ns - R R'
-// with R = Kxs' L^-T, optional rider row, then its Cholesky.  Caller holds g_mu.
+// Dense-H posterior: R (nr x NC, ldr; rows (l, s) = l ns + s, rows >= m ns zero) = K(xs, x)' L^-T.  Caller holds g_mu.
+static void dense_post_cross(const lmm_post* P, const double* xsd, int d, int ns, int nr, double* R, int ldr, hipStream_t st) {
+  const lmm_post* D = dense_state(P);
+  guard_extent(R, nr, ldr, P->NC, true, "dense-H cross-Gram");
+  launch_dense_cross(R, ldr, nr, P->NC, xsd, ns, D->x.p, P->n, d, P->m, D->latd.p, st);
+  trsm_rec(R, ldr, nr, D->L[0].p, P->ld, D->W[0].p, 0, P->NC, st);
+}
+// Latent posterior means at xs, ml[l ns + s].  Float64: mu_l + K(x*, x) alpha_l (no solve needed).  fp32 compute mode: that sum cancels
+// over weights alpha = Kt^-1 delta whose Float32-factor error is amplified by cond |alpha| (section 4.3 of DESIGN.md: 0.15 absolute at
+// n = 1100 on the per-latent path), so the means take the rider form mu_l + R (L^-1 delta) from the cross-solve block R (which the
+// caller has computed: dense_post_cross; rows >= m ns of R are zero).
+static void dense_post_means(const lmm_post* P, const double* xsd, int d, int ns, const double* R, int ldr, double* ml, hipStream_t st) {
+  const lmm_post* D = dense_state(P);
+  const int m = P->m, n = P->n;
+  if (!g_f32) {
+    Buf<double> pm_part(post_mean_partial_elems(ns, n));
+    for (int l = 0; l < m; ++l)
+      launch_post_mean(xsd, ns, D->x.p, n, d, D->alpha[0].p + (size_t)l * n, to_dev(P->gps[l]), pm_part.p, ml + (size_t)l * ns, st);
+    HIPCHK(hipStreamSynchronize(st));              // pm_part is released on return
+    return;
+  }
+  Buf<double> part(strip_partial_elems(m * ns, m * n, 1)), mu((size_t)m * ns);
+  rider_stats_g(R, ldr, m * ns, m * n, D->z[0].p, 0.0, 0.0, part.p, ml, nullptr, st);
+  for (int l = 0; l < m; ++l) launch_fill(mu.p + (size_t)l * ns, ns, P->gps[l].mean, st);
+  launch_vec_lin(ml, mu.p, 1.0, m * ns, ml, st);
+  HIPCHK(hipStreamSynchronize(st));
+}
+// Latent joint covariance at xs as a factor matrix,  blockdiag(K_l(xs,xs)) + SigAdd (x) I_ns - R R'  (R from dense_post_cross with
+// nr = Ds.NC rows), optional rider row, then its Cholesky.
 static void dense_post_cov_factor(const lmm_post* P, const double* xsd, int d, int ns, const double* sigadd_dev,
-                                  const double* rider, const Dims& Ds, double* A, double* WA, double* R, int ldr, int* info,
+                                  const double* rider, const Dims& Ds, double* A, double* WA, const double* R, int ldr, int* info,
                                   hipStream_t st, bool factor = true) {
   const int m = P->m;
   const lmm_post* D = dense_state(P);
   DenseArgs a{};
   a.A = A; a.ld = Ds.ld; a.nrows = Ds.NR; a.ncols = Ds.NC; a.x = xsd; a.d = d; a.n = ns; a.m = m;
   a.lat = D->latd.p; a.sigmaT = sigadd_dev; a.rider = rider; a.rider_ld = m * ns; a.nrider = rider ? 1 : 0;
+  guard_extent(A, Ds.NR, Ds.ld, Ds.NC, true, "dense-H posterior covariance");
   launch_dense_assemble(a, st);
-  launch_dense_cross(R, ldr, Ds.NC, P->NC, xsd, ns, D->x.p, P->n, d, m, D->latd.p, st);
-  trsm_rec(R, ldr, Ds.NC, D->L[0].p, P->ld, D->W[0].p, 0, P->NC, st);
   gemm_nt_g(A, Ds.ld, R, ldr, R, ldr, Ds.NC, Ds.NC, P->NC, 1, false, st, "Schur complement (dense-H posterior covariance)");
   if (factor) potrf_rec(A, Ds.ld, Ds.NR, 0, Ds.NC, WA, m * ns, info, st);
 }
@@ -2414,7 +2422,7 @@ int lmm_ilmm_post_mean_and_cov(const lmm_post_t* post, double sigma2, const doub
   std::lock_guard<std::mutex> lk(g_mu);
   REQUIRE_INIT();
   LMM_TRY
-  REQUIRE_F64("the dense-H ILMM posterior");
+  if (post && post->f32 != g_f32) return fail(LMM_ERR_ARG, "posterior handle was built in the other compute dtype (lmm_set_compute_dtype)");
   if (!post || !xs || !mean_out || !cov_out || d <= 0 || ns <= 0) return fail(LMM_ERR_ARG, "bad arguments");
   const lmm_post* P = post;
   if (P->kind != 1) return fail(LMM_ERR_ARG, "not a dense-H ILMM posterior");
@@ -2426,12 +2434,12 @@ int lmm_ilmm_post_mean_and_cov(const lmm_post_t* post, double sigma2, const doub
   hipStream_t st0 = g.streams[0];
   DevIn xsd(xs, (size_t)d * ns, st0);
   Uploaded Hd(P->H, st0), Zd(std::vector<double>((size_t)m * m, 0.0), st0);
-  Buf<double> ml((size_t)Ns), pm_part(post_mean_partial_elems(ns, n));
-  for (int l = 0; l < m; ++l)
-    launch_post_mean(xsd.p, ns, D->x.p, n, d, D->alpha[0].p + (size_t)l * n, to_dev(P->gps[l]), pm_part.p, ml.p + (size_t)l * ns, st0);
+  Buf<double> ml((size_t)Ns);
   Dims Ds(Ns, 0);
   int ldr = Ds.NC; if ((ldr % 512) == 0) ldr += 16;
-  Buf<double> A(Ds.elems()), R((size_t)ldr * P->NC), T((size_t)p * ns * Ns);
+  Buf<double> A(mat_count(Ds.elems())), R(mat_count((size_t)ldr * P->NC)), T((size_t)p * ns * Ns);
+  dense_post_cross(P, xsd.p, d, ns, Ds.NC, R.p, ldr, st0);
+  dense_post_means(P, xsd.p, d, ns, R.p, ldr, ml.p, st0);
   dense_post_cov_factor(P, xsd.p, d, ns, Zd.buf.p, nullptr, Ds, A.p, nullptr, R.p, ldr, nullptr, st0, false);
   DevOut mo(mean_out, (size_t)ns * p), co(cov_out, (size_t)ns * p * ns * p);
   launch_mix(ml.p, ns, m, Hd.buf.p, p, 1, 0.0, 0.0, nullptr, 0.0, mo.p, st0);
@@ -2449,7 +2457,7 @@ int lmm_ilmm_post_logpdf(const lmm_post_t* post, double sigma2, const double* xs
   std::lock_guard<std::mutex> lk(g_mu);
   REQUIRE_INIT();
   LMM_TRY
-  REQUIRE_F64("the dense-H ILMM posterior");
+  if (post && post->f32 != g_f32) return fail(LMM_ERR_ARG, "posterior handle was built in the other compute dtype (lmm_set_compute_dtype)");
   if (!post || !xs || !ys || !out || d <= 0 || ns <= 0) return fail(LMM_ERR_ARG, "bad arguments");
   const lmm_post* P = post;
   if (P->kind != 1) return fail(LMM_ERR_ARG, "not a dense-H ILMM posterior");
@@ -2466,13 +2474,12 @@ int lmm_ilmm_post_logpdf(const lmm_post_t* post, double sigma2, const double* xs
   Buf<double> Ty((size_t)ns * m), ml((size_t)ns * m), delta((size_t)ns * m), partial(tall_skinny_partials(ns, p)), resid_dev(1);
   project_on_device(ysd.p, ns, p, Td.buf, m, 0, m, nullptr, Ty.p, st0);
   residual_on_device(ysd.p, ns, p, Ty.p, m, Hd.buf, partial.p, resid_dev.p, st0);
-  Buf<double> pm_part(post_mean_partial_elems(ns, n));
-  for (int l = 0; l < m; ++l)
-    launch_post_mean(xsd.p, ns, D->x.p, n, d, D->alpha[0].p + (size_t)l * n, to_dev(P->gps[l]), pm_part.p, ml.p + (size_t)l * ns, st0);
-  launch_vec_lin(Ty.p, ml.p, -1.0, Ns, delta.p, st0);
   Dims Ds(Ns, 1);
   int ldr = Ds.NC; if ((ldr % 512) == 0) ldr += 16;
-  Buf<double> A(Ds.elems()), WA((size_t)(Ds.NC / 64) * 4096), R((size_t)ldr * P->NC), lml_dev(1);
+  Buf<double> A(mat_count(Ds.elems())), WA(mat_count((size_t)(Ds.NC / 64) * 4096)), R(mat_count((size_t)ldr * P->NC)), lml_dev(1);
+  dense_post_cross(P, xsd.p, d, ns, Ds.NC, R.p, ldr, st0);
+  dense_post_means(P, xsd.p, d, ns, R.p, ldr, ml.p, st0);
+  launch_vec_lin(Ty.p, ml.p, -1.0, Ns, delta.p, st0);
   Buf<int> info(1);
   HIPCHK(hipMemsetAsync(info.p, 0, sizeof(int), st0));
   dense_post_cov_factor(P, xsd.p, d, ns, STd.buf.p, delta.p, Ds, A.p, WA.p, R.p, ldr, info.p, st0);
@@ -2496,7 +2503,7 @@ int lmm_ilmm_post_rand(const lmm_post_t* post, double sigma2, int add_noise, con
   std::lock_guard<std::mutex> lk(g_mu);
   REQUIRE_INIT();
   LMM_TRY
-  REQUIRE_F64("the dense-H ILMM posterior");
+  if (post && post->f32 != g_f32) return fail(LMM_ERR_ARG, "posterior handle was built in the other compute dtype (lmm_set_compute_dtype)");
   if (!post || !xs || !z_lat || !out || d <= 0 || ns <= 0 || (add_noise && !eps)) return fail(LMM_ERR_ARG, "bad arguments");
   const lmm_post* P = post;
   if (P->kind != 1) return fail(LMM_ERR_ARG, "not a dense-H ILMM posterior");
@@ -2510,12 +2517,11 @@ int lmm_ilmm_post_rand(const lmm_post_t* post, double sigma2, int add_noise, con
   DevIn xsd(xs, (size_t)d * ns, st0), zd(z_lat, (size_t)Ns, st0), epsd(add_noise ? eps : nullptr, (size_t)ns * p, st0);
   Uploaded Jd(J, st0), Hd(P->H, st0);
   Buf<double> ml((size_t)Ns), X((size_t)Ns);
-  Buf<double> pm_part(post_mean_partial_elems(ns, n));
-  for (int l = 0; l < m; ++l)
-    launch_post_mean(xsd.p, ns, D->x.p, n, d, D->alpha[0].p + (size_t)l * n, to_dev(P->gps[l]), pm_part.p, ml.p + (size_t)l * ns, st0);
   Dims Ds(Ns, 0);
   int ldr = Ds.NC; if ((ldr % 512) == 0) ldr += 16;
-  Buf<double> A(Ds.elems()), WA((size_t)(Ds.NC / 64) * 4096), R((size_t)ldr * P->NC), part(strip_partial_elems(Ns, Ns, 1));
+  Buf<double> A(mat_count(Ds.elems())), WA(mat_count((size_t)(Ds.NC / 64) * 4096)), R(mat_count((size_t)ldr * P->NC)), part(strip_partial_elems(Ns, Ns, 1));
+  dense_post_cross(P, xsd.p, d, ns, Ds.NC, R.p, ldr, st0);
+  dense_post_means(P, xsd.p, d, ns, R.p, ldr, ml.p, st0);
   Buf<int> info(1);
   HIPCHK(hipMemsetAsync(info.p, 0, sizeof(int), st0));
   dense_post_cov_factor(P, xsd.p, d, ns, Jd.buf.p, nullptr, Ds, A.p, WA.p, R.p, ldr, info.p, st0);

@@ -446,7 +446,8 @@ __global__ __launch_bounds__(256) void ilmm_dense_assemble_kernel(DenseArgs a) {
 
 // Dense-ILMM cross-covariance riders: row (l, s) of R (m*ns rows) is K_l(xs_s, x) placed in the column block of
 // latent l (reference src/independent_mogp.jl:66-71: block-diagonal cov(f, x, y)); zero elsewhere and in the pad.
-__global__ __launch_bounds__(256) void dense_cross_kernel(double* __restrict__ R, int ldr, int nrows, int /*ncols*/,
+template <typename TS>
+__global__ __launch_bounds__(256) void dense_cross_kernel(void* __restrict__ R, int ldr, int nrows, int /*ncols*/,
                                                           const double* __restrict__ xs, int ns,
                                                           const double* __restrict__ x, int n, int d, int m,
                                                           const LatentDev* __restrict__ lat) {
@@ -465,14 +466,15 @@ __global__ __launch_bounds__(256) void dense_cross_kernel(double* __restrict__ R
       val = kappa(g.kind, g.var, rr, r2);
     }
   }
-  R[(size_t)j * ldr + r] = val;
+  MatIO<TS>::st1(R, (size_t)j * ldr + r, val);
 }
 
 // Dense-ILMM posterior variance (reference src/ilmm.jl:122-129 on a PosteriorGP latent):
 //   V[o, s] = sum_l H[o,l]^2 (k_l(0) + jitter) + sigma2 - sum_k ( sum_l H[o,l] R[(l,s), k] )^2,   R = Kxs' L^-T.
 // Thread per output element e = o * ns + s, the k range cut into chunks of kc columns (blockIdx.y) whose partial sums
 // dense_var_finish_kernel subtracts from the prior term in a fixed order.
-__global__ __launch_bounds__(256) void dense_var_kernel(const double* __restrict__ R, int ldr, int ns, int m, int Ncols, int kc,
+template <typename TS>
+__global__ __launch_bounds__(256) void dense_var_kernel(const void* __restrict__ R, int ldr, int ns, int m, int Ncols, int kc,
                                                         const double* __restrict__ Hm, int p, double* __restrict__ partial) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= p * ns) return;
@@ -481,10 +483,10 @@ __global__ __launch_bounds__(256) void dense_var_kernel(const double* __restrict
   int k1 = k0 + kc; if (k1 > Ncols) k1 = Ncols;
   double q = 0.0;
   for (int k = k0; k < k1; ++k) {
-    const double* col = R + (size_t)k * ldr + s;
+    const size_t col = (size_t)k * ldr + s;
     double t = 0.0;
 #pragma unroll 4
-    for (int l = 0; l < m; ++l) t = __builtin_fma(Hm[o + (size_t)l * p], col[(size_t)l * ns], t);
+    for (int l = 0; l < m; ++l) t = __builtin_fma(Hm[o + (size_t)l * p], MatIO<TS>::ld1(R, col + (size_t)l * ns), t);
     q = __builtin_fma(t, t, q);
   }
   partial[(size_t)blockIdx.y * ((size_t)p * ns) + e] = q;
@@ -2786,7 +2788,8 @@ __global__ __launch_bounds__(256) void mix_bf16_kernel(const double* __restrict_
 // Dense-H posterior full covariance (reference src/ilmm.jl:132-139 with coupled latents): C = H_full S H_full' + sigma2 I
 // for the latent joint covariance S ((m ns) x (m ns), lower triangle of a factor-layout buffer, index l*ns + i), in two
 // passes:  T[(o,i), (l',j)] = sum_l H[o,l] S[(l,i),(l',j)]   then   C[(o,i),(o',j)] = sum_l' T[(o,i),(l',j)] H[o',l'].
-__global__ __launch_bounds__(256) void dense_cov_half_kernel(const double* __restrict__ S, int lds, int ns, int m,
+template <typename TS>
+__global__ __launch_bounds__(256) void dense_cov_half_kernel(const void* __restrict__ S, int lds, int ns, int m,
                                                              const double* __restrict__ Hm, int p, double jitter,
                                                              double* __restrict__ T) {
   const int a = blockIdx.x * 256 + threadIdx.x;      // (o, i)
@@ -2797,7 +2800,7 @@ __global__ __launch_bounds__(256) void dense_cov_half_kernel(const double* __res
   for (int l = 0; l < m; ++l) {
     const int r = l * ns + i;
     const int hi = r > c ? r : c, lo = r > c ? c : r;
-    double v = S[(size_t)lo * lds + hi];
+    double v = MatIO<TS>::ld1(S, (size_t)lo * lds + hi);
     if (r == c) v += jitter;
     acc = __builtin_fma(Hm[o + (size_t)l * p], v, acc);
   }
@@ -3103,7 +3106,7 @@ void launch_gram_batch(const GramArgs* args, int nb, hipStream_t st) {
 void launch_dense_cross(double* R, int ldr, int nrows, int ncols, const double* xs, int ns, const double* x, int n, int d,
                         int m, const LatentDev* lat, hipStream_t st) {
   dim3 grid((nrows + 255) / 256, ncols);
-  hipLaunchKernelGGL(dense_cross_kernel, grid, dim3(256), 0, st, R, ldr, nrows, ncols, xs, ns, x, n, d, m, lat);
+  LMM_TS_LAUNCH((dense_cross_kernel<TS>), grid, dim3(256), 0, st, (void*)R, ldr, nrows, ncols, xs, ns, x, n, d, m, lat);
 }
 
 int dense_var_kc(int Ncols) { int kc = ((Ncols + 127) / 128 + 63) / 64 * 64; return kc < 64 ? 64 : kc; }   // <= 128 chunks
@@ -3115,7 +3118,7 @@ size_t dense_var_partial_elems(int ns, int p, int Ncols) {
 void launch_dense_var(const double* R, int ldr, int ns, int m, int Ncols, const double* Hm, int p, const LatentDev* lat,
                       double jitter, double sigma2, double* partial, double* out, hipStream_t st) {
   const int kc = dense_var_kc(Ncols), nch = (Ncols + kc - 1) / kc, ne = p * ns;
-  hipLaunchKernelGGL(dense_var_kernel, dim3((ne + 255) / 256, nch), dim3(256), 0, st, R, ldr, ns, m, Ncols, kc, Hm, p, partial);
+  LMM_TS_LAUNCH((dense_var_kernel<TS>), dim3((ne + 255) / 256, nch), dim3(256), 0, st, (const void*)R, ldr, ns, m, Ncols, kc, Hm, p, partial);
   hipLaunchKernelGGL(dense_var_finish_kernel, dim3((ne + 255) / 256), dim3(256), 0, st, partial, nch, ns, m, Hm, p, lat, jitter,
                      sigma2, out);
 }
@@ -3124,7 +3127,7 @@ void launch_dense_var(const double* R, int ldr, int ns, int m, int Ncols, const 
 void launch_dense_cov(const double* S, int lds, int ns, int m, const double* Hm, int p, double jitter, double sigma2, double* T,
                       double* out, hipStream_t st) {
   const int na = p * ns;
-  hipLaunchKernelGGL(dense_cov_half_kernel, dim3((na + 255) / 256, m * ns), dim3(256), 0, st, S, lds, ns, m, Hm, p, jitter, T);
+  LMM_TS_LAUNCH((dense_cov_half_kernel<TS>), dim3((na + 255) / 256, m * ns), dim3(256), 0, st, (const void*)S, lds, ns, m, Hm, p, jitter, T);
   hipLaunchKernelGGL(dense_cov_full_kernel, dim3((na + 255) / 256, na), dim3(256), 0, st, T, ns, m, Hm, p, sigma2, out);
 }
 

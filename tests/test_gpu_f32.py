@@ -159,6 +159,54 @@ def test_f32_dense_ilmm_logpdf(lmm32):
     np.testing.assert_allclose(got, [O.ilmm_logpdf(gps, H, x, 0.3, Y[:, c]) for c in range(3)], rtol=RTOL32)
 
 
+@pytest.mark.parametrize("ns", [9, 70])
+def test_f32_dense_posterior_vs_f64_oracle(lmm32, ns):
+    """Round 4: the dense-H ILMM posterior (reference src/ilmm.jl:184-198, generic over T <: Real) in the fp32 compute mode --
+    posterior, mean_and_var, logpdf of pi(x*), rand, mean_and_cov and the latent view -- against the Float64 oracle at the mode's
+    stated tolerance (RTOL32 at sigma2 = 0.1, unit-scale kernels).  The means take the rider form mu + R (L^-1 delta): the shortcut
+    mu + K(x*, x) alpha cancels over weights whose Float32-factor error is amplified by the condition number."""
+    lmm = lmm32
+    rng = np.random.default_rng(4400 + ns)
+    n, m, p, s2 = 150, 3, 4, 0.1
+    x, xs = np.sort(rng.uniform(0, 6, n)), np.sort(rng.uniform(0, 6, ns))
+    gps = [{"kind": k, "variance": float(rng.uniform(0.7, 1.3)), "lengthscale": float(rng.uniform(0.8, 1.5)), "mean": float(rng.normal())}
+           for k in ["se", "matern32", "matern52"]]
+    H = rng.uniform(0.2, 1.0, size=(p, m))
+    y, ys = rng.standard_normal(n * p), rng.standard_normal(ns * p)
+    fx = lmm.ILMM(_model(lmm, gps), H)(lmm.MOInputIsotopicByOutputs(x, p), s2)
+    post = lmm.posterior(fx, y)
+    pix = post(lmm.MOInputIsotopicByOutputs(xs, p), s2)
+    po = O.ilmm_posterior(gps, H, x, s2, y)
+    mo, vo = O.ilmm_mean_var(po, H, xs, s2)
+    mu, v = lmm.mean_and_var(pix)
+    scale = np.abs(mo).max()
+    np.testing.assert_allclose(mu, mo, rtol=RTOL32, atol=RTOL32 * scale)
+    np.testing.assert_allclose(v, vo, rtol=5 * RTOL32)
+    assert lmm.logpdf(pix, ys) == pytest.approx(O.ilmm_logpdf(po, H, xs, s2, ys), rel=5 * RTOL32)
+    jit = (1e-9, 1e-4, 1e-4)
+    smp = lmm.rand(np.random.default_rng(21), pix, jitters=jit)
+    g2 = np.random.default_rng(21); z = g2.standard_normal(m * ns); eps = g2.standard_normal(ns * p)
+    mlat, Clat = O._ilmm_latent_joint(po, xs)
+    lat = mlat + np.linalg.cholesky(Clat + 1e-4 * np.eye(m * ns)) @ z
+    ref = (H @ lat.reshape(m, ns)).reshape(-1) + math.sqrt(s2) * eps
+    np.testing.assert_allclose(smp, ref, rtol=20 * RTOL32, atol=20 * RTOL32 * np.abs(ref).max())
+    Mg, Cg = lmm.mean_and_cov(pix)
+    Mo, Co = O.ilmm_mean_cov(po, H, xs, s2)
+    np.testing.assert_allclose(Mg, Mo, rtol=RTOL32, atol=RTOL32 * scale)
+    np.testing.assert_allclose(Cg, Co, rtol=5 * RTOL32, atol=5 * RTOL32 * np.abs(Co).max())
+    lat_fx = lmm.get_latent_gp(post)(lmm.MOInputIsotopicByOutputs(xs, m), 0.07)
+    ml, vl = lmm.mean_and_var(lat_fx)
+    np.testing.assert_allclose(ml, mlat, rtol=RTOL32, atol=RTOL32 * np.abs(mlat).max())
+    np.testing.assert_allclose(vl, np.diag(Clat) + 0.07, rtol=5 * RTOL32)
+    # sequential conditioning on the dense-H posterior (posterior(pi(x2, s2), y2): src/ilmm.jl:184-198 again)
+    x2 = np.sort(rng.uniform(0, 6, 40)); y2 = rng.standard_normal(40 * p)
+    post2 = lmm.posterior(post(lmm.MOInputIsotopicByOutputs(x2, p), 0.2), y2)
+    mo2, vo2 = O.ilmm_mean_var(O.ilmm_posterior_condition(po, H, x2, 0.2, y2), H, xs, s2)
+    mu2, v2 = lmm.mean_and_var(post2(lmm.MOInputIsotopicByOutputs(xs, p), s2))
+    np.testing.assert_allclose(mu2, mo2, rtol=RTOL32, atol=RTOL32 * np.abs(mo2).max())
+    np.testing.assert_allclose(v2, vo2, rtol=5 * RTOL32)
+
+
 def test_f32_mode_boundaries(lmm32):
     """Handles remember their dtype; unsupported paths say so instead of computing in the wrong precision; switching back to
     Float64 restores the parity mode bit for bit."""
@@ -173,8 +221,9 @@ def test_f32_mode_boundaries(lmm32):
     assert g32["value"] == pytest.approx(v32, rel=1e-6)
     with pytest.raises(NotImplementedError):
         lmm.mean_and_cov(f(lmm.MOInputIsotopicByOutputs(P["x"][:8], 5), 0.1))
-    with pytest.raises(NotImplementedError):                       # the dense (mn) x (mn) paths stay Float64-only
-        lmm.logpdf_and_gradient(lmm.ILMM(_model(lmm, P["gps"]), np.abs(P["U"]) + 0.1)(xin, 0.1), P["y"])
+    with pytest.raises(NotImplementedError):                       # the dense (mn) x (mn) GRADIENTS stay Float64-only (the posterior
+        lmm.logpdf_and_gradient(lmm.ILMM(_model(lmm, P["gps"]), np.abs(P["U"]) + 0.1)(xin, 0.1), P["y"])      # verbs are served: round 4)
+    pd32 = lmm.posterior(lmm.ILMM(_model(lmm, P["gps"]), np.abs(P["U"]) + 0.1)(xin, 0.1), P["y"])
     lmm.set_compute_dtype("f64")
     v64 = lmm.logpdf(f(xin, 0.1), P["y"])
     ref = O.oilmm_logpdf(P["gps"], P["U"], P["S"], P["x"], 0.1, P["y"])
@@ -182,8 +231,12 @@ def test_f32_mode_boundaries(lmm32):
     assert v32 == pytest.approx(ref, rel=RTOL32) and v32 != v64
     with pytest.raises(ValueError, match="other compute dtype"):
         lmm.mean_and_var(post32(lmm.MOInputIsotopicByOutputs(P["x"][:8], 5), 0.1))
+    with pytest.raises(ValueError, match="other compute dtype"):   # ... and so does a dense-H handle
+        lmm.mean_and_var(pd32(lmm.MOInputIsotopicByOutputs(P["x"][:8], 5), 0.1))
     lmm.set_compute_dtype("f32")
     mu, _ = lmm.mean_and_var(post32(lmm.MOInputIsotopicByOutputs(P["x"][:8], 5), 0.1))
+    assert np.all(np.isfinite(mu))
+    mu, _ = lmm.mean_and_var(pd32(lmm.MOInputIsotopicByOutputs(P["x"][:8], 5), 0.1))
     assert np.all(np.isfinite(mu))
 
 
