@@ -9,7 +9,8 @@ from typing import Optional, Sequence, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblmm_hip.so")
+# LMM_HIP_LIB (the variable the Julia shim reads too): another build of the library, for same-box A/B runs of two kernel versions
+LIB_PATH = os.environ.get("LMM_HIP_LIB") or os.path.join(_HERE, "liblmm_hip.so")
 
 LMM_OK, LMM_ERR_DIM, LMM_ERR_NOT_ORTHOGONAL, LMM_ERR_NOT_PD, LMM_ERR_HIP, LMM_ERR_ARG, LMM_ERR_UNSUPPORTED, LMM_ERR_RCCL = range(8)
 UNIQUE_ID_BYTES = 128

@@ -681,6 +681,200 @@ __device__ __forceinline__ unsigned long long diag64m_wave(void* __restrict__ A,
       for (int r = 0; r < 4; ++r) Wl[(16 * cb + c) * DIAG_LS + 16 * rb + 4 * r + g] = cb <= rb ? st.V[rb][cb][r] : 0.0;
   return st.badmask;
 }
+// ---------------------------------------------------------------------------------------------------
+// K2a, two-wave form (round 4): the same elimination with the FACTOR and the INVERSE on different waves (different SIMDs).
+// Nothing in the factorisation depends on the inverse being built: per step the factor wave needs the block column of S, the 4 x 4
+// pivot factor, its panel rows Y and the S updates; the inverse wave needs only Y and the rows k of the 4 x 4 inverse from it, and
+// owns everything about W (the pivot rows through Wt, Z = Lp^-1 Wtop, the V updates).  So wave 0 runs the factor chain -- its step
+// sheds the Z dot products, the Wt round trip and 4-6 of its 9-14 MFMAs -- and hands (Y, k) of each step to wave 1 through a
+// double-buffered LDS exchange area; wave 1 follows one step behind and writes the W image at the end.  Every accumulator sees the
+// same operations in the same order as in the one-wave form: the results are bitwise identical.  (A split of the MFMAs over four waves
+// would leave the ~120 f64 VALU instructions of a step -- 8 issue cycles each -- in every wave: priced at 1.15x; this split removes
+// instructions from the critical wave instead.)
+//   xch: 2 x 8 x 64 doubles ([parity][v][lane]: v < 4 the panel rows -Y of block row v, v >= 4 the inverse row entries k_{v-4}),
+//   flags (LDS ints, monotonic over the kernel's lifetime, zeroed once at kernel start): [0] steps produced, [1] steps consumed;
+//   `base` = 16 x (number of two-wave factorisations this workgroup has run before): uniform over the workgroup.
+// ---------------------------------------------------------------------------------------------------
+struct DiagFState {
+  d4 S[4][4];
+  double Ym[2][4], nY[2][4];
+  double e0, e1, e2, e3;
+  unsigned long long badmask;
+};
+struct DiagWState { d4 V[4][4]; };
+constexpr int DIAG_XCH = 2 * 8 * 64;                               // doubles of the exchange area
+__device__ __forceinline__ void diag_flag_wait(const int* f, int need) {
+  while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(0);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void diag_flag_set(int* f, int v, int l) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");            // this wave's LDS writes (or reads: s_waitcnt lgkmcnt(0)) are complete
+  if (l == 0) __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+template <int T, int GROUP>
+__device__ __forceinline__ void diagf_mfmas(DiagFState& st) {
+  constexpr int jb = T >> 2, q = T & 3, jn = (T + 1) >> 2, o = T & 1;
+#pragma unroll
+  for (int rb = jb; rb < 4; ++rb) {
+    if (rb == jb && q == 3) continue;
+#pragma unroll
+    for (int cb = jb; cb <= rb; ++cb) {
+      if (cb == jb && q == 3) continue;
+      if ((cb == jn ? (rb == jn ? 0 : 1) : 2) != GROUP) continue;
+      st.S[rb][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(st.nY[o][rb], st.Ym[o][cb], st.S[rb][cb], 0, 0, 0);
+    }
+  }
+}
+template <int s, typename TS>
+__device__ __forceinline__ void diagf_step(DiagFState& st, double* __restrict__ Sp, double* __restrict__ xch, int* __restrict__ flags, int base,
+                                           int c, int g, int l, void* __restrict__ Ag, size_t offAg, int ldg) {
+  constexpr int SP = DIAG_SP;
+  constexpr int J = 4 * s, jb = s >> 2, q = s & 3, o = s & 1;
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int rb = jb; rb < 4; ++rb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Sp[(16 * rb + 4 * r + g) * SP + c] = st.S[rb][jb][r];
+  const d2 pr0 = *reinterpret_cast<const d2*>(&Sp[(J + 0) * SP + 4 * q]);
+  const d2 pr1 = *reinterpret_cast<const d2*>(&Sp[(J + 1) * SP + 4 * q]);
+  const d2 pr2a = *reinterpret_cast<const d2*>(&Sp[(J + 2) * SP + 4 * q]), pr2b = *reinterpret_cast<const d2*>(&Sp[(J + 2) * SP + 4 * q + 2]);
+  const d2 pr3a = *reinterpret_cast<const d2*>(&Sp[(J + 3) * SP + 4 * q]), pr3b = *reinterpret_cast<const d2*>(&Sp[(J + 3) * SP + 4 * q + 2]);
+  d2 bo[4][2];
+#pragma unroll
+  for (int rb = jb; rb < 4; ++rb) {
+    bo[rb][0] = *reinterpret_cast<const d2*>(&Sp[(16 * rb + c) * SP + 4 * q]);
+    bo[rb][1] = *reinterpret_cast<const d2*>(&Sp[(16 * rb + c) * SP + 4 * q + 2]);
+  }
+  if constexpr (s > 0) diagf_mfmas<s - 1, 2>(st);                  // the previous step's lagging blocks
+  auto rsq = [](double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    y = y * __builtin_fma(-h * y, y, 1.5);
+    y = y * __builtin_fma(-h * y, y, 1.5);
+    return y;
+  };
+  const double d0 = pr0.x, r0 = rsq(d0);
+  const double l10 = pr1.x * r0, l20 = pr2a.x * r0, l30 = pr3a.x * r0;
+  const double d1 = __builtin_fma(-l10, l10, pr1.y), r1 = rsq(d1);
+  const double l21 = __builtin_fma(-l20, l10, pr2a.y) * r1, l31 = __builtin_fma(-l30, l10, pr3a.y) * r1;
+  const double d2v = __builtin_fma(-l21, l21, __builtin_fma(-l20, l20, pr2b.x)), r2 = rsq(d2v);
+  const double l32 = __builtin_fma(-l31, l21, __builtin_fma(-l30, l20, pr3b.x)) * r2;
+  const double d3 = __builtin_fma(-l32, l32, __builtin_fma(-l31, l31, __builtin_fma(-l30, l30, pr3b.y))), r3 = rsq(d3);
+  const double k3 = st.e3 * r3;
+  const double k2 = __builtin_fma(-k3, l32, st.e2) * r2;
+  const double k1 = __builtin_fma(-k2, l21, __builtin_fma(-k3, l31, st.e1)) * r1;
+  const double k0 = __builtin_fma(-k1, l10, __builtin_fma(-k2, l20, __builtin_fma(-k3, l30, st.e0))) * r0;
+#pragma unroll
+  for (int rb = jb; rb < 4; ++rb) {
+    const double y = __builtin_fma(bo[rb][1].y, k3, __builtin_fma(bo[rb][1].x, k2, __builtin_fma(bo[rb][0].y, k1, bo[rb][0].x * k0)));
+    const int row = 16 * rb + c;
+    if (row >= J + g) MatIO<TS>::st1(Ag, offAg + (size_t)(J + g) * ldg + row, y);
+    st.Ym[o][rb] = (rb > jb || row > J + 3) ? y : 0.0;
+    st.nY[o][rb] = -st.Ym[o][rb];
+  }
+  // hand (-Y, k) to the inverse wave: buffer o was last read for step s - 2
+  if constexpr (s >= 2) diag_flag_wait(flags + 1, base + s - 1);
+  double* xo = xch + o * 512 + l;
+#pragma unroll
+  for (int rb = jb; rb < 4; ++rb) xo[rb * 64] = st.nY[o][rb];
+  xo[4 * 64] = k0; xo[5 * 64] = k1; xo[6 * 64] = k2; xo[7 * 64] = k3;
+  diag_flag_set(flags, base + s + 1, l);
+  diagf_mfmas<s, 0>(st); diagf_mfmas<s, 1>(st);
+  __builtin_amdgcn_sched_barrier(0);
+  if (__builtin_amdgcn_ballot_w64(!(d0 > 0.0) | !(d1 > 0.0) | !(d2v > 0.0) | !(d3 > 0.0)) != 0ull) {
+    const unsigned m4 = (!(d0 > 0.0) ? 1u : 0u) | (!(d1 > 0.0) ? 2u : 0u) | (!(d2v > 0.0) ? 4u : 0u) | (!(d3 > 0.0) ? 8u : 0u);
+    st.badmask |= (unsigned long long)__builtin_amdgcn_readfirstlane(m4) << J;
+  }
+}
+template <int s>
+__device__ __forceinline__ void diagw_step(DiagWState& st, double* __restrict__ Wt, const double* __restrict__ xch, int* __restrict__ flags,
+                                           int base, int c, int g, int l) {
+  constexpr int jb = s >> 2, q = s & 3, o = s & 1;
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int cb = 0; cb <= jb; ++cb) Wt[(16 * cb + c) * 4 + g] = st.V[jb][cb][q];
+  d2 wo[4][2];
+#pragma unroll
+  for (int cb = 0; cb <= jb; ++cb) {
+    wo[cb][0] = *reinterpret_cast<const d2*>(&Wt[(16 * cb + c) * 4]);
+    wo[cb][1] = *reinterpret_cast<const d2*>(&Wt[(16 * cb + c) * 4 + 2]);
+  }
+  diag_flag_wait(flags, base + s + 1);
+  const double* xo = xch + o * 512 + l;
+  double nY[4];
+#pragma unroll
+  for (int rb = jb; rb < 4; ++rb) nY[rb] = xo[rb * 64];
+  const double k0 = xo[4 * 64], k1 = xo[5 * 64], k2 = xo[6 * 64], k3 = xo[7 * 64];
+  diag_flag_set(flags + 1, base + s + 1, l);                       // (its release waits for the reads above)
+  double Z[4];
+#pragma unroll
+  for (int cb = 0; cb <= jb; ++cb)
+    Z[cb] = __builtin_fma(wo[cb][1].y, k3, __builtin_fma(wo[cb][1].x, k2, __builtin_fma(wo[cb][0].y, k1, wo[cb][0].x * k0)));
+#pragma unroll
+  for (int cb = 0; cb <= jb; ++cb) st.V[jb][cb][q] = Z[cb];
+#pragma unroll
+  for (int rb = jb; rb < 4; ++rb) {
+    if (rb == jb && q == 3) continue;
+#pragma unroll
+    for (int cb = 0; cb <= jb; ++cb) st.V[rb][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(nY[rb], Z[cb], st.V[rb][cb], 0, 0, 0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <int s, typename TS>
+__device__ __forceinline__ void diagf_steps(DiagFState& st, double* Sp, double* xch, int* flags, int base, int c, int g, int l,
+                                            void* __restrict__ Ag, size_t offAg, int ldg) {
+  if constexpr (s < 16) { diagf_step<s, TS>(st, Sp, xch, flags, base, c, g, l, Ag, offAg, ldg); diagf_steps<s + 1, TS>(st, Sp, xch, flags, base, c, g, l, Ag, offAg, ldg); }
+}
+template <int s>
+__device__ __forceinline__ void diagw_steps(DiagWState& st, double* Wt, const double* xch, int* flags, int base, int c, int g, int l) {
+  if constexpr (s < 16) { diagw_step<s>(st, Wt, xch, flags, base, c, g, l); diagw_steps<s + 1>(st, Wt, xch, flags, base, c, g, l); }
+}
+// Waves 0 and 1 of the workgroup call this (w = wave index, uniform); the other waves do not.  work: 64 * DIAG_SP + 256 + DIAG_XCH
+// doubles of LDS (Sp, Wt, exchange area); Wl: the W image (MAY overlap `work`: it is written after the last step, by wave 1, which
+// finishes behind wave 0); src as in diag64m_wave.  Returns the mask of non-positive pivots in wave 0 (0 in wave 1).  The caller
+// follows with a workgroup barrier before anybody reads Wl.
+constexpr int DIAG_PAIR_WORK = 64 * DIAG_SP + 256 + DIAG_XCH;
+template <typename TS>
+__device__ __forceinline__ unsigned long long diag64_pair(void* __restrict__ A, size_t offA, int ld, double* work, double* Wl, int* flags, int base,
+                                                          int w, int l, const double* src = nullptr) {
+  const int c = l & 15, g = l >> 4;
+  double* Sp = work;
+  double* Wt = work + 64 * DIAG_SP;
+  double* xch = Wt + 256;
+  if (w == 0) {
+    DiagFState st;
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+      for (int cb = 0; cb <= rb; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * rb + 4 * r + g, col = 16 * cb + c;
+          st.S[rb][cb][r] = (row >= col) ? (src ? src[col * DIAG_LS + row] : MatIO<TS>::ld1(A, offA + (size_t)col * ld + row)) : 0.0;
+        }
+    st.e0 = g == 0 ? 1.0 : 0.0; st.e1 = g == 1 ? 1.0 : 0.0; st.e2 = g == 2 ? 1.0 : 0.0; st.e3 = g == 3 ? 1.0 : 0.0;
+    st.badmask = 0ull;
+    diagf_steps<0, TS>(st, Sp, xch, flags, base, c, g, l, A, offA, ld);
+    return st.badmask;
+  }
+  DiagWState st;
+#pragma unroll
+  for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+    for (int cb = 0; cb <= rb; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) st.V[rb][cb][r] = (16 * rb + 4 * r + g == 16 * cb + c) ? 1.0 : 0.0;
+  diagw_steps<0>(st, Wt, xch, flags, base, c, g, l);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Wl[(16 * cb + c) * DIAG_LS + 16 * rb + 4 * r + g] = cb <= rb ? st.V[rb][cb][r] : 0.0;
+  return 0ull;
+}
+
 // first non-positive pivot among the real columns gcol0 .. of a 64-pivot mask -> LAPACK-style info (0: none)
 __device__ __forceinline__ int diag_info_of(unsigned long long badmask, int gcol0, int n_real) {
   const int lim = n_real - gcol0;                                  // pivots k < lim are real columns
@@ -1273,13 +1467,20 @@ __global__ __launch_bounds__(256, 2) void gemm16h_kernel(BatchPtr Cb, size_t gof
 // DEEP: two chunks in flight ahead of the one being multiplied (three register sets; for the one-workgroup-per-CU build, which has
 // the registers: a global load takes ~2 us, a chunk's MFMAs 0.85 us); else one.
 struct MM64Chunk { double fa[8][2], fr[8][2]; };
+// A load of data that ANOTHER workgroup of the same launch has published (write-through ST_PUB stores, drained, then a flag): an
+// agent-scope relaxed atomic load = `global_load ... sc1`, which bypasses this CU's vector L1 (MI355X_MICROARCH.md, "Valid forms").  With
+// EVERY load of handed-off bytes in this form the consumer needs no agent-scope acquire fence after its flag poll -- 1.7 us each
+// (buffer_inv sc1 + its wait), twice per 64-column block on the chain walker -> helper -> walker.
+__device__ __forceinline__ double ld_pub(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// SC1 bit 0: the A operand is handed-off global data (ld_pub), bit 1: the R operand is
+template <int SC1 = 0>
 __device__ __forceinline__ void mm64_load(MM64Chunk& b, const double* pa, size_t sai, size_t sak, const double* pr, size_t srk, size_t srj) {
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) b.fa[ks][u] = pa[16 * u * sai + 4 * ks * sak];
+    for (int u = 0; u < 2; ++u) b.fa[ks][u] = (SC1 & 1) ? ld_pub(pa + 16 * u * sai + 4 * ks * sak) : pa[16 * u * sai + 4 * ks * sak];
 #pragma unroll
-    for (int v = 0; v < 2; ++v) b.fr[ks][v] = pr[4 * ks * srk + 16 * v * srj];
+    for (int v = 0; v < 2; ++v) b.fr[ks][v] = (SC1 & 2) ? ld_pub(pr + 4 * ks * srk + 16 * v * srj) : pr[4 * ks * srk + 16 * v * srj];
   }
 }
 __device__ __forceinline__ void mm64_mul(d4 (&acc)[2][2], const MM64Chunk& b) {
@@ -1290,7 +1491,7 @@ __device__ __forceinline__ void mm64_mul(d4 (&acc)[2][2], const MM64Chunk& b) {
 #pragma unroll
       for (int v = 0; v < 2; ++v) acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(b.fa[ks][u], b.fr[ks][v], acc[u][v], 0, 0, 0);
 }
-template <bool DEEP = false>
+template <bool DEEP = false, int SC1 = 0>
 __device__ __forceinline__ void wg_mm64_core(d4 (&acc)[2][2], const double* As, size_t sai, size_t sak, const double* Rs, size_t srk, size_t srj,
                                              int w, int l, int nblk = 1) {
   const int c = l & 15, g = l >> 4, wi = 32 * (w & 1), wj = 32 * (w >> 1);
@@ -1300,29 +1501,29 @@ __device__ __forceinline__ void wg_mm64_core(d4 (&acc)[2][2], const double* As, 
   const size_t da = 32 * sak, dr = 32 * srk;
   if (DEEP && nch > 2) {
     MM64Chunk b0, b1, b2;
-    mm64_load(b0, pa, sai, sak, pr, srk, srj);
-    mm64_load(b1, pa + da, sai, sak, pr + dr, srk, srj);
+    mm64_load<SC1>(b0, pa, sai, sak, pr, srk, srj);
+    mm64_load<SC1>(b1, pa + da, sai, sak, pr + dr, srk, srj);
     for (int ch = 0; ch < nch; ch += 3) {
-      if (ch + 2 < nch) mm64_load(b2, pa + (ch + 2) * da, sai, sak, pr + (ch + 2) * dr, srk, srj);
+      if (ch + 2 < nch) mm64_load<SC1>(b2, pa + (ch + 2) * da, sai, sak, pr + (ch + 2) * dr, srk, srj);
       mm64_mul(acc, b0);
       if (ch + 1 < nch) {
-        if (ch + 3 < nch) mm64_load(b0, pa + (ch + 3) * da, sai, sak, pr + (ch + 3) * dr, srk, srj);
+        if (ch + 3 < nch) mm64_load<SC1>(b0, pa + (ch + 3) * da, sai, sak, pr + (ch + 3) * dr, srk, srj);
         mm64_mul(acc, b1);
       }
       if (ch + 2 < nch) {
-        if (ch + 4 < nch) mm64_load(b1, pa + (ch + 4) * da, sai, sak, pr + (ch + 4) * dr, srk, srj);
+        if (ch + 4 < nch) mm64_load<SC1>(b1, pa + (ch + 4) * da, sai, sak, pr + (ch + 4) * dr, srk, srj);
         mm64_mul(acc, b2);
       }
     }
     return;
   }
   MM64Chunk b0, b1;
-  mm64_load(b0, pa, sai, sak, pr, srk, srj);
+  mm64_load<SC1>(b0, pa, sai, sak, pr, srk, srj);
   for (int ch = 0; ch < nch; ch += 2) {
-    if (ch + 1 < nch) mm64_load(b1, pa + (ch + 1) * da, sai, sak, pr + (ch + 1) * dr, srk, srj);
+    if (ch + 1 < nch) mm64_load<SC1>(b1, pa + (ch + 1) * da, sai, sak, pr + (ch + 1) * dr, srk, srj);
     mm64_mul(acc, b0);
     if (ch + 1 < nch) {
-      if (ch + 2 < nch) mm64_load(b0, pa + (ch + 2) * da, sai, sak, pr + (ch + 2) * dr, srk, srj);
+      if (ch + 2 < nch) mm64_load<SC1>(b0, pa + (ch + 2) * da, sai, sak, pr + (ch + 2) * dr, srk, srj);
       mm64_mul(acc, b1);
     }
   }
@@ -1379,7 +1580,8 @@ __device__ __forceinline__ bool region_aborted(const int* abort_word, int epoch)
   const int v = __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return (v >> 5) == epoch && (v & 31) != 0;
 }
-template <int SLEEP = 1>
+// ACQ = false: no acquire fence -- for consumers whose EVERY load of the handed-off bytes is an sc1 load (ld_pub; one workgroup per CU)
+template <int SLEEP = 1, bool ACQ = true>
 __device__ __forceinline__ void region_wait_ge(const int* f, int epoch, int need, int* abort_word, int* info) {
   if (threadIdx.x == 0) {
     const long long t0 = wall_clock64();
@@ -1399,7 +1601,7 @@ __device__ __forceinline__ void region_wait_ge(const int* f, int epoch, int need
     }
   }
   __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (ACQ) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 // Publishing.  An agent-scope release fence writes back EVERY dirty line of the XCD's L2 -- including the megabytes the row streams
 // of the same launch keep producing -- and costs 4-13 us under load (tools/fence_probe, profiles/r03), twice per 64-column block of
@@ -1417,7 +1619,7 @@ __device__ __forceinline__ void region_publish(int* f, int epoch, int count) {
 // LDS of the node kernel: the update's staging (2 x 2 x 16 x 144 doubles = 73 728 bytes, as gemm16p_kernel) >= the leaf's two 64 x 64
 // images X, Y (2 x 64 x 68 doubles); the diagonal-block work areas Sp / Wt live inside whichever image is dead in that phase.
 constexpr int LEAF_LDS_DOUBLES = 4 * 16 * 144;
-static_assert(2 * 64 * DIAG_LS <= LEAF_LDS_DOUBLES && 64 * DIAG_SP + 256 <= 64 * DIAG_LS, "leaf128 LDS layout");
+static_assert(2 * 64 * DIAG_LS <= LEAF_LDS_DOUBLES && DIAG_PAIR_WORK <= 64 * DIAG_LS, "leaf128 LDS layout");
 // lds: LEAF_LDS_DOUBLES doubles.  A: the matrix (double), offD: element offset of the diagonal block; W: 64 x 64 inverse blocks
 // (offW: block of the first 64 columns; the second follows at + 4096); W2p: this panel's 128 x 128 inverse (column-major, ld 128).
 // All 256 threads of the workgroup call it; it starts and ends with everything in LDS free for reuse.
@@ -1425,7 +1627,7 @@ static_assert(2 * 64 * DIAG_LS <= LEAF_LDS_DOUBLES && 64 * DIAG_SP + 256 <= 64 *
 template <bool PUB = false>
 __device__ __forceinline__ void leaf128_dev(double* __restrict__ lds, double* __restrict__ A, size_t offD, int ld,
                                             double* __restrict__ W, size_t offW, double* __restrict__ W2p, int gcol0, int n_real,
-                                            int* __restrict__ info) {
+                                            int* __restrict__ info, int* __restrict__ dflags) {
   constexpr int LS = DIAG_LS;
   double* X = lds;
   double* Y = X + 64 * LS;
@@ -1434,10 +1636,10 @@ __device__ __forceinline__ void leaf128_dev(double* __restrict__ lds, double* __
   const size_t off21 = offD + 64, off22 = offD + (size_t)64 * ld + 64;
   unsigned long long bad1 = 0ull, bad2 = 0ull;
   // A   (work areas of the diagonal-block factorisation inside X, which is dead until W11 lands in it after the last step)
-  if (w == 0) {
-    bad1 = diag64m_wave<double>(A, offD, ld, X, X + 64 * DIAG_SP, X, l);
+  if (w < 2) {                                                     // waves 0, 1: factor and inverse of A11 (two-wave form)
+    bad1 = diag64_pair<double>(A, offD, ld, X, X, dflags, 0, w, l);
   } else {
-    for (int e = t - 64; e < 4096; e += 192) { const int row = e & 63, col = e >> 6; Y[col * LS + row] = A[off21 + (size_t)col * ld + row]; }
+    for (int e = t - 128; e < 4096; e += 128) { const int row = e & 63, col = e >> 6; Y[col * LS + row] = A[off21 + (size_t)col * ld + row]; }
   }
   __syncthreads();
   // W11 (X) -> the 64 x 64 inverse block and the top-left block of the panel inverse; zeros into the panel's top-right block
@@ -1498,7 +1700,7 @@ __device__ __forceinline__ void leaf128_dev(double* __restrict__ lds, double* __
         for (int r = 0; r < 4; ++r) X[(wj + 16 * v + c_) * LS + wi + 16 * u + 4 * r + g_] = tt[u][v][r];
   }
   // C
-  if (w == 0) bad2 = diag64m_wave<double>(A, off22, ld, Y, Y + 64 * DIAG_SP, Y, l);       // work areas inside Y (L21 is in global memory)
+  if (w < 2) bad2 = diag64_pair<double>(A, off22, ld, Y, Y, dflags, 16, w, l);            // work areas inside Y (L21 is in global memory)
   __syncthreads();                                               // X = T, Y = W22
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
@@ -1526,7 +1728,10 @@ __device__ __forceinline__ void leaf128_dev(double* __restrict__ lds, double* __
 __global__ __launch_bounds__(256) void leaf128_kernel(BatchPtr Ab, size_t offD, int ld, BatchPtr Wb, size_t offW, BatchPtr W2b, size_t offW2,
                                                       int gcol0, int n_real, BatchInfo infob) {
   extern __shared__ __attribute__((aligned(16))) double node_lds[];
-  leaf128_dev(node_lds, Ab.p[blockIdx.x], offD, ld, Wb.p[blockIdx.x], offW, W2b.p[blockIdx.x] + offW2, gcol0, n_real, infob.p[blockIdx.x]);
+  __shared__ int dflags[2];                                        // hand-off counters of the two-wave diagonal-block factorisation
+  if (threadIdx.x == 0) { dflags[0] = 0; dflags[1] = 0; }
+  __syncthreads();
+  leaf128_dev(node_lds, Ab.p[blockIdx.x], offD, ld, Wb.p[blockIdx.x], offW, W2b.p[blockIdx.x] + offW2, gcol0, n_real, infob.p[blockIdx.x], dflags);
 }
 
 // FUSE: the NODE_FUSE work items exist (their waits and write-through stores cost the hot loop 3-4 spilled registers: 0.3 % on the
@@ -1534,6 +1739,8 @@ __global__ __launch_bounds__(256) void leaf128_kernel(BatchPtr Ab, size_t offD, 
 template <int DEPTH, bool FUSE = false>
 __global__ __launch_bounds__(256, 2) void potrf_node_kernel(NodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) double node_lds[];
+  __shared__ int dflags[2];                                        // two-wave diagonal-block factorisation of the leaf (zero before its first barrier)
+  if (threadIdx.x == 0) { dflags[0] = 0; dflags[1] = 0; }
   constexpr int BM = 128, BN = 128, BK = 16;
   constexpr int SA = BM + 16, SB = BN + 16;
   double (*As)[BK * SA] = reinterpret_cast<double (*)[BK * SA]>(node_lds);
@@ -1695,11 +1902,11 @@ __global__ __launch_bounds__(256, 2) void potrf_node_kernel(NodeArgs a) {
     __syncthreads();                                               // the tile's stores are issued; the staging LDS is free
     if (fuse) {
       leaf128_dev<true>(node_lds, Am, (size_t)r0 * a.ld + r0, a.ld, a.W.p[bidx], (size_t)(r0 / 64) * 4096,
-                        a.W2.p[bidx] + (size_t)(r0 / 128) * 16384, r0, a.n_real, a.info.p[bidx]);
+                        a.W2.p[bidx] + (size_t)(r0 / 128) * 16384, r0, a.n_real, a.info.p[bidx], dflags);
       region_publish(nf + 1, a.epoch, 1);
     } else {
       leaf128_dev(node_lds, Am, (size_t)r0 * a.ld + r0, a.ld, a.W.p[bidx], (size_t)(r0 / 64) * 4096,
-                  a.W2.p[bidx] + (size_t)(r0 / 128) * 16384, r0, a.n_real, a.info.p[bidx]);
+                  a.W2.p[bidx] + (size_t)(r0 / 128) * 16384, r0, a.n_real, a.info.p[bidx], dflags);
     }
   }
 }
@@ -1766,6 +1973,7 @@ __device__ __forceinline__ void pipe128_accumulate(d4 (&acc)[4][4], double* __re
 }
 
 // the same for up to three flags at once (one barrier, one fence); f2 / f3 may be nullptr
+template <bool ACQ = true>
 __device__ __forceinline__ void region_wait3(const int* f1, int n1, const int* f2, int n2, const int* f3, int n3, int epoch, int* abort_word, int* info) {
   if (threadIdx.x == 0) {
     const long long t0 = wall_clock64();
@@ -1787,7 +1995,7 @@ __device__ __forceinline__ void region_wait3(const int* f1, int n1, const int* f
     }
   }
   __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (ACQ) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 // 64 x 64 block G (column-major, leading dimension ldg) -> LDS image img[col * DIAG_LS + row]; all 256 threads, 512-byte row runs
 __device__ __forceinline__ void img_load(double* __restrict__ img, const double* __restrict__ G, int ldg) {
@@ -1831,7 +2039,10 @@ __device__ __forceinline__ void region_store_W(const RegionArgs& a, int b, const
 #define MM64_FOREACH(BODY) _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int v = 0; v < 2; ++v) _Pragma("unroll") \
     for (int q = 0; q < 4; ++q) { const int i = wi + 16 * u + 4 * q + g_, j = wj + 16 * v + c_; BODY }
 
-__device__ __forceinline__ void potrf_region_walker(const RegionArgs& a, double* __restrict__ lds, double* __restrict__ Am, int b) {
+// NF ("no fence", the one-workgroup-per-CU build): hand-offs on the chain are consumed through sc1 loads instead of acquire fences
+template <bool NF>
+__device__ __forceinline__ void potrf_region_walker(const RegionArgs& a, double* __restrict__ lds, double* __restrict__ Am, int b, int* __restrict__ dflags) {
+  int dbase = 0;                             // 16 x two-wave diagonal-block factorisations run so far (uniform)
   constexpr int LS = DIAG_LS;
   int* fl = a.flags.p[b];
   int* abort_word = fl; int* wk = fl + 1; int* upd = fl + 18;
@@ -1865,16 +2076,16 @@ __device__ __forceinline__ void potrf_region_walker(const RegionArgs& a, double*
     }
     if (r > 0) {
       const size_t gcol = grow - 64;
-      if (r >= 2) region_wait_ge(upd + r, a.epoch, r - 1, abort_word, info);     // tiles (r, r-1), (r, r) updated through block r - 2
+      if (r >= 2) region_wait_ge<1, !NF>(upd + r, a.epoch, r - 1, abort_word, info);     // tiles (r, r-1), (r, r) updated through block r - 2
       if (tr2 && t == 0) tr2[16 + r] = wall_clock64();
       // the diagonal tile (row j, column i) in the lanes that will hold its update D[i][j]
       double dt[2][2][4];
       const double* Ct = Am + grow * a.ld + grow;
-      MM64_FOREACH(dt[u][v][q] = (j >= i) ? Ct[(size_t)i * a.ld + j] : 0.0;)
+      MM64_FOREACH(dt[u][v][q] = (j >= i) ? (NF ? ld_pub(&Ct[(size_t)i * a.ld + j]) : Ct[(size_t)i * a.ld + j]) : 0.0;)
       // L[r, r-1]' = W_{r-1} A[r, r-1]'   (A-operand W = X: (1, LS); R[k'][j] = A[r, r-1][j][k'], straight from global: (ld, 1))
       d4 acc[2][2];
       MM64_ZERO(acc);
-      wg_mm64_core(acc, X, 1, LS, Am + gcol * a.ld + grow, a.ld, 1, w, l);
+      wg_mm64_core<false, NF ? 2 : 0>(acc, X, 1, LS, Am + gcol * a.ld + grow, a.ld, 1, w, l);
       __syncthreads();                                                   // previous readers of Y (work areas of the last diag64m) are done
       MM64_FOREACH(Y[i * LS + j] = acc[u][v][q]; ST_PUB(&Am[(gcol + i) * a.ld + grow + j], acc[u][v][q]);)        // D[i][j] = L[r, r-1][j][i]
       region_publish(wk, a.epoch, r);                                    // W_{r-1} (stored last iteration) and L[r, r-1] are final;
@@ -1888,7 +2099,8 @@ __device__ __forceinline__ void potrf_region_walker(const RegionArgs& a, double*
     __syncthreads();                                                     // the image (r > 0) is complete, Y is free
     unsigned long long bad = 0ull;
     if (tr2 && t == 0) tr2[32 + r] = wall_clock64();
-    if (w == 0) bad = diag64m_wave<double>(Am, grow * a.ld + grow, a.ld, Y, Y + 64 * DIAG_SP, X, l, src);      // L[r, r] -> global, W_r -> X
+    if (w < 2) bad = diag64_pair<double>(Am, grow * a.ld + grow, a.ld, Y, X, dflags, dbase, w, l, src);      // L[r, r] -> global, W_r -> X
+    dbase += 16;
     __syncthreads();
     if (tr2 && t == 0) tr2[48 + r] = wall_clock64();
     region_store_W(a, b, X, grow, (r & 1) != 0);
@@ -1904,7 +2116,7 @@ __device__ __forceinline__ void potrf_region_walker(const RegionArgs& a, double*
 // and once c = r - 2 is done:  A[r, r-1] -= pa,  A[r, r] -= pd  (their only read-modify-write);  publish upd[r] = r - 1.
 // The walker's request "tiles (r, r-1), (r, r) updated through block r - 2" thus costs, after W_{r-2} arrives, one solve, two 64^3
 // products in registers and one write -- about the time the walker spends in diag64m of block r - 1.
-template <bool DEEP, bool ASST>
+template <bool DEEP, bool ASST, bool NF>
 __device__ __forceinline__ void potrf_region_helper(const RegionArgs& a, double* __restrict__ lds, double* __restrict__ Am, int b, int r) {
   constexpr int LS = DIAG_LS;
   int* fl = a.flags.p[b];
@@ -1934,23 +2146,23 @@ __device__ __forceinline__ void potrf_region_helper(const RegionArgs& a, double*
       MM64_ZERO(acc);
       if (c > 0) {
         // row c final through block c - 1: its helper's blocks (c >= 2) and the walker's subdiagonal block
-        if (c >= 2) region_wait_ge(trs + c, a.epoch, c - 1, abort_word, info);
-        region_wait_ge(wk, a.epoch, c, abort_word, info);
+        if (c >= 2) region_wait_ge<1, !NF>(trs + c, a.epoch, c - 1, abort_word, info);
+        region_wait_ge<1, !NF>(wk, a.epoch, c, abort_word, info);
         // (tile update)' = L[c, 0:c] L[r, 0:c]'   (A[i][k'] = L[c][i][k']: (1, ld); R[k'][j] = L[r][j][k']: (ld, 1)), K = 64 c.
         // From column block LMM_REGION_ASST_MIN_C on, this row's ASSISTANT has formed the part over the blocks [0, cs) ahead of time
         // (its inputs are final several steps earlier); this workgroup multiplies the blocks [cs, c) and adds the assistant's tile.
         const int cs = (ASST && a.na > 0 && r >= LMM_REGION_ASST_MIN_R && c >= LMM_REGION_ASST_MIN_C) ? c / 2 : 0;
         const size_t koff = (size_t)cs * 64 * a.ld;
-        wg_mm64_core<DEEP>(acc, Am + col0 + koff + gcol, 1, a.ld, Am + col0 + koff + grow, a.ld, 1, w, l, c - cs);
+        wg_mm64_core<DEEP, NF ? 1 : 0>(acc, Am + col0 + koff + gcol, 1, a.ld, Am + col0 + koff + grow, a.ld, 1, w, l, c - cs);      // row c: handed off; row r: own
         if (ASST && cs > 0) {
-          region_wait_ge(fl + 42 + r, a.epoch, c, abort_word, info);
+          region_wait_ge<1, !NF>(fl + 42 + r, a.epoch, c, abort_word, info);
           const double* St = a.S.p[b] + ((size_t)(r - LMM_REGION_ASST_MIN_R) * 16 + c) * 4096;
 #pragma unroll
           for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int v = 0; v < 2; ++v)
 #pragma unroll
-              for (int q = 0; q < 4; ++q) acc[u][v][q] += St[((u * 2 + v) * 4 + q) * 256 + t];
+              for (int q = 0; q < 4; ++q) acc[u][v][q] += NF ? ld_pub(&St[((u * 2 + v) * 4 + q) * 256 + t]) : St[((u * 2 + v) * 4 + q) * 256 + t];
         }
       }
       const double* Ct = Am + gcol * a.ld + grow;
@@ -1959,16 +2171,16 @@ __device__ __forceinline__ void potrf_region_helper(const RegionArgs& a, double*
       if constexpr (LAST) {
         MM64_FOREACH(pc1[u][v][q] = C1[(size_t)i * a.ld + j]; pc2[u][v][q] = (j >= i) ? C2[(size_t)i * a.ld + j] : 0.0;)
       }
-      region_wait_ge(wk, a.epoch, c + 1, abort_word, info);              // W_c (its barrier completes the image)
+      region_wait_ge<1, !NF>(wk, a.epoch, c + 1, abort_word, info);      // W_c (its barrier completes the image)
       // L[r, c]' = W_c tile'   (A[i][k'] = W_c[i][k'] global: (1, 64); R[k'][j] = tile[j][k'] = Y[k' LS + j]: (LS, 1))
       MM64_ZERO(acc);
-      wg_mm64_core(acc, Wm + (size_t)(gcol / 64) * 4096, 1, 64, Y, LS, 1, w, l);
+      wg_mm64_core<false, NF ? 1 : 0>(acc, Wm + (size_t)(gcol / 64) * 4096, 1, 64, Y, LS, 1, w, l);
       __syncthreads();                                                   // reads of the tile image done
       MM64_FOREACH(Y[i * LS + j] = acc[u][v][q]; ST_PUB(&Am[(gcol + i) * a.ld + grow + j], acc[u][v][q]);)        // D[i][j] = L[r, c][j][i]
       region_publish(trs + r, a.epoch, c + 1);                           // (release; its barrier completes Y = L[r, c])
       // pair accumulators:  (r, r-1): D[i][j] += L[r-1, c][i][k'] L[r, c][j][k'];   (r, r): D[i][j] += L[r, c][i][k'] L[r, c][j][k']
-      if (c <= r - 3) region_wait_ge(trs + r - 1, a.epoch, c + 1, abort_word, info);      // helper r-1's L[r-1, c]; c = r-2: the walker's
-      wg_mm64_core(pa, Am + gcol * a.ld + grow - 64, 1, a.ld, Y, LS, 1, w, l);
+      if (c <= r - 3) region_wait_ge<1, !NF>(trs + r - 1, a.epoch, c + 1, abort_word, info);      // helper r-1's L[r-1, c]; c = r-2: the walker's
+      wg_mm64_core<false, NF ? 1 : 0>(pa, Am + gcol * a.ld + grow - 64, 1, a.ld, Y, LS, 1, w, l);
       wg_mm64_core(pd, Y, 1, LS, Y, LS, 1, w, l);
       if constexpr (LAST) {
         MM64_FOREACH(ST_PUB(&C1[(size_t)i * a.ld + j], pc1[u][v][q] - pa[u][v][q]);
@@ -1981,19 +2193,19 @@ __device__ __forceinline__ void potrf_region_helper(const RegionArgs& a, double*
   }
   if ((r & 1) && !skip) {
     // Dinv of panel j = r / 2 (a = r - 1, b = r), once the walker has published W_b:  T = L[b, a] W_a;  W21 = -W_b T
-    region_wait_ge(wk, a.epoch, r + 1, abort_word, info);
+    region_wait_ge<1, !NF>(wk, a.epoch, r + 1, abort_word, info);
     const size_t gcol = grow - 64;
     d4 acc[2][2];
     MM64_ZERO(acc);
     // T = L[b, a] W_a   (A[i][k'] = L[i][k'] global: (1, ld); R[k'][j] = W_a[k'][j] global: (1, 64))
-    wg_mm64_core(acc, Am + gcol * a.ld + grow, 1, a.ld, Wm + (size_t)(gcol / 64) * 4096, 1, 64, w, l);
+    wg_mm64_core<false, NF ? 3 : 0>(acc, Am + gcol * a.ld + grow, 1, a.ld, Wm + (size_t)(gcol / 64) * 4096, 1, 64, w, l);
     __syncthreads();
     MM64_FOREACH(Y[j * LS + i] = acc[u][v][q];)                          // Y = image of T: T[row i][col j] -> Y[col * LS + row]
     __syncthreads();
     double* W2p = a.W2.p[b] + (size_t)(grow / 128) * 16384;
     // D = T' W_b'  (A[i][k'] = T[k'][i] = Y[i LS + k']: (LS, 1); R[k'][j] = W_b[j][k'] global: (64, 1))  ->  W21[j][i] = -D[i][j]
     MM64_ZERO(acc);
-    wg_mm64_core(acc, Y, LS, 1, Wm + (size_t)(grow / 64) * 4096, 64, 1, w, l);
+    wg_mm64_core<false, NF ? 2 : 0>(acc, Y, LS, 1, Wm + (size_t)(grow / 64) * 4096, 64, 1, w, l);
     MM64_FOREACH(ST_PUB(&W2p[(size_t)i * 128 + 64 + j], -acc[u][v][q]);)
     region_publish(dinv + (r >> 1), a.epoch, 0);
   } else if (skip && r == 1) {
@@ -2007,6 +2219,7 @@ __device__ __forceinline__ void potrf_region_helper(const RegionArgs& a, double*
 // profiles/r03).  The first half of that product, over the blocks [0, c / 2), depends only on blocks that were final c / 2 steps
 // earlier: the assistant forms it ahead of time into a scratch tile (in the helper's own lane layout: element ((u 2 + v) 4 + q) 256 + t,
 // coalesced both ways) and flags it; the helper multiplies the blocks [c / 2, c) and adds the tile.
+template <bool NF>
 __device__ __forceinline__ void potrf_region_assistant(const RegionArgs& a, double* __restrict__ Am, int b, int r) {
   int* fl = a.flags.p[b];
   int* abort_word = fl; int* trs = fl + 2; int* asst = fl + 42;
@@ -2018,10 +2231,10 @@ __device__ __forceinline__ void potrf_region_assistant(const RegionArgs& a, doub
   for (int c = LMM_REGION_ASST_MIN_C; c <= r - 2; ++c) {
     const int cs = c / 2;
     const size_t gcol = (size_t)a.c0 + 64 * (size_t)c;
-    region_wait3(trs + c, cs, trs + r, cs, nullptr, 0, a.epoch, abort_word, info);       // L[c, 0:cs], L[r, 0:cs] final
+    region_wait3<!NF>(trs + c, cs, trs + r, cs, nullptr, 0, a.epoch, abort_word, info);       // L[c, 0:cs], L[r, 0:cs] final
     d4 acc[2][2];
     MM64_ZERO(acc);
-    wg_mm64_core(acc, Am + col0 + gcol, 1, a.ld, Am + col0 + grow, a.ld, 1, w, l, cs);
+    wg_mm64_core<false, NF ? 3 : 0>(acc, Am + col0 + gcol, 1, a.ld, Am + col0 + grow, a.ld, 1, w, l, cs);
     double* St = a.S.p[b] + ((size_t)(r - LMM_REGION_ASST_MIN_R) * 16 + c) * 4096;
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -2202,6 +2415,8 @@ __device__ __forceinline__ void potrf_region_row_thin(const RegionArgs& a, doubl
 template <int OCC>       // 1: one workgroup per CU (no register spills in the walker); 2: two (the row streams' natural occupancy)
 __global__ __launch_bounds__(256, OCC) void potrf_region_kernel(RegionArgs a) {
   extern __shared__ __attribute__((aligned(16))) double node_lds[];
+  __shared__ int dflags[2];                  // the walker's two-wave diagonal-block factorisation (zero before the walker's first barrier)
+  if (threadIdx.x == 0) { dflags[0] = 0; dflags[1] = 0; }
   const int b = blockIdx.x % a.nb, idx = blockIdx.x / a.nb;
   double* Am = a.A.p[b];
   const int Q = 2 * a.P;
@@ -2215,9 +2430,9 @@ __global__ __launch_bounds__(256, OCC) void potrf_region_kernel(RegionArgs a) {
     r = LMM_REGION_ASST_MIN_R + (k >> 1); role = 1 + (k & 1);
   }
   if (idx >= Q + a.na) role = 3;
-  if (role == 0) potrf_region_walker(a, node_lds, Am, b);
-  else if (role == 1) potrf_region_helper<false, OCC == 1>(a, node_lds, Am, b, r);      // DEEP (two chunks ahead) spills even at one workgroup per CU
-  else if (role == 2) { if (OCC == 1) potrf_region_assistant(a, Am, b, r); }             // (the two-per-CU build has no assistants)
+  if (role == 0) potrf_region_walker<OCC == 1>(a, node_lds, Am, b, dflags);
+  else if (role == 1) potrf_region_helper<false, OCC == 1, OCC == 1>(a, node_lds, Am, b, r);      // DEEP (two chunks ahead) spills even at one workgroup per CU
+  else if (role == 2) { if (OCC == 1) potrf_region_assistant<true>(a, Am, b, r); }       // (the two-per-CU build has no assistants)
   else {
     const int ti = a.P + idx - Q - a.na;
     const int real = a.M_real - 128 * ti;                // rows of this tile that hold data (the rest is zero padding, before and after)
