@@ -91,6 +91,11 @@ struct RegionArgs {
 #define LMM_REGION_MAX_PANELS 8
 #define LMM_REGION_ASST_MIN_C 4           // a helper's product for column block c >= this is split with its row's assistant
 #define LMM_REGION_ASST_MIN_R (LMM_REGION_ASST_MIN_C + 2)
+// the assistant of a row takes the blocks [0, LMM_REGION_ASST_SPLIT(c)) of the helper's K-long product for column block c.  Round 3:
+// c / 2; round 4: 3 c / 4 -- once the chain's hand-offs got cheaper (sc1 loads instead of acquire fences) the helpers of rows >= 9 were
+// again the slower side of the walker <-> helper cycle (walker waits of 3-10 us at n = 1024), and what a helper does per column AFTER
+// W_c arrives cannot shrink, so the part before it must: the blocks [0, 3 c / 4) are final c / 4 - 1 block periods before they are needed.
+#define LMM_REGION_ASST_SPLIT(c) ((3 * (c)) / 4)
 #define LMM_REGION_ASST_TILES ((2 * LMM_REGION_MAX_PANELS - LMM_REGION_ASST_MIN_R) * 16)
 // Bound of every dependency spin of the dataflow kernels, in ticks of the 100 MHz wall clock (4 s).  The deadlock argument (a workgroup
 // only waits for workgroups dispatched before it, the walker excepted) covers one launch on an otherwise free device; kernels of other

@@ -692,7 +692,9 @@ __device__ __forceinline__ unsigned long long diag64m_wave(void* __restrict__ A,
 // would leave the ~120 f64 VALU instructions of a step -- 8 issue cycles each -- in every wave: priced at 1.15x; this split removes
 // instructions from the critical wave instead.)
 //   xch: 2 x 8 x 64 doubles ([parity][v][lane]: v < 4 the panel rows -Y of block row v, v >= 4 the inverse row entries k_{v-4}),
-//   flags (LDS ints, monotonic over the kernel's lifetime, zeroed once at kernel start): [0] steps produced, [1] steps consumed;
+//   flags (LDS ints, monotonic over the kernel's lifetime, zeroed once at kernel start): [0] steps produced, [1] steps consumed by the
+//   inverse wave, [2] by the store wave (wave 2 takes the global stores of the finished L entries -- their address arithmetic and
+//   execution masks -- off the factor wave as well);
 //   `base` = 16 x (number of two-wave factorisations this workgroup has run before): uniform over the workgroup.
 // ---------------------------------------------------------------------------------------------------
 struct DiagFState {
@@ -764,19 +766,20 @@ __device__ __forceinline__ void diagf_step(DiagFState& st, double* __restrict__ 
   const double k2 = __builtin_fma(-k3, l32, st.e2) * r2;
   const double k1 = __builtin_fma(-k2, l21, __builtin_fma(-k3, l31, st.e1)) * r1;
   const double k0 = __builtin_fma(-k1, l10, __builtin_fma(-k2, l20, __builtin_fma(-k3, l30, st.e0))) * r0;
+  double yy[4];
 #pragma unroll
   for (int rb = jb; rb < 4; ++rb) {
     const double y = __builtin_fma(bo[rb][1].y, k3, __builtin_fma(bo[rb][1].x, k2, __builtin_fma(bo[rb][0].y, k1, bo[rb][0].x * k0)));
     const int row = 16 * rb + c;
-    if (row >= J + g) MatIO<TS>::st1(Ag, offAg + (size_t)(J + g) * ldg + row, y);
+    yy[rb] = y;
     st.Ym[o][rb] = (rb > jb || row > J + 3) ? y : 0.0;
     st.nY[o][rb] = -st.Ym[o][rb];
   }
-  // hand (-Y, k) to the inverse wave: buffer o was last read for step s - 2
-  if constexpr (s >= 2) diag_flag_wait(flags + 1, base + s - 1);
+  // hand (Y, k) to the inverse wave and to the store wave: buffer o was last read for step s - 2
+  if constexpr (s >= 2) { diag_flag_wait(flags + 1, base + s - 1); diag_flag_wait(flags + 2, base + s - 1); }
   double* xo = xch + o * 512 + l;
 #pragma unroll
-  for (int rb = jb; rb < 4; ++rb) xo[rb * 64] = st.nY[o][rb];
+  for (int rb = jb; rb < 4; ++rb) xo[rb * 64] = yy[rb];
   xo[4 * 64] = k0; xo[5 * 64] = k1; xo[6 * 64] = k2; xo[7 * 64] = k3;
   diag_flag_set(flags, base + s + 1, l);
   diagf_mfmas<s, 0>(st); diagf_mfmas<s, 1>(st);
@@ -803,7 +806,10 @@ __device__ __forceinline__ void diagw_step(DiagWState& st, double* __restrict__ 
   const double* xo = xch + o * 512 + l;
   double nY[4];
 #pragma unroll
-  for (int rb = jb; rb < 4; ++rb) nY[rb] = xo[rb * 64];
+  for (int rb = jb; rb < 4; ++rb) {                                // Y of the step: rows of and above the pivot block take no part in the update
+    const double y = xo[rb * 64];
+    nY[rb] = -((rb > jb || 16 * rb + c > 4 * s + 3) ? y : 0.0);
+  }
   const double k0 = xo[4 * 64], k1 = xo[5 * 64], k2 = xo[6 * 64], k3 = xo[7 * 64];
   diag_flag_set(flags + 1, base + s + 1, l);                       // (its release waits for the reads above)
   double Z[4];
@@ -820,6 +826,28 @@ __device__ __forceinline__ void diagw_step(DiagWState& st, double* __restrict__ 
   }
   __builtin_amdgcn_sched_barrier(0);
 }
+// store wave: the finished L entries of step s -- L[row][J + g] = Y of lane (g, c) of row block rb, final for row >= J + g -- leave for
+// global memory from the exchange area (four columns x sixteen consecutive rows per store instruction: four 128-byte segments)
+template <int s, typename TS>
+__device__ __forceinline__ void diags_step(const double* __restrict__ xch, int* __restrict__ flags, int base, int c, int g, int l,
+                                           void* __restrict__ Ag, size_t offAg, int ldg) {
+  constexpr int J = 4 * s, jb = s >> 2, o = s & 1;
+  diag_flag_wait(flags, base + s + 1);
+  const double* xo = xch + o * 512 + l;
+  double y[4];
+#pragma unroll
+  for (int rb = jb; rb < 4; ++rb) y[rb] = xo[rb * 64];
+  diag_flag_set(flags + 2, base + s + 1, l);
+#pragma unroll
+  for (int rb = jb; rb < 4; ++rb) {
+    const int row = 16 * rb + c;
+    if (row >= J + g) MatIO<TS>::st1(Ag, offAg + (size_t)(J + g) * ldg + row, y[rb]);
+  }
+}
+template <int s, typename TS>
+__device__ __forceinline__ void diags_steps(const double* xch, int* flags, int base, int c, int g, int l, void* __restrict__ Ag, size_t offAg, int ldg) {
+  if constexpr (s < 16) { diags_step<s, TS>(xch, flags, base, c, g, l, Ag, offAg, ldg); diags_steps<s + 1, TS>(xch, flags, base, c, g, l, Ag, offAg, ldg); }
+}
 template <int s, typename TS>
 __device__ __forceinline__ void diagf_steps(DiagFState& st, double* Sp, double* xch, int* flags, int base, int c, int g, int l,
                                             void* __restrict__ Ag, size_t offAg, int ldg) {
@@ -829,7 +857,7 @@ template <int s>
 __device__ __forceinline__ void diagw_steps(DiagWState& st, double* Wt, const double* xch, int* flags, int base, int c, int g, int l) {
   if constexpr (s < 16) { diagw_step<s>(st, Wt, xch, flags, base, c, g, l); diagw_steps<s + 1>(st, Wt, xch, flags, base, c, g, l); }
 }
-// Waves 0 and 1 of the workgroup call this (w = wave index, uniform); the other waves do not.  work: 64 * DIAG_SP + 256 + DIAG_XCH
+// Waves 0, 1 and 2 of the workgroup call this (w = wave index, uniform: 0 factor, 1 inverse, 2 stores of L); wave 3 does not.  work: 64 * DIAG_SP + 256 + DIAG_XCH
 // doubles of LDS (Sp, Wt, exchange area); Wl: the W image (MAY overlap `work`: it is written after the last step, by wave 1, which
 // finishes behind wave 0); src as in diag64m_wave.  Returns the mask of non-positive pivots in wave 0 (0 in wave 1).  The caller
 // follows with a workgroup barrier before anybody reads Wl.
@@ -857,6 +885,7 @@ __device__ __forceinline__ unsigned long long diag64_pair(void* __restrict__ A, 
     diagf_steps<0, TS>(st, Sp, xch, flags, base, c, g, l, A, offA, ld);
     return st.badmask;
   }
+  if (w == 2) { diags_steps<0, TS>(xch, flags, base, c, g, l, A, offA, ld); return 0ull; }
   DiagWState st;
 #pragma unroll
   for (int rb = 0; rb < 4; ++rb)
@@ -1636,10 +1665,10 @@ __device__ __forceinline__ void leaf128_dev(double* __restrict__ lds, double* __
   const size_t off21 = offD + 64, off22 = offD + (size_t)64 * ld + 64;
   unsigned long long bad1 = 0ull, bad2 = 0ull;
   // A   (work areas of the diagonal-block factorisation inside X, which is dead until W11 lands in it after the last step)
-  if (w < 2) {                                                     // waves 0, 1: factor and inverse of A11 (two-wave form)
+  if (w < 3) {                                                     // waves 0-2: factor, inverse, L stores of A11
     bad1 = diag64_pair<double>(A, offD, ld, X, X, dflags, 0, w, l);
   } else {
-    for (int e = t - 128; e < 4096; e += 128) { const int row = e & 63, col = e >> 6; Y[col * LS + row] = A[off21 + (size_t)col * ld + row]; }
+    for (int e = t - 192; e < 4096; e += 64) { const int row = e & 63, col = e >> 6; Y[col * LS + row] = A[off21 + (size_t)col * ld + row]; }
   }
   __syncthreads();
   // W11 (X) -> the 64 x 64 inverse block and the top-left block of the panel inverse; zeros into the panel's top-right block
@@ -1700,7 +1729,7 @@ __device__ __forceinline__ void leaf128_dev(double* __restrict__ lds, double* __
         for (int r = 0; r < 4; ++r) X[(wj + 16 * v + c_) * LS + wi + 16 * u + 4 * r + g_] = tt[u][v][r];
   }
   // C
-  if (w < 2) bad2 = diag64_pair<double>(A, off22, ld, Y, Y, dflags, 16, w, l);            // work areas inside Y (L21 is in global memory)
+  if (w < 3) bad2 = diag64_pair<double>(A, off22, ld, Y, Y, dflags, 16, w, l);            // work areas inside Y (L21 is in global memory)
   __syncthreads();                                               // X = T, Y = W22
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
@@ -1728,8 +1757,8 @@ __device__ __forceinline__ void leaf128_dev(double* __restrict__ lds, double* __
 __global__ __launch_bounds__(256) void leaf128_kernel(BatchPtr Ab, size_t offD, int ld, BatchPtr Wb, size_t offW, BatchPtr W2b, size_t offW2,
                                                       int gcol0, int n_real, BatchInfo infob) {
   extern __shared__ __attribute__((aligned(16))) double node_lds[];
-  __shared__ int dflags[2];                                        // hand-off counters of the two-wave diagonal-block factorisation
-  if (threadIdx.x == 0) { dflags[0] = 0; dflags[1] = 0; }
+  __shared__ int dflags[3];                                        // hand-off counters of the two-wave diagonal-block factorisation
+  if (threadIdx.x == 0) { dflags[0] = 0; dflags[1] = 0; dflags[2] = 0; }
   __syncthreads();
   leaf128_dev(node_lds, Ab.p[blockIdx.x], offD, ld, Wb.p[blockIdx.x], offW, W2b.p[blockIdx.x] + offW2, gcol0, n_real, infob.p[blockIdx.x], dflags);
 }
@@ -1739,8 +1768,8 @@ __global__ __launch_bounds__(256) void leaf128_kernel(BatchPtr Ab, size_t offD, 
 template <int DEPTH, bool FUSE = false>
 __global__ __launch_bounds__(256, 2) void potrf_node_kernel(NodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) double node_lds[];
-  __shared__ int dflags[2];                                        // two-wave diagonal-block factorisation of the leaf (zero before its first barrier)
-  if (threadIdx.x == 0) { dflags[0] = 0; dflags[1] = 0; }
+  __shared__ int dflags[3];                                        // two-wave diagonal-block factorisation of the leaf (zero before its first barrier)
+  if (threadIdx.x == 0) { dflags[0] = 0; dflags[1] = 0; dflags[2] = 0; }
   constexpr int BM = 128, BN = 128, BK = 16;
   constexpr int SA = BM + 16, SB = BN + 16;
   double (*As)[BK * SA] = reinterpret_cast<double (*)[BK * SA]>(node_lds);
@@ -2099,7 +2128,7 @@ __device__ __forceinline__ void potrf_region_walker(const RegionArgs& a, double*
     __syncthreads();                                                     // the image (r > 0) is complete, Y is free
     unsigned long long bad = 0ull;
     if (tr2 && t == 0) tr2[32 + r] = wall_clock64();
-    if (w < 2) bad = diag64_pair<double>(Am, grow * a.ld + grow, a.ld, Y, X, dflags, dbase, w, l, src);      // L[r, r] -> global, W_r -> X
+    if (w < 3) bad = diag64_pair<double>(Am, grow * a.ld + grow, a.ld, Y, X, dflags, dbase, w, l, src);      // L[r, r] -> global, W_r -> X
     dbase += 16;
     __syncthreads();
     if (tr2 && t == 0) tr2[48 + r] = wall_clock64();
@@ -2151,7 +2180,7 @@ __device__ __forceinline__ void potrf_region_helper(const RegionArgs& a, double*
         // (tile update)' = L[c, 0:c] L[r, 0:c]'   (A[i][k'] = L[c][i][k']: (1, ld); R[k'][j] = L[r][j][k']: (ld, 1)), K = 64 c.
         // From column block LMM_REGION_ASST_MIN_C on, this row's ASSISTANT has formed the part over the blocks [0, cs) ahead of time
         // (its inputs are final several steps earlier); this workgroup multiplies the blocks [cs, c) and adds the assistant's tile.
-        const int cs = (ASST && a.na > 0 && r >= LMM_REGION_ASST_MIN_R && c >= LMM_REGION_ASST_MIN_C) ? c / 2 : 0;
+        const int cs = (ASST && a.na > 0 && r >= LMM_REGION_ASST_MIN_R && c >= LMM_REGION_ASST_MIN_C) ? LMM_REGION_ASST_SPLIT(c) : 0;
         const size_t koff = (size_t)cs * 64 * a.ld;
         wg_mm64_core<DEEP, NF ? 1 : 0>(acc, Am + col0 + koff + gcol, 1, a.ld, Am + col0 + koff + grow, a.ld, 1, w, l, c - cs);      // row c: handed off; row r: own
         if (ASST && cs > 0) {
@@ -2229,7 +2258,7 @@ __device__ __forceinline__ void potrf_region_assistant(const RegionArgs& a, doub
   const size_t grow = (size_t)a.c0 + 64 * (size_t)r;
   const size_t col0 = (size_t)a.c0 * a.ld;
   for (int c = LMM_REGION_ASST_MIN_C; c <= r - 2; ++c) {
-    const int cs = c / 2;
+    const int cs = LMM_REGION_ASST_SPLIT(c);
     const size_t gcol = (size_t)a.c0 + 64 * (size_t)c;
     region_wait3<!NF>(trs + c, cs, trs + r, cs, nullptr, 0, a.epoch, abort_word, info);       // L[c, 0:cs], L[r, 0:cs] final
     d4 acc[2][2];
@@ -2415,8 +2444,8 @@ __device__ __forceinline__ void potrf_region_row_thin(const RegionArgs& a, doubl
 template <int OCC>       // 1: one workgroup per CU (no register spills in the walker); 2: two (the row streams' natural occupancy)
 __global__ __launch_bounds__(256, OCC) void potrf_region_kernel(RegionArgs a) {
   extern __shared__ __attribute__((aligned(16))) double node_lds[];
-  __shared__ int dflags[2];                  // the walker's two-wave diagonal-block factorisation (zero before the walker's first barrier)
-  if (threadIdx.x == 0) { dflags[0] = 0; dflags[1] = 0; }
+  __shared__ int dflags[3];                  // the walker's two-wave diagonal-block factorisation (zero before the walker's first barrier)
+  if (threadIdx.x == 0) { dflags[0] = 0; dflags[1] = 0; dflags[2] = 0; }
   const int b = blockIdx.x % a.nb, idx = blockIdx.x / a.nb;
   double* Am = a.A.p[b];
   const int Q = 2 * a.P;
