@@ -895,6 +895,10 @@ __device__ __forceinline__ unsigned long long diag64_pair(void* __restrict__ A, 
       for (int r = 0; r < 4; ++r) st.V[rb][cb][r] = (16 * rb + 4 * r + g == 16 * cb + c) ? 1.0 : 0.0;
   diagw_steps<0>(st, Wt, xch, flags, base, c, g, l);
   __builtin_amdgcn_sched_barrier(0);
+  // Wl may overlap the exchange area (leaf128 does that): the store wave must have read its last buffer before the image is written
+  // (the factor wave is done with Sp by then: it published step 15 before either consumer could finish).  Found by tools/stress_region.py:
+  // without this wait the last columns of L came out of a clobbered buffer once in ~10 evaluations of the panel path.
+  diag_flag_wait(flags + 2, base + 16);
 #pragma unroll
   for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
