@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>
@@ -795,10 +796,13 @@ void residual_on_device(const double* Y, int n, int p, const double* Ty_all, int
 // scalar per-latent noise by a per-point diagonal.
 int latent_lmls(const double* xd, int d, int n, const lmm_gp_t* gps, const double* noise, int l0, int l1,
                 const double* delta, std::vector<double>& lml, int nrhs = 1, const double* noisevec = nullptr,
-                const double* rider_sub = nullptr) {       // rider_sub[latent] (host): subtracted from that latent's riders
+                const double* rider_sub = nullptr,         // rider_sub[latent] (host): subtracted from that latent's riders
+                const std::function<void()>* pre_launch = nullptr) {      // launches that PRODUCE delta, issued on streams[0] once this
+                                                           // function's host-side preparation is done (see lmm_oilmm_logpdf)
   const int ms = l1 - l0;
   lml.assign((size_t)ms * nrhs, 0.0);
   if (ms == 0) {
+    if (pre_launch) (*pre_launch)();
     // callers read pinned results (regulariser residual) and release their device buffers after this returns: the main stream
     // must be drained even when this rank holds no latent
     HIPCHK(hipStreamSynchronize(g.streams[0]));
@@ -820,6 +824,9 @@ int latent_lmls(const double* xd, int d, int n, const lmm_gp_t* gps, const doubl
   char* pk = static_cast<char*>(pin_take(nbytes));
   char* pk_dev = pin_dev(pk);
   if (!pk) { pageable.resize(nbytes / sizeof(double)); pk = reinterpret_cast<char*>(pageable.data()); }
+  // The kernels that produce the riders go out only now: issued before the plan / slot / pool work above, they finished while the
+  // host was still preparing and the device then idled ~5 us ahead of the Gram launch (a twentieth of a C0-sized evaluation)
+  if (pre_launch) (*pre_launch)();
   fork_slots(nslots);
   int bi = 0;
   for (int k0 = 0; k0 < ms; k0 += nb_per, ++bi) {
@@ -1166,12 +1173,14 @@ int lmm_oilmm_logpdf(const double* x, int d, int n, const double* y, int p, cons
     const double* Tdev = THd.buf.p;
     const double* Hdev = THd.buf.p + (size_t)m * p;
     Buf<double> Ty((size_t)n * m), resid_dev(1), partial(tall_skinny_partials(n, p));
-    project_on_device(yd.p, n, p, Tdev, m, 0, m, nullptr, Ty.p, st0);
-    // reference src/oilmm.jl:112: sum(abs2, (I - U U') Y)  ==  |Y - H T Y|_F^2 since H T = U U'
     double* resid_direct = (resid != &resid_pageable) ? pin_dev(resid) : nullptr;      // the reduction writes into host memory
-    residual_on_device(yd.p, n, p, Ty.p, m, Hdev, partial.p, resid_direct ? resid_direct : resid_dev.p, st0);
-    if (!resid_direct) HIPCHK(hipMemcpyAsync(resid, resid_dev.p, sizeof(double), hipMemcpyDeviceToHost, st0));    // read after latent_lmls' sync
-    if (int rc = latent_lmls(xd.p, d, n, gps, ST.data(), l0, l1, Ty.p + (size_t)l0 * n, lml, 1, nullptr, means.data())) return rc;
+    const std::function<void()> produce = [&]() {
+      project_on_device(yd.p, n, p, Tdev, m, 0, m, nullptr, Ty.p, st0);
+      // reference src/oilmm.jl:112: sum(abs2, (I - U U') Y)  ==  |Y - H T Y|_F^2 since H T = U U'
+      residual_on_device(yd.p, n, p, Ty.p, m, Hdev, partial.p, resid_direct ? resid_direct : resid_dev.p, st0);
+      if (!resid_direct) HIPCHK(hipMemcpyAsync(resid, resid_dev.p, sizeof(double), hipMemcpyDeviceToHost, st0));    // read after latent_lmls' sync
+    };
+    if (int rc = latent_lmls(xd.p, d, n, gps, ST.data(), l0, l1, Ty.p + (size_t)l0 * n, lml, 1, nullptr, means.data(), &produce)) return rc;
   } else {
     Uploaded Td(T, st0), meansd(means, st0);
     Buf<double> delta((size_t)n * std::max(ms, 1));

@@ -713,6 +713,14 @@ __device__ __forceinline__ void diag_flag_set(int* f, int v, int l) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");            // this wave's LDS writes (or reads: s_waitcnt lgkmcnt(0)) are complete
   if (l == 0) __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+// The producer's form: the LDS executes one wave's instructions in issue order, so a flag store issued behind the data stores is
+// performed behind them -- no s_waitcnt between them (it sat on the factor wave's chain, 16 times per block); the asm statements only
+// keep the compiler from reordering.
+__device__ __forceinline__ void diag_flag_set_inorder(int* f, int v, int l) {
+  asm volatile("" ::: "memory");
+  if (l == 0) __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  asm volatile("" ::: "memory");
+}
 template <int T, int GROUP>
 __device__ __forceinline__ void diagf_mfmas(DiagFState& st) {
   constexpr int jb = T >> 2, q = T & 3, jn = (T + 1) >> 2, o = T & 1;
@@ -737,6 +745,13 @@ __device__ __forceinline__ void diagf_step(DiagFState& st, double* __restrict__ 
   for (int rb = jb; rb < 4; ++rb)
 #pragma unroll
     for (int r = 0; r < 4; ++r) Sp[(16 * rb + 4 * r + g) * SP + c] = st.S[rb][jb][r];
+  // the consumers' counters, read together with the pivot data (their LDS latency then costs nothing): the exchange buffer of this
+  // step was last read for step s - 2, and both consumers are normally long past it
+  int cons1 = 0, cons2 = 0;
+  if constexpr (s >= 2) {
+    cons1 = __hip_atomic_load(flags + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    cons2 = __hip_atomic_load(flags + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
   const d2 pr0 = *reinterpret_cast<const d2*>(&Sp[(J + 0) * SP + 4 * q]);
   const d2 pr1 = *reinterpret_cast<const d2*>(&Sp[(J + 1) * SP + 4 * q]);
   const d2 pr2a = *reinterpret_cast<const d2*>(&Sp[(J + 2) * SP + 4 * q]), pr2b = *reinterpret_cast<const d2*>(&Sp[(J + 2) * SP + 4 * q + 2]);
@@ -776,12 +791,15 @@ __device__ __forceinline__ void diagf_step(DiagFState& st, double* __restrict__ 
     st.nY[o][rb] = -st.Ym[o][rb];
   }
   // hand (Y, k) to the inverse wave and to the store wave: buffer o was last read for step s - 2
-  if constexpr (s >= 2) { diag_flag_wait(flags + 1, base + s - 1); diag_flag_wait(flags + 2, base + s - 1); }
+  if constexpr (s >= 2) {
+    if (cons1 < base + s - 1) diag_flag_wait(flags + 1, base + s - 1);      // (uniform; the slow path, rarely taken)
+    if (cons2 < base + s - 1) diag_flag_wait(flags + 2, base + s - 1);
+  }
   double* xo = xch + o * 512 + l;
 #pragma unroll
   for (int rb = jb; rb < 4; ++rb) xo[rb * 64] = yy[rb];
   xo[4 * 64] = k0; xo[5 * 64] = k1; xo[6 * 64] = k2; xo[7 * 64] = k3;
-  diag_flag_set(flags, base + s + 1, l);
+  diag_flag_set_inorder(flags, base + s + 1, l);
   diagf_mfmas<s, 0>(st); diagf_mfmas<s, 1>(st);
   __builtin_amdgcn_sched_barrier(0);
   if (__builtin_amdgcn_ballot_w64(!(d0 > 0.0) | !(d1 > 0.0) | !(d2v > 0.0) | !(d3 > 0.0)) != 0ull) {
@@ -2210,7 +2228,10 @@ __device__ __forceinline__ void potrf_region_helper(const RegionArgs& a, double*
       wg_mm64_core<false, NF ? 1 : 0>(acc, Wm + (size_t)(gcol / 64) * 4096, 1, 64, Y, LS, 1, w, l);
       __syncthreads();                                                   // reads of the tile image done
       MM64_FOREACH(Y[i * LS + j] = acc[u][v][q]; ST_PUB(&Am[(gcol + i) * a.ld + grow + j], acc[u][v][q]);)        // D[i][j] = L[r, c][j][i]
-      region_publish(trs + r, a.epoch, c + 1);                           // (release; its barrier completes Y = L[r, c])
+      region_publish(trs + r, a.epoch, c + 1);                           // (release; its barrier completes Y = L[r, c].  The rows below need
+                                                                         // L[r, c] for THEIR pair tiles: delaying this flag to the end of the
+                                                                         // last column -- one drain for both flags -- cost 5-10 us of walker
+                                                                         // wait per block, round 4)
       // pair accumulators:  (r, r-1): D[i][j] += L[r-1, c][i][k'] L[r, c][j][k'];   (r, r): D[i][j] += L[r, c][i][k'] L[r, c][j][k']
       if (c <= r - 3) region_wait_ge<1, !NF>(trs + r - 1, a.epoch, c + 1, abort_word, info);      // helper r-1's L[r-1, c]; c = r-2: the walker's
       wg_mm64_core<false, NF ? 1 : 0>(pa, Am + gcol * a.ld + grow - 64, 1, a.ld, Y, LS, 1, w, l);

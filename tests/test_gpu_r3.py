@@ -519,7 +519,7 @@ def test_two_concurrent_batches_with_region_base(lmm):
     assert lmm.logpdf(fx, y) == pytest.approx(O.oilmm_logpdf(gps, U, S, x, s2, y), rel=1e-9)
 
 
-@pytest.mark.parametrize("n,m", [(552, 20), (1024, 8)])
+@pytest.mark.parametrize("n,m", [(552, 20), (1024, 8), (1100, 36), (2048, 16)])
 def test_region_kernel_is_bitwise_reproducible(lmm, n, m):
     """potrf_region_kernel (walker, helpers, assistants, thin row streams; flags + write-through publishing) uses no atomics on data: a
     repeated evaluation must return the same bits -- a missed dependency would show as a differing value (tools/stress_region.py runs the
@@ -530,8 +530,10 @@ def test_region_kernel_is_bitwise_reproducible(lmm, n, m):
     fs = lmm.independent_mogp([lmm.GP(lmm.Matern52Kernel()) for _ in range(m)])
     fx = lmm.ILMM(fs, lmm.Orthogonal(P["U"], P["S"]))(lmm.MOInputIsotopicByOutputs(torch.from_numpy(P["x"]).cuda(), 2 * m), 0.1)
     yd = torch.from_numpy(P["y"]).cuda()
-    vals = {lmm.logpdf(fx, yd) for _ in range(60)}
-    assert len(vals) == 1, vals
+    # (1100, 36), (2048, 16): the panel recursion with the leaf inside the update launches, many matrices per launch -- the shapes on
+    # which round 4's three-wave diagonal block first lost a hand-off (a clobbered exchange buffer: NaN once in ~10 evaluations)
+    vals = {lmm.logpdf(fx, yd) for _ in range(60 if n <= 1024 else 24)}
+    assert len(vals) == 1 and all(np.isfinite(v) for v in vals), vals
 
 
 def test_alternating_problems_never_see_recycled_memory(lmm):
