@@ -593,6 +593,8 @@ void make_slots(std::vector<Slot>& slots, int count, int nb_per, size_t a_elems,
 
 void fork_slots(int count) {       // slot streams wait for everything queued on the main stream
   g_slots_in_flight = count > 1 ? count : 1;
+  if (count <= 1) return;          // (one slot = the main stream itself: no event -- a recorded event is a marker packet the queue
+                                   // takes microseconds to retire, in front of a small problem's Gram launch)
   HIPCHK(hipEventRecord(g.ev_main, g.streams[0]));
   for (int s = 1; s < count; ++s) HIPCHK(hipStreamWaitEvent(g.streams[s], g.ev_main, 0));
 }
