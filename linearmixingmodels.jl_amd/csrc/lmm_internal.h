@@ -86,6 +86,7 @@ struct RegionArgs {
   BatchPtr S;             // optional scratch (LMM_REGION_ASST_TILES 64 x 64 tiles per matrix): partial products of the ASSISTANT tasks
   int na;                 // assistant tasks per matrix (square rows LMM_REGION_ASST_MIN_R .. 2P - 1), 0: none
   int ntasks;             // workgroups per matrix (trace layout)
+  int n128;               // the first n128 row tiles below the square are 128 rows high, the following ones 64
   long long* trace;       // optional (LMM_REGION_TRACE=1, tools/region_trace.py): start / end wall-clock ticks of every workgroup
 };
 #define LMM_REGION_MAX_PANELS 8

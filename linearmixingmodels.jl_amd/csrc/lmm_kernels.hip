@@ -18,6 +18,11 @@
 #include <algorithm>
 #include <cstdio>
 #include <vector>
+#include <map>
+#include <queue>
+#include <tuple>
+#include <functional>
+#include <mutex>
 #include <type_traits>
 #include <cstdlib>
 #include "lmm_internal.h"
@@ -2023,6 +2028,96 @@ __device__ __forceinline__ void pipe128_accumulate(d4 (&acc)[4][4], double* __re
   }
 }
 
+// The 64-row form (gemm16h_kernel's pipeline: 64 x 128 output, 4 waves side by side, 64 x 32 each = 4 x 2 MFMA blocks):
+// acc += A (64 rows x 16 nk k-columns) * B' (128 rows likewise); lane (l15, lk) of wave w holds acc[v][u][r] = entry
+// (row 16 u + l15, column 32 w + 16 v + 4 r + lk).  LDS: 2 x 16 x 80 + 2 x 16 x 144 doubles.
+__device__ __forceinline__ void pipe64_accumulate(d4 (&acc)[2][4], double* __restrict__ lds, const double* __restrict__ A, int lda,
+                                                  const double* __restrict__ B, int ldb, int nk = 8) {
+  constexpr int BK = 16, SA = 80, SB = 144;
+  double (*As)[BK * SA] = reinterpret_cast<double (*)[BK * SA]>(lds);
+  double (*Bs)[BK * SB] = reinterpret_cast<double (*)[BK * SB]>(lds + 2 * BK * SA);
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int wc = w * 32;
+  const double* ga0 = A + (size_t)(t >> 5) * lda + 2 * (t & 31);
+  const double* gb0 = B + (size_t)(t >> 6) * ldb + 2 * (t & 63);
+  const int sa0 = (t >> 5) * SA + 2 * (t & 31);
+  const int sb0 = (t >> 6) * SB + 2 * (t & 63);
+  d2 ra[2], rb[4];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) ra[q] = *reinterpret_cast<const d2*>(ga0 + (size_t)(8 * q) * lda);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) rb[q] = *reinterpret_cast<const d2*>(gb0 + (size_t)(4 * q) * ldb);
+  __syncthreads();                                       // the previous user of the staging buffers is done with them
+#pragma unroll
+  for (int q = 0; q < 2; ++q) *reinterpret_cast<d2*>(&As[0][sa0 + 8 * q * SA]) = ra[q];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) *reinterpret_cast<d2*>(&Bs[0][sb0 + 4 * q * SB]) = rb[q];
+  {
+    const int k1 = nk > 1 ? 1 : 0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) ra[q] = *reinterpret_cast<const d2*>(ga0 + (size_t)k1 * BK * lda + (size_t)(8 * q) * lda);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) rb[q] = *reinterpret_cast<const d2*>(gb0 + (size_t)k1 * BK * ldb + (size_t)(4 * q) * ldb);
+  }
+  __syncthreads();
+  const int l15 = lane & 15, lk = lane >> 4;
+  const int offA = lk * SA + l15, offB = lk * SB + wc + l15;
+  double fa[2][4], fb[2][2];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) fa[0][u] = As[0][offA + 16 * u];
+#pragma unroll
+  for (int v = 0; v < 2; ++v) fb[0][v] = Bs[0][offB + 16 * v];
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    const double* as = &As[buf][0];
+    const double* bs = &Bs[buf][0];
+    double* asn = &As[buf ^ 1][0];
+    double* bsn = &Bs[buf ^ 1][0];
+    const int kn = (kt + 2 < nk) ? kt + 2 : nk - 1;
+    const double* pa = ga0 + (size_t)kn * BK * lda;
+    const double* pb = gb0 + (size_t)kn * BK * ldb;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) fa[1][u] = as[offA + 4 * SA + 16 * u];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) fb[1][v] = bs[offB + 4 * SB + 16 * v];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) { *reinterpret_cast<d2*>(&asn[sa0 + 8 * q * SA]) = ra[q]; ra[q] = *reinterpret_cast<const d2*>(pa + (size_t)(8 * q) * lda); }
+    LMM_MFMA16H_ALL(0);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x100, 1); }
+    LMM_SGB(0x008, 1); LMM_SGB(0x200, 1); LMM_SGB(0x020, 1); LMM_SGB(0x008, 1); LMM_SGB(0x200, 1); LMM_SGB(0x020, 1);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) fa[0][u] = as[offA + 8 * SA + 16 * u];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) fb[0][v] = bs[offB + 8 * SB + 16 * v];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) { *reinterpret_cast<d2*>(&bsn[sb0 + 4 * q * SB]) = rb[q]; rb[q] = *reinterpret_cast<const d2*>(pb + (size_t)(4 * q) * ldb); }
+    LMM_MFMA16H_ALL(1);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x100, 1); }
+    LMM_SGB(0x008, 1); LMM_SGB(0x200, 1); LMM_SGB(0x020, 1); LMM_SGB(0x008, 1); LMM_SGB(0x200, 1); LMM_SGB(0x020, 1);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) fa[1][u] = as[offA + 12 * SA + 16 * u];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) fb[1][v] = bs[offB + 12 * SB + 16 * v];
+#pragma unroll
+    for (int q = 2; q < 4; ++q) { *reinterpret_cast<d2*>(&bsn[sb0 + 4 * q * SB]) = rb[q]; rb[q] = *reinterpret_cast<const d2*>(pb + (size_t)(4 * q) * ldb); }
+    LMM_MFMA16H_ALL(0);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x100, 1); }
+    LMM_SGB(0x008, 1); LMM_SGB(0x200, 1); LMM_SGB(0x020, 1); LMM_SGB(0x008, 1); LMM_SGB(0x200, 1); LMM_SGB(0x020, 1);
+    LMM_MFMA16(1, 0, 0); LMM_MFMA16(1, 0, 1); LMM_MFMA16(1, 0, 2); LMM_MFMA16(1, 0, 3); LMM_MFMA16(1, 1, 3);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) fa[0][u] = asn[offA + 16 * u];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) fb[0][v] = bsn[offB + 16 * v];
+    LMM_MFMA16(1, 1, 2); LMM_MFMA16(1, 1, 1); LMM_MFMA16(1, 1, 0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x100, 2); }
+  }
+}
+
 // the same for up to three flags at once (one barrier, one fence); f2 / f3 may be nullptr
 template <bool ACQ = true>
 __device__ __forceinline__ void region_wait3(const int* f1, int n1, const int* f2, int n2, const int* f3, int n3, int epoch, int* abort_word, int* info) {
@@ -2325,9 +2420,7 @@ __device__ __forceinline__ void potrf_region_row(const RegionArgs& a, double* __
 #pragma unroll
         for (int u = 0; u < 4; ++u) acc[v][u] = (d4){0.0, 0.0, 0.0, 0.0};
       // the square's rows 2 tj, 2 tj + 1 final through block column 2 tj - 1: helpers' blocks + the walker's subdiagonal block
-      region_wait_ge(trs + 2 * tj, a.epoch, 2 * tj - 1, abort_word, a.info.p[b]);
-      region_wait_ge(wk, a.epoch, 2 * tj, abort_word, a.info.p[b]);
-      region_wait_ge(trs + 2 * tj + 1, a.epoch, 2 * tj, abort_word, a.info.p[b]);
+      region_wait3(trs + 2 * tj, 2 * tj - 1, wk, 2 * tj, trs + 2 * tj + 1, 2 * tj, a.epoch, abort_word, a.info.p[b]);
       const size_t col0 = (size_t)a.c0 * a.ld;
       pipe128_accumulate(acc, lds, Am + col0 + row_i, a.ld, rows_i, Am + col0 + row_j, a.ld, 128, 8 * tj);
       if (active) {
@@ -2367,6 +2460,60 @@ __device__ __forceinline__ void potrf_region_row(const RegionArgs& a, double* __
   }
 }
 
+// The same row task on a 64-row tile (rows c0 + roff .. + 63 of matrix b): half the work per workgroup, twice the workgroups -- for
+// launches whose 128-row tiles leave CUs idle or come to a little more than a whole number of waves (launch_region's rule).
+__device__ __forceinline__ void potrf_region_row64(const RegionArgs& a, double* __restrict__ lds, double* __restrict__ Am, int b, int roff) {
+  int* abort_word = a.flags.p[b];
+  int* wk = abort_word + 1; int* trs = abort_word + 2; int* dinv = abort_word + 34;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int wc = 32 * w;
+  const int l15 = lane & 15, lk = lane >> 4;
+  const size_t row_i = (size_t)a.c0 + (size_t)roff;
+  for (int tj = 0; tj < a.P; ++tj) {
+    const size_t row_j = (size_t)a.c0 + 128 * (size_t)tj;
+    double* C = Am + row_j * a.ld + row_i;
+    d4 acc[2][4];
+    if (tj > 0) {
+#pragma unroll
+      for (int v = 0; v < 2; ++v)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[v][u] = (d4){0.0, 0.0, 0.0, 0.0};
+      region_wait3(trs + 2 * tj, 2 * tj - 1, wk, 2 * tj, trs + 2 * tj + 1, 2 * tj, a.epoch, abort_word, a.info.p[b]);
+      const size_t col0 = (size_t)a.c0 * a.ld;
+      pipe64_accumulate(acc, lds, Am + col0 + row_i, a.ld, Am + col0 + row_j, a.ld, 8 * tj);
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        double* cpv = C + (size_t)(wc + 16 * v + lk) * a.ld + l15;
+        double cv[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) cv[u][r] = cpv[(size_t)(4 * r) * a.ld + 16 * u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) cpv[(size_t)(4 * r) * a.ld + 16 * u] = cv[u][r] - acc[v][u][r];
+      }
+      __syncthreads();
+    }
+    region_wait_ge(dinv + tj, a.epoch, 0, abort_word, a.info.p[b]);                          // Dinv_j
+#pragma unroll
+    for (int v = 0; v < 2; ++v)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[v][u] = (d4){0.0, 0.0, 0.0, 0.0};
+    pipe64_accumulate(acc, lds, C, a.ld, a.W2.p[b] + (size_t)(row_j / 128) * 16384, 128, 8);
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      double* cpv = C + (size_t)(wc + 16 * v + lk) * a.ld + l15;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cpv[(size_t)(4 * r) * a.ld + 16 * u] = acc[v][u][r];
+    }
+    __syncthreads();                                               // X[i, j] is in memory for this workgroup's own later passes
+  }
+}
+
 // THIN row task: a row tile with at most 16 real rows -- the rider rows of a logpdf (ONE projected observation vector per latent,
 // zero-padded to 64 rows).  The full-tile stream above multiplies 128 x 128 tiles whatever the row count and, alone on its CU, runs
 // ~60 us per panel behind the square at P = 5 (notebook shape: walker done at 200 us, row stream at 306).  Here the 16 rows are ONE
@@ -2378,14 +2525,14 @@ __device__ __forceinline__ void potrf_region_row(const RegionArgs& a, double* __
 //                                                    Dinv is lower triangular: wave w stops at k = 32 (w + 1).
 // Rows 16 .. of the tile are padding (zeros before and after).  Nothing is published: nobody reads a row stream inside the launch.
 struct ThinChunk { double fb[8], fa[8][2]; };
-__device__ __forceinline__ void potrf_region_row_thin(const RegionArgs& a, double* __restrict__ lds, double* __restrict__ Am, int b, int ti) {
+__device__ __forceinline__ void potrf_region_row_thin(const RegionArgs& a, double* __restrict__ lds, double* __restrict__ Am, int b, int roff) {
   int* abort_word = a.flags.p[b];
   int* wk = abort_word + 1; int* trs = abort_word + 2; int* dinv = abort_word + 34;
   int* info = a.info.p[b];
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int l15 = lane & 15, lk = lane >> 4;
-  const size_t row_i = (size_t)a.c0 + 128 * (size_t)ti;
+  const size_t row_i = (size_t)a.c0 + (size_t)roff;       // the tile's first row (its rows 16 .. are padding)
   double* cT = lds;                                      // c'[k][row]: 128 x 16 doubles
   for (int tj = 0; tj < a.P; ++tj) {
     const size_t row_j = (size_t)a.c0 + 128 * (size_t)tj;
@@ -2488,10 +2635,12 @@ __global__ __launch_bounds__(256, OCC) void potrf_region_kernel(RegionArgs a) {
   else if (role == 1) potrf_region_helper<false, OCC == 1, OCC == 1>(a, node_lds, Am, b, r);      // DEEP (two chunks ahead) spills even at one workgroup per CU
   else if (role == 2) { if (OCC == 1) potrf_region_assistant<true>(a, Am, b, r); }       // (the two-per-CU build has no assistants)
   else {
-    const int ti = a.P + idx - Q - a.na;
-    const int real = a.M_real - 128 * ti;                // rows of this tile that hold data (the rest is zero padding, before and after)
-    if (real > 16) potrf_region_row(a, node_lds, Am, b, ti);
-    else if (real > 0) potrf_region_row_thin(a, node_lds, Am, b, ti);
+    const int k = idx - Q - a.na;                        // row tasks in dispatch order: n128 tiles of 128 rows, then 64-row tiles
+    const bool tall = k < a.n128;
+    const int roff = tall ? 128 * (a.P + k) : 128 * (a.P + a.n128) + 64 * (k - a.n128);
+    const int real = a.M_real - roff;                    // rows of this tile that hold data (the rest is zero padding, before and after)
+    if (real > 16) { if (tall) potrf_region_row(a, node_lds, Am, b, a.P + k); else potrf_region_row64(a, node_lds, Am, b, roff); }
+    else if (real > 0) potrf_region_row_thin(a, node_lds, Am, b, roff);
   }
   if (a.trace && threadIdx.x == 0) a.trace[2 * blockIdx.x + 1] = wall_clock64();
 }
@@ -3518,6 +3667,64 @@ bool launch_update_leaf(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2
   return fuse;
 }
 
+// Plan of a region launch's row tasks.  One workgroup per row tile, dispatched in order behind the square's workgroups, one per CU:
+// with 128-row tiles throughout, a launch of a little more than a whole number of "waves" ends with most CUs idle for a chain's
+// length (4 latents, n = 16384, first block column: 484 chains of ~640 us on 192 + 64 CUs: 1.50 ms against 1.21 ms of work), and a
+// launch that fills less than the device is as long as one chain however few there are.  64-row tiles (half the chain, ~7 % more
+// time per row: the square's rows are streamed twice as often) fix both when used for the LAST tasks only.  The split is chosen by
+// simulating the dispatch (greedy list scheduling on `cus` CUs) with the measured task lengths for nine candidate splits.
+struct RegionPlan { int n128, row_tasks, na; };
+static RegionPlan region_plan(int P, int nb, int Mb, int Mb_real, int cus, int na_full, bool asst_always, int force_th) {
+  const int T128 = (Mb + 127) / 128;
+  struct Key { int P, nb, Mb, Mr, na, f; bool operator<(const Key& o) const { return std::tie(P, nb, Mb, Mr, na, f) < std::tie(o.P, o.nb, o.Mb, o.Mr, o.na, o.f); } };
+  static std::map<Key, RegionPlan> cache;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  const Key key{P, nb, Mb, Mb_real, na_full, force_th * 2 + (asst_always ? 1 : 0)};
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  const double unit = 17.5;                                 // us per 128^3 product on one CU inside this kernel (profiles/r04: chains of 36 units take 600-680 us)
+  const double d128 = unit * P * (P + 1) / 2.0, d64 = 0.54 * d128;
+  RegionPlan best{T128, T128, 0}; double best_t = 1e30;
+  for (int c = 8; c >= 0; --c) {
+    int x = (int)((long long)T128 * c / 8);
+    if (force_th == 128) x = T128; else if (force_th == 64) x = 0;
+    const int rest = Mb - 128 * x;
+    const int t64 = rest > 0 ? (rest + 63) / 64 : 0;
+    if (x < T128 && t64 == 0) continue;
+    const int ntask = x + t64;
+    int full = 0;
+    for (int k = 0; k < ntask; ++k) { const int roff = k < x ? 128 * k : 128 * x + 64 * (k - x); if (Mb_real - roff > 16) ++full; }
+    const int na = (na_full > 0 && (asst_always || (2LL * P + na_full + full) * nb <= cus)) ? na_full : 0;
+    const double sq_end = 2.0 * P * (na ? 19.0 : 30.0);
+    std::priority_queue<double, std::vector<double>, std::greater<double>> free_at;
+    const long long nsq = (2LL * P + na) * nb;
+    for (int i = 0; i < cus; ++i) {
+      if (i < nsq) { const int idx = i / nb; const int r = idx < LMM_REGION_ASST_MIN_R || !na ? idx : LMM_REGION_ASST_MIN_R + (idx - LMM_REGION_ASST_MIN_R) / 2; free_at.push(sq_end * (std::min(r, 2 * P - 1) + 1) / (2.0 * P)); }
+      else free_at.push(0.0);
+    }
+    // (more square workgroups than CUs: the rule of potrf_batch keeps such launches on the panel path; treat the excess as row time)
+    double end = sq_end;
+    for (int k = 0; k < ntask; ++k) {
+      const int roff = k < x ? 128 * k : 128 * x + 64 * (k - x);
+      const int real = Mb_real - roff;
+      if (real <= 0) continue;
+      const double d = real > 16 ? (k < x ? d128 : d64) : 0.1 * d128;
+      const double tail = real > 16 ? 2.0 * d / (P + 1) : 0.05 * d128;          // the last column follows the square's end
+      for (int b = 0; b < nb; ++b) {
+        const double t0 = free_at.top(); free_at.pop();
+        const double t1 = std::max(t0 + d, sq_end + tail);
+        free_at.push(t1);
+        if (t1 > end) end = t1;
+      }
+    }
+    if (end < best_t - 1e-9) { best_t = end; best = RegionPlan{x, ntask, na}; }
+    if (force_th == 128 || force_th == 64) break;
+  }
+  cache[key] = best;
+  return best;
+}
+
 size_t region_flag_ints(int) { return REGION_FLAG_INTS; }
 void launch_region(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2, const BatchInfo& info, const BatchInfo& flags, int ld, int NR,
                    int c0, int width, int n_real, int nb, bool first_done, hipStream_t st, int rows_real, const BatchPtr* S) {
@@ -3538,8 +3745,6 @@ void launch_region(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2, con
   // they cost more than they bring (8 latents, n = 2048: 1.60 -> 1.87 ms)
   // Row tiles that take the thin stream (or hold padding only) need not be resident from the start: they wait for the square, never
   // the square for them, and catch up within a panel's time.  What must fit one workgroup per CU for that build: square + full rows.
-  int full_rows = 0;
-  for (int ti = P; ti < R; ++ti) if (a.M_real - 128 * ti > 16) ++full_rows;
   // LMM_REGION_OCC=1 / 2 forces a build; default: one workgroup per CU (414 registers per lane, no spills in the walker)
   static int occ_env = -1;
   if (occ_env < 0) { const char* e = getenv("LMM_REGION_OCC"); occ_env = e ? atoi(e) : 0; }
@@ -3548,11 +3753,17 @@ void launch_region(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2, con
   // against 3.42, 8 x 4096: 5.23 against 5.65, 8 x 8192: 26.5 against 28.6 -- the walker's 432 spilled registers sit on the chain every
   // other task waits for, while tasks that are dispatched late (helpers of high rows, row streams) are also needed late.)
   int occ = 1;
-  if ((2LL * P + a.na + full_rows) * nb > cus && asst_env != 2) a.na = 0;          // assistants only while everything is resident from the start
   if (occ_env) occ = occ_env;
   if (occ != 1) a.na = 0;
+  // Row tiles: the first n128 are 128 rows high, the rest 64 (region_plan: a list-scheduling estimate of the launch for a few splits;
+  // LMM_REGION_TH=128 / 64 forces all-128 / all-64).  Assistants only while everything is resident from the start.
+  static int th_env = -1;
+  if (th_env < 0) { const char* e = getenv("LMM_REGION_TH"); th_env = e ? atoi(e) : 0; }
+  const RegionPlan plan = region_plan(P, nb, M - 128 * P, a.M_real - 128 * P, cus, a.na, asst_env == 2, (M % 64) != 0 || occ != 1 ? 128 : th_env);
+  a.n128 = plan.n128; a.na = plan.na;
   if (a.na > 0) a.S = *S;
-  const long long tasks = 2LL * P + a.na + (R - P);       // the square's 64-row blocks + assistants + one task per 128-row tile below it
+  const int row_tasks = plan.row_tasks;
+  const long long tasks = 2LL * P + a.na + row_tasks;     // the square's 64-row blocks + assistants + one task per row tile below it
   // LMM_REGION_TRACE=1: per-workgroup start / end ticks (100 MHz) of every region launch, printed to stderr (a debugging aid: it
   // synchronises the stream after each launch)
   static int trace_env = -1;
