@@ -592,7 +592,7 @@ void make_slots(std::vector<Slot>& slots, int count, int nb_per, size_t a_elems,
 }
 
 void fork_slots(int count) {       // slot streams wait for everything queued on the main stream
-  g_slots_in_flight = count > 1 ? count : 1;
+  g_slots_in_flight = count > 1 ? count : 1; g_concurrent_batches = g_slots_in_flight;
   if (count <= 1) return;          // (one slot = the main stream itself: no event -- a recorded event is a marker packet the queue
                                    // takes microseconds to retire, in front of a small problem's Gram launch)
   HIPCHK(hipEventRecord(g.ev_main, g.streams[0]));
@@ -600,7 +600,7 @@ void fork_slots(int count) {       // slot streams wait for everything queued on
 }
 
 void join_slots(int count) {       // main stream waits for every slot stream
-  g_slots_in_flight = 1;
+  g_slots_in_flight = 1; g_concurrent_batches = 1;
   for (int s = 1; s < count; ++s) {
     HIPCHK(hipEventRecord(g.ev_slot[s], g.streams[s]));
     HIPCHK(hipStreamWaitEvent(g.streams[0], g.ev_slot[s], 0));

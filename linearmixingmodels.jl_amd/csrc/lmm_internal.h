@@ -75,6 +75,7 @@ struct NodeArgs {
   // NODE_FUSE: the bulk rows of the panel this launch's leaf factors run as the LAST work items of the same launch, behind
   // device-side flags (nflags: per matrix [0] abort word, [1] leaf done, [2 + ti] column-0 tile ti updated; values epoch * 32 + 1)
   int* nflags; int nf_stride, epoch;
+  int strip_n, strip0;    // column tiles of the ragged last 64 rows run as work items of this launch (0: none / separate launch); their first item
   int Mb, MTb, bulk0;     // rows / 128-row tiles the bulk items cover (a ragged last 64 rows included); index of the first bulk item
 };
 // Arguments of potrf_region_kernel (lmm_kernels.hip K2d): the columns [c0, c0 + 128 P) of every matrix of the batch, rows c0 .. c0 + M - 1.
@@ -104,6 +105,7 @@ struct RegionArgs {
 #define LMM_REGION_SPIN_TICKS 400000000LL
 #define LMM_INFO_SYNC_TIMEOUT (-7777)     // pivot-info value a region launch leaves when a dependency wait timed out (never expected)
 void region_flags_register(int* base, size_t ints);     // the context's persistent flag array (cleared when the launch epoch wraps)
+extern int g_concurrent_batches;          // batches in flight on the slot streams (set by lmm_api.hip's fork_slots / join_slots)
 size_t region_flag_ints(int NR);          // ints per matrix that the flags of any region of a matrix with NR rows need
 void launch_region(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2, const BatchInfo& info, const BatchInfo& flags, int ld, int NR,
                    int c0, int width, int n_real, int nb, bool first_done, hipStream_t st, int rows_real = -1, const BatchPtr* S = nullptr);

@@ -1790,6 +1790,96 @@ __global__ __launch_bounds__(256) void leaf128_kernel(BatchPtr Ab, size_t offD, 
   leaf128_dev(node_lds, Ab.p[blockIdx.x], offD, ld, Wb.p[blockIdx.x], offW, W2b.p[blockIdx.x] + offW2, gcol0, n_real, infob.p[blockIdx.x], dflags);
 }
 
+// The 64-row form (gemm16h_kernel's pipeline: 64 x 128 output, 4 waves side by side, 64 x 32 each = 4 x 2 MFMA blocks):
+// acc += A (64 rows x 16 nk k-columns) * B' (128 rows likewise); lane (l15, lk) of wave w holds acc[v][u][r] = entry
+// (row 16 u + l15, column 32 w + 16 v + 4 r + lk).  LDS: 2 x 16 x 80 + 2 x 16 x 144 doubles.
+__device__ __forceinline__ void pipe64_accumulate(d4 (&acc)[2][4], double* __restrict__ lds, const double* __restrict__ A, int lda,
+                                                  const double* __restrict__ B, int ldb, int nk = 8) {
+  constexpr int BK = 16, SA = 80, SB = 144;
+  double (*As)[BK * SA] = reinterpret_cast<double (*)[BK * SA]>(lds);
+  double (*Bs)[BK * SB] = reinterpret_cast<double (*)[BK * SB]>(lds + 2 * BK * SA);
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int wc = w * 32;
+  const double* ga0 = A + (size_t)(t >> 5) * lda + 2 * (t & 31);
+  const double* gb0 = B + (size_t)(t >> 6) * ldb + 2 * (t & 63);
+  const int sa0 = (t >> 5) * SA + 2 * (t & 31);
+  const int sb0 = (t >> 6) * SB + 2 * (t & 63);
+  d2 ra[2], rb[4];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) ra[q] = *reinterpret_cast<const d2*>(ga0 + (size_t)(8 * q) * lda);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) rb[q] = *reinterpret_cast<const d2*>(gb0 + (size_t)(4 * q) * ldb);
+  __syncthreads();                                       // the previous user of the staging buffers is done with them
+#pragma unroll
+  for (int q = 0; q < 2; ++q) *reinterpret_cast<d2*>(&As[0][sa0 + 8 * q * SA]) = ra[q];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) *reinterpret_cast<d2*>(&Bs[0][sb0 + 4 * q * SB]) = rb[q];
+  {
+    const int k1 = nk > 1 ? 1 : 0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) ra[q] = *reinterpret_cast<const d2*>(ga0 + (size_t)k1 * BK * lda + (size_t)(8 * q) * lda);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) rb[q] = *reinterpret_cast<const d2*>(gb0 + (size_t)k1 * BK * ldb + (size_t)(4 * q) * ldb);
+  }
+  __syncthreads();
+  const int l15 = lane & 15, lk = lane >> 4;
+  const int offA = lk * SA + l15, offB = lk * SB + wc + l15;
+  double fa[2][4], fb[2][2];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) fa[0][u] = As[0][offA + 16 * u];
+#pragma unroll
+  for (int v = 0; v < 2; ++v) fb[0][v] = Bs[0][offB + 16 * v];
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    const double* as = &As[buf][0];
+    const double* bs = &Bs[buf][0];
+    double* asn = &As[buf ^ 1][0];
+    double* bsn = &Bs[buf ^ 1][0];
+    const int kn = (kt + 2 < nk) ? kt + 2 : nk - 1;
+    const double* pa = ga0 + (size_t)kn * BK * lda;
+    const double* pb = gb0 + (size_t)kn * BK * ldb;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) fa[1][u] = as[offA + 4 * SA + 16 * u];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) fb[1][v] = bs[offB + 4 * SB + 16 * v];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) { *reinterpret_cast<d2*>(&asn[sa0 + 8 * q * SA]) = ra[q]; ra[q] = *reinterpret_cast<const d2*>(pa + (size_t)(8 * q) * lda); }
+    LMM_MFMA16H_ALL(0);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x100, 1); }
+    LMM_SGB(0x008, 1); LMM_SGB(0x200, 1); LMM_SGB(0x020, 1); LMM_SGB(0x008, 1); LMM_SGB(0x200, 1); LMM_SGB(0x020, 1);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) fa[0][u] = as[offA + 8 * SA + 16 * u];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) fb[0][v] = bs[offB + 8 * SB + 16 * v];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) { *reinterpret_cast<d2*>(&bsn[sb0 + 4 * q * SB]) = rb[q]; rb[q] = *reinterpret_cast<const d2*>(pb + (size_t)(4 * q) * ldb); }
+    LMM_MFMA16H_ALL(1);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x100, 1); }
+    LMM_SGB(0x008, 1); LMM_SGB(0x200, 1); LMM_SGB(0x020, 1); LMM_SGB(0x008, 1); LMM_SGB(0x200, 1); LMM_SGB(0x020, 1);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) fa[1][u] = as[offA + 12 * SA + 16 * u];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) fb[1][v] = bs[offB + 12 * SB + 16 * v];
+#pragma unroll
+    for (int q = 2; q < 4; ++q) { *reinterpret_cast<d2*>(&bsn[sb0 + 4 * q * SB]) = rb[q]; rb[q] = *reinterpret_cast<const d2*>(pb + (size_t)(4 * q) * ldb); }
+    LMM_MFMA16H_ALL(0);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x100, 1); }
+    LMM_SGB(0x008, 1); LMM_SGB(0x200, 1); LMM_SGB(0x020, 1); LMM_SGB(0x008, 1); LMM_SGB(0x200, 1); LMM_SGB(0x020, 1);
+    LMM_MFMA16(1, 0, 0); LMM_MFMA16(1, 0, 1); LMM_MFMA16(1, 0, 2); LMM_MFMA16(1, 0, 3); LMM_MFMA16(1, 1, 3);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) fa[0][u] = asn[offA + 16 * u];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) fb[0][v] = bsn[offB + 16 * v];
+    LMM_MFMA16(1, 1, 2); LMM_MFMA16(1, 1, 1); LMM_MFMA16(1, 1, 0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x100, 2); }
+  }
+}
+
 // FUSE: the NODE_FUSE work items exist (their waits and write-through stores cost the hot loop 3-4 spilled registers: 0.3 % on the
 // K >= 4096 launches, which is why it is a template parameter and the long launches run without it)
 template <int DEPTH, bool FUSE = false>
@@ -1821,9 +1911,48 @@ __global__ __launch_bounds__(256, 2) void potrf_node_kernel(NodeArgs a) {
     if (a.mode & NODE_UPDATE) {
       const int n0 = a.nb * a.MT;
       if (item < n0) { ti = item / a.nb; bidx = item - ti * a.nb; col0 = true; }
+      else if (item >= a.strip0 && item < a.strip0 + a.nb * a.strip_n) {
+        // the ragged last 64 rows of the region (rows a.M .. a.M + 63 below every column), one item per column tile: the 64 x 128 pipeline
+        // (a separate gemm16h_kernel launch behind this one until round 4: N / 128 workgroups per matrix alone on the device for half
+        // a tile time -- 55 us of a 1.08 ms K = 1024 launch, 435 us of the 30 ms K = 8192 one)
+        const int q = item - a.strip0;                  // column tile by column tile, matrices interleaved: every matrix's column 0 first
+        tj = q / a.nb; bidx = q - tj * a.nb;
+        double* Am = a.A.p[bidx];
+        const size_t r0s = (size_t)a.j0 + a.h;
+        const double* Ap = Am + (size_t)a.j0 * a.ld + r0s;
+        d4 acc[2][4];
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc[v][u] = (d4){0.0, 0.0, 0.0, 0.0};
+        pipe64_accumulate(acc, node_lds, Ap + a.M, a.ld, Ap + 128 * tj, a.ld, a.h / 16);
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l15 = lane & 15, lk = lane >> 4;
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+          double* cpv = Am + (r0s + 128 * tj + 32 * w + 16 * v + lk) * a.ld + r0s + a.M + l15;
+          double cv[4][4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cv[u][r] = cpv[(size_t)(4 * r) * a.ld + 16 * u];
+          if (fuse && tj == 0) {                          // the bulk tile of these rows reads column tile 0 in this launch
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) ST_PUB(cpv + (size_t)(4 * r) * a.ld + 16 * u, cv[u][r] - acc[v][u][r]);
+          } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) cpv[(size_t)(4 * r) * a.ld + 16 * u] = cv[u][r] - acc[v][u][r];
+          }
+        }
+        if (fuse && tj == 0) region_publish(a.nflags + (size_t)bidx * a.nf_stride + 2 + a.MT, a.epoch, 1);
+        return;
+      }
       else if (fuse && item >= a.bulk0) { bulk = true; const int q = item - a.bulk0; ti = q / a.nb; bidx = q - ti * a.nb; ti += 1; }
       else {
-        const int q = item - n0;
+        const int q = item - n0 - a.nb * a.strip_n;
         bidx = q / a.rest_items;
         if (bidx < a.nb - 1) gemm_work_item_from(q - bidx * a.rest_items, 1, BM, BN, a.N, 1, a.MT, a.full_items, a.splitk, part, nparts, ti, tj);
         else {                                                     // the last matrix carries the launch's split-K tail
@@ -1839,7 +1968,7 @@ __global__ __launch_bounds__(256, 2) void potrf_node_kernel(NodeArgs a) {
   int* nf = fuse ? a.nflags + (size_t)bidx * a.nf_stride : nullptr;
   if (bulk && fuse) {
     region_wait_ge<16>(nf + 1, a.epoch, 1, nf, a.info.p[bidx]);                          // the panel inverse
-    if (ti < a.MT) region_wait_ge<16>(nf + 2 + ti, a.epoch, 1, nf, a.info.p[bidx]);      // this tile's rows of the panel, updated
+    if (ti < a.MT + (a.strip_n ? 1 : 0)) region_wait_ge<16>(nf + 2 + ti, a.epoch, 1, nf, a.info.p[bidx]);      // this tile's rows of the panel, updated (ti = MT: by the ragged-row item)
   }
   double* C = Am + (size_t)r0 * a.ld + r0;
   const double* A = bulk ? C : Am + (size_t)a.j0 * a.ld + r0;
@@ -2025,96 +2154,6 @@ __device__ __forceinline__ void pipe128_accumulate(d4 (&acc)[4][4], double* __re
     double* bsn = &Bs[buf ^ 1][0];
     const int kn = (kt + 2 < nk) ? kt + 2 : nk - 1;
     LMM_TILE_BODY(ra, rb, kn)
-  }
-}
-
-// The 64-row form (gemm16h_kernel's pipeline: 64 x 128 output, 4 waves side by side, 64 x 32 each = 4 x 2 MFMA blocks):
-// acc += A (64 rows x 16 nk k-columns) * B' (128 rows likewise); lane (l15, lk) of wave w holds acc[v][u][r] = entry
-// (row 16 u + l15, column 32 w + 16 v + 4 r + lk).  LDS: 2 x 16 x 80 + 2 x 16 x 144 doubles.
-__device__ __forceinline__ void pipe64_accumulate(d4 (&acc)[2][4], double* __restrict__ lds, const double* __restrict__ A, int lda,
-                                                  const double* __restrict__ B, int ldb, int nk = 8) {
-  constexpr int BK = 16, SA = 80, SB = 144;
-  double (*As)[BK * SA] = reinterpret_cast<double (*)[BK * SA]>(lds);
-  double (*Bs)[BK * SB] = reinterpret_cast<double (*)[BK * SB]>(lds + 2 * BK * SA);
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const int wc = w * 32;
-  const double* ga0 = A + (size_t)(t >> 5) * lda + 2 * (t & 31);
-  const double* gb0 = B + (size_t)(t >> 6) * ldb + 2 * (t & 63);
-  const int sa0 = (t >> 5) * SA + 2 * (t & 31);
-  const int sb0 = (t >> 6) * SB + 2 * (t & 63);
-  d2 ra[2], rb[4];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) ra[q] = *reinterpret_cast<const d2*>(ga0 + (size_t)(8 * q) * lda);
-#pragma unroll
-  for (int q = 0; q < 4; ++q) rb[q] = *reinterpret_cast<const d2*>(gb0 + (size_t)(4 * q) * ldb);
-  __syncthreads();                                       // the previous user of the staging buffers is done with them
-#pragma unroll
-  for (int q = 0; q < 2; ++q) *reinterpret_cast<d2*>(&As[0][sa0 + 8 * q * SA]) = ra[q];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) *reinterpret_cast<d2*>(&Bs[0][sb0 + 4 * q * SB]) = rb[q];
-  {
-    const int k1 = nk > 1 ? 1 : 0;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) ra[q] = *reinterpret_cast<const d2*>(ga0 + (size_t)k1 * BK * lda + (size_t)(8 * q) * lda);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) rb[q] = *reinterpret_cast<const d2*>(gb0 + (size_t)k1 * BK * ldb + (size_t)(4 * q) * ldb);
-  }
-  __syncthreads();
-  const int l15 = lane & 15, lk = lane >> 4;
-  const int offA = lk * SA + l15, offB = lk * SB + wc + l15;
-  double fa[2][4], fb[2][2];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) fa[0][u] = As[0][offA + 16 * u];
-#pragma unroll
-  for (int v = 0; v < 2; ++v) fb[0][v] = Bs[0][offB + 16 * v];
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    const double* as = &As[buf][0];
-    const double* bs = &Bs[buf][0];
-    double* asn = &As[buf ^ 1][0];
-    double* bsn = &Bs[buf ^ 1][0];
-    const int kn = (kt + 2 < nk) ? kt + 2 : nk - 1;
-    const double* pa = ga0 + (size_t)kn * BK * lda;
-    const double* pb = gb0 + (size_t)kn * BK * ldb;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) fa[1][u] = as[offA + 4 * SA + 16 * u];
-#pragma unroll
-    for (int v = 0; v < 2; ++v) fb[1][v] = bs[offB + 4 * SB + 16 * v];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) { *reinterpret_cast<d2*>(&asn[sa0 + 8 * q * SA]) = ra[q]; ra[q] = *reinterpret_cast<const d2*>(pa + (size_t)(8 * q) * lda); }
-    LMM_MFMA16H_ALL(0);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x100, 1); }
-    LMM_SGB(0x008, 1); LMM_SGB(0x200, 1); LMM_SGB(0x020, 1); LMM_SGB(0x008, 1); LMM_SGB(0x200, 1); LMM_SGB(0x020, 1);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) fa[0][u] = as[offA + 8 * SA + 16 * u];
-#pragma unroll
-    for (int v = 0; v < 2; ++v) fb[0][v] = bs[offB + 8 * SB + 16 * v];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) { *reinterpret_cast<d2*>(&bsn[sb0 + 4 * q * SB]) = rb[q]; rb[q] = *reinterpret_cast<const d2*>(pb + (size_t)(4 * q) * ldb); }
-    LMM_MFMA16H_ALL(1);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x100, 1); }
-    LMM_SGB(0x008, 1); LMM_SGB(0x200, 1); LMM_SGB(0x020, 1); LMM_SGB(0x008, 1); LMM_SGB(0x200, 1); LMM_SGB(0x020, 1);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) fa[1][u] = as[offA + 12 * SA + 16 * u];
-#pragma unroll
-    for (int v = 0; v < 2; ++v) fb[1][v] = bs[offB + 12 * SB + 16 * v];
-#pragma unroll
-    for (int q = 2; q < 4; ++q) { *reinterpret_cast<d2*>(&bsn[sb0 + 4 * q * SB]) = rb[q]; rb[q] = *reinterpret_cast<const d2*>(pb + (size_t)(4 * q) * ldb); }
-    LMM_MFMA16H_ALL(0);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x100, 1); }
-    LMM_SGB(0x008, 1); LMM_SGB(0x200, 1); LMM_SGB(0x020, 1); LMM_SGB(0x008, 1); LMM_SGB(0x200, 1); LMM_SGB(0x020, 1);
-    LMM_MFMA16(1, 0, 0); LMM_MFMA16(1, 0, 1); LMM_MFMA16(1, 0, 2); LMM_MFMA16(1, 0, 3); LMM_MFMA16(1, 1, 3);
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < 4; ++u) fa[0][u] = asn[offA + 16 * u];
-#pragma unroll
-    for (int v = 0; v < 2; ++v) fb[0][v] = bsn[offB + 16 * v];
-    LMM_MFMA16(1, 1, 2); LMM_MFMA16(1, 1, 1); LMM_MFMA16(1, 1, 0);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { LMM_SGB(0x008, 1); LMM_SGB(0x100, 2); }
   }
 }
 
@@ -3594,6 +3633,7 @@ static int next_flag_epoch() {
   }
   return g_region_epoch;
 }
+int g_concurrent_batches = 1;        // batches in flight on the slot streams (lmm_api.hip's fork_slots)
 size_t node_flag_ints(int NR) { return (size_t)(2 + (NR + 127) / 128 + 1); }
 bool launch_update_leaf(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2, const BatchInfo& info, int ld, int NR, int j0, int h,
                         int N, int n_real, int nb, hipStream_t st, int* nflags, int nf_stride) {
@@ -3615,7 +3655,12 @@ bool launch_update_leaf(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2
     hipLaunchKernelGGL((gemm16h_kernel<true>), dim3(N / 128, nb), dim3(256), 0, st, A, (size_t)r0 * ld + r0 + (size_t)M, ld, A, offA, ld,
                        A, (size_t)j0 * ld + r0, ld, N, h, 0);
   };
-  if (strip && fuse) launch_strip();
+  static int strip_items = -1;                     // LMM_STRIP_ITEMS=0: the ragged rows as a separate launch (the round-2/3 form)
+  if (strip_items < 0) { const char* e = getenv("LMM_STRIP_ITEMS"); strip_items = e ? atoi(e) : 1; }
+  // ... and only while no other batch runs beside this one: with two batches in flight (C2 at N = 1) the other stream's kernels fill the
+  // CUs a separate strip launch leaves idle, and the in-launch items measured slower (687.2 -> 689.9 ms per step)
+  const bool strip_in = strip && strip_items && (g_concurrent_batches <= 1 || strip_items == 2);
+  if (strip && !strip_in && fuse) launch_strip();
   static int cus = 0;
   if (cus == 0) { int dev = 0; cus = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); }
   long long T = 0;                                            // tiles of the column tiles 1 .. NT-1 (lower trapezoid)
@@ -3649,7 +3694,10 @@ bool launch_update_leaf(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2
   const int rest_last = full_l + (int)(T - full_l) * split_l;
   if (a.rest_items < 1) a.rest_items = 1;          // divisor in the kernel's item decode (no item reaches it when T = 0)
   a.mode = NODE_UPDATE | NODE_LEAF;
-  long long items = nb * MT + (T > 0 ? (long long)(nb - 1) * a.rest_items + rest_last : 0);
+  // the ragged rows' half-height items follow the column-0 tiles (at the END of the update part they lengthen the launch's tail:
+  // 4 latents at n = 16384 90.15 ms against 89.69 here)
+  a.strip_n = strip_in ? N / 128 : 0; a.strip0 = nb * MT;
+  long long items = nb * MT + (long long)nb * a.strip_n + (T > 0 ? (long long)(nb - 1) * a.rest_items + rest_last : 0);
   a.Mb = Mfull; a.MTb = MTb; a.bulk0 = (int)items;
   if (fuse) {
     a.mode |= NODE_FUSE; a.nflags = nflags; a.nf_stride = nf_stride; a.epoch = next_flag_epoch();
@@ -3663,7 +3711,7 @@ bool launch_update_leaf(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2
     if (h >= 1024) hipLaunchKernelGGL(potrf_node_kernel<2>, grid, dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
     else hipLaunchKernelGGL(potrf_node_kernel<1>, grid, dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
   }
-  if (strip && !fuse) launch_strip();
+  if (strip && !strip_in && !fuse) launch_strip();
   return fuse;
 }
 
@@ -3683,20 +3731,25 @@ static RegionPlan region_plan(int P, int nb, int Mb, int Mb_real, int cus, int n
   const Key key{P, nb, Mb, Mb_real, na_full, force_th * 2 + (asst_always ? 1 : 0)};
   auto it = cache.find(key);
   if (it != cache.end()) return it->second;
-  const double unit = 17.5;                                 // us per 128^3 product on one CU inside this kernel (profiles/r04: chains of 36 units take 600-680 us)
-  const double d128 = unit * P * (P + 1) / 2.0, d64 = 0.54 * d128;
+  const double unit = 17.4;                                 // us per 128^3 product on one CU inside this kernel (profiles/r04: chains of 36 units take 590-640 us)
+  const double d128 = unit * P * (P + 1) / 2.0, d64 = 0.525 * d128;
   RegionPlan best{T128, T128, 0}; double best_t = 1e30;
-  for (int c = 8; c >= 0; --c) {
-    int x = (int)((long long)T128 * c / 8);
-    if (force_th == 128) x = T128; else if (force_th == 64) x = 0;
+  std::vector<int> xs;                                       // candidate splits, tallest first (ties keep the fewer workgroups)
+  if (force_th == 128) xs.push_back(T128);
+  else if (force_th == 64) xs.push_back(0);
+  else { const int step = std::max(1, T128 / 32); for (int x = T128; x > 0; x -= step) xs.push_back(x); xs.push_back(0); }
+  for (int pass = 0; pass < (asst_always ? 1 : 2); ++pass)        // pass 1: assistants although the rows are not all resident
+  for (int x : xs) {
     const int rest = Mb - 128 * x;
     const int t64 = rest > 0 ? (rest + 63) / 64 : 0;
     if (x < T128 && t64 == 0) continue;
     const int ntask = x + t64;
     int full = 0;
     for (int k = 0; k < ntask; ++k) { const int roff = k < x ? 128 * k : 128 * x + 64 * (k - x); if (Mb_real - roff > 16) ++full; }
-    const int na = (na_full > 0 && (asst_always || (2LL * P + na_full + full) * nb <= cus)) ? na_full : 0;
-    const double sq_end = 2.0 * P * (na ? 19.0 : 30.0);
+    const bool resident = (2LL * P + na_full + full) * nb <= cus;
+    if (pass == 1 && (resident || na_full == 0 || (2LL * P + na_full) * nb > cus)) continue;
+    const int na = (na_full > 0 && (asst_always || pass == 1 || resident)) ? na_full : 0;
+    const double sq_end = 2.0 * P * (na ? 17.7 : 29.0);
     std::priority_queue<double, std::vector<double>, std::greater<double>> free_at;
     const long long nsq = (2LL * P + na) * nb;
     for (int i = 0; i < cus; ++i) {
@@ -3719,7 +3772,6 @@ static RegionPlan region_plan(int P, int nb, int Mb, int Mb_real, int cus, int n
       }
     }
     if (end < best_t - 1e-9) { best_t = end; best = RegionPlan{x, ntask, na}; }
-    if (force_th == 128 || force_th == 64) break;
   }
   cache[key] = best;
   return best;
@@ -3779,7 +3831,7 @@ void launch_region(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2, con
     (void)hipMemcpy(h.data(), tr, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
     long long t0 = h[0];
     for (size_t i = 0; i < (size_t)tasks * nb * 2; i += 2) if (h[i] < t0) t0 = h[i];
-    fprintf(stderr, "[region-trace] c0=%d P=%d R=%d nb=%d occ=%d\n", c0, P, R, nb, occ);
+    fprintf(stderr, "[region-trace] c0=%d P=%d R=%d nb=%d occ=%d square=%d n128=%d\n", c0, P, R, nb, occ, 2 * P + a.na, a.n128);
     for (long long i = 0; i < tasks * nb; ++i)
       fprintf(stderr, "[region-trace] wg=%lld b=%lld idx=%lld start_us=%.2f end_us=%.2f\n", i, i % nb, i / nb, (h[2 * i] - t0) / 100.0, (h[2 * i + 1] - t0) / 100.0);
     {                                                             // matrix 0's walker: per block [arrive, flag seen, diag start, diag end]

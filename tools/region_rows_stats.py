@@ -4,17 +4,18 @@ import re, sys
 import numpy as np
 launch = None; launches = []
 for line in open(sys.argv[1]):
-    m = re.match(r"\[region-trace\] c0=(\d+) P=(\d+) R=(\d+) nb=(\d+) occ=(\d+)", line)
+    m = re.match(r"\[region-trace\] c0=(\d+) P=(\d+) R=(\d+) nb=(\d+) occ=(\d+)(?: square=(\d+) n128=(\d+))?", line)
     if m:
-        launch = {"c0": int(m[1]), "P": int(m[2]), "R": int(m[3]), "nb": int(m[4]), "wg": []}; launches.append(launch); continue
+        launch = {"c0": int(m[1]), "P": int(m[2]), "R": int(m[3]), "nb": int(m[4]), "wg": [], "sq": int(m[6]) if m[6] else None,
+                  "n128": int(m[7]) if m[7] else None}; launches.append(launch); continue
     m = re.match(r"\[region-trace\] wg=(\d+) b=(\d+) idx=(\d+) start_us=([\d.]+) end_us=([\d.]+)", line)
     if m and launch is not None: launch["wg"].append((int(m[3]), float(m[4]), float(m[5])))
 for L in launches:
     P, R, nb = L["P"], L["R"], L["nb"]
     ntask = len(L["wg"]) // nb
-    nsq = ntask - (R - P)
+    nsq = L["sq"] if L["sq"] is not None else ntask - (R - P)
     sq = np.array([(s, e) for i, s, e in L["wg"] if i < nsq]); rw = np.array([(s, e) for i, s, e in L["wg"] if i >= nsq])
-    out = f"c0={L['c0']:6d} P={P} R={R:3d} nb={nb} tasks/matrix={ntask} (square {nsq}): kernel end {max(e for _, _, e in L['wg']):8.1f} us; square end {sq[:, 1].max():7.1f}"
+    out = f"c0={L['c0']:6d} P={P} R={R:3d} nb={nb} tasks/matrix={ntask} (square {nsq}, n128 {L['n128']}): kernel end {max(e for _, _, e in L['wg']):8.1f} us; square end {sq[:, 1].max():7.1f}"
     if len(rw):
         d = rw[:, 1] - rw[:, 0]
         first = rw[rw[:, 0] < 50.0]
