@@ -3,7 +3,8 @@
     covariance at x* is rounded to 128 columns, the cross-solve blocks used to keep rup(n*, 64) rows -- the round-3 out-of-bounds read
     (DESIGN.md "faults and aborts").  OILMM, IndependentMOGP and dense-H posteriors, values against the oracle.
 (b) The allocation-extent guard of lmm_api.hip turns such a mismatch into LMM_ERR_ARG before anything is launched.
-(c) Block-column factorisation (round 4: rows kernel + look-ahead squares) against the recursive panel path and against LAPACK."""
+(c) The round-4 launch shapes of the factorisation against LAPACK: region launches whose row tasks mix 128- and 64-row tiles
+    (region_plan), and update launches that carry the ragged last 64 rows as work items -- with and without the fused bulk tiles."""
 import ctypes as C
 import math
 
@@ -173,3 +174,24 @@ def test_posterior_handle_freed_without_gc(lmm):
         assert used[-1] <= used[1] + (1 << 20), used       # steady after the first iteration's pool warm-up
     finally:
         gc.enable()
+
+
+# ---------------------------------------------------------------------------------------------------
+# (c) row-tile plans and in-launch ragged rows
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,m", [(1280, 8), (1792, 8), (2560, 4), (3072, 8), (4096, 8), (4096, 24)])
+def test_logpdf_mid_sizes_vs_lapack(lmm, n, m):
+    """OILMM logpdf (reference src/oilmm.jl:79-93) at sizes between the one-launch path and C2, against the oracle's LAPACK
+    factorisations.  (1280, 8) .. (3072, 8): region launches with all-64 / mixed row tiles; (4096, 8): + K >= 1024 updates with the
+    ragged rows as work items (dataflow base case); (4096, 24): the panel recursion with fused bulk tiles waiting for the strip's
+    column-0 item."""
+    import torch
+    p = m + 2
+    P = O.synthetic_problem(m, p, n, "matern52", True, s2=0.1, seed=n + m)
+    fs = lmm.independent_mogp([lmm.GP(lmm.Matern52Kernel()) for _ in range(m)])
+    fx = lmm.ILMM(fs, lmm.Orthogonal(P["U"], P["S"]))(lmm.MOInputIsotopicByOutputs(torch.from_numpy(P["x"]).cuda(), p), 0.1)
+    got = float(lmm.logpdf(fx, torch.from_numpy(P["y"]).cuda()))
+    want = O.oilmm_logpdf(P["gps"], P["U"], P["S"], P["x"], 0.1, P["y"])
+    assert got == pytest.approx(want, rel=1e-9)
+    again = float(lmm.logpdf(fx, torch.from_numpy(P["y"]).cuda()))
+    assert again == pytest.approx(got, rel=1e-12)      # (split-K atomics on the K >= 1024 levels: not bitwise)

@@ -6,7 +6,7 @@ bash tools/collect_profiles.sh final > gpurun_out/collect_final.log 2>&1
 for w in c0 notebook c1; do python bench.py --workload $w --steps 300 --warmup 30 > gpurun_out/final/bench_$w.json 2> gpurun_out/final/bench_$w.err || exit 1; done
 python bench.py --workload c1dense --steps 10 --warmup 2 > gpurun_out/final/bench_c1dense.json 2> gpurun_out/final/bench_c1dense.err
 python bench.py --workload c3 --steps 5 --warmup 1 > gpurun_out/final/bench_c3.json 2> gpurun_out/final/bench_c3.err
-python bench.py --workload c3 --proj bf16 --steps 5 --warmup 1 --no-cpu-baseline > gpurun_out/final/bench_c3_bf16proj.json 2> gpurun_out/final/bench_c3_bf16.err
+python bench.py --workload c3 --proj bf16 --steps 5 --warmup 1 > gpurun_out/final/bench_c3_bf16proj.json 2> gpurun_out/final/bench_c3_bf16.err
 python bench.py --steps 10 --warmup 2 > gpurun_out/final/bench_c2.json 2> gpurun_out/final/bench_c2.err
 python bench.py --workload c4 --dtype f32 --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/final/bench_c4_f32.json 2> gpurun_out/final/bench_c4_f32.err
 python - <<'PY'
