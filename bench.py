@@ -347,8 +347,8 @@ def main():
                     traffic = tj.get("update_kernel", {}).get("bytes_per_launch")
             roof = {"bound": "mfma", "kernel": ("gemm32w_kernel (v_mfma_f32_32x32x2_f32 SYRK/GEMM trailing update on 256 x 256 tiles, AccVGPR accumulators; gemm32_kernel<128> where those do not fill the device)" if args.dtype == "f32"
                                                 else "potrf_node_kernel<2> (v_mfma_f64_16x16x4_f64, VGPR accumulators, software-pipelined SYRK/GEMM trailing update, K >= 1024; "
-                                                     "one workgroup per matrix also factors the next panel's 128 x 128 diagonal block, and at K = 1024, 2048 the "
-                                                     "launch ends with that panel's bulk rows; + gemm16h_kernel<true> on a ragged last 64 rows)"),
+                                                     "one workgroup per matrix also factors the next panel's 128 x 128 diagonal block; the ragged last 64 rows are "
+                                                     "half-height work items of the launch -- or gemm16h_kernel<true> behind it while several batches are in flight)"),
                     "achieved": round(ach, 3), "peak": peak_tf, "unit": "TFLOP/s",
                     "frac": round(ach / peak_tf, 4), "traffic": traffic if args.dtype == "f64" else None,
                     "traffic_source": ("profiles/pmc_traffic.json: fabric bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
@@ -365,9 +365,15 @@ def main():
                     "achieved": round(ach, 4), "peak": peak_tf, "unit": "TFLOP/s", "frac": round(ach / peak_tf, 5), "traffic": None,
                     "launches": rg["launches"], "avg_launch_ms": round(rg["ms"] / rg["launches"], 4), "flops_per_launch": rg["work"] / rg["launches"],
                     "mode": f"serial-stream instrumented pass over {nprof} latent(s)"}
+        if roof is not None and rg and rg["launches"] and rg["ms"] > 0 and roof.get("kernel", "").startswith("potrf_node_kernel"):
+            # the levels below K = 1024 (or 512) as dataflow launches: the base case of the recursion
+            extra["roofline_region"] = {"bound": "mfma", "kernel": "potrf_region_kernel (a 512- or 1024-column block column per launch: walker + helpers + row streams)",
+                                        "achieved": round(rg["work"] / (rg["ms"] * 1e-3) / 1e12, 3), "peak": peak_tf, "unit": "TFLOP/s",
+                                        "frac": round(rg["work"] / (rg["ms"] * 1e-3) / 1e12 / peak_tf, 4), "launches": rg["launches"],
+                                        "avg_launch_ms": round(rg["ms"] / rg["launches"], 4)}
         us = prof.get("update_short")
         if us and us["launches"] and us["ms"] > 0:
-            extra["roofline_update_short"] = {"bound": "mfma", "kernel": "potrf_node_kernel<1> (the same fused update + leaf, K < 1024: epilogue- and latency-bound levels)",
+            extra["roofline_update_short"] = {"bound": "mfma", "kernel": "potrf_node_kernel<1> (the same fused update + leaf at K < 1024: the K = 512 updates between two dataflow launches, or every level of the panel recursion)",
                                                "achieved": round(us["work"] / (us["ms"] * 1e-3) / 1e12, 3), "peak": peak_tf, "unit": "TFLOP/s",
                                                "frac": round(us["work"] / (us["ms"] * 1e-3) / 1e12 / peak_tf, 4), "launches": us["launches"],
                                                "avg_launch_ms": round(us["ms"] / us["launches"], 4)}

@@ -361,11 +361,11 @@ static int g_slots_in_flight = 1;       // batches that run concurrently on the 
 static int g_region_whole = 1;          // LMM_REGION_ALL=1: also as the base case of the recursion for larger matrices (measured: no gain)
 static int g_region_cols = -1;          // widest block column potrf_region_kernel takes in one launch (LMM_REGION=<columns>, up to 1024; default 0: off)
 // bulk_done (implies first_done): the rows below that block are solved as well (the update launch that factored it ran them too).
-struct NodeFlags { int* p = nullptr; int stride = 0; int min_k = 0, max_k = 1 << 30; int rows_real = -1; BatchPtr S{}; };   // S: region assistants' scratch      // rows_real: rows that hold data (-1: all NR)
+struct NodeFlags { int* p = nullptr; int stride = 0; int min_k = 0, max_k = 1 << 30; int rows_real = -1; BatchPtr S{}; int region_cols = 0; };   // region_cols: widest block column that becomes ONE dataflow launch in this factorisation   // S: region assistants' scratch      // rows_real: rows that hold data (-1: all NR)
 void potrf_rec_panel(const Batch& B, const BatchPtr& W2, const BatchInfo& flags, const NodeFlags& nfl, int ld, int NR, int j0, int w, int n_real,
                      hipStream_t st, bool first_done, bool bulk_done = false) {
   const double nb = B.nb;
-  if (g_region_cols > 0 && w <= g_region_cols && w >= 128 && (w % 128) == 0 && flags.p[0] != nullptr) {
+  if (nfl.region_cols > 0 && w <= nfl.region_cols && w >= 128 && (w % 128) == 0 && flags.p[0] != nullptr) {
     // the whole block column as ONE dataflow launch (lmm_kernels.hip K2d): leaves, bulk products and all updates inside it
     const double Mr = (nfl.rows_real >= 0 ? std::min(NR, nfl.rows_real) : NR) - j0, Wd = w;
     const double fl = Mr * Wd * Wd - 2.0 * Wd * Wd * Wd / 3.0;           // flops of factoring an Mr x Wd tall panel: Mr Wd^2 - 2 Wd^3 / 3
@@ -450,7 +450,16 @@ void potrf_batch(const Batch& B, int ld, int NR, int NC, int n_real, hipStream_t
     // flight do not -- 724 -> 748 ms per step with the dataflow base case, the same effect as for C2's two 16-latent batches)
     region_base = tasks * B.nb * g_slots_in_flight <= (long long)(2.3 * cus);
   }
-  const bool region_here = g_region_cols > 0 && (region_base || (NC <= g_region_cols && (NC % 128) == 0));
+  // Round 4: when the 1024-column block column is over that bound -- many matrices per launch: C2's 16-latent batches, 32 latents at
+  // n = 2048 ... 4096 -- the base case is a 512-column block column instead of the panel launches: its row chains are 10 units long
+  // instead of 36 (finer tasks for a machine that is oversubscribed many times over), the square's workgroups hold their CUs half as
+  // long, and the K = 512 update between two of them runs at 60-64 TFLOP/s.  32 x 2048: 2.98 -> 2.64 ms, 32 x 4096: 15.2 -> 14.0,
+  // 16 x 16384 on one stream: 346.8 -> 343.6, C2 at N = 1: 685.7-687.5 -> 683.1-684.2 ms (LMM_REGION_SMALL=<columns>, 0: panel launches).
+  static int region_small = -1;
+  if (region_small < 0) { const char* e = getenv("LMM_REGION_SMALL"); region_small = e ? atoi(e) : 512; if (region_small % 128) region_small = 0; if (region_small > g_region_cols) region_small = g_region_cols; }
+  int region_cols = g_region_cols;
+  if (region_auto && g_region_cols >= 1024 && NC > g_region_cols && (NC % 128) == 0 && !region_base && region_small > 0) { region_cols = region_small; region_base = true; }
+  const bool region_here = region_cols > 0 && (region_base || (NC <= region_cols && (NC % 128) == 0));
   if (region_here) {                       // dependency flags of the region launches: this stream's slice of the persistent, once-zeroed
     int si = -1;                           // array (launches are told apart by epoch); an unknown stream gets a zeroed scratch
     for (int s = 0; s < kMaxStreams; ++s) if (g.streams[s] == st) si = s;
@@ -474,13 +483,14 @@ void potrf_batch(const Batch& B, int ld, int NR, int NC, int n_real, hipStream_t
   NodeFlags nfl;
   nfl.min_k = fuse_min_k; nfl.max_k = fuse_max_k;
   nfl.rows_real = rows_real;
+  nfl.region_cols = region_here ? region_cols : 0;
   if (fuse_bulk && !region_here && NC > 128) {
     nfl.stride = (int)node_flag_ints(NR);
     const size_t ints = (size_t)nfl.stride * B.nb;
     nfl.p = reinterpret_cast<int*>(call_scratch((ints + 1) / 2));
     HIPCHK(hipMemsetAsync(nfl.p, 0, ints * sizeof(int), st));
   }
-  if (region_here && std::min(NC, g_region_cols) > 64 * LMM_REGION_ASST_MIN_R) {      // block columns with assistant rows: their scratch tiles
+  if (region_here && std::min(NC, region_cols) > 64 * LMM_REGION_ASST_MIN_R) {      // block columns with assistant rows: their scratch tiles
     const size_t per_s = (size_t)LMM_REGION_ASST_TILES * 4096;
     double* sb = call_scratch(per_s * B.nb);
     for (int j = 0; j < B.nb; ++j) nfl.S.p[j] = sb + per_s * j;
