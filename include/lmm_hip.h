@@ -350,6 +350,11 @@ int lmm_dev_check_info(const int* info, int count, int latent_begin);
  * launch site checks the rows x cols (ld) block it touches against the pooled allocation the pointer lies in and returns LMM_ERR_ARG
  * instead of launching): applies it to a fresh pooled block of alloc_bytes, a block of Float64 elements. */
 int lmm_dev_extent_check(size_t alloc_bytes, size_t rows, size_t ld, size_t cols);
+/* Test hook of the region kernel's row-task plan (host arithmetic only, no device needed): for a block column of P 128-column panels of
+ * nb matrices with rows_below rows under the square (rows_real of them holding data) on a device of `cus` CUs, with `assistants`
+ * assistant workgroups available per matrix: out[0] = row tiles that stay 128 rows high, out[1] = row tasks per matrix (128-row tiles
+ * + 64-row tiles), out[2] = assistants used.  The tiles cover the rows: 128 out[0] + 64 (out[1] - out[0]) >= rows_below. */
+int lmm_dev_region_plan(int P, int nb, int rows_below, int rows_real, int cus, int assistants, int out[3]);
 /* C[MxN] -= A[MxK] * B[NxK]^T (column-major, device). lower != 0: only tiles on/below the diagonal. */
 int lmm_dev_gemm_nt_sub(double* C, int ldc, const double* A, int lda, const double* B, int ldb,
                         int M, int N, int K, int lower);

@@ -3076,6 +3076,13 @@ int lmm_dev_potrf(double* A, int nrows, int ncols, int ld, double* Winv, int n_r
 
 // The allocation-extent guard on a freshly pooled block of alloc_bytes: LMM_OK when a rows x cols block of doubles with leading
 // dimension ld fits, LMM_ERR_ARG (and nothing launched) when it does not.  Exists so that the guard itself has a test.
+int lmm_dev_region_plan(int P, int nb, int rows_below, int rows_real, int cus, int assistants, int out[3]) {
+  if (!out || P < 1 || P > LMM_REGION_MAX_PANELS || nb < 1 || nb > LMM_MAX_BATCH || rows_below < 0 || rows_real > rows_below || cus < 1 || assistants < 0) {
+    return fail(LMM_ERR_ARG, "lmm_dev_region_plan: bad arguments");
+  }
+  region_plan_probe(P, nb, rows_below, rows_real, cus, assistants, out);
+  return LMM_OK;
+}
 int lmm_dev_extent_check(size_t alloc_bytes, size_t rows, size_t ld, size_t cols) {
   std::lock_guard<std::mutex> lk(g_mu);
   REQUIRE_INIT();

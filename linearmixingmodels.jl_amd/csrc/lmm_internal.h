@@ -106,6 +106,7 @@ struct RegionArgs {
 #define LMM_INFO_SYNC_TIMEOUT (-7777)     // pivot-info value a region launch leaves when a dependency wait timed out (never expected)
 void region_flags_register(int* base, size_t ints);     // the context's persistent flag array (cleared when the launch epoch wraps)
 extern int g_concurrent_batches;          // batches in flight on the slot streams (set by lmm_api.hip's fork_slots / join_slots)
+void region_plan_probe(int P, int nb, int Mb, int Mb_real, int cus, int na_full, int out[3]);   // lmm_dev_region_plan
 size_t region_flag_ints(int NR);          // ints per matrix that the flags of any region of a matrix with NR rows need
 void launch_region(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2, const BatchInfo& info, const BatchInfo& flags, int ld, int NR,
                    int c0, int width, int n_real, int nb, bool first_done, hipStream_t st, int rows_real = -1, const BatchPtr* S = nullptr);

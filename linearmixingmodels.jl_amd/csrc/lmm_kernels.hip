@@ -3777,6 +3777,10 @@ static RegionPlan region_plan(int P, int nb, int Mb, int Mb_real, int cus, int n
   return best;
 }
 
+void region_plan_probe(int P, int nb, int Mb, int Mb_real, int cus, int na_full, int out[3]) {
+  const RegionPlan r = region_plan(P, nb, Mb, Mb_real, cus, na_full, false, (Mb % 64) != 0 ? 128 : 0);
+  out[0] = r.n128; out[1] = r.row_tasks; out[2] = r.na;
+}
 size_t region_flag_ints(int) { return REGION_FLAG_INTS; }
 void launch_region(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2, const BatchInfo& info, const BatchInfo& flags, int ld, int NR,
                    int c0, int width, int n_real, int nb, bool first_done, hipStream_t st, int rows_real, const BatchPtr* S) {

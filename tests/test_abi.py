@@ -205,3 +205,35 @@ def test_check_info_translation_and_ordering():
         L.check(status([0, -7777]))
     with pytest.raises(lmm_amd.PosDefException):
         L.check(status([0, 2]))
+
+
+def test_region_plan_covers_the_rows_and_is_deterministic():
+    """lmm_dev_region_plan (host arithmetic of launch_region, no GPU): whatever split of 128- / 64-row tiles the list-scheduling
+    estimate picks, the row tasks cover every row below the square exactly once, the assistants are all or none, and the same
+    shape gets the same plan again (the plan is cached per shape and feeds the kernel's task decode)."""
+    import ctypes as C
+    from lmm_amd import _lib as L
+    lib = L.load()
+    lib.lmm_dev_region_plan.argtypes = [C.c_int] * 6 + [C.POINTER(C.c_int)]
+    seen = set()
+    for P in (1, 2, 5, 8):
+        for nb in (1, 3, 4, 8, 16, 32):
+            for rows_below, real in [(0, 0), (64, 1), (64, 64), (192, 130), (320, 257), (1088, 1025), (3136, 3073), (7232, 7169), (15424, 15361)]:
+                na = max(0, 2 * P - 6)
+                out = (C.c_int * 3)()
+                assert lib.lmm_dev_region_plan(P, nb, rows_below, real, 256, na, out) == L.LMM_OK
+                n128, tasks, used = out[0], out[1], out[2]
+                t128 = (rows_below + 127) // 128
+                assert 0 <= n128 <= t128 and tasks >= n128 and used in (0, na)
+                rest = rows_below - 128 * n128
+                if n128 == t128:
+                    assert tasks == t128                                  # all tall: the last tile may be a half tile
+                else:
+                    assert rest > 0 and tasks - n128 == (rest + 63) // 64 and rows_below % 64 == 0
+                again = (C.c_int * 3)()
+                assert lib.lmm_dev_region_plan(P, nb, rows_below, real, 256, na, again) == L.LMM_OK
+                assert list(again) == list(out)
+                seen.add((n128 == t128, n128 == 0))
+    assert (True, False) in seen and (False, True) in seen               # both pure forms occur; mixed ones are shape dependent
+    out = (C.c_int * 3)()
+    assert lib.lmm_dev_region_plan(9, 4, 128, 128, 256, 0, out) == L.LMM_ERR_ARG
