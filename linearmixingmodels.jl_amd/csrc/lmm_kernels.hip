@@ -3679,6 +3679,11 @@ bool launch_update_leaf(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2
     if (all <= cap / 2) {
       int sk = (int)(cap / all); if (sk > nk / 4) sk = nk / 4; if (sk < 1) sk = 1;
       if (sk > 1) { full_a = full_l = 0; split_a = split_l = sk; }
+    } else if (all <= 2LL * cap && nk >= 32) {
+      // (a') up to two rounds of whole tiles: every tile in two K halves -- whole tiles pair up on some CUs (each at half rate) while
+      // other CUs idle or run one; halves fill the slots evenly (8 x 2048, K = 1024: 268 -> 220 us; 8 x 3072: 588 -> 554; 8 x 4096's
+      // three launches 2.06 -> 2.01 ms)
+      full_a = full_l = 0; split_a = split_l = 2;
     } else {                                // (b): always the last cap / s tiles
       // (splitting exactly the tiles of the last partial "round" instead measured no better: equal tiles do not stay in lock-step --
       // of the two workgroups of a CU the older one gets the matrix pipe -- and the slots are 94-96 % busy either way; profiles/r03)
