@@ -92,8 +92,11 @@ int lmm_release_cached_memory(void);      /* return the caching device-memory po
  *   lmm_ilmm_logpdf_multi: Float32 (mn)x(mn) matrix, rtol 2e-4 on the value) and (round 4) the dense-H POSTERIOR (reference
  *   src/ilmm.jl:184-198: lmm_ilmm_posterior_create, lmm_ilmm_post_condition, _post_mean_and_var, _post_mean_and_cov, _post_logpdf,
  *   _post_rand, the latent view): Float32 (mn)x(mn) factor, cross-solve block and posterior covariance; means in the rider form
- *   mu + R (L^-1 delta); rtol 2e-4 on means, 1e-3 on variances / covariances / logpdf at sigma2 = 0.1).  The dense-H GRADIENTS and the
- *   full covariance of independent latents (lmm_lmm_mean_and_cov) return LMM_ERR_UNSUPPORTED.
+ *   mu + R (L^-1 delta); rtol 2e-4 on means, 1e-3 on variances / covariances / logpdf at sigma2 = 0.1), the full covariance of
+ *   independent latents (lmm_lmm_mean_and_cov: Float32 latent covariances, Float64 mixing; entries within 5e-5 of the largest) and the
+ *   dense-H GRADIENTS (lmm_ilmm_logpdf_grad, lmm_ilmm_post_logpdf_grad: Float32 (mn)x(mn) factor and explicit inverse; value rtol
+ *   2e-5, d/dy within 1e-4, d/dy_train and d/dH within 5e-4 of their largest component, d/dsigma2 rtol 1e-4, kernel parameters
+ *   rtol 2e-3 + 1e-2 absolute at sigma2 = 0.1, mn ~ 10^3 -- tests/test_gpu_f32.py).  No entry point refuses the fp32 mode any more.
  *   Jitters stay explicit arguments: the reference's 1e-18 / 1e-12 defaults are below Float32 resolution, so prior sampling
  *   needs a caller-chosen jitter (>= ~1e-5 x kernel variance).  A posterior handle remembers the dtype it was built in. */
 typedef enum { LMM_F64 = 0, LMM_F32 = 1 } lmm_dtype;

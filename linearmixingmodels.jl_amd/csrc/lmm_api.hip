@@ -201,7 +201,8 @@ inline int rup(int v, int m) { return (v + m - 1) / m * m; }
 // mat_count(elements) doubles.  Vectors stay double.
 inline size_t mat_count(size_t elems) { return g_f32 ? (elems + 1) / 2 : elems; }
 inline double mat_bytes(double elems) { return elems * (g_f32 ? 4.0 : 8.0); }
-#define REQUIRE_F64(what) if (g_f32) return fail(LMM_ERR_UNSUPPORTED, what " is not built for the fp32 compute mode (lmm_set_compute_dtype)")
+// element `off` of a matrix buffer in the current storage type, as the double* the launch wrappers take
+inline double* mat_at(double* p, size_t off) { return g_f32 ? reinterpret_cast<double*>(reinterpret_cast<float*>(p) + off) : p + off; }
 
 // ---- allocation-extent guard -------------------------------------------------------------------------------------------------
 // Every launch below that reads or writes a rows x cols block (leading dimension ld) of a POOLED buffer is preceded by this check of
@@ -1839,7 +1840,7 @@ int ilmm_grad_core(const double* xd, int d, int n, int nsplit, const double* yd,
     launch_sum_partials(partial.p, tall_skinny_partials(nb_, p), resid_dev.p + b, st0);
   }
   Dims D(N, 1);
-  Buf<double> A(D.elems()), W((size_t)(D.NC / 64) * 4096), R((size_t)D.ld * D.NC), alpha((size_t)D.NC), lml_dev(1);
+  Buf<double> A(mat_count(D.elems())), W(mat_count((size_t)(D.NC / 64) * 4096)), R(mat_count((size_t)D.ld * D.NC)), alpha((size_t)D.NC), lml_dev(1);
   Buf<int> info(1);
   HIPCHK(hipMemsetAsync(info.p, 0, sizeof(int), st0));
   HIPCHK(hipMemsetAsync(alpha.p, 0, (size_t)D.NC * sizeof(double), st0));
@@ -1858,7 +1859,7 @@ int ilmm_grad_core(const double* xd, int d, int n, int nsplit, const double* yd,
   const size_t mm = (size_t)m * m, mp = (size_t)m * p;
   Buf<double> red((size_t)NGR * m), gpart((size_t)grad_partials(n)), Btr(2 * mm), AAt(2 * mm), AY(2 * mp);
   for (int l = 0; l < m; ++l)
-    launch_grad_reduce(A.p + (size_t)l * n * D.ld + (size_t)l * n, D.ld, n, n, alpha.p + (size_t)l * n, delta.p + (size_t)l * n, xd, d,
+    launch_grad_reduce(mat_at(A.p, (size_t)l * n * D.ld + (size_t)l * n), D.ld, n, n, alpha.p + (size_t)l * n, delta.p + (size_t)l * n, xd, d,
                        lat[l], gpart.p, red.p + (size_t)NGR * l, st0);
   // regulariser pieces: Rm = Y - (T Y)' H' (n x p), RH = Rm H (n x m), per block Rm' Ty (p x m), RH' Y (m x p)
   Buf<double> HTY((size_t)n * p), Rm((size_t)n * p), RH((size_t)N), RtTy(2 * mp), RHtY(2 * mp);
@@ -2006,7 +2007,6 @@ int lmm_ilmm_logpdf_grad(const double* x, int d, int n, const double* y, int p, 
   std::lock_guard<std::mutex> lk(g_mu);
   REQUIRE_INIT();
   LMM_TRY
-  REQUIRE_F64("the dense-H ILMM gradient");
   if (!x || !y || !H || !out_logpdf || d <= 0 || n <= 0 || p <= 0 || m <= 0) return fail(LMM_ERR_ARG, "bad arguments");
   if (int rc = check_gps(gps, m)) return rc;
   if (!(sigma2 > 0.0)) return fail(LMM_ERR_ARG, "sigma2 must be > 0");
@@ -2035,7 +2035,6 @@ int lmm_ilmm_post_logpdf_grad(const double* x, int d, int n, const double* y, co
   std::lock_guard<std::mutex> lk(g_mu);
   REQUIRE_INIT();
   LMM_TRY
-  REQUIRE_F64("the dense-H predictive-logpdf gradient");
   if (!x || !y || !xs || !ys || !H || !out_logpdf || d <= 0 || n <= 0 || ns <= 0 || p <= 0 || m <= 0) return fail(LMM_ERR_ARG, "bad arguments");
   if (int rc = check_gps(gps, m)) return rc;
   if (!(sigma2 > 0.0) || !(sigma2_s > 0.0)) return fail(LMM_ERR_ARG, "sigma2 must be > 0");
@@ -2820,7 +2819,7 @@ extern "C" int lmm_lmm_mean_and_cov(const lmm_post_t* post, const lmm_gp_t* gps,
   std::lock_guard<std::mutex> lk(g_mu);
   REQUIRE_INIT();
   LMM_TRY
-  REQUIRE_F64("the full covariance");
+  if (post && post->f32 != g_f32) return fail(LMM_ERR_ARG, "posterior handle was built in the other compute dtype (lmm_set_compute_dtype)");
   if (!U || !xs || !mean_out || !cov_out || d <= 0 || ns <= 0 || p <= 0 || m <= 0) return fail(LMM_ERR_ARG, "bad arguments");
   if ((double)p * ns * (double)p * ns > 4e8) return fail(LMM_ERR_UNSUPPORTED, "full covariance (p*ns)^2 too large");
   if (!jit) jit = &kDefaultJit;
@@ -2847,8 +2846,8 @@ extern "C" int lmm_lmm_mean_and_cov(const lmm_post_t* post, const lmm_gp_t* gps,
   int ldr = nsr; if ((ldr % 512) == 0) ldr += 16;
   const int CH = LMM_MAX_BATCH;
   std::vector<Buf<double>> Cm;
-  for (int c = 0; c < std::min(CH, std::max(ms, 1)); ++c) Cm.emplace_back(Ds.elems());
-  Buf<double> R(P ? (size_t)ldr * P->NC : 1), part(strip_partial_elems(nsr, P ? P->NC : 1, 1));
+  for (int c = 0; c < std::min(CH, std::max(ms, 1)); ++c) Cm.emplace_back(mat_count(Ds.elems()));
+  Buf<double> R(P ? mat_count((size_t)ldr * P->NC) : 1), part(strip_partial_elems(nsr, P ? P->NC : 1, 1));
   if (ms == 0) {
     HIPCHK(hipMemsetAsync(mo.p, 0, (size_t)ns * p * sizeof(double), st0));
     BatchPtr none{};

@@ -3279,6 +3279,7 @@ __global__ __launch_bounds__(256) void dense_cov_full_kernel(const double* __res
 // Full mixed covariance (reference src/ilmm.jl:132-139 / AbstractGPs cov):
 //   out[(o,i),(o',j)] (+)= sum_{l in chunk} H[o,l] H[o',l] (C_l[i,j] + jitter [i==j])  (+ sigma2 [o==o', i==j] on init)
 // C_l is the lower triangle of a factor-matrix-layout buffer (mirrored here).  out is (p ns) x (p ns) column-major.
+template <typename TS>
 __global__ __launch_bounds__(256) void cov_mix_kernel(BatchPtr Cl, int ldcl, int nl, const double* __restrict__ Hs, int p,
                                                       int ns, double jitter, double sigma2, int init,
                                                       double* __restrict__ out) {
@@ -3288,7 +3289,7 @@ __global__ __launch_bounds__(256) void cov_mix_kernel(BatchPtr Cl, int ldcl, int
   double acc = 0.0;
   const int hi = i > j ? i : j, lo = i > j ? j : i;
   for (int l = 0; l < nl; ++l) {
-    double c = Cl.p[l][(size_t)lo * ldcl + hi];
+    double c = MatIO<TS>::ld1(Cl.p[l], (size_t)lo * ldcl + hi);
     if (i == j) c += jitter;
     acc = __builtin_fma(Hs[o + (size_t)l * p] * Hs[o2 + (size_t)l * p], c, acc);
   }
@@ -3392,13 +3393,14 @@ __global__ __launch_bounds__(256) void grad_finish_kernel(const double* __restri
 
 // out[l + l2*m] = sum_i Minv[(l n + i), (l2 n + i)]  for l >= l2 (mirrored into l < l2): the m x m matrix of traces of the diagonals of
 // the n x n blocks of a symmetric (m n) x (m n) matrix whose lower triangle is stored (dense-H ILMM gradient: dL/dSigmaT).
-__global__ __launch_bounds__(256) void block_trace_kernel(const double* __restrict__ Minv, int ld, int n, int m, int i0, int i1,
+template <typename TS>
+__global__ __launch_bounds__(256) void block_trace_kernel(const void* __restrict__ Minv, int ld, int n, int m, int i0, int i1,
                                                           double* __restrict__ out) {
   __shared__ double sh[4];
   const int l = blockIdx.x, l2 = blockIdx.y;
   if (l < l2) return;
   double s = 0.0;
-  for (int i = i0 + threadIdx.x; i < i1; i += 256) s += Minv[(size_t)(l2 * n + i) * ld + (l * n + i)];
+  for (int i = i0 + threadIdx.x; i < i1; i += 256) s += MatIO<TS>::ld1(Minv, (size_t)(l2 * n + i) * ld + (l * n + i));
   const double tot = block_sum_256(s, sh);
   if (threadIdx.x == 0) { out[l + (size_t)l2 * m] = tot; out[l2 + (size_t)l * m] = tot; }
 }
@@ -4066,7 +4068,7 @@ void launch_mix_bf16(const double* lat, int ns, int ml, const double* Hm, int p,
 void launch_cov_mix(const BatchPtr& Cl, int ldcl, int nl, const double* Hs, int p, int ns, double jitter, double sigma2,
                     int init, double* out, hipStream_t st) {
   dim3 grid((ns + 15) / 16, (ns + 15) / 16, p * p);
-  hipLaunchKernelGGL(cov_mix_kernel, grid, dim3(256), 0, st, Cl, ldcl, nl, Hs, p, ns, jitter, sigma2, init, out);
+  LMM_TS_LAUNCH((cov_mix_kernel<TS>), grid, dim3(256), 0, st, Cl, ldcl, nl, Hs, p, ns, jitter, sigma2, init, out);
 }
 
 // out = mu + L z for the leading n x n lower triangle of L (ld); partial: strip_partial_elems(n, n, 1) doubles.
@@ -4098,7 +4100,7 @@ void launch_vec_axpby(const double* a, double sa, const double* b, double sb, si
 }
 
 void launch_block_trace(const double* Minv, int ld, int n, int m, int i0, int i1, double* out, hipStream_t st) {
-  hipLaunchKernelGGL(block_trace_kernel, dim3(m, m), dim3(256), 0, st, Minv, ld, n, m, i0, i1, out);
+  LMM_TS_LAUNCH((block_trace_kernel<TS>), dim3(m, m), dim3(256), 0, st, (const void*)Minv, ld, n, m, i0, i1, out);
 }
 
 void launch_vec_lin2(const double* a, const double* b, double sa, double sb, int nsplit, int N, size_t count, double* out, hipStream_t st) {

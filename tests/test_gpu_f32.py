@@ -219,10 +219,8 @@ def test_f32_mode_boundaries(lmm32):
     v32 = lmm.logpdf(f(xin, 0.1), P["y"])
     g32 = lmm.logpdf_and_gradient(f(xin, 0.1), P["y"])            # round 3: served in fp32 (values: test_f32_oilmm_logpdf_gradient)
     assert g32["value"] == pytest.approx(v32, rel=1e-6)
-    with pytest.raises(NotImplementedError):
-        lmm.mean_and_cov(f(lmm.MOInputIsotopicByOutputs(P["x"][:8], 5), 0.1))
-    with pytest.raises(NotImplementedError):                       # the dense (mn) x (mn) GRADIENTS stay Float64-only (the posterior
-        lmm.logpdf_and_gradient(lmm.ILMM(_model(lmm, P["gps"]), np.abs(P["U"]) + 0.1)(xin, 0.1), P["y"])      # verbs are served: round 4)
+    # (round 4: the full covariance and the dense-H gradients are served in fp32 too: test_f32_full_covariance,
+    # test_f32_dense_gradients; nothing on the path returns LMM_ERR_UNSUPPORTED for the compute dtype any more)
     pd32 = lmm.posterior(lmm.ILMM(_model(lmm, P["gps"]), np.abs(P["U"]) + 0.1)(xin, 0.1), P["y"])
     lmm.set_compute_dtype("f64")
     v64 = lmm.logpdf(f(xin, 0.1), P["y"])
@@ -326,3 +324,90 @@ def test_f32_oilmm_logpdf_gradient(lmm32):
     assert Gp["sigma2"] == pytest.approx(Gp64["sigma2"], rel=2e-2, abs=2e-2)
     print("f32 gradient errors:", {k: (float(np.max(np.abs(np.asarray(G[k]) - np.asarray(R[k])))), float(np.max(np.abs(np.asarray(R[k]))))) for k in ("y", "S", "U")},
           "sigma2", G["sigma2"], R["sigma2"], "gps", [(G["gps"][l], R["gps"][l]) for l in range(m)])
+
+
+def test_f32_full_covariance(lmm32):
+    """Round 4: cov / mean_and_cov of independent latents (reference src/ilmm.jl:132-147, src/independent_mogp.jl:60-63) in the fp32
+    compute mode -- prior OILMM, posterior OILMM and the IndependentMOGP -- against the Float64 oracle.  The latent covariances at x*
+    (Gram minus the Schur complement R R' of a Float32 cross-solve) are Float32 matrices, the mixing sum_l H H' C_l is Float64.
+    STATED TOLERANCE (sigma2 = 0.1, unit-scale kernels, n = 600): means within 2e-4 of the largest, covariance entries within 5e-5 of
+    the largest (observed on the box: 2.8e-5 and 3.5e-6; tools/f32_cov_errors.py)."""
+    lmm = lmm32
+    rng = np.random.default_rng(23)
+    n, ns, p, m, s2 = 600, 70, 4, 3, 0.1
+    x, xs = np.sort(rng.uniform(0, 20, n)), np.sort(rng.uniform(0, 20, ns))
+    gps = [{"kind": k, "variance": float(rng.uniform(0.7, 1.4)), "lengthscale": float(rng.uniform(0.7, 1.5)), "mean": float(rng.normal())}
+           for k in ["matern52", "se", "matern32"]]
+    U, _ = np.linalg.qr(rng.standard_normal((p, m)))
+    S = np.linspace(1.5, 0.8, m)
+    H = O.orthogonal_dense(U, S)
+    y = rng.standard_normal(n * p)
+    f = lmm.ILMM(_model(lmm, gps), lmm.Orthogonal(U, S))
+    xsin = lmm.MOInputIsotopicByOutputs(xs, p)
+    # prior
+    M0, C0 = lmm.mean_and_cov(f(xsin, s2))
+    # posterior against the naive dense GP of the oracle
+    post = lmm.posterior(f(lmm.MOInputIsotopicByOutputs(x, p), s2), y)
+    M1, C1 = lmm.mean_and_cov(post(xsin, s2))
+    Mo, Co = O.naive_posterior_mean_cov(gps, H, x, s2, y, xs)
+    Co = Co + s2 * np.eye(ns * p)
+    np.testing.assert_allclose(M1, Mo, rtol=0, atol=2e-4 * np.abs(Mo).max())
+    np.testing.assert_allclose(C1, Co, rtol=0, atol=5e-5 * np.abs(Co).max())
+    # the prior: against the Float64 HIP path (itself pinned by tests/test_gpu_parity.py::test_cov_and_mean_and_cov)
+    lmm.set_compute_dtype("f64")
+    M64, C64 = lmm.mean_and_cov(f(xsin, s2))
+    lmm.set_compute_dtype("f32")
+    np.testing.assert_allclose(M0, M64, rtol=0, atol=1e-6 * max(1.0, np.abs(M64).max()))
+    np.testing.assert_allclose(C0, C64, rtol=0, atol=5e-5 * np.abs(C64).max())
+    assert np.allclose(C1, C1.T, atol=1e-12)
+    # IndependentMOGP posterior covariance (block diagonal)
+    ft = _model(lmm, gps)(lmm.MOInputIsotopicByOutputs(x, m), s2)
+    pm = lmm.posterior(ft, y[:n * m])
+    Cm = lmm.cov(pm(lmm.MOInputIsotopicByOutputs(xs, m), s2))
+    po = O.mogp_posterior(gps, x, s2, y[:n * m])
+    Cr = O.mogp_cov(po, xs) + s2 * np.eye(ns * m)
+    np.testing.assert_allclose(Cm, Cr, rtol=0, atol=5e-5 * np.abs(Cr).max())
+
+
+def test_f32_dense_gradients(lmm32):
+    """Round 4: value and gradient of the dense-H ILMM logpdf (reference src/ilmm.jl:150-181 differentiated; test/ilmm.jl:31) and of
+    the dense-H posterior's predictive logpdf (test/ilmm.jl:32) in the fp32 compute mode: Float32 (mn) x (mn) factor, triangular
+    inverse and explicit inverse on v_mfma_f32, every reduction and the chain rule through project(H, sigma2) in Float64.  Against
+    the Float64 HIP path (pinned to finite differences of the oracle in tests/test_gpu_parity.py).  STATED TOLERANCE (sigma2 = 0.1,
+    m n ~ 10^3): value rtol 2e-5; d/dy within 1e-4, d/dy_train and d/dH within 5e-4 of their largest component; d/dsigma2 rtol 1e-4;
+    kernel parameters rtol 2e-3 + 1e-2 absolute (differences of O(mn) terms).  Observed on the box: 6e-7 / 5e-6 / 4e-5 / 4e-5 / 5e-7 /
+    <= 1e-3 absolute (tools/f32_dense_grad_errors.py)."""
+    lmm = lmm32
+    rng = np.random.default_rng(31)
+    n, ns, p, m, s2 = 300, 60, 4, 3, 0.1
+    x, xs = np.sort(rng.uniform(0, 12, n)), np.sort(rng.uniform(0, 12, ns))
+    gps = [{"kind": k, "variance": float(rng.uniform(0.7, 1.4)), "lengthscale": float(rng.uniform(0.7, 1.5)), "mean": float(rng.normal())}
+           for k in ["se", "matern52", "matern32"]]
+    H = rng.uniform(0.2, 1.0, size=(p, m))
+    y, ys = rng.standard_normal(n * p), rng.standard_normal(ns * p)
+    fx = lmm.ILMM(_model(lmm, gps), H)(lmm.MOInputIsotopicByOutputs(x, p), s2)
+
+    def both(fn):
+        g32 = fn()
+        lmm.set_compute_dtype("f64")
+        try:
+            g64 = fn()
+        finally:
+            lmm.set_compute_dtype("f32")
+        return g32, g64
+
+    def compare(G, R, ykeys):
+        assert G["value"] == pytest.approx(R["value"], rel=2e-5)
+        for k in ykeys:
+            np.testing.assert_allclose(G[k], R[k], rtol=0, atol=(1e-4 if k == "y" else 5e-4) * np.abs(R[k]).max())
+        np.testing.assert_allclose(G["H"], R["H"], rtol=0, atol=5e-4 * np.abs(R["H"]).max())
+        assert G["sigma2"] == pytest.approx(R["sigma2"], rel=1e-4)
+        for l in range(m):
+            for key in ("variance", "lengthscale", "mean"):
+                assert G["gps"][l][key] == pytest.approx(R["gps"][l][key], rel=2e-3, abs=1e-2), (l, key)
+
+    G, R = both(lambda: lmm.logpdf_and_gradient(fx, y))
+    compare(G, R, ["y"])
+    assert G["value"] != R["value"]                      # really computed in the other precision
+    Gp, Rp = both(lambda: lmm.logpdf_and_gradient(lmm.posterior(fx, y)(lmm.MOInputIsotopicByOutputs(xs, p), 0.2), ys))
+    compare(Gp, Rp, ["y", "y_train"])
