@@ -31,6 +31,17 @@
  *     pinned staging arena, which concurrent calls would have to share).  Concurrency across GPUs = one process per GPU.
  *   - device pointers produced by another stream (e.g. a PyTorch tensor still being written by torch's stream): call
  *     lmm_stream_wait_caller(that stream) first; the library's streams then order themselves behind it.
+ *   - process-global modes: the compute dtype (lmm_set_compute_dtype) and the projection dtype (lmm_set_projection_dtype) are state
+ *     of the process's one context, NOT call arguments: they apply to every later call of every thread until changed (a posterior
+ *     handle remembers the dtype it was built in and refuses the other one).
+ *   - forward progress of the dataflow kernels (LMM_ERR_HIP "dependency wait timed out"): potrf_region_kernel and the fused update
+ *     launches run cooperating workgroups that wait on flags written by other workgroups of the SAME launch.  Every workgroup takes
+ *     its task from a ticket drawn at kernel entry (an atomic counter, so tasks are claimed in the order workgroups actually start,
+ *     whatever order the hardware dispatches blockIdx in); a task waits only for tasks with LOWER tickets -- which are therefore
+ *     already running or finished -- with one exception: a walker waits for the helper of its current row, a higher ticket, after it
+ *     has published everything the lower-ticket helpers need to finish and free their slots.  So the launch completes with any number
+ *     of resident workgroups >= 1 per matrix chain.  Every wait is additionally bounded (4 s of the 100-MHz wall clock, or another
+ *     workgroup's abort word): a violation drains the grid and surfaces as LMM_ERR_HIP, never as a hang or a wrong value.
  */
 #ifndef LMM_HIP_H
 #define LMM_HIP_H
@@ -309,6 +320,18 @@ int lmm_lmm_mean_and_cov(const lmm_post_t* post, const lmm_gp_t* gps, const doub
                          const double* xs, int d, int ns, const lmm_jitters_t* jit,
                          double* mean_out, double* cov_out);
 
+/* cov(f::IndependentMOGP, x, y) -- the two-input cross-covariance: reference src/independent_mogp.jl:66-71 (x, y both
+ * MOInputIsotopicByOutputs: Matrix(BlockDiagonal(cov(f_l, x.x, y.x)))) and :184-215 (either input MOInputIsotopicByFeatures: the same
+ * blocks with rows / columns permuted by indices_which_reorder_outputs_to_features); tested by the reference at
+ * test/independent_mogp.jl:136-141.  post == NULL: prior latents `gps` (block l = kernelmatrix(k_l, x, y)); post != NULL (a handle
+ * of lmm_mogp_posterior_create / lmm_oilmm_posterior_create / lmm_post_condition): PosteriorGP latents, block l =
+ * K_l(x, y) - A_x' A_y with A_z = C_l.U' \ K_l(x_train, z).  x is d x n, y is d x n2.  cov_out: (m n) x (m n2) column-major; entry
+ * ((l, i), (l', j)) sits at row  l n + i  (x by outputs)  or  i m + l  (x_by_features != 0), column  l' n2 + j  or  j m + l'.  Only the
+ * blocks of the shard [latent_begin, latent_end) are filled, everything else is zero (shards sum to the whole).  (m n)(m n2) <= 4e8. */
+int lmm_mogp_cross_cov(const lmm_post_t* post, const lmm_gp_t* gps, int m, int latent_begin, int latent_end,
+                       const double* x, int d, int n, int x_by_features, const double* y, int n2, int y_by_features,
+                       double* cov_out);
+
 /* logpdf(po(xs, sigma2), ys) where po is the posterior OILMM (reference test/oilmm.jl:25; the posterior
  * is again an OILMM with the same H, reference src/oilmm.jl:133): per-latent posterior covariance at
  * xs (Schur complement) + the reference src/oilmm.jl:79-93 algorithm. */
@@ -358,6 +381,9 @@ int lmm_dev_extent_check(size_t alloc_bytes, size_t rows, size_t ld, size_t cols
  * assistant workgroups available per matrix: out[0] = row tiles that stay 128 rows high, out[1] = row tasks per matrix (128-row tiles
  * + 64-row tiles), out[2] = assistants used.  The tiles cover the rows: 128 out[0] + 64 (out[1] - out[0]) >= rows_below. */
 int lmm_dev_region_plan(int P, int nb, int rows_below, int rows_real, int cus, int assistants, int out[3]);
+/* Test hook of the dataflow kernels' dependency flags: they carry a 26-bit launch epoch and are never reset; when the epoch wraps,
+ * every persistent flag word is cleared.  *old_epoch (may be NULL) = the current epoch; set_to >= 0 replaces it (-1: read only). */
+int lmm_dev_flag_epoch(int set_to, int* old_epoch);
 /* C[MxN] -= A[MxK] * B[NxK]^T (column-major, device). lower != 0: only tiles on/below the diagonal. */
 int lmm_dev_gemm_nt_sub(double* C, int ldc, const double* A, int lda, const double* B, int ldb,
                         int M, int N, int K, int lower);
@@ -397,6 +423,10 @@ typedef enum {
 typedef struct { long long launches; double ms; double work; double bytes; /* algorithmic HBM bytes */ } lmm_prof_entry_t;
 int lmm_profile_begin(int serial);
 int lmm_profile_end(lmm_prof_entry_t* out /* LMM_PROF_COUNT entries */);
+
+/* Write-only yardstick next to the Gram assembly's HBM roofline (bench.py roofline_gram.achievable_write_gbs): GB/s of `reps`
+ * hipMemsetAsync fills of a pooled device block of `bytes` (>= 1 MiB), timed with HIP events on the library's main stream. */
+int lmm_dev_write_rate(size_t bytes, int reps, double* gbs);
 
 /* f64 MFMA issue-rate microbenchmark: measured TFLOP/s of v_mfma_f64_16x16x4_f64 in the form the update kernels issue it (16
  * accumulator blocks in architectural VGPRs, 4 + 4 operand fragments per k-step; tools/mfma_probe4: 77.7 = 98.9 % of the 78.6

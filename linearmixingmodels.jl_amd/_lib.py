@@ -23,9 +23,9 @@ SYMBOLS = [
     "lmm_comm_destroy",
     "lmm_orthogonal_validate", "lmm_oilmm_logpdf", "lmm_oilmm_logpdf_grad", "lmm_oilmm_post_logpdf_grad", "lmm_ilmm_logpdf_grad", "lmm_ilmm_post_logpdf_grad", "lmm_oilmm_logpdf_multi", "lmm_reorder", "lmm_ilmm_logpdf", "lmm_ilmm_logpdf_ex", "lmm_ilmm_logpdf_multi", "lmm_mogp_logpdf", "lmm_mogp_logpdf_diag",
     "lmm_oilmm_posterior_create", "lmm_mogp_posterior_create", "lmm_post_condition", "lmm_ilmm_posterior_create", "lmm_post_destroy", "lmm_ilmm_post_latent_view", "lmm_ilmm_post_mean_and_var", "lmm_ilmm_post_mean_and_cov", "lmm_ilmm_post_condition", "lmm_ilmm_post_logpdf", "lmm_ilmm_post_rand",
-    "lmm_latent_marginals", "lmm_oilmm_mean_and_var", "lmm_lmm_mean_and_cov", "lmm_oilmm_post_logpdf", "lmm_lmm_rand", "lmm_lmm_rand_multi", "lmm_normals",
+    "lmm_latent_marginals", "lmm_oilmm_mean_and_var", "lmm_lmm_mean_and_cov", "lmm_mogp_cross_cov", "lmm_oilmm_post_logpdf", "lmm_lmm_rand", "lmm_lmm_rand_multi", "lmm_normals",
     "lmm_profile_begin", "lmm_profile_end",
-    "lmm_dev_potrf", "lmm_dev_check_info", "lmm_dev_extent_check", "lmm_dev_region_plan", "lmm_dev_gemm_nt_sub", "lmm_dev_gram", "lmm_dev_mfma_f64_peak",
+    "lmm_dev_potrf", "lmm_dev_check_info", "lmm_dev_extent_check", "lmm_dev_region_plan", "lmm_dev_flag_epoch", "lmm_dev_gemm_nt_sub", "lmm_dev_gram", "lmm_dev_write_rate", "lmm_dev_mfma_f64_peak",
 ]
 
 

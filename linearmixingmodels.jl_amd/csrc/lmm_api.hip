@@ -885,6 +885,9 @@ const lmm_jitters_t kDefaultJit = {1e-9, 1e-12, 1e-18};
 
 void drain_after_error() {
   if (g.init) { (void)hipDeviceSynchronize(); (void)hipGetLastError(); }
+  // a throw between fork_slots and join_slots must not leave "several batches in flight" behind: the base-case rule of potrf_batch
+  // and the ragged-row choice of the update launches read these, so later calls would silently take another launch plan
+  g_slots_in_flight = 1; g_concurrent_batches = 1;
 }
 
 }  // namespace
@@ -2875,6 +2878,61 @@ extern "C" int lmm_lmm_mean_and_cov(const lmm_post_t* post, const lmm_gp_t* gps,
   LMM_CATCH
 }
 
+// cov(f::IndependentMOGP, x, y): reference src/independent_mogp.jl:66-71 (both inputs by outputs) and :184-215 (by features / mixed:
+// the same blocks at permuted rows / columns).  Block l = cov(f_l, x.x, y.x): kernelmatrix(k_l, x, y) for a prior latent,
+// K(x, y) - A_x' A_y with A_z = C.U' \ K(x_train, z) for a PosteriorGP latent (AbstractGPs).
+extern "C" int lmm_mogp_cross_cov(const lmm_post_t* post, const lmm_gp_t* gps, int m, int latent_begin, int latent_end,
+                                  const double* x, int d, int n, int x_by_features, const double* y, int n2, int y_by_features,
+                                  double* cov_out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  REQUIRE_INIT();
+  LMM_TRY
+  if (post && post->f32 != g_f32) return fail(LMM_ERR_ARG, "posterior handle was built in the other compute dtype (lmm_set_compute_dtype)");
+  if (!x || !y || !cov_out || d <= 0 || n <= 0 || n2 <= 0 || m <= 0) return fail(LMM_ERR_ARG, "bad arguments");
+  if ((double)m * n * (double)m * n2 > 4e8) return fail(LMM_ERR_UNSUPPORTED, "cross-covariance (m n) x (m n2) too large");
+  const lmm_post* P = post;
+  int l0 = latent_begin, l1 = latent_end;
+  if (P) {
+    if (P->kind != 0) return fail(LMM_ERR_UNSUPPORTED, "cross-covariance of the coupled latents of a dense-H posterior is not built");
+    l0 = P->l0; l1 = P->l1;
+    if (P->m != m) return fail(LMM_ERR_DIM, "posterior has %d latents, m = %d", P->m, m);
+    if (P->d != d) return fail(LMM_ERR_DIM, "input dimension mismatch: posterior has d=%d, x has d=%d", P->d, d);
+  } else if (int rc = check_gps(gps, m)) return rc;
+  if (l0 < 0 || l1 > m || l0 > l1) return fail(LMM_ERR_ARG, "bad latent shard");
+  hipStream_t st0 = g.streams[0];
+  DevIn xd(x, (size_t)d * n, st0), yd(y, (size_t)d * n2, st0);
+  const size_t R = (size_t)m * n, Ccols = (size_t)m * n2;
+  DevOut co(cov_out, R * Ccols);
+  HIPCHK(hipMemsetAsync(co.p, 0, R * Ccols * sizeof(double), st0));        // the off-diagonal blocks (and latents outside the shard)
+  // K(x, y) as the "rider rows" of a Gram launch whose column points are y: rows [NCy, NCy + nxr) of a (NCy + nxr) x NCy layout,
+  // stored from buffer row 0 (the cross-Gram form of the predictive paths)
+  const int nxr = rup(n, 128), NCy = rup(n2, 128);
+  int ldk = nxr; if ((ldk % 512) == 0) ldk += 16;
+  Buf<double> Kb(mat_count((size_t)ldk * NCy));
+  int ldr = std::max(nxr, NCy); if ((ldr % 512) == 0) ldr += 16;
+  Buf<double> Rx(P ? mat_count((size_t)ldr * P->NC) : 1), Ry(P ? mat_count((size_t)ldr * P->NC) : 1);
+  for (int l = l0; l < l1; ++l) {
+    const lmm_gp_t& gp = P ? P->gps[l] : gps[l];
+    GramArgs a{};
+    a.A = Kb.p; a.ld = ldk; a.nrows = NCy + nxr; a.ncols = NCy; a.row_tile0 = NCy / 64; a.row_shift = NCy; a.full = 1;
+    a.x = yd.p; a.d = d; a.n = n2; a.kind = gp.kind; a.var = gp.variance; a.inv_ls = 1.0 / gp.lengthscale;
+    a.xs = xd.p; a.ns = n;
+    gram_g(a, st0, "cross-covariance K(x, y)");
+    if (P) {
+      const int k = l - l0;
+      cross_solve(P, k, gp, xd.p, d, n, Rx.p, ldr, nxr, st0);              // R_x = K(x, X) L^-T
+      cross_solve(P, k, gp, yd.p, d, n2, Ry.p, ldr, NCy, st0);             // R_y = K(y, X) L^-T
+      gemm_nt_g(Kb.p, ldk, Rx.p, ldr, Ry.p, ldr, nxr, NCy, P->NC, 0, false, st0, "cross-covariance Schur complement");
+    }
+    launch_block_scatter(Kb.p, ldk, n, n2, co.p, R, x_by_features ? (size_t)l : (size_t)l * n, x_by_features ? m : 1,
+                         y_by_features ? (size_t)l : (size_t)l * n2, y_by_features ? m : 1, st0);
+  }
+  co.finish(st0);
+  HIPCHK(hipStreamSynchronize(st0));
+  return LMM_OK;
+  LMM_CATCH
+}
+
 int lmm_oilmm_post_logpdf(const lmm_post_t* post, const double* U, const double* S, int p, int m, double sigma2,
                           const double* xs, int d, int ns, const double* ys, int with_regulariser, double* out) {
   std::lock_guard<std::mutex> lk(g_mu);
@@ -3073,15 +3131,26 @@ int lmm_dev_potrf(double* A, int nrows, int ncols, int ld, double* Winv, int n_r
   LMM_CATCH
 }
 
-// The allocation-extent guard on a freshly pooled block of alloc_bytes: LMM_OK when a rows x cols block of doubles with leading
-// dimension ld fits, LMM_ERR_ARG (and nothing launched) when it does not.  Exists so that the guard itself has a test.
+// The region kernel's row-task plan for one block column (host arithmetic only; no device, no lmm_init needed).
 int lmm_dev_region_plan(int P, int nb, int rows_below, int rows_real, int cus, int assistants, int out[3]) {
+  std::lock_guard<std::mutex> lk(g_mu);
   if (!out || P < 1 || P > LMM_REGION_MAX_PANELS || nb < 1 || nb > LMM_MAX_BATCH || rows_below < 0 || rows_real > rows_below || cus < 1 || assistants < 0) {
     return fail(LMM_ERR_ARG, "lmm_dev_region_plan: bad arguments");
   }
   region_plan_probe(P, nb, rows_below, rows_real, cus, assistants, out);
   return LMM_OK;
 }
+// Test hook of the dataflow kernels' launch-epoch counter: *old_epoch (may be NULL) = the current value; set_to >= 0 replaces it (set
+// it to 2^26 - 2 and the next launches execute the wrap-around clear of the persistent flag words).
+int lmm_dev_flag_epoch(int set_to, int* old_epoch) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (set_to >= (1 << 26)) return fail(LMM_ERR_ARG, "lmm_dev_flag_epoch: the epoch has 26 bits");
+  const int old = region_flag_epoch(set_to);
+  if (old_epoch) *old_epoch = old;
+  return LMM_OK;
+}
+// The allocation-extent guard on a freshly pooled block of alloc_bytes: LMM_OK when a rows x cols block of doubles with leading
+// dimension ld fits, LMM_ERR_ARG (and nothing launched) when it does not.  Exists so that the guard itself has a test.
 int lmm_dev_extent_check(size_t alloc_bytes, size_t rows, size_t ld, size_t cols) {
   std::lock_guard<std::mutex> lk(g_mu);
   REQUIRE_INIT();
@@ -3158,6 +3227,30 @@ int lmm_profile_end(lmm_prof_entry_t* out) {
   }
   g.prof_recs.clear();
   g.prof = false; g.prof_serial = false;
+  return LMM_OK;
+  LMM_CATCH
+}
+
+// Write-only yardstick for the Gram assembly's roofline line: GB/s of hipMemsetAsync into a pooled block of `bytes` (median-free mean
+// of `reps` back-to-back fills between two events on the main stream, after one untimed fill that touches the block).
+int lmm_dev_write_rate(size_t bytes, int reps, double* gbs) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  REQUIRE_INIT();
+  LMM_TRY
+  if (!gbs || bytes < (1u << 20) || reps < 1) return fail(LMM_ERR_ARG, "bad arguments");
+  Buf<double> blk(bytes / 8);
+  hipStream_t st = g.streams[0];
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  HIPCHK(hipMemsetAsync(blk.p, 0, bytes, st));
+  HIPCHK(hipEventRecord(e0, st));
+  for (int r = 0; r < reps; ++r) HIPCHK(hipMemsetAsync(blk.p, 0, bytes, st));
+  HIPCHK(hipEventRecord(e1, st));
+  HIPCHK(hipStreamSynchronize(st));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  *gbs = (double)bytes * reps / (ms * 1e-3) / 1e9;
   return LMM_OK;
   LMM_CATCH
 }

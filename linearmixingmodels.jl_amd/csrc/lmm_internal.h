@@ -107,6 +107,7 @@ struct RegionArgs {
 void region_flags_register(int* base, size_t ints);     // the context's persistent flag array (cleared when the launch epoch wraps)
 extern int g_concurrent_batches;          // batches in flight on the slot streams (set by lmm_api.hip's fork_slots / join_slots)
 void region_plan_probe(int P, int nb, int Mb, int Mb_real, int cus, int na_full, int out[3]);   // lmm_dev_region_plan
+int region_flag_epoch(int set_to);                       // lmm_dev_flag_epoch: returns the current launch epoch; set_to >= 0 replaces it
 size_t region_flag_ints(int NR);          // ints per matrix that the flags of any region of a matrix with NR rows need
 void launch_region(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2, const BatchInfo& info, const BatchInfo& flags, int ld, int NR,
                    int c0, int width, int n_real, int nb, bool first_done, hipStream_t st, int rows_real = -1, const BatchPtr* S = nullptr);
@@ -171,5 +172,8 @@ void launch_atb(const double* X, int ldx, const double* Z, int ldz, int n, int n
 void launch_fill(double* p, int n, double v, hipStream_t st);
 void launch_reorder(const double* in, int n, int p, int to_outputs, double* out, hipStream_t st);
 void launch_vec_lin(const double* a, const double* b, double sb, int n, double* out, hipStream_t st);  // out = a + sb*b
+// out[(row0 + i rs) + (col0 + j cs) ldo] = src[i + j lds] (src a MATRIX in the compute dtype, out Float64): a block of cov(f, x, y)
+void launch_block_scatter(const double* src, int lds, int nr, int nc, double* out, size_t ldo, size_t row0, int rs, size_t col0, int cs,
+                          hipStream_t st);
 void launch_normals(unsigned long long seed, unsigned long long stream, size_t count, double* out, hipStream_t st);
 void launch_mfma_peak(double* out, int blocks, int iters, hipStream_t st);

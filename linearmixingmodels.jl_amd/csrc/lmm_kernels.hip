@@ -3435,6 +3435,15 @@ __global__ void reorder_kernel(const double* __restrict__ in, int n, int p, int 
   else { const int i = k / p, o = k - i * p; out[k] = in[(size_t)o * n + i]; }
 }
 
+// One diagonal block of cov(f::IndependentMOGP, x, y) (reference src/independent_mogp.jl:66-71; :184-215 for the by-features orders):
+// out[(row0 + i rs) + (col0 + j cs) ldo] = src[i + j lds], i < nr, j < nc.  by-outputs: row0 = l nr, rs = 1; by-features: row0 = l, rs = m.
+template <typename TS>
+__global__ __launch_bounds__(256) void block_scatter_kernel(const void* __restrict__ src, int lds, int nr, int nc, double* __restrict__ out,
+                                                            size_t ldo, size_t row0, int rs, size_t col0, int cs) {
+  const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+  if (i < nr && j < nc) out[(row0 + (size_t)i * rs) + (col0 + (size_t)j * cs) * ldo] = MatIO<TS>::ld1(src, (size_t)j * lds + i);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // K7 (optional): standard normals on the device -- Philox4x32-10 counter RNG (Salmon et al. 2011) + Box-Muller in Float64.
 // Normal 2j and 2j+1 come from counter (j, stream) under key `seed`, so a buffer is reproducible for (seed, stream) whatever
@@ -3635,6 +3644,13 @@ static int next_flag_epoch() {
   }
   return g_region_epoch;
 }
+// test hook (lmm_dev_flag_epoch): read the launch-epoch counter, and set it when set_to >= 0 -- to just below 2^26, so that a test
+// executes the wrap-around clear above
+int region_flag_epoch(int set_to) {
+  const int old = g_region_epoch;
+  if (set_to >= 0) g_region_epoch = set_to;
+  return old;
+}
 int g_concurrent_batches = 1;        // batches in flight on the slot streams (lmm_api.hip's fork_slots)
 size_t node_flag_ints(int NR) { return (size_t)(2 + (NR + 127) / 128 + 1); }
 bool launch_update_leaf(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2, const BatchInfo& info, int ld, int NR, int j0, int h,
@@ -3731,11 +3747,11 @@ bool launch_update_leaf(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2
 struct RegionPlan { int n128, row_tasks, na; };
 static RegionPlan region_plan(int P, int nb, int Mb, int Mb_real, int cus, int na_full, bool asst_always, int force_th) {
   const int T128 = (Mb + 127) / 128;
-  struct Key { int P, nb, Mb, Mr, na, f; bool operator<(const Key& o) const { return std::tie(P, nb, Mb, Mr, na, f) < std::tie(o.P, o.nb, o.Mb, o.Mr, o.na, o.f); } };
+  struct Key { int P, nb, Mb, Mr, na, f, cus; bool operator<(const Key& o) const { return std::tie(P, nb, Mb, Mr, na, f, cus) < std::tie(o.P, o.nb, o.Mb, o.Mr, o.na, o.f, o.cus); } };
   static std::map<Key, RegionPlan> cache;
   static std::mutex mu;
   std::lock_guard<std::mutex> lock(mu);
-  const Key key{P, nb, Mb, Mb_real, na_full, force_th * 2 + (asst_always ? 1 : 0)};
+  const Key key{P, nb, Mb, Mb_real, na_full, force_th * 2 + (asst_always ? 1 : 0), cus};
   auto it = cache.find(key);
   if (it != cache.end()) return it->second;
   const double unit = 17.4;                                 // us per 128^3 product on one CU inside this kernel (profiles/r04: chains of 36 units take 590-640 us)
@@ -4117,6 +4133,12 @@ void launch_fill(double* p, int n, double v, hipStream_t st) {
 
 void launch_reorder(const double* in, int n, int p, int to_outputs, double* out, hipStream_t st) {
   hipLaunchKernelGGL(reorder_kernel, dim3((n * p + 255) / 256), dim3(256), 0, st, in, n, p, to_outputs, out);
+}
+
+void launch_block_scatter(const double* src, int lds, int nr, int nc, double* out, size_t ldo, size_t row0, int rs, size_t col0, int cs,
+                          hipStream_t st) {
+  if (nr <= 0 || nc <= 0) return;
+  LMM_TS_LAUNCH((block_scatter_kernel<TS>), dim3((nr + 255) / 256, nc), dim3(256), 0, st, (const void*)src, lds, nr, nc, out, ldo, row0, rs, col0, cs);
 }
 
 void launch_vec_lin(const double* a, const double* b, double sb, int n, double* out, hipStream_t st) {

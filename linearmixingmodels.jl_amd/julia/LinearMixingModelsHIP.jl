@@ -203,7 +203,9 @@ end
 # general Diagonal noise on a by-outputs IndependentMOGP (what reference src/independent_mogp.jl:222-229 reaches after
 # reorder_by_outputs, :149-159): per-point noise variances ride the Gram diagonal
 function AbstractGPs.logpdf(ft::FiniteGP{<:HIPMOGP,<:MOInputIsotopicByOutputs,<:Diagonal{<:Real,<:Vector}}, y::AbstractVector{<:Real})
+    isposterior(ft.f) && error("logpdf with a general Diagonal noise is served for the prior IndependentMOGP only")
     X = _xmat(ft.x.x); d, n = size(X); m = length(ft.f.fs)
+    ft.x.out_dim == m || throw(ErrorException("out dim of x != out dim of f."))
     gps = _gps(ft.f.fs); yv = Vector{Float64}(y); nv = Vector{Float64}(ft.Σy.diag)
     out = Ref{Cdouble}(0.0)
     GC.@preserve X yv nv gps check(ccall((:lmm_mogp_logpdf_diag, liblmm), Cint,
@@ -418,7 +420,8 @@ _by_outputs(Σy::Diagonal{<:Real}, x::MOInputIsotopicByFeatures) = Diagonal(_reo
 _by_outputs(ft::ByFeatures{HIPMOGP}) = FiniteGP(ft.f, _by_outputs(ft.x), _by_outputs(ft.Σy, ft.x))        # :157-159
 _to_features(v::AbstractVector{<:Real}, x::MOInputIsotopicByFeatures) = _reorder(v, _nx(x), x.out_dim, false)
 
-# src/independent_mogp.jl:222-229 (any Diagonal noise: a Fill stays a Fill, a general diagonal is permuted with the data)
+# src/independent_mogp.jl:222-229 (any Diagonal noise: a Fill stays a Fill and reaches the ByOutputsFill method; a general diagonal is
+# permuted with the data into a Diagonal{Float64,Vector{Float64}} and reaches the per-point-noise method above, lmm_mogp_logpdf_diag)
 AbstractGPs.logpdf(ft::ByFeatures{HIPMOGP}, y::AbstractVector{<:Real}) =
     logpdf(_by_outputs(ft), _reorder(y, _nx(ft.x), ft.x.out_dim, true))
 # src/independent_mogp.jl:217-220: the by-outputs sample, permuted (the normals are drawn latent by latent, as in the reference)
@@ -464,6 +467,42 @@ function Distributions._rand!(rng::AbstractRNG, ft::ByFeaturesFill{HIPMOGP}, y::
         y .= AbstractGPs.rand(rng, ft, N)
     end
 end
+
+# ---- cov(f, x, y), mean(f, x), var(f, x) on the GP itself (AbstractGPs' internal interface) --------------------------------------
+# reference src/independent_mogp.jl:66-71 (x, y by outputs: Matrix(BlockDiagonal(cov(f_l, x.x, y.x)))) and :184-215 (either input by
+# features: the same blocks at rows / columns permuted with indices_which_reorder_outputs_to_features) -- the library writes every
+# block at its final place (lmm_mogp_cross_cov); cov(f, x) = cov(f, x, x) (:60-63, :177-182).  Reference tests:
+# test/independent_mogp.jl:136-141.
+const MOIsotopic = Union{MOInputIsotopicByOutputs,MOInputIsotopicByFeatures}
+_byfeat(::MOInputIsotopicByOutputs) = Cint(0)
+_byfeat(::MOInputIsotopicByFeatures) = Cint(1)
+function AbstractGPs.cov(f::HIPMOGP, x::MOIsotopic, y::MOIsotopic)
+    m = length(f.fs)
+    (x.out_dim == m && y.out_dim == m) || throw(ErrorException("out dim of x != out dim of f."))
+    X = _xmat(x.x); Y = _xmat(y.x); d, n = size(X); n2 = size(Y, 2)
+    gps = isposterior(f) ? LmmGp[] : _gps(f.fs)
+    Cm = Matrix{Float64}(undef, m * n, m * n2)
+    GC.@preserve X Y gps Cm check(ccall((:lmm_mogp_cross_cov, liblmm), Cint,
+        (Ptr{Cvoid}, Ptr{LmmGp}, Cint, Cint, Cint, Ptr{Cdouble}, Cint, Cint, Cint, Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}),
+        f.handle, isposterior(f) ? Ptr{LmmGp}(C_NULL) : pointer(gps), m, 0, m, X, d, n, _byfeat(x), Y, n2, _byfeat(y), Cm))
+    return Cm
+end
+AbstractGPs.cov(f::HIPMOGP, x::MOIsotopic) = cov(f, x, x)
+# reference src/independent_mogp.jl:50,55 (by outputs: vcat of the latent marginals) and :169-175 (by features: permuted)
+function _mean_var(f::HIPMOGP, x::MOIsotopic)
+    m = length(f.fs)
+    x.out_dim == m || throw(ErrorException("out dim of x != out dim of f."))
+    X = _xmat(x.x); d, ns = size(X)
+    gps = isposterior(f) ? LmmGp[] : _gps(f.fs)
+    M = Vector{Float64}(undef, ns * m); V = similar(M)
+    GC.@preserve X gps M V check(ccall((:lmm_latent_marginals, liblmm), Cint,
+        (Ptr{Cvoid}, Ptr{LmmGp}, Cint, Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}),
+        f.handle, isposterior(f) ? Ptr{LmmGp}(C_NULL) : pointer(gps), m, X, d, ns, M, V))
+    x isa MOInputIsotopicByFeatures && return _to_features(M, x), _to_features(V, x)
+    return M, V
+end
+AbstractGPs.mean(f::HIPMOGP, x::MOIsotopic) = _mean_var(f, x)[1]
+AbstractGPs.var(f::HIPMOGP, x::MOIsotopic) = _mean_var(f, x)[2]
 
 # ---- gradients: ChainRulesCore.rrule around the ccall --------------------------------------------------------------------
 # The reference's tests take Zygote.gradient(logpdf, fx, y) on prior and posterior models (test/oilmm.jl:31-32,

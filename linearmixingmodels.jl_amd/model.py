@@ -689,9 +689,38 @@ def mean_and_cov(fx: FiniteGP):
     return mean, cov.reshape(n * p, n * p).T       # column-major -> (row, col); symmetric
 
 
-def cov(fx: FiniteGP):
-    """reference src/ilmm.jl:147."""
+def cov(fx, x=None, y=None):
+    """cov(fx): reference src/ilmm.jl:147.
+    cov(f::IndependentMOGP, x, y): the two-input cross-covariance, reference src/independent_mogp.jl:66-71 (both inputs by outputs)
+    and :184-215 (either one MOInputIsotopicByFeatures); cov(f::IndependentMOGP, x) = cov(f, x, x) (:60-63, :176-181).  Prior or
+    (independent) posterior latents; (m n) x (m n2), one lmm_mogp_cross_cov call."""
+    if isinstance(fx, IndependentMOGP):
+        if x is None:
+            raise TypeError("cov(f::IndependentMOGP, x[, y]) needs the inputs")
+        return _mogp_cross_cov(fx, x, x if y is None else y)
+    if x is not None or y is not None:
+        raise TypeError("cov(f, x, y) is defined for an IndependentMOGP (reference src/independent_mogp.jl:66-71)")
     return mean_and_cov(fx)[1]
+
+
+def _mogp_cross_cov(f: IndependentMOGP, x, y) -> np.ndarray:
+    L.ensure_init()
+    m = len(f.fs)
+    if x.out_dim != m or y.out_dim != m:
+        raise RuntimeError("out dim of x != out dim of f.")
+    if f._post is not None and f._post.dense:
+        raise NotImplementedError("cov(f, x, y) of the coupled latent PosteriorGP of a dense-H posterior is not built")
+    xb = x.by_outputs() if isinstance(x, MOInputIsotopicByFeatures) else x
+    yb = y.by_outputs() if isinstance(y, MOInputIsotopicByFeatures) else y
+    if xb.dim != yb.dim:
+        raise ValueError("x and y have different input dimensions")
+    n, n2 = xb.n, yb.n
+    out = np.empty((m * n) * (m * n2))
+    post = f._post.ptr if f._post is not None else None
+    L.check(L.load().lmm_mogp_cross_cov(post, L.gps_array([g.desc() for g in f.fs]), m, 0, m, xb.carr().ptr, xb.dim, n,
+                                        int(isinstance(x, MOInputIsotopicByFeatures)), yb.carr().ptr, n2,
+                                        int(isinstance(y, MOInputIsotopicByFeatures)), L.Arr(out, True).ptr))
+    return out.reshape(m * n2, m * n).T          # column-major (m n) x (m n2) -> (row, col)
 
 
 def mean(fx: FiniteGP):

@@ -272,6 +272,37 @@ def mogp_cov(gps: Sequence[Dict], x: np.ndarray) -> np.ndarray:
     return sla.block_diag(*[gp_mean_cov(g, x)[1] for g in gps])
 
 
+def gp_cross_cov(gp: Dict, x: np.ndarray, y: np.ndarray) -> np.ndarray:
+    """AbstractGPs cov(f, x, y) for a prior GP (kernelmatrix(k, x, y)) or a PosteriorGP
+    (K(x, y) - A_x' A_y with A_z = C.U' \\ K(x_train, z))."""
+    K = kernelmatrix(gp, x, y)
+    post = gp.get("post")
+    if post is not None:
+        Ax = sla.solve_triangular(post["L"], kernelmatrix(gp, post["x"], x), lower=True)
+        Ay = sla.solve_triangular(post["L"], kernelmatrix(gp, post["x"], y), lower=True)
+        K = K - Ax.T @ Ay
+    return K
+
+
+def reorder_indices_outputs_to_features(n: int, p: int) -> np.ndarray:
+    """src/independent_mogp.jl:135-139 (0-based): applied to a by-outputs vector it orders it by features."""
+    return np.arange(n * p).reshape(p, n).T.reshape(-1)
+
+
+def mogp_cross_cov(gps: Sequence[Dict], x: np.ndarray, y: np.ndarray, x_by_features: bool = False,
+                   y_by_features: bool = False) -> np.ndarray:
+    """cov(f::IndependentMOGP, x, y): src/independent_mogp.jl:66-71 (both MOInputIsotopicByOutputs: the dense block
+    diagonal of the per-latent cov(f_l, x.x, y.x)); :184-215 for the by-features / mixed forms (rows and / or columns
+    permuted with indices_which_reorder_outputs_to_features)."""
+    C = sla.block_diag(*[gp_cross_cov(g, x, y) for g in gps])
+    m = len(gps)
+    if x_by_features:
+        C = C[reorder_indices_outputs_to_features(npoints(x), m), :]
+    if y_by_features:
+        C = C[:, reorder_indices_outputs_to_features(npoints(y), m)]
+    return C
+
+
 def mogp_rand(gps: Sequence[Dict], x: np.ndarray, s2: float, z: np.ndarray) -> np.ndarray:
     """src/independent_mogp.jl:83-86: vcat of rand(rng, f_l(x, s2)); z is m blocks of n normals."""
     n = npoints(x)

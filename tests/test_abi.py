@@ -235,5 +235,12 @@ def test_region_plan_covers_the_rows_and_is_deterministic():
                 assert list(again) == list(out)
                 seen.add((n128 == t128, n128 == 0))
     assert (True, False) in seen and (False, True) in seen               # both pure forms occur; mixed ones are shape dependent
+    # the plan cache is keyed on the CU count too: the same shape on a smaller device must be planned for THAT device --
+    # the split of 128- / 64-row tiles that balances 256 CUs is not the one that balances 120; the second call is planned afresh, not replayed
+    big, small, big2 = (C.c_int * 3)(), (C.c_int * 3)(), (C.c_int * 3)()
+    assert lib.lmm_dev_region_plan(8, 4, 15424, 15361, 256, 10, big) == L.LMM_OK
+    assert lib.lmm_dev_region_plan(8, 4, 15424, 15361, 120, 10, small) == L.LMM_OK
+    assert lib.lmm_dev_region_plan(8, 4, 15424, 15361, 256, 10, big2) == L.LMM_OK
+    assert list(big) == list(big2) and list(small) != list(big)           # (a cache keyed without the CU count replays the first plan)
     out = (C.c_int * 3)()
     assert lib.lmm_dev_region_plan(9, 4, 128, 128, 256, 0, out) == L.LMM_ERR_ARG

@@ -1,0 +1,174 @@
+"""-m gpu, round 5.
+(a) cov(f::IndependentMOGP, x, y), the two-input cross-covariance (reference src/independent_mogp.jl:66-71 by outputs, :184-215 by
+    features / mixed; the reference's own checks: test/independent_mogp.jl:136-141): lmm_mogp_cross_cov against the oracle's restatement
+    and against the naive LinearMixingModelKernel with H = I, prior and posterior latents, all four input-order combinations.
+(b) The headline number has a check: the full configs[2] value (32 latents, the N = 1 plan of bench.py: two concurrent 16-latent
+    batches, 512-column dataflow base case) equals the sum of the eight latent_shard(32, r, 8) partials -- what the eight ranks of the
+    8-GPU job compute, each through the 4-latent plan (one batch, 1024-column base case) -- and latent 0's term equals host LAPACK.
+(c) The flag-epoch wrap-around clear of the dataflow kernels (lmm_kernels.hip next_flag_epoch) executed once: two region evaluations
+    across the wrap against the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import lmm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lmm():
+    import lmm_amd
+    lmm_amd.init(0)
+    return lmm_amd
+
+
+def _model(lmm, gps):
+    K = {"se": lmm.SEKernel, "matern32": lmm.Matern32Kernel, "matern52": lmm.Matern52Kernel}
+    return lmm.independent_mogp([lmm.GP(g["mean"], K[g["kind"]](g["variance"], g["lengthscale"])) for g in gps])
+
+
+def _gps(m, rng):
+    kinds = ["matern52", "se", "matern32"]
+    return [{"kind": kinds[l % 3], "variance": float(rng.uniform(0.6, 1.4)), "lengthscale": float(rng.uniform(0.7, 1.6)),
+             "mean": float(rng.normal())} for l in range(m)]
+
+
+def _inp(lmm, x, m, by_features):
+    return (lmm.MOInputIsotopicByFeatures if by_features else lmm.MOInputIsotopicByOutputs)(x, m)
+
+
+# ---------------------------------------------------------------------------------------------------
+# (a) cov(f, x, y)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("d", [1, 2])
+@pytest.mark.parametrize("n,n2", [(4, 3), (70, 130), (200, 65)])
+def test_mogp_cross_cov_prior(lmm, n, n2, d):
+    """reference src/independent_mogp.jl:66-71, :184-215 on prior latents; relation test/independent_mogp.jl:140-141:
+    cov(f, x, x') == cov(GP(LinearMixingModelKernel(kernels, I)), x, x')."""
+    rng = np.random.default_rng(31 * n + n2 + d)
+    m = 3
+    gps = _gps(m, rng)
+    x = rng.uniform(0, 6, n) if d == 1 else rng.uniform(0, 3, (d, n))
+    y = rng.uniform(0, 6, n2) if d == 1 else rng.uniform(0, 3, (d, n2))
+    f = _model(lmm, gps)
+    naive = O.naive_cov(gps, np.eye(m), x, y)                      # by-outputs rows and columns
+    for xf in (False, True):
+        for yf in (False, True):
+            got = lmm.cov(f, _inp(lmm, x, m, xf), _inp(lmm, y, m, yf))
+            ref = O.mogp_cross_cov(gps, x, y, xf, yf)
+            assert got.shape == (m * n, m * n2)
+            np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-14)
+            ri = O.reorder_indices_outputs_to_features(n, m) if xf else np.arange(m * n)
+            ci = O.reorder_indices_outputs_to_features(n2, m) if yf else np.arange(m * n2)
+            np.testing.assert_allclose(got, naive[np.ix_(ri, ci)], rtol=1e-12, atol=1e-14)
+    # cov(f, x) = cov(f, x, x): reference src/independent_mogp.jl:60-63
+    np.testing.assert_allclose(lmm.cov(f, _inp(lmm, x, m, False)), O.mogp_cov(gps, x), rtol=1e-12, atol=1e-14)
+
+
+@pytest.mark.parametrize("n,n2", [(9, 70), (130, 40)])
+def test_mogp_cross_cov_posterior(lmm, n, n2):
+    """The same on PosteriorGP latents (posterior(f(x0, s2), y0): src/independent_mogp.jl:119-126; the posterior's latents answer
+    cov(f_l, x, y) = K(x, y) - A_x' A_y), including a sequentially conditioned posterior and the latents of a posterior OILMM."""
+    rng = np.random.default_rng(77 + n)
+    m, n0, s2 = 3, 150, 0.2
+    gps = _gps(m, rng)
+    x0 = np.sort(rng.uniform(0, 8, n0))
+    y0 = rng.standard_normal(n0 * m)
+    x, y = rng.uniform(0, 8, n), rng.uniform(0, 8, n2)
+    f = _model(lmm, gps)
+    fp = lmm.posterior(f(lmm.MOInputIsotopicByOutputs(x0, m), s2), y0)
+    po = O.mogp_posterior(gps, x0, s2, y0)
+    for xf, yf in [(False, False), (True, False), (False, True), (True, True)]:
+        got = lmm.cov(fp, _inp(lmm, x, m, xf), _inp(lmm, y, m, yf))
+        np.testing.assert_allclose(got, O.mogp_cross_cov(po, x, y, xf, yf), rtol=1e-9, atol=1e-11)
+    # symmetric use: cov(f, x, x) is the block-diagonal posterior covariance the existing cov(fx) path serves (without noise)
+    cxx = lmm.cov(fp, lmm.MOInputIsotopicByOutputs(x, m))
+    np.testing.assert_allclose(cxx, O.mogp_cov(po, x), rtol=1e-9, atol=1e-11)
+    # sequential conditioning: posterior(fp(x1, s2b), y1)
+    n1, s2b = 40, 0.3
+    x1 = np.sort(rng.uniform(0, 8, n1)); y1 = rng.standard_normal(n1 * m)
+    fp2 = lmm.posterior(fp(lmm.MOInputIsotopicByOutputs(x1, m), s2b), y1)
+    po2 = [O.gp_posterior(g, x1, s2b, y1.reshape(m, n1)[l]) for l, g in enumerate(po)]
+    np.testing.assert_allclose(lmm.cov(fp2, _inp(lmm, x, m, False), _inp(lmm, y, m, True)),
+                               O.mogp_cross_cov(po2, x, y, False, True), rtol=1e-8, atol=1e-10)
+    # latents of a posterior OILMM: get_latent_gp(posterior(fx, y)) (reference src/ilmm.jl:39 on src/oilmm.jl:133)
+    p = 4
+    U, _ = np.linalg.qr(rng.standard_normal((p, m)))
+    S = np.linspace(1.5, 0.9, m)
+    yo = rng.standard_normal(n0 * p)
+    post = lmm.posterior(lmm.ILMM(f, lmm.Orthogonal(U, S))(lmm.MOInputIsotopicByOutputs(x0, p), s2), yo)
+    lat = O.oilmm_posterior(gps, U, S, x0, s2, yo)
+    np.testing.assert_allclose(lmm.cov(lmm.get_latent_gp(post), _inp(lmm, x, m, False), _inp(lmm, y, m, False)),
+                               O.mogp_cross_cov(lat, x, y), rtol=1e-9, atol=1e-11)
+
+
+def test_mogp_cross_cov_shards_and_errors(lmm):
+    """Shards fill disjoint blocks and sum to the whole; wrong out_dim raises the reference's error text (src/ilmm.jl:52 wording)."""
+    from lmm_amd import _lib as L
+    rng = np.random.default_rng(5)
+    m, n, n2 = 4, 33, 21
+    gps = _gps(m, rng)
+    x, y = rng.uniform(0, 5, n), rng.uniform(0, 5, n2)
+    lib = lmm.load()
+    acc = np.zeros((m * n2, m * n))
+    for l0, l1 in [(0, 1), (1, 3), (3, 4)]:
+        out = np.empty((m * n) * (m * n2))
+        L.check(lib.lmm_mogp_cross_cov(None, L.gps_array(gps), m, l0, l1, L.Arr(x).ptr, 1, n, 0, L.Arr(y).ptr, n2, 1,
+                                       L.Arr(out, True).ptr))
+        acc += out.reshape(m * n2, m * n)
+    np.testing.assert_allclose(acc.T, O.mogp_cross_cov(gps, x, y, False, True), rtol=1e-12, atol=1e-14)
+    with pytest.raises(RuntimeError, match="out dim of x != out dim of f."):
+        lmm.cov(_model(lmm, gps), lmm.MOInputIsotopicByOutputs(x, m + 1), lmm.MOInputIsotopicByOutputs(y, m))
+
+
+# ---------------------------------------------------------------------------------------------------
+# (b) the headline value
+# ---------------------------------------------------------------------------------------------------
+def test_c2_full_value_equals_sum_of_eight_shares(lmm):
+    """bench.py's N = 1 evaluation of BASELINE configs[2] (the number in BENCH_rNN.json) against the sum of the eight per-rank partials
+    of the 8-GPU job -- two different launch plans of the same arithmetic (reference src/oilmm.jl:79-93: sum(lmls) + regulariser)."""
+    import torch
+    from lmm_amd.workloads import synthetic_problem
+    m, p, n, s2 = 32, 64, 16384, 0.1
+    P = synthetic_problem(m, p, n, "matern52", True, s2=s2, seed=0)
+    fs = lmm.independent_mogp([lmm.GP(lmm.Matern52Kernel()) for _ in range(m)])
+    H = lmm.Orthogonal(P["U"], P["S"])
+    xd, yd = torch.from_numpy(P["x"]).cuda(), torch.from_numpy(P["y"]).cuda()
+    xin = lmm.MOInputIsotopicByOutputs(xd, p)
+    whole = lmm.logpdf(lmm.ILMM(fs, H)(xin, s2), yd, True)
+    parts = [lmm.logpdf(lmm.ILMM(fs, H, shard=lmm.latent_shard(m, r, 8))(xin, s2), yd, r == 0) for r in range(8)]
+    assert np.isfinite(whole)
+    assert abs(sum(parts) - whole) <= 1e-12 * abs(whole), (whole, sum(parts))
+    # anchor: latent 0's log marginal likelihood against host LAPACK (same check as test_c2_share_properties, on THIS plan's inputs)
+    one = lmm.logpdf(lmm.ILMM(fs, H, shard=(0, 1))(xin, s2), yd, False)
+    T, ST = O.project_orthogonal(P["U"], P["S"], s2)
+    ref = O.gp_logpdf(P["gps"][0], P["x"], ST[0], T[0] @ O.reshape_y(P["y"], n))
+    assert abs(one - ref) <= 1e-9 * abs(ref), (one, ref)
+    lmm.load().lmm_release_cached_memory()
+
+
+# ---------------------------------------------------------------------------------------------------
+# (c) flag-epoch wrap-around
+# ---------------------------------------------------------------------------------------------------
+def test_flag_epoch_wraparound_clear(lmm):
+    """The dependency flags of the dataflow kernels are tagged with a 26-bit launch epoch and never reset; when the epoch wraps every
+    persistent flag word is cleared (lmm_kernels.hip next_flag_epoch).  Set the epoch just below the wrap and evaluate across it."""
+    lib = lmm.load()
+    rng = np.random.default_rng(11)
+    m, p, n, s2 = 4, 6, 600, 0.1
+    P = O.synthetic_problem(m, p, n, "matern52", True, s2=s2, seed=4)
+    f = lmm.ILMM(_model(lmm, P["gps"]), lmm.Orthogonal(P["U"], P["S"]))
+    fx = f(lmm.MOInputIsotopicByOutputs(P["x"], p), s2)
+    ref = O.oilmm_logpdf(P["gps"], P["U"], P["S"], P["x"], s2, P["y"])
+    before = lmm.logpdf(fx, P["y"])
+    old = C.c_int()
+    assert lib.lmm_dev_flag_epoch(C.c_int((1 << 26) - 2), C.byref(old)) == 0
+    vals = [lmm.logpdf(fx, P["y"]) for _ in range(4)]              # epochs 2^26 - 1, then the wrap to 1, 2, 3
+    now = C.c_int()
+    assert lib.lmm_dev_flag_epoch(C.c_int(-1), C.byref(now)) == 0
+    assert 1 <= now.value <= 16, now.value                          # the counter wrapped
+    for v in [before] + vals:
+        assert abs(v - ref) <= 1e-9 * abs(ref), (v, ref)
+    del rng

@@ -246,3 +246,23 @@ def test_workload_generator_matches_oracle_copy():
                 np.testing.assert_array_equal(a[k], b[k])
             else:
                 assert a[k] == b[k]
+
+
+def test_mogp_cross_cov_equals_naive_lmm_kernel_with_identity_mixing():
+    """reference test/independent_mogp.jl:140-141: cov(f, x, x') == cov(GP(LinearMixingModelKernel(kernels, I)), x, x') for by-features
+    x and by-outputs x' (and every other combination: src/independent_mogp.jl:66-71, 184-215)."""
+    rng = np.random.default_rng(8)
+    m, n, n2 = 2, 3, 4
+    gps = [{"kind": "se", "variance": 1.0, "lengthscale": 1.0, "mean": 0.0}, {"kind": "se", "variance": 0.5, "lengthscale": 1.0, "mean": 0.0}]
+    x, y = rng.uniform(0, 3, n), np.linspace(0.0, 3.0, n2)
+    naive = O.naive_cov(gps, np.eye(m), x, y)
+    for xf in (False, True):
+        for yf in (False, True):
+            ri = O.reorder_indices_outputs_to_features(n, m) if xf else np.arange(m * n)
+            ci = O.reorder_indices_outputs_to_features(n2, m) if yf else np.arange(m * n2)
+            np.testing.assert_allclose(O.mogp_cross_cov(gps, x, y, xf, yf), naive[np.ix_(ri, ci)], rtol=1e-14, atol=1e-15)
+    # known answer of the index vector (test/independent_mogp.jl:86-98: [1,1,1,2,2,2] <-> [1,2,1,2,1,2], 0-based here)
+    assert list(np.array([1, 1, 1, 2, 2, 2])[O.reorder_indices_outputs_to_features(3, 2)]) == [1, 2, 1, 2, 1, 2]
+    # posterior latents: cov(f, x, x) of the cross form is the posterior covariance
+    po = O.mogp_posterior(gps, x, 0.1, rng.standard_normal(m * n))
+    np.testing.assert_allclose(O.mogp_cross_cov(po, y, y), O.mogp_cov(po, y), rtol=1e-12, atol=1e-14)

@@ -123,8 +123,11 @@ def test_shim_covers_the_reference_method_families():
                 "lmm_oilmm_mean_and_var", "lmm_ilmm_post_mean_and_var", "lmm_latent_marginals", "lmm_lmm_mean_and_cov",
                 "lmm_ilmm_post_mean_and_cov", "lmm_lmm_rand_multi", "lmm_ilmm_post_rand", "lmm_oilmm_logpdf_grad",
                 "lmm_oilmm_post_logpdf_grad", "lmm_ilmm_logpdf_grad", "lmm_ilmm_post_logpdf_grad", "lmm_reorder",
-                "lmm_ilmm_post_latent_view", "lmm_post_destroy"]:
+                "lmm_ilmm_post_latent_view", "lmm_post_destroy", "lmm_mogp_cross_cov"]:
         assert sym in used, sym
     assert "Distributions._rand!" in src
+    # cov(f, x, y) on the GP itself, every input-order combination through one method (reference src/independent_mogp.jl:66-71, 184-215)
+    assert re.search(r"AbstractGPs\.cov\(f::HIPMOGP, x::MOIsotopic, y::MOIsotopic\)", src)
+    assert "MOIsotopic = Union{MOInputIsotopicByOutputs,MOInputIsotopicByFeatures}" in src
     for verb in ["logpdf", "rand", "mean", "var", "cov", "posterior"]:
         assert re.search(r"AbstractGPs\.%s\([^)]*ByFeatures" % verb, src), verb
