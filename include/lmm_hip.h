@@ -35,13 +35,16 @@
  *     of the process's one context, NOT call arguments: they apply to every later call of every thread until changed (a posterior
  *     handle remembers the dtype it was built in and refuses the other one).
  *   - forward progress of the dataflow kernels (LMM_ERR_HIP "dependency wait timed out"): potrf_region_kernel and the fused update
- *     launches run cooperating workgroups that wait on flags written by other workgroups of the SAME launch.  Every workgroup takes
- *     its task from a ticket drawn at kernel entry (an atomic counter, so tasks are claimed in the order workgroups actually start,
- *     whatever order the hardware dispatches blockIdx in); a task waits only for tasks with LOWER tickets -- which are therefore
- *     already running or finished -- with one exception: a walker waits for the helper of its current row, a higher ticket, after it
- *     has published everything the lower-ticket helpers need to finish and free their slots.  So the launch completes with any number
- *     of resident workgroups >= 1 per matrix chain.  Every wait is additionally bounded (4 s of the 100-MHz wall clock, or another
- *     workgroup's abort word): a violation drains the grid and surfaces as LMM_ERR_HIP, never as a hang or a wrong value.
+ *     launches (NODE_FUSE) run cooperating workgroups that wait on flags written by other workgroups of the SAME launch.  A workgroup's
+ *     task is its blockIdx.x, and the deadlock-freedom argument ASSUMES that the hardware starts the workgroups of a 1-D grid in index
+ *     order -- what every AMD GPU to date does, but not something HIP promises: a task waits only for tasks with LOWER indices (already
+ *     running or finished under that assumption), with one exception, the walker of a matrix, which waits for the helper of its current
+ *     row -- a higher index -- only after it has published everything the lower-indexed helpers need to finish and free their slots.
+ *     Under the assumption a launch completes with any number of resident workgroups.  Should a device ever dispatch out of order, the
+ *     library does not hang and does not return a wrong value: every wait is bounded (4 s of the 100-MHz wall clock, or another
+ *     workgroup's epoch-tagged abort word); the grid drains and the call returns LMM_ERR_HIP.  (A ticket drawn from an atomic counter at
+ *     workgroup entry would remove the assumption; it costs ~1.5 us at the head of the latency-bound chain of the small problems --
+ *     1-2 % of a BASELINE configs[0] evaluation -- and is not taken.)
  */
 #ifndef LMM_HIP_H
 #define LMM_HIP_H
