@@ -362,8 +362,7 @@ static int g_slots_in_flight = 1;       // batches that run concurrently on the 
 static int g_region_whole = 1;          // LMM_REGION_ALL=1: also as the base case of the recursion for larger matrices (measured: no gain)
 static int g_region_cols = -1;          // widest block column potrf_region_kernel takes in one launch (LMM_REGION=<columns>, up to 1024; default 0: off)
 // bulk_done (implies first_done): the rows below that block are solved as well (the update launch that factored it ran them too).
-struct NodeFlags { int* p = nullptr; int stride = 0; int min_k = 0, max_k = 1 << 30; int rows_real = -1; BatchPtr S{}; int region_cols = 0;
-                   const RegionGram* gram = nullptr; };      // gram: the matrix is ONE region launch that assembles its own Gram (round 5)   // region_cols: widest block column that becomes ONE dataflow launch in this factorisation   // S: region assistants' scratch      // rows_real: rows that hold data (-1: all NR)
+struct NodeFlags { int* p = nullptr; int stride = 0; int min_k = 0, max_k = 1 << 30; int rows_real = -1; BatchPtr S{}; int region_cols = 0; };   // region_cols: widest block column that becomes ONE dataflow launch in this factorisation   // S: region assistants' scratch      // rows_real: rows that hold data (-1: all NR)
 void potrf_rec_panel(const Batch& B, const BatchPtr& W2, const BatchInfo& flags, const NodeFlags& nfl, int ld, int NR, int j0, int w, int n_real,
                      hipStream_t st, bool first_done, bool bulk_done = false) {
   const double nb = B.nb;
@@ -372,8 +371,7 @@ void potrf_rec_panel(const Batch& B, const BatchPtr& W2, const BatchInfo& flags,
     const double Mr = (nfl.rows_real >= 0 ? std::min(NR, nfl.rows_real) : NR) - j0, Wd = w;
     const double fl = Mr * Wd * Wd - 2.0 * Wd * Wd * Wd / 3.0;           // flops of factoring an Mr x Wd tall panel: Mr Wd^2 - 2 Wd^3 / 3
     ProfScope ps(LMM_PROF_REGION, nb * fl, st, NR - j0, w, w);
-    if (nfl.gram != nullptr && (j0 != 0 || first_done)) throw fail(LMM_ERR_HIP, "internal: fused Gram assembly needs the whole matrix in one region launch");
-    launch_region(B.A, B.W, W2, B.info, flags, ld, NR, j0, w, n_real, B.nb, first_done, st, nfl.rows_real, &nfl.S, nfl.gram);
+    launch_region(B.A, B.W, W2, B.info, flags, ld, NR, j0, w, n_real, B.nb, first_done, st, nfl.rows_real, &nfl.S);
     return;
   }
   if (w == 128) {
@@ -421,29 +419,15 @@ void potrf_rec_panel(const Batch& B, const BatchPtr& W2, const BatchInfo& flags,
 
 // Entry point of the factorisation of a batch: columns [0, NC) of every matrix.  Float64 batches take the 128-column panel path
 // (LMM_PANEL128=0: the round-2 path); its W2 scratch -- one 128 x 128 inverse per panel and matrix -- lives until the API call ends.
-static int g_panel128 = -1;
-static void potrf_config_init() {
-  if (g_panel128 < 0) { const char* e = getenv("LMM_PANEL128"); g_panel128 = e ? (atoi(e) != 0) : 1; }
-  if (g_region_cols < 0) { const char* e = getenv("LMM_REGION"); g_region_cols = e ? atoi(e) : 1024; const char* ea = getenv("LMM_REGION_ALL"); g_region_whole = (ea && atoi(ea) != 0) ? 0 : 1; if (g_region_cols > 128 * LMM_REGION_MAX_PANELS) g_region_cols = 128 * LMM_REGION_MAX_PANELS; }
-}
-// Will potrf_batch factor a matrix of this shape by ONE region launch that can also assemble the Gram and reduce the result (RegionGram)?
-// The caller then skips the Gram launch and the lml_reduce launch.  LMM_GRAM_FUSE=0: never (the separate launches of rounds 1-4).
-bool potrf_fuses_gram(int ld, int NR, int NC, int nrhs) {
-  potrf_config_init();
-  static int fuse_env = -1;
-  if (fuse_env < 0) { const char* e = getenv("LMM_GRAM_FUSE"); fuse_env = e ? atoi(e) : 1; }
-  return fuse_env && !g_f32 && g_panel128 && NC >= 128 && (NC % 128) == 0 && !(ld & 1) && g_region_cols > 0 && NC <= g_region_cols &&
-         nrhs >= 1 && nrhs <= 16 && NR - NC == 64;
-}
-void potrf_batch(const Batch& B, int ld, int NR, int NC, int n_real, hipStream_t st, int rows_real = -1, const RegionGram* gram = nullptr) {
+void potrf_batch(const Batch& B, int ld, int NR, int NC, int n_real, hipStream_t st, int rows_real = -1) {
   for (int j = 0; j < B.nb; ++j) {
     guard_extent(B.A.p[j], NR, ld, NC, true, "factorisation (factor matrix)");
     guard_extent(B.W.p[j], 64, 64, (size_t)(NC / 64) * 64, true, "factorisation (inverse diagonal blocks)");
   }
-  potrf_config_init();
-  const int panel128 = g_panel128;
-  if (gram != nullptr && !potrf_fuses_gram(ld, NR, NC, gram->nrider)) throw fail(LMM_ERR_HIP, "internal: fused Gram assembly requested for a shape that does not take it");
+  static int panel128 = -1;
+  if (panel128 < 0) { const char* e = getenv("LMM_PANEL128"); panel128 = e ? (atoi(e) != 0) : 1; }
   if (g_f32 || !panel128 || NC < 128 || (ld & 1)) { potrf_rec(B, ld, NR, 0, NC, n_real, st); return; }
+  if (g_region_cols < 0) { const char* e = getenv("LMM_REGION"); g_region_cols = e ? atoi(e) : 1024; const char* ea = getenv("LMM_REGION_ALL"); g_region_whole = (ea && atoi(ea) != 0) ? 0 : 1; if (g_region_cols > 128 * LMM_REGION_MAX_PANELS) g_region_cols = 128 * LMM_REGION_MAX_PANELS; }
   const size_t per = (size_t)(NC / 128) * 16384;
   double* w2 = call_scratch(per * B.nb);
   BatchPtr W2{};
@@ -501,7 +485,6 @@ void potrf_batch(const Batch& B, int ld, int NR, int NC, int n_real, hipStream_t
   nfl.min_k = fuse_min_k; nfl.max_k = fuse_max_k;
   nfl.rows_real = rows_real;
   nfl.region_cols = region_here ? region_cols : 0;
-  nfl.gram = gram;
   if (fuse_bulk && !region_here && NC > 128) {
     nfl.stride = (int)node_flag_ints(NR);
     const size_t ints = (size_t)nfl.stride * B.nb;
@@ -854,13 +837,6 @@ int latent_lmls(const double* xd, int d, int n, const lmm_gp_t* gps, const doubl
   char* pk = static_cast<char*>(pin_take(nbytes));
   char* pk_dev = pin_dev(pk);
   if (!pk) { pageable.resize(nbytes / sizeof(double)); pk = reinterpret_cast<char*>(pageable.data()); }
-  // Round 5, small problems: when a factor matrix is ONE region launch, that launch also assembles the Gram (every tile computed by the
-  // workgroup that touches it first) and reduces the result (log det from the walker, ||L^-1 delta||^2 from the thin row stream), both
-  // written straight into the pinned arena: [ms log-dets | 16 ms squared norms | ms pivot-info ints]
-  double* fz = nullptr;
-  if (pk_dev && potrf_fuses_gram(D.ld, D.NR, D.NC, nrhs)) fz = static_cast<double*>(pin_take(((size_t)17 * ms + ((size_t)ms + 1) / 2) * sizeof(double)));
-  double* fz_dev = pin_dev(fz);
-  const bool fuse = fz != nullptr && fz_dev != nullptr;
   // The kernels that produce the riders go out only now: issued before the plan / slot / pool work above, they finished while the
   // host was still preparing and the device then idled ~5 us ahead of the Gram launch (a twentieth of a C0-sized evaluation)
   if (pre_launch) (*pre_launch)();
@@ -870,23 +846,6 @@ int latent_lmls(const double* xd, int d, int n, const lmm_gp_t* gps, const doubl
     Slot& s = slots[bi % nslots];
     const int nb = std::min(nb_per, ms - k0);
     Batch B;
-    if (fuse) {
-      RegionGram rg{};
-      rg.x = xd; rg.d = d; rg.n = n; rg.nrider = nrhs; rg.rider_ld = n; rg.pad_diag = 1.0;
-      for (int j = 0; j < nb; ++j) {
-        const int k = k0 + j;
-        const lmm_gp_t& gp = gps[l0 + k];
-        rg.kind[j] = gp.kind; rg.var[j] = gp.variance; rg.inv_ls[j] = 1.0 / gp.lengthscale;
-        rg.diag_add[j] = noisevec ? 0.0 : noise[l0 + k];
-        rg.diag_vec[j] = noisevec ? noisevec + (size_t)k * n : nullptr;
-        rg.rider[j] = delta + (size_t)k * nrhs * n;
-        rg.rider_sub[j] = rider_sub ? rider_sub[l0 + k] : 0.0;
-        B.add(s.A[j].p, s.W[j].p, info.p + k);
-      }
-      rg.logdet = fz_dev + k0; rg.quad = fz_dev + ms + (size_t)16 * k0; rg.info_out = reinterpret_cast<int*>(fz_dev + (size_t)17 * ms) + k0;
-      potrf_batch(B, D.ld, D.NR, D.NC, n, s.st, D.NC + nrhs, &rg);
-      continue;
-    }
     {
     // the batch's Gram launches share one event pair (back-to-back launches: the event overhead is not charged per launch)
     const double gb = (double)n * ((double)n + 1.0) / 2.0 * 8.0;
@@ -915,16 +874,6 @@ int latent_lmls(const double* xd, int d, int n, const lmm_gp_t* gps, const doubl
   }
   join_slots(nslots);
   std::vector<int> hinfo(ms);
-  if (fuse) {
-    HIPCHK(hipStreamSynchronize(g.streams[0]));
-    const int* fi = reinterpret_cast<const int*>(fz + (size_t)17 * ms);
-    for (int k = 0; k < ms; ++k) {
-      hinfo[k] = fi[k];
-      // AbstractGPs generic logpdf: -(n log 2 pi + logdet(C) + ||C.U' \ delta||^2) / 2 with logdet(C) = 2 sum log L_kk
-      for (int r = 0; r < nrhs; ++r) lml[(size_t)k * nrhs + r] = -0.5 * ((double)n * kLog2Pi + 2.0 * fz[k] + fz[ms + (size_t)16 * k + r]);
-    }
-    return check_info(hinfo, l0);
-  }
   if (!pk_dev) HIPCHK(hipMemcpyAsync(pk, out.p, nbytes, hipMemcpyDeviceToHost, g.streams[0]));
   HIPCHK(hipStreamSynchronize(g.streams[0]));
   std::memcpy(lml.data(), pk, nout * sizeof(double));

@@ -90,22 +90,6 @@ struct RegionArgs {
   int n128;               // the first n128 row tiles below the square are 128 rows high, the following ones 64
   long long* trace;       // optional (LMM_REGION_TRACE=1, tools/region_trace.py): start / end wall-clock ticks of every workgroup
 };
-// Round 5, small problems (a matrix that is ONE region launch): the Gram assembly and the final reduction ride in potrf_region_kernel --
-// every tile of K + noise is computed by the workgroup that touches it first (the walker: block (0, 0) into its LDS image; helper 1: the
-// tiles (1, 0), (1, 1); helper r >= 2: its own row, column by column, ahead of the products that need it), the rider rows are read from the
-// projection's output, the walker sums log L_kk from the inverse blocks it holds and the thin row stream the squared norms of L^-1 delta:
-// no gram_batch_kernel launch, no lml_reduce_kernel launch, no round trip of the Gram through HBM.  x == nullptr: not fused.
-struct RegionGram {
-  const double* x; int d, n, nrider, rider_ld;         // inputs (d x n), riders: nrider (<= 16) rows of rider_ld entries per matrix
-  double pad_diag;
-  int kind[LMM_MAX_BATCH];
-  double var[LMM_MAX_BATCH], inv_ls[LMM_MAX_BATCH], diag_add[LMM_MAX_BATCH], rider_sub[LMM_MAX_BATCH];
-  const double* diag_vec[LMM_MAX_BATCH];               // optional per-point diagonal term (n values), or nullptr
-  const double* rider[LMM_MAX_BATCH];
-  double* logdet;                                      // out, [matrix]: sum_k log L_kk over the real columns
-  double* quad;                                        // out, [matrix][16]: ||L^-1 (rider_r - rider_sub)||^2 per rider row
-  int* info_out;                                       // out, [matrix]: the pivot-info word at the end of the factorisation
-};
 #define LMM_REGION_MAX_PANELS 8
 #define LMM_REGION_ASST_MIN_C 4           // a helper's product for column block c >= this is split with its row's assistant
 #define LMM_REGION_ASST_MIN_R (LMM_REGION_ASST_MIN_C + 2)
@@ -126,8 +110,7 @@ void region_plan_probe(int P, int nb, int Mb, int Mb_real, int cus, int na_full,
 int region_flag_epoch(int set_to);                       // lmm_dev_flag_epoch: returns the current launch epoch; set_to >= 0 replaces it
 size_t region_flag_ints(int NR);          // ints per matrix that the flags of any region of a matrix with NR rows need
 void launch_region(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2, const BatchInfo& info, const BatchInfo& flags, int ld, int NR,
-                   int c0, int width, int n_real, int nb, bool first_done, hipStream_t st, int rows_real = -1, const BatchPtr* S = nullptr,
-                   const RegionGram* gram = nullptr);
+                   int c0, int width, int n_real, int nb, bool first_done, hipStream_t st, int rows_real = -1, const BatchPtr* S = nullptr);
 // plain trailing update (no leaf) through the node kernel: C -= A B' for the region at j0 + h
 void launch_leaf128(const BatchPtr& A, size_t offD, int ld, const BatchPtr& W, size_t offW, const BatchPtr& W2, size_t offW2,
                     int gcol0, int n_real, const BatchInfo& info, int nb, hipStream_t st);

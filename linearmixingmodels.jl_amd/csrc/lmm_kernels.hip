@@ -1627,9 +1627,7 @@ __device__ __forceinline__ void wg_mm64(const double* __restrict__ As, int sai, 
 // A wait spins on thread 0 (bounded: LMM_REGION_SPIN_TICKS = 4 s of the 100 MHz wall clock, or until another workgroup raised the abort word -- the grid
 // always drains), then an agent-scope acquire fence makes the producer's data visible to the whole workgroup.
 //   [42 + r] asst[r]: column blocks whose first-half partial product the ASSISTANT of square row r has left in the scratch (count c)
-//   [58] asm1: helper 1 has assembled the Gram tiles (1, 0), (1, 1) (fused small-problem form, RegionGram)
-#define REGION_FLAG_ASM1 (34 + LMM_REGION_MAX_PANELS + 16)
-#define REGION_FLAG_INTS (REGION_FLAG_ASM1 + 1)
+#define REGION_FLAG_INTS (34 + LMM_REGION_MAX_PANELS + 16)
 // SLEEP: s_sleep argument between polls (64 clocks each).  1 on the region kernel's chain (a handful of pollers, every 30 ns counts); the
 // hundreds of bulk workgroups of a fused node launch poll the same few words and use 16 (~0.5 us), or they slow the leaf they wait for.
 // The abort word is epoch-tagged like every other flag (epoch * 32 + 1): a word raised by an EARLIER launch on the same slice of the
@@ -2226,38 +2224,9 @@ __device__ __forceinline__ void region_store_W(const RegionArgs& a, int b, const
 #define MM64_FOREACH(BODY) _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int v = 0; v < 2; ++v) _Pragma("unroll") \
     for (int q = 0; q < 4; ++q) { const int i = wi + 16 * u + 4 * q + g_, j = wj + 16 * v + c_; BODY }
 
-// One matrix's parameters of the fused Gram assembly (RegionGram resolved for matrix b); x == nullptr: the Gram is in memory already
-struct GramOne {
-  const double* x; int d, n, kind, nrider, rider_ld;
-  double var, inv_ls, diag_add, pad_diag, rider_sub;
-  const double* diag_vec; const double* rider;
-  double* logdet; double* quad; int* info_out;
-};
-__device__ __forceinline__ GramOne gram_one(const RegionGram& g, int b) {
-  GramOne o;
-  o.x = g.x; o.d = g.d; o.n = g.n; o.kind = g.kind[b]; o.nrider = g.nrider; o.rider_ld = g.rider_ld;
-  o.var = g.var[b]; o.inv_ls = g.inv_ls[b]; o.diag_add = g.diag_add[b]; o.pad_diag = g.pad_diag; o.rider_sub = g.rider_sub[b];
-  o.diag_vec = g.diag_vec[b]; o.rider = g.rider[b];
-  o.logdet = g.logdet ? g.logdet + b : nullptr; o.quad = g.quad ? g.quad + 16 * b : nullptr; o.info_out = g.info_out ? g.info_out + b : nullptr;
-  return o;
-}
-// entry (i, j) of the factor matrix's square as gram_kernel assembles it: kappa(x_i, x_j) (+ noise on the diagonal) for data points, the
-// identity in the padding columns / rows (reference: kernelmatrix of KernelFunctions + the FiniteGP's Sigma_y)
-__device__ __forceinline__ double gram_elem(const GramOne& g, int i, int j) {
-  if (i >= g.n || j >= g.n) return (i == j) ? g.pad_diag : 0.0;
-  double r, r2;
-  if (g.d == 1) { r = fabs(g.x[i] - g.x[j]) * g.inv_ls; r2 = r * r; }
-  else { r2 = scaled_dist2(g.x + (size_t)i * g.d, g.x + (size_t)j * g.d, g.d, g.inv_ls); r = sqrt(r2); }
-  double v = kappa(g.kind, g.var, r, r2);
-  if (i == j) v += g.diag_add + (g.diag_vec ? g.diag_vec[j] : 0.0);
-  return v;
-}
-
 // NF ("no fence", the one-workgroup-per-CU build): hand-offs on the chain are consumed through sc1 loads instead of acquire fences
-// gm.x != nullptr (c0 = 0, the region is the whole matrix): the Gram is assembled at first touch (RegionGram)
 template <bool NF>
-__device__ __forceinline__ void potrf_region_walker(const RegionArgs& a, double* __restrict__ lds, double* __restrict__ Am, int b, int* __restrict__ dflags,
-                                                    const GramOne& gm) {
+__device__ __forceinline__ void potrf_region_walker(const RegionArgs& a, double* __restrict__ lds, double* __restrict__ Am, int b, int* __restrict__ dflags) {
   int dbase = 0;                             // 16 x two-wave diagonal-block factorisations run so far (uniform)
   constexpr int LS = DIAG_LS;
   int* fl = a.flags.p[b];
@@ -2270,9 +2239,6 @@ __device__ __forceinline__ void potrf_region_walker(const RegionArgs& a, double*
   const int c_ = l & 15, g_ = l >> 4, wi = 32 * (w & 1), wj = 32 * (w >> 1);
   const int Q = 2 * a.P;
   int r0 = 0;
-  const bool fusedg = gm.x != nullptr;
-  double logdet = 0.0;                       // fused form: sum of log L_kk over the real columns, collected from the inverse blocks (lane 0 of wave 0)
-  if (fusedg && t == 0) *info = 0;           // (the Gram launch used to zero the pivot-info word; nobody else writes it before the first pivot)
   if (a.first_done) {                        // panel 0 came factored out of the preceding update launch (leaf128)
     r0 = 2;
     img_load(X, a.W.p[b] + (size_t)((a.c0 + 64) / 64) * 4096, 64);     // W_1
@@ -2293,15 +2259,8 @@ __device__ __forceinline__ void potrf_region_walker(const RegionArgs& a, double*
       region_store_W(a, b, X, grow, (r & 1) != 0);                       // (region_publish's barrier completed the image)
       continue;
     }
-    if (fusedg && r == 0) {
-      // block (0, 0) of K + noise straight into the image the factorisation reads (lower triangle; the rest is never read)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) { const int q = t + 256 * e, row = q & 63, col = q >> 6; if (row >= col) X[col * LS + row] = gram_elem(gm, row, col); }
-      src = X;
-    }
     if (r > 0) {
       const size_t gcol = grow - 64;
-      if (fusedg && r == 1) region_wait_ge<1, !NF>(fl + REGION_FLAG_ASM1, a.epoch, 1, abort_word, info);      // helper 1 assembled the tiles (1, 0), (1, 1)
       if (r >= 2) region_wait_ge<1, !NF>(upd + r, a.epoch, r - 1, abort_word, info);     // tiles (r, r-1), (r, r) updated through block r - 2
       if (tr2 && t == 0) tr2[16 + r] = wall_clock64();
       // the diagonal tile (row j, column i) in the lanes that will hold its update D[i][j]
@@ -2331,16 +2290,8 @@ __device__ __forceinline__ void potrf_region_walker(const RegionArgs& a, double*
     if (tr2 && t == 0) tr2[48 + r] = wall_clock64();
     region_store_W(a, b, X, grow, (r & 1) != 0);
     if (t == 0) { const int i = diag_info_of(bad, (int)grow, a.n_real); if (i) atomicCAS(info, 0, i); }
-    if (fusedg && w == 0) {                  // log L_kk = -log W_kk of this block's real columns (W_r is the image in X)
-      const double wkk = X[l * LS + l];
-      logdet += wave_sum(((int)grow + l < a.n_real && wkk > 0.0) ? -log(wkk) : 0.0);
-    }
   }
   region_publish(wk, a.epoch, Q);
-  if (fusedg && t == 0) {                    // results straight into the (device-mapped, pinned) host arena: no reduction launch, no copy
-    if (gm.logdet) *gm.logdet = logdet;
-    if (gm.info_out) *gm.info_out = __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
 }
 
 // HELPER of square row r >= 2, LEFT-LOOKING: column blocks c = 0 .. r-2 in turn,
@@ -2351,7 +2302,7 @@ __device__ __forceinline__ void potrf_region_walker(const RegionArgs& a, double*
 // The walker's request "tiles (r, r-1), (r, r) updated through block r - 2" thus costs, after W_{r-2} arrives, one solve, two 64^3
 // products in registers and one write -- about the time the walker spends in diag64m of block r - 1.
 template <bool DEEP, bool ASST, bool NF>
-__device__ __forceinline__ void potrf_region_helper(const RegionArgs& a, double* __restrict__ lds, double* __restrict__ Am, int b, int r, const GramOne& gm) {
+__device__ __forceinline__ void potrf_region_helper(const RegionArgs& a, double* __restrict__ lds, double* __restrict__ Am, int b, int r) {
   constexpr int LS = DIAG_LS;
   int* fl = a.flags.p[b];
   int* abort_word = fl; int* wk = fl + 1; int* trs = fl + 2; int* upd = fl + 18; int* dinv = fl + 34;
@@ -2364,14 +2315,6 @@ __device__ __forceinline__ void potrf_region_helper(const RegionArgs& a, double*
   const size_t col0 = (size_t)a.c0 * a.ld;
   const double* Wm = a.W.p[b];
   const bool skip = a.first_done && r < 2;
-  const bool fusedg = gm.x != nullptr;
-  if (fusedg && r == 1) {
-    // this workgroup idles until the walker has finished block 1: it assembles the walker's inputs of that block, the Gram tiles
-    // (1, 0) and (1, 1) (lower triangle), write-through
-    MM64_FOREACH(ST_PUB(&Am[(size_t)i * a.ld + grow + j], gram_elem(gm, (int)grow + j, i));
-                 if (j >= i) ST_PUB(&Am[(grow + i) * a.ld + grow + j], gram_elem(gm, (int)grow + j, (int)grow + i));)
-    region_publish(fl + REGION_FLAG_ASM1, a.epoch, 1);
-  }
   if (r >= 2) {
     d4 pa[2][2], pd[2][2];
     MM64_ZERO(pa); MM64_ZERO(pd);
@@ -2385,15 +2328,6 @@ __device__ __forceinline__ void potrf_region_helper(const RegionArgs& a, double*
       d4 pc1[2][2], pc2[2][2];
       const size_t gcol = (size_t)a.c0 + 64 * (size_t)c;
       d4 acc[2][2];
-      // fused form: this column's Gram tile (and, in the last column, the two pair tiles) computed here, ahead of the waits below --
-      // the evaluations of kappa sit in the slack this workgroup has while the walker is still on an earlier block
-      d4 gt[2][2];
-      if (fusedg) {
-        MM64_FOREACH(gt[u][v][q] = gram_elem(gm, (int)grow + j, (int)gcol + i);)
-        if constexpr (LAST) {
-          MM64_FOREACH(pc1[u][v][q] = gram_elem(gm, (int)grow + j, (int)grow - 64 + i); pc2[u][v][q] = (j >= i) ? gram_elem(gm, (int)grow + j, (int)grow + i) : 0.0;)
-        }
-      }
       MM64_ZERO(acc);
       if (c > 0) {
         // row c final through block c - 1: its helper's blocks (c >= 2) and the walker's subdiagonal block
@@ -2418,13 +2352,9 @@ __device__ __forceinline__ void potrf_region_helper(const RegionArgs& a, double*
       }
       const double* Ct = Am + gcol * a.ld + grow;
       __syncthreads();                                                   // the previous column's readers of Y are done
-      if (fusedg) {
-        MM64_FOREACH(Y[i * LS + j] = gt[u][v][q] - acc[u][v][q];)
-      } else {
-        MM64_FOREACH(Y[i * LS + j] = Ct[(size_t)i * a.ld + j] - acc[u][v][q];)       // tile element (row j, column i) -> image Y[col][row]
-        if constexpr (LAST) {
-          MM64_FOREACH(pc1[u][v][q] = C1[(size_t)i * a.ld + j]; pc2[u][v][q] = (j >= i) ? C2[(size_t)i * a.ld + j] : 0.0;)
-        }
+      MM64_FOREACH(Y[i * LS + j] = Ct[(size_t)i * a.ld + j] - acc[u][v][q];)       // tile element (row j, column i) -> image Y[col][row]
+      if constexpr (LAST) {
+        MM64_FOREACH(pc1[u][v][q] = C1[(size_t)i * a.ld + j]; pc2[u][v][q] = (j >= i) ? C2[(size_t)i * a.ld + j] : 0.0;)
       }
       region_wait_ge<1, !NF>(wk, a.epoch, c + 1, abort_word, info);      // W_c (its barrier completes the image)
       // L[r, c]' = W_c tile'   (A[i][k'] = W_c[i][k'] global: (1, 64); R[k'][j] = tile[j][k'] = Y[k' LS + j]: (LS, 1))
@@ -2634,7 +2564,7 @@ __device__ __forceinline__ void potrf_region_row64(const RegionArgs& a, double* 
 //                                                    Dinv is lower triangular: wave w stops at k = 32 (w + 1).
 // Rows 16 .. of the tile are padding (zeros before and after).  Nothing is published: nobody reads a row stream inside the launch.
 struct ThinChunk { double fb[8], fa[8][2]; };
-__device__ __forceinline__ void potrf_region_row_thin(const RegionArgs& a, double* __restrict__ lds, double* __restrict__ Am, int b, int roff, const GramOne& gm) {
+__device__ __forceinline__ void potrf_region_row_thin(const RegionArgs& a, double* __restrict__ lds, double* __restrict__ Am, int b, int roff) {
   int* abort_word = a.flags.p[b];
   int* wk = abort_word + 1; int* trs = abort_word + 2; int* dinv = abort_word + 34;
   int* info = a.info.p[b];
@@ -2643,8 +2573,6 @@ __device__ __forceinline__ void potrf_region_row_thin(const RegionArgs& a, doubl
   const int l15 = lane & 15, lk = lane >> 4;
   const size_t row_i = (size_t)a.c0 + (size_t)roff;       // the tile's first row (its rows 16 .. are padding)
   double* cT = lds;                                      // c'[k][row]: 128 x 16 doubles
-  const bool fusedg = gm.x != nullptr;
-  double quad = 0.0;                                     // fused form: this lane's share of ||z_row||^2, row = l15
   for (int tj = 0; tj < a.P; ++tj) {
     const size_t row_j = (size_t)a.c0 + 128 * (size_t)tj;
     const size_t jw = row_j + 32 * (size_t)w;            // this wave's panel columns = rows jw .. jw + 31 of the square
@@ -2689,12 +2617,7 @@ __device__ __forceinline__ void potrf_region_row_thin(const RegionArgs& a, doubl
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int col = 32 * w + 16 * v + 4 * r + lk;
-        double c0v;
-        if (fusedg) {                                    // the rider rows straight from the projection's output (the Gram launch used to copy them in)
-          const int cg = (int)row_j + col;
-          c0v = (l15 < gm.nrider && cg < gm.n) ? gm.rider[(size_t)l15 * gm.rider_ld + cg] - gm.rider_sub : 0.0;
-        } else c0v = Am[(row_j + col) * a.ld + row_i + l15];
-        cT[col * 16 + l15] = c0v - acc[v][r];
+        cT[col * 16 + l15] = Am[(row_j + col) * a.ld + row_i + l15] - acc[v][r];
       }
     region_wait_ge(dinv + tj, a.epoch, 0, abort_word, info);                          // Dinv_j (its barrier completes cT)
     const double* Dv = a.W2.p[b] + (size_t)(row_j / 128) * 16384;                      // Dinv[out][k] = Dv[k * 128 + out]
@@ -2719,16 +2642,8 @@ __device__ __forceinline__ void potrf_region_row_thin(const RegionArgs& a, doubl
 #pragma unroll
     for (int v = 0; v < 2; ++v)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { Am[(row_j + 32 * w + 16 * v + 4 * r + lk) * a.ld + row_i + l15] = xo[v][r]; quad = __builtin_fma(xo[v][r], xo[v][r], quad); }
+      for (int r = 0; r < 4; ++r) Am[(row_j + 32 * w + 16 * v + 4 * r + lk) * a.ld + row_i + l15] = xo[v][r];
     __syncthreads();                                     // X[i, j] is in memory for this workgroup's own later passes
-  }
-  if (fusedg && gm.quad) {
-    // ||L^-1 delta_row||^2 per rider row: lanes (l15, lk = 0 .. 3) of the four waves hold the partial sums of row l15
-    quad += __shfl_xor(quad, 16, 64);
-    quad += __shfl_xor(quad, 32, 64);
-    if (lane < 16) cT[w * 16 + lane] = quad;             // (cT is free: the last panel's barrier has passed)
-    __syncthreads();
-    if (t < 16) gm.quad[t] = (cT[t] + cT[16 + t]) + (cT[32 + t] + cT[48 + t]);
   }
 }
 
@@ -2738,15 +2653,12 @@ __device__ __forceinline__ void potrf_region_row_thin(const RegionArgs& a, doubl
 // published everything the helpers of rows < r need to finish (they never wait beyond wk = r - 1), so they complete and free their
 // slots however few workgroups are resident, helper r gets dispatched and runs.  One workgroup per CU (414 registers per lane).
 template <int OCC>       // 1: one workgroup per CU (no register spills in the walker); 2: two (the row streams' natural occupancy)
-__global__ __launch_bounds__(256, OCC) void potrf_region_kernel(RegionArgs a, RegionGram gram) {
+__global__ __launch_bounds__(256, OCC) void potrf_region_kernel(RegionArgs a) {
   extern __shared__ __attribute__((aligned(16))) double node_lds[];
   __shared__ int dflags[3];                  // the walker's two-wave diagonal-block factorisation (zero before the walker's first barrier)
   if (threadIdx.x == 0) { dflags[0] = 0; dflags[1] = 0; dflags[2] = 0; }
   const int b = blockIdx.x % a.nb, idx = blockIdx.x / a.nb;
   double* Am = a.A.p[b];
-  GramOne gm;
-  gm.x = nullptr;
-  if (gram.x != nullptr) gm = gram_one(gram, b);
   const int Q = 2 * a.P;
   if (a.trace && threadIdx.x == 0) a.trace[2 * blockIdx.x] = wall_clock64();
   // square tasks in dispatch order: walker, helper 1, ..., helper MIN_R - 1, then (helper r, assistant r) pairs -- a helper's assistant is
@@ -2758,8 +2670,8 @@ __global__ __launch_bounds__(256, OCC) void potrf_region_kernel(RegionArgs a, Re
     r = LMM_REGION_ASST_MIN_R + (k >> 1); role = 1 + (k & 1);
   }
   if (idx >= Q + a.na) role = 3;
-  if (role == 0) potrf_region_walker<OCC == 1>(a, node_lds, Am, b, dflags, gm);
-  else if (role == 1) potrf_region_helper<false, OCC == 1, OCC == 1>(a, node_lds, Am, b, r, gm);      // DEEP (two chunks ahead) spills even at one workgroup per CU
+  if (role == 0) potrf_region_walker<OCC == 1>(a, node_lds, Am, b, dflags);
+  else if (role == 1) potrf_region_helper<false, OCC == 1, OCC == 1>(a, node_lds, Am, b, r);      // DEEP (two chunks ahead) spills even at one workgroup per CU
   else if (role == 2) { if (OCC == 1) potrf_region_assistant<true>(a, Am, b, r); }       // (the two-per-CU build has no assistants)
   else {
     const int k = idx - Q - a.na;                        // row tasks in dispatch order: n128 tiles of 128 rows, then 64-row tiles
@@ -2767,7 +2679,7 @@ __global__ __launch_bounds__(256, OCC) void potrf_region_kernel(RegionArgs a, Re
     const int roff = tall ? 128 * (a.P + k) : 128 * (a.P + a.n128) + 64 * (k - a.n128);
     const int real = a.M_real - roff;                    // rows of this tile that hold data (the rest is zero padding, before and after)
     if (real > 16) { if (tall) potrf_region_row(a, node_lds, Am, b, a.P + k); else potrf_region_row64(a, node_lds, Am, b, roff); }
-    else if (real > 0) potrf_region_row_thin(a, node_lds, Am, b, roff, gm);
+    else if (real > 0) potrf_region_row_thin(a, node_lds, Am, b, roff);
   }
   if (a.trace && threadIdx.x == 0) a.trace[2 * blockIdx.x + 1] = wall_clock64();
 }
@@ -3894,7 +3806,7 @@ void region_plan_probe(int P, int nb, int Mb, int Mb_real, int cus, int na_full,
 }
 size_t region_flag_ints(int) { return REGION_FLAG_INTS; }
 void launch_region(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2, const BatchInfo& info, const BatchInfo& flags, int ld, int NR,
-                   int c0, int width, int n_real, int nb, bool first_done, hipStream_t st, int rows_real, const BatchPtr* S, const RegionGram* gram) {
+                   int c0, int width, int n_real, int nb, bool first_done, hipStream_t st, int rows_real, const BatchPtr* S) {
   const int P = width / 128, M = NR - c0, R = (M + 127) / 128;
   if (nb <= 0 || P <= 0) return;
   node_lds_attr();
@@ -3938,10 +3850,8 @@ void launch_region(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2, con
   long long* tr = nullptr;
   if (trace_env) { if (hipMalloc((void**)&tr, ((size_t)tasks * nb * 2 + 64 * (size_t)nb) * sizeof(long long)) != hipSuccess) tr = nullptr; }
   a.trace = tr; a.ntasks = (int)tasks;
-  RegionGram gz{};                              // x == nullptr: the Gram is in memory (every caller but the fused small-problem logpdf)
-  if (gram != nullptr) gz = *gram;
-  if (occ == 1) hipLaunchKernelGGL(potrf_region_kernel<1>, dim3((unsigned)(tasks * nb)), dim3(256), LEAF_LDS_DOUBLES * 8, st, a, gz);
-  else hipLaunchKernelGGL(potrf_region_kernel<2>, dim3((unsigned)(tasks * nb)), dim3(256), LEAF_LDS_DOUBLES * 8, st, a, gz);
+  if (occ == 1) hipLaunchKernelGGL(potrf_region_kernel<1>, dim3((unsigned)(tasks * nb)), dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
+  else hipLaunchKernelGGL(potrf_region_kernel<2>, dim3((unsigned)(tasks * nb)), dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
   if (tr) {
     (void)hipStreamSynchronize(st);
     std::vector<long long> h((size_t)tasks * nb * 2 + 64 * (size_t)nb);

@@ -172,3 +172,4 @@ def test_flag_epoch_wraparound_clear(lmm):
     for v in [before] + vals:
         assert abs(v - ref) <= 1e-9 * abs(ref), (v, ref)
     del rng
+
