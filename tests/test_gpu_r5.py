@@ -173,3 +173,32 @@ def test_flag_epoch_wraparound_clear(lmm):
         assert abs(v - ref) <= 1e-9 * abs(ref), (v, ref)
     del rng
 
+
+# ---------------------------------------------------------------------------------------------------
+# (d) LMM_DETERMINISTIC=1: bitwise reproducibility above 1024 columns too
+# ---------------------------------------------------------------------------------------------------
+def test_deterministic_mode_is_bitwise_reproducible_above_1024_columns():
+    """by default the K >= 1024 update launches split some tiles along K and combine the parts with f64 atomics, so above
+    1024 columns repeated evaluations agree to ~1e-13, not bitwise (test_region_kernel_is_bitwise_reproducible had to be loosened there:
+    a lost hand-off that perturbs only low bits would pass it).  With LMM_DETERMINISTIC=1 no tile is split: the same shapes -- dataflow
+    block columns with assistants, fused update + leaf launches, many matrices per launch -- must return identical bits every time."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, json; sys.path.insert(0, %r); import numpy as np, torch, lmm_amd; from lmm_amd.workloads import synthetic_problem as sp; "
+            "lmm_amd.init(0); out = {}\n"
+            "for n, m in [(1100, 36), (2048, 16), (3072, 8), (4096, 4)]:\n"
+            "    P = sp(m, 2 * m, n, 'matern52', True, s2=0.1, seed=n + m)\n"
+            "    fx = lmm_amd.ILMM(lmm_amd.independent_mogp([lmm_amd.GP(lmm_amd.Matern52Kernel()) for _ in range(m)]), lmm_amd.Orthogonal(P['U'], P['S']))("
+            "lmm_amd.MOInputIsotopicByOutputs(torch.from_numpy(P['x']).cuda(), 2 * m), 0.1)\n"
+            "    yd = torch.from_numpy(P['y']).cuda()\n"
+            "    out['%%d,%%d' %% (n, m)] = sorted({lmm_amd.logpdf(fx, yd).hex() for _ in range(16)})\n"
+            "print('RESULT' + json.dumps(out))") % root
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LMM_DETERMINISTIC="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    vals = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT")][-1][len("RESULT"):])
+    for shape, v in vals.items():
+        assert len(v) == 1, (shape, v)
+        assert np.isfinite(float.fromhex(v[0])), (shape, v)
