@@ -202,3 +202,25 @@ def test_deterministic_mode_is_bitwise_reproducible_above_1024_columns():
     for shape, v in vals.items():
         assert len(v) == 1, (shape, v)
         assert np.isfinite(float.fromhex(v[0])), (shape, v)
+
+
+def test_mogp_cross_cov_fp32_mode(lmm):
+    """cov(f, x, y) under lmm_set_compute_dtype(LMM_F32): Float32 cross-Gram / solve blocks, Float64 output; stated tolerance as for the
+    other covariances of that mode (entries within 5e-5 of the largest, include/lmm_hip.h)."""
+    rng = np.random.default_rng(41)
+    m, n0, n, n2, s2 = 2, 300, 70, 45, 0.2
+    gps = _gps(m, rng)
+    x0 = np.sort(rng.uniform(0, 8, n0)); y0 = rng.standard_normal(n0 * m)
+    x, y = rng.uniform(0, 8, n), rng.uniform(0, 8, n2)
+    lmm.set_compute_dtype("f32")
+    try:
+        f = _model(lmm, gps)
+        got_prior = lmm.cov(f, _inp(lmm, x, m, False), _inp(lmm, y, m, True))
+        fp = lmm.posterior(f(lmm.MOInputIsotopicByOutputs(x0, m), s2), y0)
+        got_post = lmm.cov(fp, _inp(lmm, x, m, True), _inp(lmm, y, m, False))
+    finally:
+        lmm.set_compute_dtype("f64")
+    ref_prior = O.mogp_cross_cov(gps, x, y, False, True)
+    ref_post = O.mogp_cross_cov(O.mogp_posterior(gps, x0, s2, y0), x, y, True, False)
+    assert np.max(np.abs(got_prior - ref_prior)) <= 5e-6 * np.max(np.abs(ref_prior))      # kappa is computed in Float64, stored Float32
+    assert np.max(np.abs(got_post - ref_post)) <= 5e-5 * np.max(np.abs(ref_prior))

@@ -1,6 +1,6 @@
 # Runs ON THE GPU BOX: the round's evidence at HEAD -- full GPU suite, rocprofv3 stats + PMC passes of the default bench command
 # (tools/collect_profiles.sh), the secondary bench lines.  Everything under gpurun_out/.
-mkdir -p gpurun_out/final
+mkdir -p gpurun_out/final; cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 timeout -k 10 900 python -m pytest tests -q -m gpu > gpurun_out/final/pytest_gpu.log 2>&1; tail -3 gpurun_out/final/pytest_gpu.log
 bash tools/collect_profiles.sh final > gpurun_out/collect_final.log 2>&1
 for w in c0 notebook c1; do python bench.py --workload $w --steps 300 --warmup 30 > gpurun_out/final/bench_$w.json 2> gpurun_out/final/bench_$w.err || exit 1; done
@@ -8,7 +8,7 @@ python bench.py --workload c1dense --steps 10 --warmup 2 > gpurun_out/final/benc
 python bench.py --workload c3 --steps 5 --warmup 1 > gpurun_out/final/bench_c3.json 2> gpurun_out/final/bench_c3.err
 python bench.py --workload c3 --proj bf16 --steps 5 --warmup 1 > gpurun_out/final/bench_c3_bf16proj.json 2> gpurun_out/final/bench_c3_bf16.err
 python bench.py --steps 10 --warmup 2 > gpurun_out/final/bench_c2.json 2> gpurun_out/final/bench_c2.err
-python bench.py --workload c4 --dtype f32 --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/final/bench_c4_f32.json 2> gpurun_out/final/bench_c4_f32.err
+python bench.py --workload c4 --dtype f32 --steps 2 --warmup 1 > gpurun_out/final/bench_c4_f32.json 2> gpurun_out/final/bench_c4_f32.err
 python - <<'PY'
 import json,glob
 for f in sorted(glob.glob("gpurun_out/final/*.json")):
