@@ -183,6 +183,18 @@ int lmm_oilmm_post_logpdf_grad(const double* x, int d, int n, const double* y, c
                                double* grad_ys, double* grad_sigma2, double* grad_sigma2_s, double* grad_S, double* grad_U,
                                lmm_gp_grad_t* grad_gps);
 
+/* The same after SEQUENTIAL conditioning, posterior(posterior(f(x1, s1), y1)(x2, s2), y2) ... (reference src/oilmm.jl:116-134
+ * applied to its own result; nbatch <= 7 batches, each with its OWN noise variance).  x (d x n) and y (n x p, by outputs over the
+ * n points) hold the batches' points in conditioning order, n = sum batch_n; grad_batch_sigma2 receives one derivative per batch.
+ * Exact conditioning makes this the posterior given all batches at once under per-batch noise, so value and total derivatives are
+ * again joint minus marginal.  lmm_oilmm_post_logpdf_grad is this entry with nbatch = 1. */
+int lmm_oilmm_post_logpdf_grad_seq(const double* x, int d, int n, const int* batch_n, const double* batch_sigma2, int nbatch,
+                                   const double* y, const double* xs, int ns, const double* ys, int p, const double* U,
+                                   const double* S, int m, double sigma2_s, const lmm_gp_t* gps, int latent_begin, int latent_end,
+                                   int with_regulariser, double* out_logpdf, double* grad_y, double* grad_ys,
+                                   double* grad_batch_sigma2, double* grad_sigma2_s, double* grad_S, double* grad_U,
+                                   lmm_gp_grad_t* grad_gps);
+
 /* Value and gradient of logpdf(fx::FiniteGP{<:ILMM}, y) for a dense H (reference src/ilmm.jl:150-181; Zygote.gradient(logpdf,
  * ilmmx, y) in test/ilmm.jl:31) w.r.t. y, sigma2, H (p x m, column-major) and each latent's (variance, lengthscale, mean).
  * The reference's dense operation plus the explicit (mn) x (mn) inverse; m*n <= 46000.  Does not shard. */
@@ -200,6 +212,14 @@ int lmm_ilmm_post_logpdf_grad(const double* x, int d, int n, const double* y, co
                               const double* H, int m, double sigma2, double sigma2_s, const lmm_gp_t* gps, const lmm_jitters_t* jit,
                               double* out_logpdf, double* grad_y, double* grad_ys, double* grad_sigma2, double* grad_sigma2_s,
                               double* grad_H, lmm_gp_grad_t* grad_gps);
+
+/* The same after sequential conditioning (src/ilmm.jl:184-198 applied to its own result): arguments as in
+ * lmm_oilmm_post_logpdf_grad_seq; lmm_ilmm_post_logpdf_grad is this entry with nbatch = 1. */
+int lmm_ilmm_post_logpdf_grad_seq(const double* x, int d, int n, const int* batch_n, const double* batch_sigma2, int nbatch,
+                                  const double* y, const double* xs, int ns, const double* ys, int p, const double* H, int m,
+                                  double sigma2_s, const lmm_gp_t* gps, const lmm_jitters_t* jit, double* out_logpdf, double* grad_y,
+                                  double* grad_ys, double* grad_batch_sigma2, double* grad_sigma2_s, double* grad_H,
+                                  lmm_gp_grad_t* grad_gps);
 
 /* logpdf(fx, Y::AbstractMatrix): one value per column of Y ((n p) x ncol, column-major) from ONE factorisation per latent
  * (the extra columns ride the factorisation as rider rows).  The reference does not overload this (it falls to AbstractGPs'

@@ -1220,28 +1220,58 @@ int lmm_oilmm_logpdf(const double* x, int d, int n, const double* y, int p, cons
 
 namespace {
 
+NoiseBlocks one_noise_block(int n, double s2) {
+  NoiseBlocks nb{};
+  nb.nblk = 1; nb.off[0] = 0; nb.off[1] = n; nb.s2[0] = s2;
+  return nb;
+}
+// the conditioning batches (batch_n[b] points with variance batch_s2[b]), optionally followed by ns test points with variance s2s
+NoiseBlocks batch_noise_blocks(const int* batch_n, const double* batch_s2, int nbatch, int ns, double s2s) {
+  NoiseBlocks nb{};
+  nb.off[0] = 0;
+  for (int b = 0; b < nbatch; ++b) { nb.off[b + 1] = nb.off[b] + batch_n[b]; nb.s2[b] = batch_s2[b]; }
+  nb.nblk = nbatch;
+  if (ns > 0) { nb.off[nbatch + 1] = nb.off[nbatch] + ns; nb.s2[nbatch] = s2s; nb.nblk = nbatch + 1; }
+  return nb;
+}
+// argument checks shared by the two *_post_logpdf_grad_seq entries; n = total number of conditioning points
+int check_batches(const int* batch_n, const double* batch_s2, int nbatch, int n) {
+  if (!batch_n || !batch_s2 || nbatch < 1) return fail(LMM_ERR_ARG, "bad arguments");
+  if (nbatch > LMM_MAX_NOISE_BLOCKS - 1) return fail(LMM_ERR_UNSUPPORTED, "more than 7 conditioning batches with their own noise variance");
+  long long tot = 0;
+  for (int b = 0; b < nbatch; ++b) {
+    if (batch_n[b] <= 0) return fail(LMM_ERR_ARG, "empty conditioning batch");
+    if (!(batch_s2[b] > 0.0)) return fail(LMM_ERR_ARG, "sigma2 must be > 0");
+    tot += batch_n[b];
+  }
+  if (tot != n) return fail(LMM_ERR_ARG, "batch sizes do not add up to n");
+  return LMM_OK;
+}
+
 struct OilmmGrad {          // host results of oilmm_grad_core (partial sums over the latent shard)
-  double value = 0.0, gs2a = 0.0, gs2b = 0.0;
+  double value = 0.0;
+  std::vector<double> gs2;    // one per noise block
   std::vector<double> gS, gU;
   std::vector<lmm_gp_grad_t> ggps;
 };
 
-// Value and gradient of the OILMM logpdf (reference src/oilmm.jl:79-113 differentiated) over N points whose first `nsplit`
-// carry observation noise s2a and the rest s2b (nsplit == N: the plain logpdf; nsplit < N: the joint density of training and
-// test points that the predictive logpdf is the difference of).  Per latent: factor, alpha = Kt^-1 delta, Kt^-1 = L^-T L^-1
+// Value and gradient of the OILMM logpdf (reference src/oilmm.jl:79-113 differentiated) over N points in NB.nblk consecutive
+// blocks, block b carrying observation noise NB.s2[b] (one block: the plain logpdf; several: the joint density of the
+// conditioning batches and the test points that the predictive logpdf is the difference of).  Per latent: factor, alpha = Kt^-1 delta, Kt^-1 = L^-T L^-1
 // (triangular solve of identity riders + an upper-triangular SYRK on the MFMA kernels), one fused contraction kernel; the chain
 // rule through T = S^-1/2 U', the projected noise s2/S and the regulariser is small host algebra.
 // xd: d x N (device), yd: N x p column-major (device), gy_dev: N x p device output or nullptr.  Caller holds g_mu.
-int oilmm_grad_core(const double* xd, int d, int N, int nsplit, const double* yd, int p, const double* U, const double* S, int m,
-                    double s2a, double s2b, const lmm_gp_t* gps, int l0, int l1, int with_regulariser, OilmmGrad& G,
-                    double* gy_dev) {
+int oilmm_grad_core(const double* xd, int d, int N, const NoiseBlocks& NB, const double* yd, int p, const double* U, const double* S,
+                    int m, const lmm_gp_t* gps, int l0, int l1, int with_regulariser, OilmmGrad& G, double* gy_dev) {
   hipStream_t st0 = g.streams[0];
-  const int ms = l1 - l0, n = N;
-  const bool two = nsplit < N;
+  const int ms = l1 - l0, n = N, nblk = NB.nblk;
+  const bool two = nblk > 1;
+  const int nsplit = nblk == 2 ? NB.off[1] : N;        // the contraction kernel splits its trace / alpha.alpha sums once
   std::vector<double> T, STa, H;
-  project_orthogonal(U, S, p, m, s2a, T, STa, H);
-  std::vector<double> STb(m);
-  for (int l = 0; l < m; ++l) STb[l] = s2b / S[l];
+  project_orthogonal(U, S, p, m, NB.s2[0], T, STa, H);
+  std::vector<std::vector<double>> ST(nblk, std::vector<double>(m));      // projected noise s2[b] / S[l]
+  for (int b = 0; b < nblk; ++b)
+    for (int l = 0; l < m; ++l) ST[b][l] = NB.s2[b] / S[l];
   Uploaded Td(T, st0);
   std::vector<double> means(m);
   for (int l = 0; l < m; ++l) means[l] = gps[l].mean;
@@ -1252,10 +1282,8 @@ int oilmm_grad_core(const double* xd, int d, int N, int nsplit, const double* yd
   if (ms > 0) project_on_device(yd, n, p, Td.buf, m, l0, ms, meansd.buf.p + l0, delta.p, st0);
   Buf<double> nv(two ? (size_t)n * std::max(ms, 1) : 1);          // per-point projected noise of the shard's latents
   if (two)
-    for (int k = 0; k < ms; ++k) {
-      launch_fill(nv.p + (size_t)k * n, nsplit, STa[l0 + k], st0);
-      launch_fill(nv.p + (size_t)k * n + nsplit, n - nsplit, STb[l0 + k], st0);
-    }
+    for (int k = 0; k < ms; ++k)
+      for (int b = 0; b < nblk; ++b) launch_fill(nv.p + (size_t)k * n + NB.off[b], NB.count(b), ST[b][l0 + k], st0);
   Dims D(n, 1);
   int nb_per = 1, nslots = 1;
   batch_plan(std::max(ms, 1), &nb_per, &nslots, 2.0 * mat_bytes((double)D.elems()));     // factor + inverse-factor matrices
@@ -1270,6 +1298,8 @@ int oilmm_grad_core(const double* xd, int d, int N, int nsplit, const double* yd
   }
   const int NGR = LMM_NGRAD;
   Buf<double> alpha((size_t)D.NC * std::max(ms, 1)), lmld(std::max(ms, 1)), red((size_t)NGR * std::max(ms, 1));
+  // more than two noise blocks: [tr Kinv, alpha.alpha] per (latent, block) from the small per-range kernels
+  Buf<double> blksum(nblk > 2 ? (size_t)2 * nblk * std::max(ms, 1) : 1);
   Buf<int> info(std::max(ms, 1));
   HIPCHK(hipMemsetAsync(info.p, 0, std::max(ms, 1) * sizeof(int), st0));
   HIPCHK(hipMemsetAsync(alpha.p, 0, (size_t)D.NC * std::max(ms, 1) * sizeof(double), st0));
@@ -1308,28 +1338,33 @@ int oilmm_grad_core(const double* xd, int d, int N, int nsplit, const double* yd
       const int k = k0 + j;
       launch_grad_reduce(Am[s][j].p, D.ld, n, nsplit, alb.p[j], delta.p + (size_t)k * n, xd, d, to_dev(gps[l0 + k]), part[s].p,
                          red.p + (size_t)NGR * k, st);
+      if (nblk > 2)
+        for (int b = 0; b < nblk; ++b) {
+          double* o = blksum.p + ((size_t)k * nblk + b) * 2;
+          launch_block_trace(Am[s][j].p, D.ld, n, 1, NB.off[b], NB.off[b + 1], o, st);
+          launch_atb(alb.p[j] + NB.off[b], n, alb.p[j] + NB.off[b], n, NB.count(b), 1, 1, o + 1, st);
+        }
     }
   }
   join_slots(nslots);
   std::vector<double> lml(std::max(ms, 1), 0.0), hred((size_t)NGR * std::max(ms, 1), 0.0);
   std::vector<int> hinfo(std::max(ms, 1), 0);
+  std::vector<double> hblk(nblk > 2 ? (size_t)2 * nblk * std::max(ms, 1) : 0, 0.0);
   HIPCHK(hipMemcpyAsync(lml.data(), lmld.p, std::max(ms, 1) * sizeof(double), hipMemcpyDeviceToHost, st0));
   HIPCHK(hipMemcpyAsync(hred.data(), red.p, (size_t)NGR * std::max(ms, 1) * sizeof(double), hipMemcpyDeviceToHost, st0));
+  if (!hblk.empty() && ms > 0) HIPCHK(hipMemcpyAsync(hblk.data(), blksum.p, hblk.size() * sizeof(double), hipMemcpyDeviceToHost, st0));
   HIPCHK(hipMemcpyAsync(hinfo.data(), info.p, std::max(ms, 1) * sizeof(int), hipMemcpyDeviceToHost, st0));
   // small dense products needed by the chain rule: YA = Y' alpha (p x ms), aTy = alpha_l . (T y)_l, M2 = Y Y' (p x p) per noise block
-  Buf<double> YAd((size_t)p * std::max(ms, 1)), aTyd((size_t)std::max(ms, 1) * m), M2ad((size_t)p * p), M2bd((size_t)p * p);
+  const size_t pp = (size_t)p * p;
+  Buf<double> YAd((size_t)p * std::max(ms, 1)), aTyd((size_t)std::max(ms, 1) * m), M2d(pp * nblk);
   if (ms > 0) {
     launch_atb(yd, n, alpha.p, D.NC, n, p, ms, YAd.p, st0);
     launch_atb(alpha.p, D.NC, Ty.p, n, n, ms, m, aTyd.p, st0);       // [k, l]; only l = l0 + k is used
   }
-  std::vector<double> YA((size_t)p * std::max(ms, 1), 0.0), aTy((size_t)std::max(ms, 1) * m, 0.0), M2a((size_t)p * p, 0.0), M2b((size_t)p * p, 0.0);
+  std::vector<double> YA((size_t)p * std::max(ms, 1), 0.0), aTy((size_t)std::max(ms, 1) * m, 0.0), M2all(pp * nblk, 0.0);
   if (with_regulariser) {
-    launch_atb(yd, n, yd, n, nsplit, p, p, M2ad.p, st0);
-    HIPCHK(hipMemcpyAsync(M2a.data(), M2ad.p, M2a.size() * sizeof(double), hipMemcpyDeviceToHost, st0));
-    if (two) {
-      launch_atb(yd + nsplit, n, yd + nsplit, n, n - nsplit, p, p, M2bd.p, st0);
-      HIPCHK(hipMemcpyAsync(M2b.data(), M2bd.p, M2b.size() * sizeof(double), hipMemcpyDeviceToHost, st0));
-    }
+    for (int b = 0; b < nblk; ++b) launch_atb(yd + NB.off[b], n, yd + NB.off[b], n, NB.count(b), p, p, M2d.p + pp * b, st0);
+    HIPCHK(hipMemcpyAsync(M2all.data(), M2d.p, M2all.size() * sizeof(double), hipMemcpyDeviceToHost, st0));
   }
   HIPCHK(hipMemcpyAsync(YA.data(), YAd.p, YA.size() * sizeof(double), hipMemcpyDeviceToHost, st0));
   HIPCHK(hipMemcpyAsync(aTy.data(), aTyd.p, aTy.size() * sizeof(double), hipMemcpyDeviceToHost, st0));
@@ -1338,24 +1373,29 @@ int oilmm_grad_core(const double* xd, int d, int N, int nsplit, const double* yd
 
   // ---- host chain rule ----
   double total = 0.0;
-  G.gs2a = G.gs2b = 0.0;
+  G.gs2.assign(nblk, 0.0);
   G.gS.assign(m, 0.0); G.gU.assign((size_t)p * m, 0.0);
   G.ggps.assign(m, lmm_gp_grad_t{0.0, 0.0, 0.0});
-  const double na = nsplit, nbk = n - nsplit;
   for (int k = 0; k < ms; ++k) {
     const int l = l0 + k;
     total += lml[k];
     const double* r = &hred[(size_t)NGR * k];
-    const double cl = r[0], tra = r[1], aaa = r[2], ad = r[3], sa = r[4], trb = r[5], aab = r[6];
-    const double sA = STa[l], sB = STb[l], v = gps[l].variance;
-    const double g_sa = 0.5 * (aaa - tra), g_sb = 0.5 * (aab - trb);           // d lml / d noise of block a, b
+    const double cl = r[0], ad = r[3], sa = r[4], v = gps[l].variance;
+    double D_aa = 0.0, D_tr = 0.0, g_s2 = 0.0;       // a'Da, tr(Kt^-1 D) with D the projected noise; sum_b s2[b] dlml/dnoise_b
+    for (int b = 0; b < nblk; ++b) {
+      // tr Kinv and alpha.alpha over the block's rows
+      const double tr = nblk > 2 ? hblk[((size_t)k * nblk + b) * 2] : r[b ? 5 : 1];
+      const double aa = nblk > 2 ? hblk[((size_t)k * nblk + b) * 2 + 1] : r[b ? 6 : 2];
+      const double gb = 0.5 * (aa - tr);                                       // d lml / d (projected noise of block b)
+      D_aa += ST[b][l] * aa; D_tr += ST[b][l] * tr;
+      G.gs2[b] += gb / S[l];
+      g_s2 += gb * NB.s2[b];
+    }
     // 1/2 tr((aa' - Kt^-1) K) / v  with K = Kt - D:  a'delta - a'Da - (n - tr(Kt^-1 D))
-    G.ggps[l].variance = 0.5 * ((ad - (sA * aaa + sB * aab)) - ((double)n - (sA * tra + sB * trb))) / v;
+    G.ggps[l].variance = 0.5 * ((ad - D_aa) - ((double)n - D_tr)) / v;
     G.ggps[l].lengthscale = cl;                                                // sum_{i>j} (a_i a_j - Kinv_ij) dK_ij/dl (x2 / 2)
     G.ggps[l].mean = sa;
-    G.gs2a += g_sa / S[l];
-    G.gs2b += g_sb / S[l];
-    G.gS[l] += -(g_sa * s2a + g_sb * s2b) / (S[l] * S[l]) + 0.5 * aTy[k + (size_t)l * ms] / S[l];
+    G.gS[l] += -g_s2 / (S[l] * S[l]) + 0.5 * aTy[k + (size_t)l * ms] / S[l];
     for (int o = 0; o < p; ++o) G.gU[o + (size_t)l * p] += -YA[o + (size_t)k * p] / std::sqrt(S[l]);
   }
   std::vector<double> PtP;       // P'P for the regulariser's dY
@@ -1377,14 +1417,14 @@ int oilmm_grad_core(const double* xd, int d, int N, int nsplit, const double* yd
     for (int l = 0; l < m; ++l) logdetS += std::log(S[l]);
     std::vector<double> Uv(U, U + (size_t)p * m);
     std::vector<double> PU = matmul(Pm, p, p, Uv, m);
-    for (int blk = 0; blk < (two ? 2 : 1); ++blk) {               // reference src/oilmm.jl:101-113, once per noise block
-      const std::vector<double>& M2 = blk ? M2b : M2a;
-      const double s2 = blk ? s2b : s2a, cnt = blk ? nbk : na;
+    for (int blk = 0; blk < nblk; ++blk) {                        // reference src/oilmm.jl:101-113, once per noise block
+      const std::vector<double> M2(M2all.begin() + pp * blk, M2all.begin() + pp * (blk + 1));
+      const double s2 = NB.s2[blk], cnt = NB.count(blk);
       double Rn = 0.0;                                           // |P Y|_F^2 = tr(P'P Y Y')
       for (int a1 = 0; a1 < p; ++a1) for (int b1 = 0; b1 < p; ++b1) Rn += PtP[a1 + (size_t)b1 * p] * M2[b1 + (size_t)a1 * p];
       total += -(cnt * (logdetS + (double)(p - m) * std::log(2.0 * M_PI * s2)) + Rn / s2) / 2.0;
       for (int l = 0; l < m; ++l) G.gS[l] += -cnt / (2.0 * S[l]);
-      (blk ? G.gs2b : G.gs2a) += -0.5 * (cnt * (double)(p - m) / s2 - Rn / (s2 * s2));
+      G.gs2[blk] += -0.5 * (cnt * (double)(p - m) / s2 - Rn / (s2 * s2));
       std::vector<double> M2U = matmul(M2, p, p, Uv, m);
       std::vector<double> t1 = matmul(Pm, p, p, M2U, m), t2 = matmul(M2, p, p, PU, m);
       for (size_t q = 0; q < G.gU.size(); ++q) G.gU[q] += (t1[q] + t2[q]) / s2;
@@ -1405,7 +1445,7 @@ int oilmm_grad_core(const double* xd, int d, int N, int nsplit, const double* yd
       Uploaded Qd(PtP, st0);
       Buf<double> gr((size_t)n * p);
       launch_tall_skinny(yd, n, n, p, Qd.buf.p, p, p, gr.p, n, nullptr, nullptr, 0, nullptr, 0, st0);   // (Y' (P'P)')' rows
-      launch_vec_lin2(ga.p, gr.p, -1.0 / s2a, -1.0 / s2b, nsplit, n, (size_t)n * p, gy_dev, st0);
+      launch_vec_lin_blocks(ga.p, gr.p, NB, -1.0, n, (size_t)n * p, gy_dev, st0);
       HIPCHK(hipStreamSynchronize(st0));       // ga, gr, Qd are released on return
     } else {
       HIPCHK(hipStreamSynchronize(st0));
@@ -1417,7 +1457,7 @@ int oilmm_grad_core(const double* xd, int d, int N, int nsplit, const double* yd
 void write_oilmm_grad(const OilmmGrad& G, int m, int p, double* out_logpdf, double* grad_sigma2, double* grad_S, double* grad_U,
                       lmm_gp_grad_t* grad_gps) {
   *out_logpdf = G.value;
-  if (grad_sigma2) *grad_sigma2 = G.gs2a + G.gs2b;
+  if (grad_sigma2) { *grad_sigma2 = 0.0; for (double v : G.gs2) *grad_sigma2 += v; }
   if (grad_S) std::copy(G.gS.begin(), G.gS.end(), grad_S);
   if (grad_U) std::copy(G.gU.begin(), G.gU.end(), grad_U);
   if (grad_gps) std::copy(G.ggps.begin(), G.ggps.end(), grad_gps);
@@ -1449,7 +1489,8 @@ int lmm_oilmm_logpdf_grad(const double* x, int d, int n, const double* y, int p,
   DevIn xd(x, (size_t)d * n, st0), yd(y, (size_t)n * p, st0);
   DevOut gy(grad_y, (size_t)n * p);
   OilmmGrad G;
-  if (int rc = oilmm_grad_core(xd.p, d, n, n, yd.p, p, U, S, m, sigma2, sigma2, gps, latent_begin, latent_end, with_regulariser, G, gy.p))
+  if (int rc = oilmm_grad_core(xd.p, d, n, one_noise_block(n, sigma2), yd.p, p, U, S, m, gps, latent_begin, latent_end, with_regulariser,
+                               G, gy.p))
     return rc;
   write_oilmm_grad(G, m, p, out_logpdf, grad_sigma2, grad_S, grad_U, grad_gps);
   if (grad_y) { gy.finish(st0); HIPCHK(hipStreamSynchronize(st0)); }
@@ -1463,21 +1504,26 @@ int lmm_oilmm_logpdf_grad(const double* x, int d, int n, const double* y, int p,
 //     log p(ys | y) = log p(y, ys) - log p(y),
 // so value and TOTAL derivatives (through alpha, the factor and the Schur complement of the posterior) are the difference of
 // two evaluations of the prior-logpdf gradient: the joint over [x; xs] with per-block noise, and the marginal over x.
-int lmm_oilmm_post_logpdf_grad(const double* x, int d, int n, const double* y, const double* xs, int ns, const double* ys, int p,
-                               const double* U, const double* S, int m, double sigma2, double sigma2_s, const lmm_gp_t* gps,
-                               int latent_begin, int latent_end, int with_regulariser, double* out_logpdf, double* grad_y,
-                               double* grad_ys, double* grad_sigma2, double* grad_sigma2_s, double* grad_S, double* grad_U,
-                               lmm_gp_grad_t* grad_gps) {
+// _seq: the posterior was conditioned SEQUENTIALLY, posterior(posterior(f(x1, s1), y1)(x2, s2), y2) ... (reference
+// src/oilmm.jl:116-134 applied to its own result); exact conditioning makes that the posterior given all batches at once with
+// per-batch noise.  x (d x n) and y (n x p by outputs) hold the batches' points in conditioning order, n = sum batch_n.
+int lmm_oilmm_post_logpdf_grad_seq(const double* x, int d, int n, const int* batch_n, const double* batch_sigma2, int nbatch,
+                                   const double* y, const double* xs, int ns, const double* ys, int p, const double* U,
+                                   const double* S, int m, double sigma2_s, const lmm_gp_t* gps, int latent_begin, int latent_end,
+                                   int with_regulariser, double* out_logpdf, double* grad_y, double* grad_ys,
+                                   double* grad_batch_sigma2, double* grad_sigma2_s, double* grad_S, double* grad_U,
+                                   lmm_gp_grad_t* grad_gps) {
   std::lock_guard<std::mutex> lk(g_mu);
   REQUIRE_INIT();
   LMM_TRY
-  // (the same core with two noise blocks: served in the fp32 compute mode too)
+  // (the same core with one noise block per conditioning batch + one for the test points: served in the fp32 compute mode too)
   if (!x || !y || !xs || !ys || !U || !S || !out_logpdf || d <= 0 || n <= 0 || ns <= 0 || p <= 0 || m <= 0)
     return fail(LMM_ERR_ARG, "bad arguments");
   if (m > p) return fail(LMM_ERR_DIM, "out dim of x != out dim of f.");
   if (latent_begin < 0 || latent_end > m || latent_begin > latent_end) return fail(LMM_ERR_ARG, "bad latent shard");
   if (int rc = check_gps(gps, m)) return rc;
-  if (!(sigma2 > 0.0) || !(sigma2_s > 0.0)) return fail(LMM_ERR_ARG, "sigma2 must be > 0");
+  if (int rc = check_batches(batch_n, batch_sigma2, nbatch, n)) return rc;
+  if (!(sigma2_s > 0.0)) return fail(LMM_ERR_ARG, "sigma2 must be > 0");
   hipStream_t st0 = g.streams[0];
   const int N = n + ns;
   DevIn xd(x, (size_t)d * n, st0), yd(y, (size_t)n * p, st0), xsd(xs, (size_t)d * ns, st0), ysd(ys, (size_t)ns * p, st0);
@@ -1488,13 +1534,13 @@ int lmm_oilmm_post_logpdf_grad(const double* x, int d, int n, const double* y, c
   HIPCHK(hipMemcpy2DAsync(yj.p + n, (size_t)N * sizeof(double), ysd.p, (size_t)ns * sizeof(double), (size_t)ns * sizeof(double), p, hipMemcpyDeviceToDevice, st0));
   const bool want_gy = grad_y != nullptr || grad_ys != nullptr;
   OilmmGrad GJ, GM;
-  if (int rc = oilmm_grad_core(xj.p, d, N, n, yj.p, p, U, S, m, sigma2, sigma2_s, gps, latent_begin, latent_end, with_regulariser, GJ,
-                               want_gy ? gj.p : nullptr)) return rc;
-  if (int rc = oilmm_grad_core(xd.p, d, n, n, yd.p, p, U, S, m, sigma2, sigma2, gps, latent_begin, latent_end, with_regulariser, GM,
-                               grad_y ? gm.p : nullptr)) return rc;
+  if (int rc = oilmm_grad_core(xj.p, d, N, batch_noise_blocks(batch_n, batch_sigma2, nbatch, ns, sigma2_s), yj.p, p, U, S, m, gps,
+                               latent_begin, latent_end, with_regulariser, GJ, want_gy ? gj.p : nullptr)) return rc;
+  if (int rc = oilmm_grad_core(xd.p, d, n, batch_noise_blocks(batch_n, batch_sigma2, nbatch, 0, 0.0), yd.p, p, U, S, m, gps,
+                               latent_begin, latent_end, with_regulariser, GM, grad_y ? gm.p : nullptr)) return rc;
   *out_logpdf = GJ.value - GM.value;
-  if (grad_sigma2) *grad_sigma2 = GJ.gs2a - (GM.gs2a + GM.gs2b);
-  if (grad_sigma2_s) *grad_sigma2_s = GJ.gs2b;
+  if (grad_batch_sigma2) for (int b = 0; b < nbatch; ++b) grad_batch_sigma2[b] = GJ.gs2[b] - GM.gs2[b];
+  if (grad_sigma2_s) *grad_sigma2_s = GJ.gs2[nbatch];
   for (int l = 0; l < m; ++l) {
     if (grad_S) grad_S[l] = GJ.gS[l] - GM.gS[l];
     if (grad_gps) {
@@ -1520,6 +1566,16 @@ int lmm_oilmm_post_logpdf_grad(const double* x, int d, int n, const double* y, c
   }
   return LMM_OK;
   LMM_CATCH
+}
+
+// One conditioning batch: posterior(f(x, sigma2), y).
+int lmm_oilmm_post_logpdf_grad(const double* x, int d, int n, const double* y, const double* xs, int ns, const double* ys, int p,
+                               const double* U, const double* S, int m, double sigma2, double sigma2_s, const lmm_gp_t* gps,
+                               int latent_begin, int latent_end, int with_regulariser, double* out_logpdf, double* grad_y,
+                               double* grad_ys, double* grad_sigma2, double* grad_sigma2_s, double* grad_S, double* grad_U,
+                               lmm_gp_grad_t* grad_gps) {
+  return lmm_oilmm_post_logpdf_grad_seq(x, d, n, &n, &sigma2, 1, y, xs, ns, ys, p, U, S, m, sigma2_s, gps, latent_begin, latent_end,
+                                        with_regulariser, out_logpdf, grad_y, grad_ys, grad_sigma2, grad_sigma2_s, grad_S, grad_U, grad_gps);
 }
 
 // logpdf(fx, Y::AbstractMatrix) -- one logpdf per column of Y with ONE factorisation per latent (SURVEY.md 8f next #3;
@@ -1790,32 +1846,36 @@ int lmm_ilmm_logpdf_multi(const double* x, int d, int n, const double* Y, int p,
 namespace {
 
 struct IlmmGrad {            // host results of ilmm_grad_core
-  double value = 0.0, gs2[2] = {0.0, 0.0};
+  double value = 0.0, gs2[LMM_MAX_NOISE_BLOCKS] = {};
   std::vector<double> gH;    // p x m
   std::vector<lmm_gp_grad_t> ggps;
 };
 
-// Value and gradient of the dense-H ILMM prior logpdf over n points of which the first nsplit carry observation noise s2[0] and
-// the rest s2[1] (nsplit == n: one block).  x (d x n), y (n x p by outputs) are DEVICE pointers; gy_dev (n x p, device) may be
-// null.  The two-block form exists for the posterior's predictive density: log p(y* | y) = log p(y, y*) - log p(y)
-// (T y is sufficient for the latents, so the reference's projected posterior, src/ilmm.jl:184-198, is the exact conditional).
-int ilmm_grad_core(const double* xd, int d, int n, int nsplit, const double* yd, int p, const double* H, int m, double s2a, double s2b,
+// Value and gradient of the dense-H ILMM prior logpdf over n points in NB.nblk consecutive blocks, block b carrying observation
+// noise NB.s2[b].  x (d x n), y (n x p by outputs) are DEVICE pointers; gy_dev (n x p, device) may be null.  The multi-block form
+// exists for the posterior's predictive density: log p(y* | y) = log p(y, y*) - log p(y)   (T y is sufficient for the latents,
+// so the reference's projected posterior, src/ilmm.jl:184-198, is the exact conditional), one block per conditioning batch.
+int ilmm_grad_core(const double* xd, int d, int n, const NoiseBlocks& NB, const double* yd, int p, const double* H, int m,
                    const lmm_gp_t* gps, const lmm_jitters_t* jit, IlmmGrad& G, double* gy_dev) {
   if ((long long)m * n > 46000) return fail(LMM_ERR_UNSUPPORTED, "m*n too large for the dense gradient (explicit (mn)^2 inverse)");
   hipStream_t st0 = g.streams[0];
-  const int nblk = nsplit < n ? 2 : 1;
-  const int bi0[2] = {0, nsplit}, bn[2] = {nblk == 2 ? nsplit : n, n - nsplit};
-  const double s2[2] = {s2a, s2b};
-  std::vector<double> T[2], ST[2];
-  double logdetST[2] = {0.0, 0.0};
+  constexpr int KB = LMM_MAX_NOISE_BLOCKS;
+  const int nblk = NB.nblk;
+  int bi0[KB] = {}, bn[KB] = {};
+  double s2[KB] = {};
+  for (int b = 0; b < nblk; ++b) { bi0[b] = NB.off[b]; bn[b] = NB.count(b); s2[b] = NB.s2[b]; }
+  std::vector<double> T[KB], ST[KB];
+  double logdetST[KB] = {};
   for (int b = 0; b < nblk; ++b)
     if (int rc = project_dense(H, p, m, s2[b], jit->project_jitter, T[b], ST[b], &logdetST[b])) return rc;
-  // host copies in the layouts the kernels read: Tt = T' (p x m), Ht = H' (m x p)
-  std::vector<double> Hv(H, H + (size_t)p * m), Tt[2], Ht((size_t)m * p), means(m), STall;
+  // host copies in the layouts the kernels read: Tt = T' (p x m), Ht = H' (m x p); the blocks' T and T' back to back
+  std::vector<double> Hv(H, H + (size_t)p * m), Ht((size_t)m * p), means(m), STall, Tall, Ttall;
   for (int b = 0; b < nblk; ++b) {
-    Tt[b].resize((size_t)p * m);
-    for (int l = 0; l < m; ++l) for (int o = 0; o < p; ++o) Tt[b][o + (size_t)l * p] = T[b][l + (size_t)o * m];
+    std::vector<double> Ttb((size_t)p * m);
+    for (int l = 0; l < m; ++l) for (int o = 0; o < p; ++o) Ttb[o + (size_t)l * p] = T[b][l + (size_t)o * m];
     STall.insert(STall.end(), ST[b].begin(), ST[b].end());
+    Tall.insert(Tall.end(), T[b].begin(), T[b].end());
+    Ttall.insert(Ttall.end(), Ttb.begin(), Ttb.end());
   }
   for (int l = 0; l < m; ++l) {
     means[l] = gps[l].mean;
@@ -1824,16 +1884,18 @@ int ilmm_grad_core(const double* xd, int d, int n, int nsplit, const double* yd,
   std::vector<LatentDev> lat(m);
   for (int l = 0; l < m; ++l) lat[l] = to_dev(gps[l]);
   std::vector<int> sidx(n);
-  for (int i = 0; i < n; ++i) sidx[i] = (i < nsplit) ? 0 : 1;
-  Uploaded Td0(T[0], st0), Td1(T[nblk - 1], st0), STd(STall, st0), Hd(Hv, st0), Ttd0(Tt[0], st0), Ttd1(Tt[nblk - 1], st0), Htd(Ht, st0), meansd(means, st0);
-  const double* Tdv[2] = {Td0.buf.p, Td1.buf.p};
-  const double* Ttdv[2] = {Ttd0.buf.p, Ttd1.buf.p};
+  for (int b = 0; b < nblk; ++b)
+    for (int i = bi0[b]; i < bi0[b] + bn[b]; ++i) sidx[i] = b;
+  Uploaded Tdall(Tall, st0), STd(STall, st0), Hd(Hv, st0), Ttdall(Ttall, st0), Htd(Ht, st0), meansd(means, st0);
+  const double* Tdv[KB] = {};
+  const double* Ttdv[KB] = {};
+  for (int b = 0; b < nblk; ++b) { Tdv[b] = Tdall.buf.p + (size_t)b * m * p; Ttdv[b] = Ttdall.buf.p + (size_t)b * m * p; }
   Buf<LatentDev> latd(m);
   Buf<int> sidxd(n);
   HIPCHK(hipMemcpyAsync(latd.p, lat.data(), m * sizeof(LatentDev), hipMemcpyHostToDevice, st0));
   HIPCHK(hipMemcpyAsync(sidxd.p, sidx.data(), n * sizeof(int), hipMemcpyHostToDevice, st0));
   const int N = m * n;
-  Buf<double> Ty((size_t)N), delta((size_t)N), partial(tall_skinny_partials(n, p)), resid_dev(2);
+  Buf<double> Ty((size_t)N), delta((size_t)N), partial(tall_skinny_partials(n, p)), resid_dev(KB);
   for (int b = 0; b < nblk; ++b) {
     const int i0 = bi0[b], nb_ = bn[b];
     launch_tall_skinny(yd + i0, n, nb_, p, Tdv[b], m, m, Ty.p + i0, n, nullptr, nullptr, 0, nullptr, 0, st0);
@@ -1849,7 +1911,7 @@ int ilmm_grad_core(const double* xd, int d, int n, int nsplit, const double* yd,
   HIPCHK(hipMemsetAsync(alpha.p, 0, (size_t)D.NC * sizeof(double), st0));
   DenseArgs a{};
   a.A = A.p; a.ld = D.ld; a.nrows = D.NR; a.ncols = D.NC; a.x = xd; a.d = d; a.n = n; a.m = m;
-  a.lat = latd.p; a.sigmaT = STd.buf.p; a.sig_idx = nblk == 2 ? sidxd.p : nullptr; a.rider = delta.p; a.rider_ld = N; a.nrider = 1;
+  a.lat = latd.p; a.sigmaT = STd.buf.p; a.sig_idx = nblk > 1 ? sidxd.p : nullptr; a.rider = delta.p; a.rider_ld = N; a.nrider = 1;
   launch_dense_assemble(a, st0);
   potrf_rec(A.p, D.ld, D.NR, 0, D.NC, W.p, N, info.p, st0);
   launch_lml_reduce(A.p, D.ld, N, D.NC, 1, lml_dev.p, st0);
@@ -1860,12 +1922,12 @@ int ilmm_grad_core(const double* xd, int d, int n, int nsplit, const double* yd,
   launch_syrk_upper_set(A.p, D.ld, R.p, D.ld, D.NC, st0);                         // lower(A) = Sigma^-1
   const int NGR = LMM_NGRAD;
   const size_t mm = (size_t)m * m, mp = (size_t)m * p;
-  Buf<double> red((size_t)NGR * m), gpart((size_t)grad_partials(n)), Btr(2 * mm), AAt(2 * mm), AY(2 * mp);
+  Buf<double> red((size_t)NGR * m), gpart((size_t)grad_partials(n)), Btr(KB * mm), AAt(KB * mm), AY(KB * mp);
   for (int l = 0; l < m; ++l)
     launch_grad_reduce(mat_at(A.p, (size_t)l * n * D.ld + (size_t)l * n), D.ld, n, n, alpha.p + (size_t)l * n, delta.p + (size_t)l * n, xd, d,
                        lat[l], gpart.p, red.p + (size_t)NGR * l, st0);
   // regulariser pieces: Rm = Y - (T Y)' H' (n x p), RH = Rm H (n x m), per block Rm' Ty (p x m), RH' Y (m x p)
-  Buf<double> HTY((size_t)n * p), Rm((size_t)n * p), RH((size_t)N), RtTy(2 * mp), RHtY(2 * mp);
+  Buf<double> HTY((size_t)n * p), Rm((size_t)n * p), RH((size_t)N), RtTy(KB * mp), RHtY(KB * mp);
   launch_tall_skinny(Ty.p, n, n, m, Hd.buf.p, p, p, HTY.p, n, nullptr, nullptr, 0, nullptr, 0, st0);
   launch_vec_lin(yd, HTY.p, -1.0, n * p, Rm.p, st0);
   launch_tall_skinny(Rm.p, n, n, p, Htd.buf.p, m, m, RH.p, n, nullptr, nullptr, 0, nullptr, 0, st0);
@@ -1877,8 +1939,8 @@ int ilmm_grad_core(const double* xd, int d, int n, int nsplit, const double* yd,
     launch_atb(Rm.p + i0, n, Ty.p + i0, n, nb_, p, m, RtTy.p + b * mp, st0);
     launch_atb(RH.p + i0, n, yd + i0, n, nb_, m, p, RHtY.p + b * mp, st0);
   }
-  std::vector<double> hred((size_t)NGR * m), hB(2 * mm), hAAt(2 * mm), hAY(2 * mp), hRtTy(2 * mp), hRHtY(2 * mp);
-  double lml = 0.0, resid[2] = {0.0, 0.0};
+  std::vector<double> hred((size_t)NGR * m), hB(KB * mm), hAAt(KB * mm), hAY(KB * mp), hRtTy(KB * mp), hRHtY(KB * mp);
+  double lml = 0.0, resid[KB] = {};
   int hinfo = 0;
   HIPCHK(hipMemcpyAsync(&lml, lml_dev.p, sizeof(double), hipMemcpyDeviceToHost, st0));
   HIPCHK(hipMemcpyAsync(resid, resid_dev.p, nblk * sizeof(double), hipMemcpyDeviceToHost, st0));
@@ -1984,10 +2046,10 @@ int ilmm_grad_core(const double* xd, int d, int n, int nsplit, const double* yd,
   if (gy_dev) {
     // dL/dY (n x p) = -((alpha - RH / sigma2_i) T_i) - Rm / sigma2_i     (alpha as the n x m matrix [point][latent])
     Buf<double> Z((size_t)N), ZT((size_t)n * p);
-    launch_vec_lin2(alpha.p, RH.p, -1.0 / s2[0], -1.0 / s2[nblk - 1], nsplit, n, (size_t)N, Z.p, st0);
+    launch_vec_lin_blocks(alpha.p, RH.p, NB, -1.0, n, (size_t)N, Z.p, st0);
     for (int b = 0; b < nblk; ++b)
       launch_tall_skinny(Z.p + bi0[b], n, bn[b], m, Ttdv[b], p, p, ZT.p + bi0[b], n, nullptr, nullptr, 0, nullptr, 0, st0);
-    launch_vec_lin2(ZT.p, Rm.p, 1.0 / s2[0], 1.0 / s2[nblk - 1], nsplit, n, (size_t)n * p, ZT.p, st0);
+    launch_vec_lin_blocks(ZT.p, Rm.p, NB, 1.0, n, (size_t)n * p, ZT.p, st0);
     launch_vec_axpby(ZT.p, -1.0, ZT.p, 0.0, (size_t)n * p, gy_dev, st0);
     HIPCHK(hipStreamSynchronize(st0));
   }
@@ -2018,7 +2080,7 @@ int lmm_ilmm_logpdf_grad(const double* x, int d, int n, const double* y, int p, 
   DevIn xd(x, (size_t)d * n, st0), yd(y, (size_t)n * p, st0);
   DevOut gy(grad_y, (size_t)n * p);
   IlmmGrad G;
-  if (int rc = ilmm_grad_core(xd.p, d, n, n, yd.p, p, H, m, sigma2, sigma2, gps, jit, G, gy.p)) return rc;
+  if (int rc = ilmm_grad_core(xd.p, d, n, one_noise_block(n, sigma2), yd.p, p, H, m, gps, jit, G, gy.p)) return rc;
   *out_logpdf = G.value;
   if (grad_sigma2) *grad_sigma2 = G.gs2[0];
   if (grad_H) std::copy(G.gH.begin(), G.gH.end(), grad_H);
@@ -2030,17 +2092,20 @@ int lmm_ilmm_logpdf_grad(const double* x, int d, int n, const double* y, int p, 
 
 // Value and TOTAL derivatives of logpdf(posterior(f(x, sigma2), y)(xs, sigma2_s), ys) for the dense-H ILMM -- what
 // Zygote.gradient(logpdf, pi, y_test) differentiates in reference test/ilmm.jl:32 -- as the joint prior density of (y, ys) under
-// two-block noise minus the prior density of y.  Does not shard.
-int lmm_ilmm_post_logpdf_grad(const double* x, int d, int n, const double* y, const double* xs, int ns, const double* ys, int p,
-                              const double* H, int m, double sigma2, double sigma2_s, const lmm_gp_t* gps, const lmm_jitters_t* jit,
-                              double* out_logpdf, double* grad_y, double* grad_ys, double* grad_sigma2, double* grad_sigma2_s,
-                              double* grad_H, lmm_gp_grad_t* grad_gps) {
+// per-block noise minus the prior density of y.  Does not shard.  _seq: sequentially conditioned posterior (src/ilmm.jl:184-198
+// applied to its own result), one noise block per conditioning batch; x, y as in lmm_oilmm_post_logpdf_grad_seq.
+int lmm_ilmm_post_logpdf_grad_seq(const double* x, int d, int n, const int* batch_n, const double* batch_sigma2, int nbatch,
+                                  const double* y, const double* xs, int ns, const double* ys, int p, const double* H, int m,
+                                  double sigma2_s, const lmm_gp_t* gps, const lmm_jitters_t* jit, double* out_logpdf, double* grad_y,
+                                  double* grad_ys, double* grad_batch_sigma2, double* grad_sigma2_s, double* grad_H,
+                                  lmm_gp_grad_t* grad_gps) {
   std::lock_guard<std::mutex> lk(g_mu);
   REQUIRE_INIT();
   LMM_TRY
   if (!x || !y || !xs || !ys || !H || !out_logpdf || d <= 0 || n <= 0 || ns <= 0 || p <= 0 || m <= 0) return fail(LMM_ERR_ARG, "bad arguments");
   if (int rc = check_gps(gps, m)) return rc;
-  if (!(sigma2 > 0.0) || !(sigma2_s > 0.0)) return fail(LMM_ERR_ARG, "sigma2 must be > 0");
+  if (int rc = check_batches(batch_n, batch_sigma2, nbatch, n)) return rc;
+  if (!(sigma2_s > 0.0)) return fail(LMM_ERR_ARG, "sigma2 must be > 0");
   if (!jit) jit = &kDefaultJit;
   hipStream_t st0 = g.streams[0];
   const int N = n + ns;
@@ -2052,11 +2117,13 @@ int lmm_ilmm_post_logpdf_grad(const double* x, int d, int n, const double* y, co
   HIPCHK(hipMemcpy2DAsync(yj.p + n, (size_t)N * sizeof(double), ysd.p, (size_t)ns * sizeof(double), (size_t)ns * sizeof(double), p, hipMemcpyDeviceToDevice, st0));
   const bool want_gy = grad_y != nullptr || grad_ys != nullptr;
   IlmmGrad GJ, GM;
-  if (int rc = ilmm_grad_core(xj.p, d, N, n, yj.p, p, H, m, sigma2, sigma2_s, gps, jit, GJ, want_gy ? gj.p : nullptr)) return rc;
-  if (int rc = ilmm_grad_core(xd.p, d, n, n, yd.p, p, H, m, sigma2, sigma2, gps, jit, GM, grad_y ? gm.p : nullptr)) return rc;
+  if (int rc = ilmm_grad_core(xj.p, d, N, batch_noise_blocks(batch_n, batch_sigma2, nbatch, ns, sigma2_s), yj.p, p, H, m, gps, jit, GJ,
+                              want_gy ? gj.p : nullptr)) return rc;
+  if (int rc = ilmm_grad_core(xd.p, d, n, batch_noise_blocks(batch_n, batch_sigma2, nbatch, 0, 0.0), yd.p, p, H, m, gps, jit, GM,
+                              grad_y ? gm.p : nullptr)) return rc;
   *out_logpdf = GJ.value - GM.value;
-  if (grad_sigma2) *grad_sigma2 = GJ.gs2[0] - GM.gs2[0];
-  if (grad_sigma2_s) *grad_sigma2_s = GJ.gs2[1];
+  if (grad_batch_sigma2) for (int b = 0; b < nbatch; ++b) grad_batch_sigma2[b] = GJ.gs2[b] - GM.gs2[b];
+  if (grad_sigma2_s) *grad_sigma2_s = GJ.gs2[nbatch];
   if (grad_H) for (size_t q = 0; q < (size_t)p * m; ++q) grad_H[q] = GJ.gH[q] - GM.gH[q];
   if (grad_gps)
     for (int l = 0; l < m; ++l) {
@@ -2080,6 +2147,15 @@ int lmm_ilmm_post_logpdf_grad(const double* x, int d, int n, const double* y, co
   }
   return LMM_OK;
   LMM_CATCH
+}
+
+// One conditioning batch: posterior(f(x, sigma2), y).
+int lmm_ilmm_post_logpdf_grad(const double* x, int d, int n, const double* y, const double* xs, int ns, const double* ys, int p,
+                              const double* H, int m, double sigma2, double sigma2_s, const lmm_gp_t* gps, const lmm_jitters_t* jit,
+                              double* out_logpdf, double* grad_y, double* grad_ys, double* grad_sigma2, double* grad_sigma2_s,
+                              double* grad_H, lmm_gp_grad_t* grad_gps) {
+  return lmm_ilmm_post_logpdf_grad_seq(x, d, n, &n, &sigma2, 1, y, xs, ns, ys, p, H, m, sigma2_s, gps, jit, out_logpdf, grad_y, grad_ys,
+                                       grad_sigma2, grad_sigma2_s, grad_H, grad_gps);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -167,7 +167,17 @@ void launch_grad_reduce(const double* Kinv, int ld, int n, int nsplit, const dou
                         LatentDev g, double* partial, double* out7, hipStream_t st);
 void launch_vec_axpby(const double* a, double sa, const double* b, double sb, size_t n, double* out, hipStream_t st);
 void launch_block_trace(const double* Minv, int ld, int n, int m, int i0, int i1, double* out, hipStream_t st);   // points i0..i1-1
-void launch_vec_lin2(const double* a, const double* b, double sa, double sb, int nsplit, int N, size_t count, double* out, hipStream_t st);
+// Consecutive point ranges [off[b], off[b + 1]) that carry the observation-noise variance s2[b]: the conditioning batches of a
+// sequentially conditioned posterior followed by the test points (gradient of the predictive logpdf).
+#define LMM_MAX_NOISE_BLOCKS 8
+struct NoiseBlocks {
+  int nblk;
+  int off[LMM_MAX_NOISE_BLOCKS + 1];
+  double s2[LMM_MAX_NOISE_BLOCKS];
+  int count(int b) const { return off[b + 1] - off[b]; }
+};
+// out[k] = a[k] + (num / s2[block of row k]) * b[k]   with row(k) = k mod N  (column-major N x p operands)
+void launch_vec_lin_blocks(const double* a, const double* b, const NoiseBlocks& nb, double num, int N, size_t count, double* out, hipStream_t st);
 void launch_atb(const double* X, int ldx, const double* Z, int ldz, int n, int na, int nb, double* out, hipStream_t st);
 void launch_fill(double* p, int n, double v, hipStream_t st);
 void launch_reorder(const double* in, int n, int p, int to_outputs, double* out, hipStream_t st);

@@ -3405,10 +3405,14 @@ __global__ __launch_bounds__(256) void block_trace_kernel(const void* __restrict
   if (threadIdx.x == 0) { out[l + (size_t)l2 * m] = tot; out[l2 + (size_t)l * m] = tot; }
 }
 
-// out[k] = a[k] + (row(k) < nsplit ? sa : sb) * b[k]  with row(k) = k mod N  (column-major N x p operands)
-__global__ void vec_lin2_kernel(const double* a, const double* b, double sa, double sb, int nsplit, int N, size_t count, double* out) {
+// out[k] = a[k] + (num / s2[block of row(k)]) * b[k]  with row(k) = k mod N  (column-major N x p operands; blocks: NoiseBlocks)
+__global__ void vec_lin_blocks_kernel(const double* a, const double* b, NoiseBlocks nb, double num, int N, size_t count, double* out) {
   const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < count) out[k] = a[k] + (((int)(k % N) < nsplit) ? sa : sb) * b[k];
+  if (k >= count) return;
+  const int row = (int)(k % N);
+  int blk = 0;
+  while (blk + 1 < nb.nblk && row >= nb.off[blk + 1]) ++blk;
+  out[k] = a[k] + (num / nb.s2[blk]) * b[k];
 }
 
 // out[a + b*na] = sum_i X[i + a*ldx] Z[i + b*ldz]   (X' Z for tall-skinny X (n x na), Z (n x nb)); one block per (a, b).
@@ -4119,8 +4123,8 @@ void launch_block_trace(const double* Minv, int ld, int n, int m, int i0, int i1
   LMM_TS_LAUNCH((block_trace_kernel<TS>), dim3(m, m), dim3(256), 0, st, (const void*)Minv, ld, n, m, i0, i1, out);
 }
 
-void launch_vec_lin2(const double* a, const double* b, double sa, double sb, int nsplit, int N, size_t count, double* out, hipStream_t st) {
-  hipLaunchKernelGGL(vec_lin2_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, a, b, sa, sb, nsplit, N, count, out);
+void launch_vec_lin_blocks(const double* a, const double* b, const NoiseBlocks& nb, double num, int N, size_t count, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(vec_lin_blocks_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, a, b, nb, num, N, count, out);
 }
 
 void launch_atb(const double* X, int ldx, const double* Z, int ldz, int n, int na, int nb, double* out, hipStream_t st) {

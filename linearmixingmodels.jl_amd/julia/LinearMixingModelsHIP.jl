@@ -62,11 +62,11 @@ __init__() = check(ccall((:lmm_init, liblmm), Cint, (Cint,), parse(Cint, get(ENV
 
 # ---- the opt-in latent container ----------------------------------------------------------------------------------
 # Prior: handle == C_NULL.  Posterior: lmm_post_t* (device-resident factors, alpha, x) + the data it was built from
-# (train: needed for TOTAL derivatives of the predictive logpdf; nothing after sequential conditioning).
+# (train: needed for TOTAL derivatives of the predictive logpdf; one entry per conditioning batch, in conditioning order).
 mutable struct HIPMOGP{Tfs<:Vector{<:AbstractGP}} <: AbstractGPs.AbstractGP
     fs::Tfs
     handle::Ptr{Cvoid}
-    train::Any               # nothing | (X::Matrix{Float64}, σ²::Float64, y::Vector{Float64})
+    train::Any               # nothing | Vector of (X::Matrix{Float64}, σ²::Float64, y::Vector{Float64}), one per batch
     # filled by the posterior logpdf rrule: the total-derivative cotangents of the predictive logpdf w.r.t. the training data and
     # training noise, (y_train = ..., sigma2_train = ...), which the pullback itself cannot route anywhere (see the rrule)
     last_train_cotangents::Base.RefValue{Any}
@@ -215,6 +215,21 @@ function AbstractGPs.logpdf(ft::FiniteGP{<:HIPMOGP,<:MOInputIsotopicByOutputs,<:
 end
 
 # ---- posterior ----------------------------------------------------------------------------------------------------
+# the conditioning batches a posterior was built from (nothing: unknown, e.g. the latent view of a dense-H posterior)
+_push_train(train, X, σ², yv) = train === nothing ? nothing : vcat(train, [(X, Float64(σ²), yv)])
+# ... as ONE set of points for the *_post_logpdf_grad_seq entries: X (d x n), sizes, variances, y by outputs over the n points
+function _merged_train(train, p::Integer)
+    length(train) <= 7 || error("gradient of the predictive logpdf after more than 7 conditioning batches is not built")
+    X0 = reduce(hcat, [t[1] for t in train])
+    y0 = vec(reduce(vcat, [reshape(t[3], :, p) for t in train]))            # (n_b x p) blocks stacked per output
+    return X0, Cint[size(t[1], 2) for t in train], Cdouble[t[2] for t in train], y0
+end
+# d/dy of the merged points back to one by-outputs vector per batch; d/dσ² per batch (a scalar for a single batch)
+function _split_train(gy0, gb, bn, p::Integer)
+    length(bn) == 1 && return (y_train=gy0, sigma2_train=gb[1])
+    G = reshape(gy0, :, p); o = cumsum(vcat(0, bn))
+    return (y_train=[vec(G[o[b]+1:o[b+1], :]) for b in eachindex(bn)], sigma2_train=copy(gb))
+end
 # reference src/oilmm.jl:116-134; on a posterior: sequential conditioning (TestUtils on `po`, test/oilmm.jl:34-37)
 function AbstractGPs.posterior(fx::ByOutputsFill{HIPOILMM}, y::AbstractVector{<:Real})
     fs, H, σ², x = unpack(fx)
@@ -224,13 +239,13 @@ function AbstractGPs.posterior(fx::ByOutputsFill{HIPOILMM}, y::AbstractVector{<:
         GC.@preserve X yv U S check(ccall((:lmm_post_condition, liblmm), Cint,
             (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Cdouble, Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Ref{Ptr{Cvoid}}),
             fs.handle, U, S, p, m, σ², X, d, n, yv, h))
-        return ILMM(HIPMOGP(fs.fs, h[], nothing), H)
+        return ILMM(HIPMOGP(fs.fs, h[], _push_train(fs.train, X, σ², yv)), H)
     end
     gps = _gps(fs.fs)
     GC.@preserve X yv U S gps check(ccall((:lmm_oilmm_posterior_create, liblmm), Cint,
         (Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cdouble, Ptr{LmmGp}, Cint, Cint, Ref{Ptr{Cvoid}}),
         X, d, n, yv, p, U, S, m, σ², gps, 0, m, h))
-    return ILMM(HIPMOGP(fs.fs, h[], (X, Float64(σ²), yv)), H)      # again an ILMM with the same H (src/oilmm.jl:133)
+    return ILMM(HIPMOGP(fs.fs, h[], [(X, Float64(σ²), yv)]), H)    # again an ILMM with the same H (src/oilmm.jl:133)
 end
 
 # reference src/independent_mogp.jl:119-126; on a posterior: sequential conditioning (test/independent_mogp.jl:68-76)
@@ -242,13 +257,13 @@ function AbstractGPs.posterior(ft::ByOutputsFill{HIPMOGP}, y::AbstractVector{<:R
         GC.@preserve X yv U S check(ccall((:lmm_post_condition, liblmm), Cint,
             (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Cdouble, Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Ref{Ptr{Cvoid}}),
             ft.f.handle, U, S, m, m, σ², X, d, n, yv, h))
-        return HIPMOGP(ft.f.fs, h[], nothing)
+        return HIPMOGP(ft.f.fs, h[], _push_train(ft.f.train, X, σ², yv))
     end
     gps = _gps(ft.f.fs)
     GC.@preserve X yv gps check(ccall((:lmm_mogp_posterior_create, liblmm), Cint,
         (Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Cint, Cdouble, Ptr{LmmGp}, Cint, Cint, Ref{Ptr{Cvoid}}),
         X, d, n, yv, m, σ², gps, 0, m, h))
-    return HIPMOGP(ft.f.fs, h[], (X, Float64(σ²), yv))
+    return HIPMOGP(ft.f.fs, h[], [(X, Float64(σ²), yv)])
 end
 
 # reference src/ilmm.jl:184-198 (one coupled (mn) x (mn) factorisation); on a posterior: TestUtils on `pi` (test/ilmm.jl:34-37)
@@ -260,13 +275,13 @@ function AbstractGPs.posterior(fx::ByOutputsFill{HIPDenseILMM}, y::AbstractVecto
         GC.@preserve X yv check(ccall((:lmm_ilmm_post_condition, liblmm), Cint,
             (Ptr{Cvoid}, Cdouble, Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Ptr{LmmJitters}, Ref{Ptr{Cvoid}}),
             f.handle, σ², X, d, n, yv, C_NULL, h))
-        return ILMM(HIPMOGP(f.fs, h[], nothing), H)
+        return ILMM(HIPMOGP(f.fs, h[], _push_train(f.train, X, σ², yv)), H)
     end
     gps = _gps(f.fs); Hm = Matrix{Float64}(H)
     GC.@preserve X yv Hm gps check(ccall((:lmm_ilmm_posterior_create, liblmm), Cint,
         (Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Cint, Cdouble, Ptr{LmmGp}, Ptr{LmmJitters}, Ref{Ptr{Cvoid}}),
         X, d, n, yv, p, Hm, m, σ², gps, C_NULL, h))
-    return ILMM(HIPMOGP(f.fs, h[], (X, Float64(σ²), yv)), H)
+    return ILMM(HIPMOGP(f.fs, h[], [(X, Float64(σ²), yv)]), H)
 end
 
 # ---- mean_and_var / marginals / mean / var / mean_and_cov / cov --------------------------------------------------------
@@ -507,7 +522,7 @@ AbstractGPs.var(f::HIPMOGP, x::MOIsotopic) = _mean_var(f, x)[2]
 # ---- gradients: ChainRulesCore.rrule around the ccall --------------------------------------------------------------------
 # The reference's tests take Zygote.gradient(logpdf, fx, y) on prior and posterior models (test/oilmm.jl:31-32,
 # test/ilmm.jl:31-32, test/independent_mogp.jl:65-66).  A ccall is opaque to Zygote, so the pullbacks come from the library
-# (lmm_oilmm_logpdf_grad, lmm_ilmm_logpdf_grad, lmm_oilmm_post_logpdf_grad, lmm_ilmm_post_logpdf_grad) and are mapped onto the reference's structs.
+# (lmm_oilmm_logpdf_grad, lmm_ilmm_logpdf_grad, lmm_oilmm_post_logpdf_grad_seq, lmm_ilmm_post_logpdf_grad_seq) and are mapped onto the reference's structs.
 
 # kernel cotangent: the library differentiates w.r.t. the EFFECTIVE (variance, lengthscale); the chain rule through the
 # kernel's construction: ScaledKernel: v = v_inner σ² -> d/dσ² = gv v_inner; ScaleTransform: ℓ = ℓ_inner / s -> d/ds = -gl ℓ_inner / s².
@@ -530,22 +545,23 @@ _htangent(H::Orthogonal, gU, gS) = Tangent{typeof(H)}(; U=gU, S=Tangent{typeof(H
 function ChainRulesCore.rrule(::typeof(AbstractGPs.logpdf), fx::ByOutputsFill{HIPOILMM}, y::AbstractVector{<:Real})
     fs, H, σ², x = unpack(fx)
     X = _xmat(x); d, n = size(X); U, S, p, m = _hargs(H); gps = _gps(fs.fs); yv = Vector{Float64}(y)
-    val = Ref{Cdouble}(0.0); gσ = Ref{Cdouble}(0.0); gσt = Ref{Cdouble}(0.0)
+    val = Ref{Cdouble}(0.0); gσ = Ref{Cdouble}(0.0)
     gy = Vector{Float64}(undef, n * p); gS = Vector{Float64}(undef, m); gU = Matrix{Float64}(undef, p, m)
     gg = Vector{LmmGpGrad}(undef, m)
     if isposterior(fs)
-        fs.train === nothing && error("gradient of the predictive logpdf after sequential conditioning is not built")
-        X0, σ0, y0 = fs.train; n0 = size(X0, 2); gy0 = Vector{Float64}(undef, n0 * p)
-        GC.@preserve X0 y0 X yv U S gps gy0 gy gS gU gg check(ccall((:lmm_oilmm_post_logpdf_grad, liblmm), Cint,
-            (Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cdouble, Cdouble,
-             Ptr{LmmGp}, Cint, Cint, Cint, Ref{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Cdouble}, Ref{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{LmmGpGrad}),
-            X0, d, n0, y0, X, n, yv, p, U, S, m, σ0, σ², gps, 0, m, 1, val, gy0, gy, gσt, gσ, gS, gU, gg))
+        fs.train === nothing && error("this posterior does not carry its training data")
+        X0, bn, bs, y0 = _merged_train(fs.train, p); n0 = size(X0, 2); gy0 = Vector{Float64}(undef, n0 * p); gb = similar(bs)
+        GC.@preserve X0 bn bs y0 X yv U S gps gy0 gy gb gS gU gg check(ccall((:lmm_oilmm_post_logpdf_grad_seq, liblmm), Cint,
+            (Ptr{Cdouble}, Cint, Cint, Ptr{Cint}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Ptr{Cdouble},
+             Cint, Cdouble, Ptr{LmmGp}, Cint, Cint, Cint, Ref{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Cdouble}, Ptr{Cdouble},
+             Ptr{Cdouble}, Ptr{LmmGpGrad}),
+            X0, d, n0, bn, bs, length(bn), y0, X, n, yv, p, U, S, m, σ², gps, 0, m, 1, val, gy0, gy, gb, gσ, gS, gU, gg))
         # The library returns TOTAL derivatives through the posterior, including those w.r.t. the training data (gy0) and the
-        # training noise (gσt).  The posterior model object has no differentiable slot for (x, σ², y) -- they entered through
+        # training noise (gb, one per conditioning batch).  The posterior model object has no differentiable slot for (x, σ², y) -- they entered through
         # `posterior`, whose own rrule would be the place to receive them -- so THIS pullback propagates the cotangents of the
-        # latent GPs, H, the predictive noise and y* only; gy0 / gσt are NOT propagated by it.  Callers who differentiate
+        # latent GPs, H, the predictive noise and y* only; gy0 / gb are NOT propagated by it.  Callers who differentiate
         # θ -> logpdf(posterior(f_θ(x, σ²), y)(x*, σ²*), y*) end to end use `predictive_logpdf_and_gradient` below, which returns them.
-        fs.last_train_cotangents[] = (y_train=gy0, sigma2_train=gσt[])
+        fs.last_train_cotangents[] = _split_train(gy0, gb, bn, p)      # one entry per conditioning batch when there are several
     else
         GC.@preserve X yv U S gps gy gS gU gg check(ccall((:lmm_oilmm_logpdf_grad, liblmm), Cint,
             (Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cdouble, Ptr{LmmGp}, Cint, Cint, Cint,
@@ -573,15 +589,16 @@ end
 function ChainRulesCore.rrule(::typeof(AbstractGPs.logpdf), ft::ByOutputsFill{HIPMOGP}, y::AbstractVector{<:Real})
     f = ft.f; X = _xmat(ft.x.x); d, n = size(X); m = length(f.fs); σ² = noise_var(ft.Σy)
     U = Matrix{Float64}(I, m, m); S = ones(m); gps = _gps(f.fs); yv = Vector{Float64}(y)
-    val = Ref{Cdouble}(0.0); gσ = Ref{Cdouble}(0.0); gσt = Ref{Cdouble}(0.0)
+    val = Ref{Cdouble}(0.0); gσ = Ref{Cdouble}(0.0)
     gy = Vector{Float64}(undef, n * m); gg = Vector{LmmGpGrad}(undef, m)
     if isposterior(f)
-        f.train === nothing && error("gradient of the predictive logpdf after sequential conditioning is not built")
-        X0, σ0, y0 = f.train; n0 = size(X0, 2)
-        GC.@preserve X0 y0 X yv U S gps gy gg check(ccall((:lmm_oilmm_post_logpdf_grad, liblmm), Cint,
-            (Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cdouble, Cdouble,
-             Ptr{LmmGp}, Cint, Cint, Cint, Ref{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Cdouble}, Ref{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{LmmGpGrad}),
-            X0, d, n0, y0, X, n, yv, m, U, S, m, σ0, σ², gps, 0, m, 0, val, C_NULL, gy, gσt, gσ, C_NULL, C_NULL, gg))
+        f.train === nothing && error("this posterior does not carry its training data")
+        X0, bn, bs, y0 = _merged_train(f.train, m); n0 = size(X0, 2)
+        GC.@preserve X0 bn bs y0 X yv U S gps gy gg check(ccall((:lmm_oilmm_post_logpdf_grad_seq, liblmm), Cint,
+            (Ptr{Cdouble}, Cint, Cint, Ptr{Cint}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Ptr{Cdouble},
+             Cint, Cdouble, Ptr{LmmGp}, Cint, Cint, Cint, Ref{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Cdouble}, Ptr{Cdouble},
+             Ptr{Cdouble}, Ptr{LmmGpGrad}),
+            X0, d, n0, bn, bs, length(bn), y0, X, n, yv, m, U, S, m, σ², gps, 0, m, 0, val, C_NULL, gy, C_NULL, gσ, C_NULL, C_NULL, gg))
     else
         GC.@preserve X yv U S gps gy gg check(ccall((:lmm_oilmm_logpdf_grad, liblmm), Cint,
             (Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cdouble, Ptr{LmmGp}, Cint, Cint, Cint,
@@ -600,15 +617,16 @@ end
 function ChainRulesCore.rrule(::typeof(AbstractGPs.logpdf), fx::ByOutputsFill{HIPDenseILMM}, y::AbstractVector{<:Real})
     f, H, σ², x = unpack(fx)
     X = _xmat(x); d, n = size(X); p, m = size(H); gps = _gps(f.fs); Hm = Matrix{Float64}(H); yv = Vector{Float64}(y)
-    val = Ref{Cdouble}(0.0); gσ = Ref{Cdouble}(0.0); gσt = Ref{Cdouble}(0.0)
+    val = Ref{Cdouble}(0.0); gσ = Ref{Cdouble}(0.0)
     gy = Vector{Float64}(undef, n * p); gH = Matrix{Float64}(undef, p, m); gg = Vector{LmmGpGrad}(undef, m)
     if isposterior(f)
-        f.train === nothing && error("gradient of the predictive logpdf after sequential conditioning is not built")
-        X0, σ0, y0 = f.train; n0 = size(X0, 2); gy0 = Vector{Float64}(undef, n0 * p)
-        GC.@preserve X0 y0 X yv Hm gps gy0 gy gH gg check(ccall((:lmm_ilmm_post_logpdf_grad, liblmm), Cint,
-            (Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Cint, Cdouble, Cdouble,
-             Ptr{LmmGp}, Ptr{LmmJitters}, Ref{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Cdouble}, Ref{Cdouble}, Ptr{Cdouble}, Ptr{LmmGpGrad}),
-            X0, d, n0, y0, X, n, yv, p, Hm, m, σ0, σ², gps, C_NULL, val, gy0, gy, gσt, gσ, gH, gg))
+        f.train === nothing && error("this posterior does not carry its training data (the latent view of a dense-H posterior)")
+        X0, bn, bs, y0 = _merged_train(f.train, p); n0 = size(X0, 2); gy0 = Vector{Float64}(undef, n0 * p); gb = similar(bs)
+        GC.@preserve X0 bn bs y0 X yv Hm gps gy0 gy gb gH gg check(ccall((:lmm_ilmm_post_logpdf_grad_seq, liblmm), Cint,
+            (Ptr{Cdouble}, Cint, Cint, Ptr{Cint}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Cint,
+             Cdouble, Ptr{LmmGp}, Ptr{LmmJitters}, Ref{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Cdouble}, Ptr{Cdouble}, Ptr{LmmGpGrad}),
+            X0, d, n0, bn, bs, length(bn), y0, X, n, yv, p, Hm, m, σ², gps, C_NULL, val, gy0, gy, gb, gσ, gH, gg))
+        f.last_train_cotangents[] = _split_train(gy0, gb, bn, p)
     else
         GC.@preserve X yv Hm gps gy gH gg check(ccall((:lmm_ilmm_logpdf_grad, liblmm), Cint,
             (Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Cint, Cdouble, Ptr{LmmGp}, Ptr{LmmJitters}, Ref{Cdouble}, Ptr{Cdouble},

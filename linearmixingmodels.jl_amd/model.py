@@ -300,27 +300,38 @@ def unpack(fx: FiniteGP):
 
 
 def _merged_train(train, p: int):
-    """The conditioning batches of a (sequentially conditioned) posterior as ONE batch: posterior(posterior(f(x1, s2), y1)(x2, s2), y2)
-    is the posterior given ([x1 x2], [y1; y2]) when the batches carry the same noise variance, which is the case the gradient entry
-    points serve (two noise blocks: training, test).  Returns (x_all, s2, y_all, sizes); y is by-outputs, so the batches interleave
-    per output."""
+    """The conditioning batches of a (sequentially conditioned) posterior as ONE set of points: posterior(posterior(f(x1, s1), y1)(x2, s2),
+    y2) is the posterior given ([x1 x2], [y1; y2]) under per-batch noise (exact conditioning), which is what the *_post_logpdf_grad_seq
+    entry points serve (one noise block per batch + one for the test points).  Returns (x_all, [s2 per batch], y_all, sizes); y is
+    by-outputs, so the batches interleave per output."""
     if train is None:
         raise NotImplementedError("this posterior does not carry its training data (built outside posterior(fx, y))")
+    if any(np.ndim(t[1]) > 0 for t in train):
+        raise NotImplementedError("gradient of the predictive logpdf after conditioning with a per-point (Diagonal) noise is not built "
+                                  "(scalar noise variances, one per conditioning batch, are)")
     if len(train) == 1:
         x0, s20, y0 = train[0]
-        return x0, s20, y0, [x0.n]
-    if any(np.ndim(t[1]) > 0 for t in train):
-        raise NotImplementedError("gradient of the predictive logpdf after sequential conditioning with a per-point (Diagonal) noise is not "
-                                  "built (scalar noise variances, equal per batch, are)")
-    s2s = {float(t[1]) for t in train}
-    if len(s2s) != 1:
-        raise NotImplementedError("gradient of the predictive logpdf after sequential conditioning with DIFFERENT noise variances per "
-                                  "batch is not built (equal variances are: the batches merge into one)")
+        return x0, [float(s20)], y0, [x0.n]
+    if len(train) > 7:
+        raise NotImplementedError("gradient of the predictive logpdf after more than 7 conditioning batches is not built")
     xs = [np.asarray(t[0].x.cpu() if L._is_torch(t[0].x) else t[0].x, dtype=np.float64) for t in train]
     ys = [np.asarray(t[2].cpu() if L._is_torch(t[2]) else t[2], dtype=np.float64).reshape(p, -1) for t in train]
     x_all = np.concatenate(xs, axis=-1)
     y_all = np.concatenate(ys, axis=1).reshape(-1)
-    return MOInputIsotopicByOutputs(x_all, p), s2s.pop(), y_all, [t[0].n for t in train]
+    return MOInputIsotopicByOutputs(x_all, p), [float(t[1]) for t in train], y_all, [t[0].n for t in train]
+
+
+def _batch_args(s2b, sizes):
+    """(batch_n, batch_sigma2, grad_batch_sigma2) ctypes arrays of a *_post_logpdf_grad_seq call."""
+    k = len(sizes)
+    return (C.c_int * k)(*sizes), (C.c_double * k)(*s2b), (C.c_double * k)()
+
+
+def _train_noise_grad(gb, s2b):
+    """d/d(training noise): ONE number when the batches share their variance (the derivative w.r.t. that shared value), else one per
+    conditioning batch."""
+    g = [float(v) for v in gb]
+    return sum(g) if len(set(s2b)) == 1 else g
 
 
 def _split_train_grad(gy, sizes, p: int):
@@ -469,14 +480,15 @@ def logpdf_and_gradient(fx: FiniteGP, y, with_regulariser: bool = True) -> dict:
         gy, gH = _alloc_like(y if L._is_torch(y) else x.x, n * p), np.empty(p * m)
         gg = (L.GpGradT * m)()
         if post is not None:          # reference test/ilmm.jl:32: gradient(logpdf, pi, y_test) on the dense-H posterior
-            x0, s20, y0, sizes = _merged_train(post.train, p)
-            gs2t = C.c_double()
+            x0, s2b, y0, sizes = _merged_train(post.train, p)
+            bn, bs, gb = _batch_args(s2b, sizes)
             gy0 = _alloc_like(y0 if L._is_torch(y0) else x0.x, x0.n * p)
-            L.check(lib.lmm_ilmm_post_logpdf_grad(x0.carr().ptr, x0.dim, x0.n, L.Arr(y0).ptr, x.carr().ptr, n, L.Arr(y).ptr, p, Ha.ptr, m,
-                                                  C.c_double(s20), C.c_double(s2), L.gps_array([g.desc() for g in f.f.fs]), None,
-                                                  C.byref(val), L.Arr(gy0, True).ptr, L.Arr(gy, True).ptr, C.byref(gs2t), C.byref(gs2),
-                                                  L.Arr(gH, True).ptr, gg))
-            return {"value": val.value, "y": gy, "y_train": _split_train_grad(gy0, sizes, p), "sigma2": gs2.value, "sigma2_train": gs2t.value,
+            L.check(lib.lmm_ilmm_post_logpdf_grad_seq(x0.carr().ptr, x0.dim, x0.n, bn, bs, len(sizes), L.Arr(y0).ptr, x.carr().ptr, n,
+                                                      L.Arr(y).ptr, p, Ha.ptr, m, C.c_double(s2), L.gps_array([g.desc() for g in f.f.fs]),
+                                                      None, C.byref(val), L.Arr(gy0, True).ptr, L.Arr(gy, True).ptr, gb, C.byref(gs2),
+                                                      L.Arr(gH, True).ptr, gg))
+            return {"value": val.value, "y": gy, "y_train": _split_train_grad(gy0, sizes, p), "sigma2": gs2.value,
+                    "sigma2_train": _train_noise_grad(gb, s2b),
                     "H": gH.reshape(m, p).T.copy(),
                     "gps": [{"variance": gg[l].variance, "lengthscale": gg[l].lengthscale, "mean": gg[l].mean} for l in range(m)]}
         L.check(lib.lmm_ilmm_logpdf_grad(x.carr().ptr, x.dim, n, L.Arr(y).ptr, p, Ha.ptr, m, C.c_double(s2),
@@ -494,7 +506,7 @@ def logpdf_and_gradient(fx: FiniteGP, y, with_regulariser: bool = True) -> dict:
         Ua, Sa, p, m = _H_args(f.H)
         descs, shard = [g.desc() for g in f.f.fs], f.shard
     n = x.n
-    val, gs2, gs2t = C.c_double(), C.c_double(), C.c_double()
+    val, gs2 = C.c_double(), C.c_double()
     gy, gS, gU = _alloc_like(y if L._is_torch(y) else x.x, n * p), np.empty(m), np.empty(p * m)
     gg = (L.GpGradT * m)()
     out = {}
@@ -503,13 +515,14 @@ def logpdf_and_gradient(fx: FiniteGP, y, with_regulariser: bool = True) -> dict:
                                           L.gps_array(descs), shard[0], shard[1], int(with_regulariser), C.byref(val),
                                           L.Arr(gy, True).ptr, C.byref(gs2), L.Arr(gS, True).ptr, L.Arr(gU, True).ptr, gg))
     else:
-        x0, s20, y0, sizes = _merged_train(post.train, p)
+        x0, s2b, y0, sizes = _merged_train(post.train, p)
+        bn, bs, gb = _batch_args(s2b, sizes)
         gy0 = _alloc_like(y0 if L._is_torch(y0) else x0.x, x0.n * p)
-        L.check(lib.lmm_oilmm_post_logpdf_grad(x0.carr().ptr, x0.dim, x0.n, L.Arr(y0).ptr, x.carr().ptr, n, L.Arr(y).ptr, p, Ua.ptr,
-                                               Sa.ptr, m, C.c_double(s20), C.c_double(s2), L.gps_array(descs), shard[0], shard[1],
-                                               int(with_regulariser), C.byref(val), L.Arr(gy0, True).ptr, L.Arr(gy, True).ptr,
-                                               C.byref(gs2t), C.byref(gs2), L.Arr(gS, True).ptr, L.Arr(gU, True).ptr, gg))
-        out.update(y_train=_split_train_grad(gy0, sizes, p), sigma2_train=gs2t.value)
+        L.check(lib.lmm_oilmm_post_logpdf_grad_seq(x0.carr().ptr, x0.dim, x0.n, bn, bs, len(sizes), L.Arr(y0).ptr, x.carr().ptr, n,
+                                                   L.Arr(y).ptr, p, Ua.ptr, Sa.ptr, m, C.c_double(s2), L.gps_array(descs), shard[0],
+                                                   shard[1], int(with_regulariser), C.byref(val), L.Arr(gy0, True).ptr,
+                                                   L.Arr(gy, True).ptr, gb, C.byref(gs2), L.Arr(gS, True).ptr, L.Arr(gU, True).ptr, gg))
+        out.update(y_train=_split_train_grad(gy0, sizes, p), sigma2_train=_train_noise_grad(gb, s2b))
     out.update({"value": val.value, "y": gy, "sigma2": gs2.value,
                 "gps": [{"variance": gg[l].variance, "lengthscale": gg[l].lengthscale, "mean": gg[l].mean} for l in range(m)]})
     if not mogp:

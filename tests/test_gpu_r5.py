@@ -224,3 +224,203 @@ def test_mogp_cross_cov_fp32_mode(lmm):
     ref_post = O.mogp_cross_cov(O.mogp_posterior(gps, x0, s2, y0), x, y, True, False)
     assert np.max(np.abs(got_prior - ref_prior)) <= 5e-6 * np.max(np.abs(ref_prior))      # kappa is computed in Float64, stored Float32
     assert np.max(np.abs(got_post - ref_post)) <= 5e-5 * np.max(np.abs(ref_prior))
+
+
+# ---------------------------------------------------------------------------------------------------
+# gradient of the predictive logpdf after SEQUENTIAL conditioning with a DIFFERENT noise variance per batch
+# (lmm_oilmm_post_logpdf_grad_seq / lmm_ilmm_post_logpdf_grad_seq: one noise block per conditioning batch + one for the test points).
+# The reference differentiates logpdf(posterior(posterior(f(x1, s1), y1)(x2, s2), y2)(xs, s2s), ys) with Zygote (src/oilmm.jl:116-134,
+# src/ilmm.jl:184-198 composed); here against central finite differences of the oracle's step-by-step conditioning.
+# ---------------------------------------------------------------------------------------------------
+def _fd(f, h=1e-6):
+    return (f(h) - f(-h)) / (2.0 * h)
+
+
+def _check_seq_common(G, F, gps, ys, ybatches, rel, ab):
+    ns_p = len(ys)
+    for k in [0, ns_p // 2 + 1, ns_p - 1]:
+        e = np.zeros(ns_p); e[k] = 1.0
+        assert G["y"][k] == pytest.approx(_fd(lambda t: F(ys=ys + t * e)), rel=rel, abs=ab)
+    assert isinstance(G["y_train"], list) and [len(g) for g in G["y_train"]] == [len(yb) for yb in ybatches]
+    for b, yb in enumerate(ybatches):
+        for k in [1, len(yb) - 2]:
+            e = np.zeros(len(yb)); e[k] = 1.0
+            def Fb(t, b=b, e=e):
+                yy = [np.array(v) for v in ybatches]; yy[b] = yy[b] + t * e
+                return F(ybs=yy)
+            assert G["y_train"][b][k] == pytest.approx(_fd(Fb), rel=rel, abs=ab), (b, k)
+    for l in range(len(gps)):
+        for key in ("variance", "lengthscale", "mean"):
+            def f1(t, l=l, key=key):
+                g2 = [dict(g) for g in gps]; g2[l][key] += t
+                return F(gps=g2)
+            assert G["gps"][l][key] == pytest.approx(_fd(f1), rel=rel, abs=ab), (l, key)
+
+
+@pytest.mark.parametrize("sizes,noises", [((40, 33), (0.1, 0.3)), ((70, 25, 48), (0.25, 0.1, 0.4)), ((20, 30, 25), (0.2, 0.2, 0.35))])
+def test_oilmm_gradient_after_sequential_conditioning_with_per_batch_noise(lmm, sizes, noises):
+    rng = np.random.default_rng(501 + len(sizes))
+    ns, p, m = 11, 4, 3
+    xb = [np.sort(rng.uniform(0, 8, nb)) for nb in sizes]
+    xs = np.sort(rng.uniform(0, 8, ns))
+    gps = _gps(m, rng)
+    U, S, _ = np.linalg.svd(rng.uniform(size=(p, m)), full_matrices=False)
+    yb = [rng.standard_normal(nb * p) for nb in sizes]
+    ys = rng.standard_normal(ns * p)
+    s2s = 0.15
+
+    def F(gps=gps, S=S, U=U, s2b=noises, s2s=s2s, ybs=yb, ys=ys):
+        post = gps
+        for x_, s_, y_ in zip(xb, s2b, ybs):
+            post = O.oilmm_posterior(post, U, S, x_, s_, y_)
+        return O.oilmm_logpdf(post, U, S, xs, s2s, ys)
+
+    f = lmm.ILMM(_model(lmm, gps), lmm.Orthogonal(U, S))
+    po = f
+    for x_, s_, y_ in zip(xb, noises, yb):
+        po = lmm.posterior(po(lmm.MOInputIsotopicByOutputs(x_, p), s_), y_)
+    fxs = po(lmm.MOInputIsotopicByOutputs(xs, p), s2s)
+    G = lmm.logpdf_and_gradient(fxs, ys)
+    assert G["value"] == pytest.approx(F(), rel=1e-8)
+    assert G["value"] == pytest.approx(lmm.logpdf(fxs, ys), rel=1e-8)
+    assert G["sigma2"] == pytest.approx(_fd(lambda t: F(s2s=s2s + t)), rel=2e-5, abs=1e-6)
+    per_batch = []
+    for b in range(len(sizes)):
+        def Fs(t, b=b):
+            s = list(noises); s[b] += t
+            return F(s2b=s)
+        per_batch.append(_fd(Fs))
+    assert isinstance(G["sigma2_train"], list) and len(G["sigma2_train"]) == len(sizes)
+    assert G["sigma2_train"] == pytest.approx(per_batch, rel=2e-5, abs=1e-6)
+    _check_seq_common(G, F, gps, ys, yb, 2e-5, 1e-6)
+    e = np.zeros(m); e[1] = 1.0
+    assert G["S"][1] == pytest.approx(_fd(lambda t: F(S=S + t * e)), rel=2e-5, abs=1e-6)
+    E = np.zeros((p, m)); E[2, 0] = 1.0
+    # (U as an unconstrained matrix, as Zygote treats the field: the oracle's T = S^-1/2 U' uses U as given)
+    assert G["U"][2, 0] == pytest.approx(_fd(lambda t: F(U=U + t * E)), rel=5e-5, abs=1e-5)
+
+
+def test_mogp_gradient_after_sequential_conditioning_with_per_batch_noise(lmm):
+    rng = np.random.default_rng(511)
+    sizes, noises, ns, m = (45, 80), (0.3, 0.12), 13, 3
+    xb = [np.sort(rng.uniform(0, 8, nb)) for nb in sizes]
+    xs = np.sort(rng.uniform(0, 8, ns))
+    gps = _gps(m, rng)
+    yb = [rng.standard_normal(nb * m) for nb in sizes]
+    ys = rng.standard_normal(ns * m)
+    s2s = 0.2
+
+    def F(gps=gps, s2b=noises, s2s=s2s, ybs=yb, ys=ys):
+        post = gps
+        for x_, s_, y_ in zip(xb, s2b, ybs):
+            post = O.mogp_posterior(post, x_, s_, y_)
+        return O.mogp_logpdf(post, xs, s2s, ys)
+
+    po = _model(lmm, gps)
+    for x_, s_, y_ in zip(xb, noises, yb):
+        po = lmm.posterior(po(lmm.MOInputIsotopicByOutputs(x_, m), s_), y_)
+    G = lmm.logpdf_and_gradient(po(lmm.MOInputIsotopicByOutputs(xs, m), s2s), ys)
+    assert G["value"] == pytest.approx(F(), rel=1e-8)
+    assert G["sigma2"] == pytest.approx(_fd(lambda t: F(s2s=s2s + t)), rel=2e-5, abs=1e-6)
+    assert G["sigma2_train"] == pytest.approx([_fd(lambda t: F(s2b=(noises[0] + t, noises[1]))),
+                                               _fd(lambda t: F(s2b=(noises[0], noises[1] + t)))], rel=2e-5, abs=1e-6)
+    _check_seq_common(G, F, gps, ys, yb, 2e-5, 1e-6)
+
+
+def test_dense_ilmm_gradient_after_sequential_conditioning_with_per_batch_noise(lmm):
+    rng = np.random.default_rng(521)
+    sizes, noises, ns, p, m = (40, 33, 21), (0.3, 0.1, 0.2), 11, 4, 3
+    xb = [np.sort(rng.uniform(0, 8, nb)) for nb in sizes]
+    xs = np.sort(rng.uniform(0, 8, ns))
+    gps = _gps(m, rng)
+    H = rng.uniform(0.2, 1.0, size=(p, m))
+    yb = [rng.standard_normal(nb * p) for nb in sizes]
+    ys = rng.standard_normal(ns * p)
+    s2s = 0.25
+
+    def F(gps=gps, H=H, s2b=noises, s2s=s2s, ybs=yb, ys=ys):
+        post = O.ilmm_posterior(gps, H, xb[0], s2b[0], ybs[0])
+        for x_, s_, y_ in zip(xb[1:], s2b[1:], ybs[1:]):
+            post = O.ilmm_posterior_condition(post, H, x_, s_, y_)
+        return O.ilmm_logpdf(post, H, xs, s2s, ys)
+
+    po = lmm.ILMM(_model(lmm, gps), H)
+    for x_, s_, y_ in zip(xb, noises, yb):
+        po = lmm.posterior(po(lmm.MOInputIsotopicByOutputs(x_, p), s_), y_)
+    fxs = po(lmm.MOInputIsotopicByOutputs(xs, p), s2s)
+    G = lmm.logpdf_and_gradient(fxs, ys)
+    assert G["value"] == pytest.approx(F(), rel=1e-7)
+    assert G["value"] == pytest.approx(lmm.logpdf(fxs, ys), rel=1e-7)
+    assert G["sigma2"] == pytest.approx(_fd(lambda t: F(s2s=s2s + t)), rel=5e-5, abs=1e-5)
+    per_batch = []
+    for b in range(len(sizes)):
+        def Fs(t, b=b):
+            s = list(noises); s[b] += t
+            return F(s2b=s)
+        per_batch.append(_fd(Fs))
+    assert G["sigma2_train"] == pytest.approx(per_batch, rel=5e-5, abs=1e-5)
+    _check_seq_common(G, F, gps, ys, yb, 5e-5, 1e-5)
+    E = np.zeros((p, m)); E[1, 2] = 1.0
+    assert G["H"][1, 2] == pytest.approx(_fd(lambda t: F(H=H + t * E)), rel=5e-5, abs=1e-5)
+
+
+def test_post_logpdf_grad_seq_argument_checks(lmm):
+    lib = lmm.load()
+    rng = np.random.default_rng(531)
+    n, ns, p, m = 30, 7, 3, 2
+    x, xs = np.sort(rng.uniform(0, 5, n)), np.sort(rng.uniform(0, 5, ns))
+    y, ys = rng.standard_normal(n * p), rng.standard_normal(ns * p)
+    U, S, _ = np.linalg.svd(rng.uniform(size=(p, m)), full_matrices=False)
+    Uc = np.asfortranarray(U).ravel(order="F").copy()
+    from lmm_amd import _lib as L
+    gps = L.gps_array(_gps(m, rng))
+    val = C.c_double()
+
+    def call(sizes, noises):
+        k = len(sizes)
+        return lib.lmm_oilmm_post_logpdf_grad_seq(x.ctypes.data_as(C.c_void_p), 1, n, (C.c_int * k)(*sizes), (C.c_double * k)(*noises), k,
+                                                  y.ctypes.data_as(C.c_void_p), xs.ctypes.data_as(C.c_void_p), ns,
+                                                  ys.ctypes.data_as(C.c_void_p), p, Uc.ctypes.data_as(C.c_void_p),
+                                                  S.ctypes.data_as(C.c_void_p), m, C.c_double(0.1), gps, 0, m, 1, C.byref(val),
+                                                  None, None, None, None, None, None, None)
+
+    assert call([20, 10], [0.1, 0.2]) == 0
+    assert call([20, 11], [0.1, 0.2]) != 0                     # sizes do not add up to n
+    assert call([20, 10], [0.1, 0.0]) != 0                     # sigma2 must be > 0
+    assert call([4, 4, 4, 4, 4, 4, 4, 2], [0.1] * 8) != 0      # more than 7 batches
+    assert b"7 conditioning batches" in lib.lmm_last_error_string()
+
+
+def test_per_batch_noise_gradient_fp32_mode(lmm):
+    """The three-noise-block core under lmm_set_compute_dtype(LMM_F32) (Float32 factor, inverse and per-block traces read from it; Float64
+    reductions) against the Float64 mode of the same call: the tolerances stated for that mode's gradients in include/lmm_hip.h."""
+    rng = np.random.default_rng(541)
+    sizes, noises, ns, p, m = (300, 260), (0.1, 0.25), 90, 4, 3
+    xb = [np.sort(rng.uniform(0, 12, nb)) for nb in sizes]
+    xs = np.sort(rng.uniform(0, 12, ns))
+    gps = _gps(m, rng)
+    U, S, _ = np.linalg.svd(rng.uniform(size=(p, m)), full_matrices=False)
+    yb = [rng.standard_normal(nb * p) for nb in sizes]
+    ys = rng.standard_normal(ns * p)
+
+    def run():
+        po = lmm.ILMM(_model(lmm, gps), lmm.Orthogonal(U, S))
+        for x_, s_, y_ in zip(xb, noises, yb):
+            po = lmm.posterior(po(lmm.MOInputIsotopicByOutputs(x_, p), s_), y_)
+        return lmm.logpdf_and_gradient(po(lmm.MOInputIsotopicByOutputs(xs, p), 0.15), ys)
+
+    G64 = run()
+    lmm.set_compute_dtype("f32")
+    try:
+        G32 = run()
+    finally:
+        lmm.set_compute_dtype("f64")
+    assert G32["value"] == pytest.approx(G64["value"], rel=2e-5)
+    assert np.max(np.abs(np.asarray(G32["y"]) - np.asarray(G64["y"]))) <= 1e-4 * np.max(np.abs(G64["y"]))
+    for b in range(2):
+        assert np.max(np.abs(G32["y_train"][b] - G64["y_train"][b])) <= 5e-4 * np.max(np.abs(G64["y_train"][b]))
+    assert G32["sigma2"] == pytest.approx(G64["sigma2"], rel=1e-4)
+    assert G32["sigma2_train"] == pytest.approx(G64["sigma2_train"], rel=2e-3, abs=1e-2)
+    for l in range(m):
+        for key in ("variance", "lengthscale", "mean"):
+            assert G32["gps"][l][key] == pytest.approx(G64["gps"][l][key], rel=2e-3, abs=1e-2), (l, key)
