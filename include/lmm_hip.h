@@ -42,9 +42,12 @@
  *     row -- a higher index -- only after it has published everything the lower-indexed helpers need to finish and free their slots.
  *     Under the assumption a launch completes with any number of resident workgroups.  Should a device ever dispatch out of order, the
  *     library does not hang and does not return a wrong value: every wait is bounded (4 s of the 100-MHz wall clock, or another
- *     workgroup's epoch-tagged abort word); the grid drains and the call returns LMM_ERR_HIP.  (A ticket drawn from an atomic counter at
- *     workgroup entry would remove the assumption; it costs ~1.5 us at the head of the latency-bound chain of the small problems --
- *     1-2 % of a BASELINE configs[0] evaluation -- and is not taken.)
+ *     workgroup's epoch-tagged abort word); the grid drains and the call returns LMM_ERR_HIP.
+ *     lmm_set_strict_progress(1) (or LMM_STRICT_PROGRESS=1 in the environment at lmm_init) REMOVES the assumption: both kernels then
+ *     take their task from an atomic ticket drawn at workgroup entry, so task t is the t-th workgroup to have STARTED and "waits only
+ *     for tasks that are running or finished" holds in any dispatch order (same values -- the tasks are the same, only who runs them
+ *     changes: bit-identical logpdf on the one-launch path, the default mode's own split-K noise elsewhere).  Its cost -- one atomic round trip at the head of every workgroup and, in the fused update launches, the
+ *     loss of the blockIdx-based XCD tile mapping -- is stated in DESIGN.md section 4.5; the default stays off.
  */
 #ifndef LMM_HIP_H
 #define LMM_HIP_H
@@ -116,6 +119,10 @@ int lmm_release_cached_memory(void);      /* return the caching device-memory po
 typedef enum { LMM_F64 = 0, LMM_F32 = 1 } lmm_dtype;
 int lmm_set_compute_dtype(int dtype);
 int lmm_get_compute_dtype(void);
+/* Strict forward progress of the dataflow kernels (conventions above): 1 = tasks by arrival ticket, 0 (default) = by blockIdx.x.
+ * Process-global like the dtype modes. */
+int lmm_set_strict_progress(int on);
+int lmm_get_strict_progress(void);
 
 /* Dtype of the H unprojection of predictive marginals,  M = H M_latent,  V = abs2.(H) V_latent .+ sigma2  (reference
  * src/oilmm.jl:69-72; lmm_oilmm_mean_and_var) -- BASELINE configs[3] "bf16 MFMA covariance projection".

@@ -888,6 +888,7 @@ void drain_after_error() {
   // a throw between fork_slots and join_slots must not leave "several batches in flight" behind: the base-case rule of potrf_batch
   // and the ragged-row choice of the update launches read these, so later calls would silently take another launch plan
   g_slots_in_flight = 1; g_concurrent_batches = 1;
+  if (g.init) strict_ticket_reset();
 }
 
 }  // namespace
@@ -977,6 +978,7 @@ int lmm_init(int device) {
     HIPCHK(hipMemset(g.region_flags, 0, fi * sizeof(int)));
     region_flags_register(g.region_flags, fi);
   }
+  { const char* e = getenv("LMM_STRICT_PROGRESS"); if (e) g_strict_progress = atoi(e) != 0; }
   g.device = device;
   g.init = true;
   return LMM_OK;
@@ -987,6 +989,7 @@ int lmm_shutdown(void) {
   std::lock_guard<std::mutex> lk(g_mu);
   if (!g.init) return LMM_OK;
   (void)hipDeviceSynchronize();
+  strict_ticket_reset();
   if (g.comm) { (void)ncclCommDestroy(g.comm); g.comm = nullptr; g.comm_world = 0; }
   if (g.ev_caller) { (void)hipEventDestroy(g.ev_caller); g.ev_caller = nullptr; }
   release_call_scratch();
@@ -1116,6 +1119,14 @@ int lmm_set_compute_dtype(int dtype) {
   return LMM_OK;
 }
 int lmm_get_compute_dtype(void) { return g_f32 ? LMM_F32 : LMM_F64; }
+
+// Strict forward progress of the dataflow kernels (include/lmm_hip.h, conventions): tasks by arrival ticket instead of blockIdx.x.
+int lmm_set_strict_progress(int on) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_strict_progress = on ? 1 : 0;
+  return LMM_OK;
+}
+int lmm_get_strict_progress(void) { return g_strict_progress; }
 
 int lmm_set_projection_dtype(int dtype) {
   std::lock_guard<std::mutex> lk(g_mu);

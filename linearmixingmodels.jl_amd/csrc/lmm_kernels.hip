@@ -1632,6 +1632,14 @@ __device__ __forceinline__ void wg_mm64(const double* __restrict__ As, int sai, 
 // hundreds of bulk workgroups of a fused node launch poll the same few words and use 16 (~0.5 us), or they slow the leaf they wait for.
 // The abort word is epoch-tagged like every other flag (epoch * 32 + 1): a word raised by an EARLIER launch on the same slice of the
 // persistent flag array never matches, so a timeout in one launch cannot make a later launch leave its waits early.
+// Strict-progress builds: the workgroup's task index is the order of its ARRIVAL (an atomic ticket minus the counter's value at launch
+// time, which the host tracks: launches that share a counter are serialised by their stream), not its blockIdx.x.
+__device__ __forceinline__ int take_ticket(unsigned* ctr, unsigned base) {
+  __shared__ unsigned tk_sh;
+  if (threadIdx.x == 0) tk_sh = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - base;
+  __syncthreads();
+  return __builtin_amdgcn_readfirstlane((int)tk_sh);
+}
 __device__ __forceinline__ bool region_aborted(const int* abort_word, int epoch) {
   const int v = __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return (v >> 5) == epoch && (v & 31) != 0;
@@ -1882,7 +1890,8 @@ __device__ __forceinline__ void pipe64_accumulate(d4 (&acc)[2][4], double* __res
 
 // FUSE: the NODE_FUSE work items exist (their waits and write-through stores cost the hot loop 3-4 spilled registers: 0.3 % on the
 // K >= 4096 launches, which is why it is a template parameter and the long launches run without it)
-template <int DEPTH, bool FUSE = false>
+// STRICT: the work item is the workgroup's arrival ticket (take_ticket) -- the strict-progress build of the fused launches
+template <int DEPTH, bool FUSE = false, bool STRICT = false>
 __global__ __launch_bounds__(256, 2) void potrf_node_kernel(NodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) double node_lds[];
   __shared__ int dflags[3];                                        // two-wave diagonal-block factorisation of the leaf (zero before its first barrier)
@@ -1907,7 +1916,11 @@ __global__ __launch_bounds__(256, 2) void potrf_node_kernel(NodeArgs a) {
   bool bulk = false, col0 = false;
   constexpr bool fuse = FUSE;
   {
-    const int item = blockIdx.x;
+    const int item = STRICT ? take_ticket(a.ticket, a.ticket_base) : (int)blockIdx.x;
+    if (STRICT && (unsigned)item >= gridDim.x) {          // host and device counters disagree (never expected): report, do nothing
+      if (threadIdx.x == 0) atomicCAS(a.info.p[0], 0, LMM_INFO_SYNC_TIMEOUT);
+      return;
+    }
     if (a.mode & NODE_UPDATE) {
       const int n0 = a.nb * a.MT;
       if (item < n0) { ti = item / a.nb; bidx = item - ti * a.nb; col0 = true; }
@@ -2652,15 +2665,22 @@ __device__ __forceinline__ void potrf_region_row_thin(const RegionArgs& a, doubl
 // dispatched before it.  The walker is the one workgroup that waits for a LATER one (helper r, at block r); but by then it has
 // published everything the helpers of rows < r need to finish (they never wait beyond wk = r - 1), so they complete and free their
 // slots however few workgroups are resident, helper r gets dispatched and runs.  One workgroup per CU (414 registers per lane).
-template <int OCC>       // 1: one workgroup per CU (no register spills in the walker); 2: two (the row streams' natural occupancy)
+// OCC 1: one workgroup per CU (no register spills in the walker); 2: two (the row streams' natural occupancy)
+// STRICT: the task is the workgroup's arrival ticket, so "dispatched before it" in the argument above holds in any dispatch order
+template <int OCC, bool STRICT = false>
 __global__ __launch_bounds__(256, OCC) void potrf_region_kernel(RegionArgs a) {
   extern __shared__ __attribute__((aligned(16))) double node_lds[];
   __shared__ int dflags[3];                  // the walker's two-wave diagonal-block factorisation (zero before the walker's first barrier)
   if (threadIdx.x == 0) { dflags[0] = 0; dflags[1] = 0; dflags[2] = 0; }
-  const int b = blockIdx.x % a.nb, idx = blockIdx.x / a.nb;
+  const int task = STRICT ? take_ticket(a.ticket, a.ticket_base) : (int)blockIdx.x;
+  if (STRICT && (unsigned)task >= gridDim.x) {            // host and device counters disagree (never expected): report, do nothing
+    if (threadIdx.x == 0) atomicCAS(a.info.p[0], 0, LMM_INFO_SYNC_TIMEOUT);
+    return;
+  }
+  const int b = task % a.nb, idx = task / a.nb;
   double* Am = a.A.p[b];
   const int Q = 2 * a.P;
-  if (a.trace && threadIdx.x == 0) a.trace[2 * blockIdx.x] = wall_clock64();
+  if (a.trace && threadIdx.x == 0) a.trace[2 * task] = wall_clock64();
   // square tasks in dispatch order: walker, helper 1, ..., helper MIN_R - 1, then (helper r, assistant r) pairs -- a helper's assistant is
   // the NEXT workgroup to be dispatched, so a helper never waits for a workgroup that other waiting workgroups keep out of the device
   int role = 1, r = idx;                      // 0 walker, 1 helper, 2 assistant
@@ -2681,7 +2701,7 @@ __global__ __launch_bounds__(256, OCC) void potrf_region_kernel(RegionArgs a) {
     if (real > 16) { if (tall) potrf_region_row(a, node_lds, Am, b, a.P + k); else potrf_region_row64(a, node_lds, Am, b, roff); }
     else if (real > 0) potrf_region_row_thin(a, node_lds, Am, b, roff);
   }
-  if (a.trace && threadIdx.x == 0) a.trace[2 * blockIdx.x + 1] = wall_clock64();
+  if (a.trace && threadIdx.x == 0) a.trace[2 * task + 1] = wall_clock64();
 }
 
 #undef LMM_MFMA16H_ALL
@@ -3620,7 +3640,38 @@ static void node_lds_attr() {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_node_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_region_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_region_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_node_kernel<1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_node_kernel<2, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_region_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_region_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   done = true;
+}
+// Strict-progress mode: one arrival counter per stream (launches of a stream are serialised, so the counter's value when a launch
+// starts is what the host has handed out so far: `base`; unsigned arithmetic makes the wrap-around harmless).
+int g_strict_progress = 0;
+static std::mutex g_ticket_mu;
+static std::map<hipStream_t, std::pair<unsigned*, unsigned>> g_ticket_ctrs;
+// after an error drained the device (lmm_api.hip's drain_after_error: a launch that never ran took no tickets) and at lmm_shutdown
+// (the streams the counters are keyed by go away): drop the counters; the next strict launch of a stream makes a fresh one
+void strict_ticket_reset() {
+  std::lock_guard<std::mutex> lock(g_ticket_mu);
+  for (auto& kv : g_ticket_ctrs) (void)hipFree(kv.second.first);       // (the caller has synchronised the device)
+  g_ticket_ctrs.clear();
+}
+static bool strict_ticket(hipStream_t st, unsigned count, unsigned** ctr, unsigned* base) {
+  std::mutex& mu = g_ticket_mu;
+  auto& ctrs = g_ticket_ctrs;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = ctrs.find(st);
+  if (it == ctrs.end()) {
+    unsigned* d = nullptr;
+    if (hipMalloc((void**)&d, sizeof(unsigned)) != hipSuccess) return false;
+    (void)hipMemsetAsync(d, 0, sizeof(unsigned), st);        // on the stream whose launches use it: ordered before the first of them
+    it = ctrs.emplace(st, std::make_pair(d, 0u)).first;
+  }
+  *ctr = it->second.first; *base = it->second.second;
+  it->second.second += count;
+  return true;
 }
 void launch_leaf128(const BatchPtr& A, size_t offD, int ld, const BatchPtr& W, size_t offW, const BatchPtr& W2, size_t offW2,
                     int gcol0, int n_real, const BatchInfo& info, int nb, hipStream_t st) {
@@ -3731,7 +3782,10 @@ bool launch_update_leaf(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2
     items += (long long)nb * (MTb - 1);
   }
   const dim3 grid((unsigned)items);
-  if (fuse) {
+  if (fuse && g_strict_progress && strict_ticket(st, grid.x, &a.ticket, &a.ticket_base)) {
+    if (h >= 1024) hipLaunchKernelGGL((potrf_node_kernel<2, true, true>), grid, dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
+    else hipLaunchKernelGGL((potrf_node_kernel<1, true, true>), grid, dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
+  } else if (fuse) {
     if (h >= 1024) hipLaunchKernelGGL((potrf_node_kernel<2, true>), grid, dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
     else hipLaunchKernelGGL((potrf_node_kernel<1, true>), grid, dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
   } else {
@@ -3854,7 +3908,10 @@ void launch_region(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2, con
   long long* tr = nullptr;
   if (trace_env) { if (hipMalloc((void**)&tr, ((size_t)tasks * nb * 2 + 64 * (size_t)nb) * sizeof(long long)) != hipSuccess) tr = nullptr; }
   a.trace = tr; a.ntasks = (int)tasks;
-  if (occ == 1) hipLaunchKernelGGL(potrf_region_kernel<1>, dim3((unsigned)(tasks * nb)), dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
+  if (g_strict_progress && strict_ticket(st, (unsigned)(tasks * nb), &a.ticket, &a.ticket_base)) {
+    if (occ == 1) hipLaunchKernelGGL((potrf_region_kernel<1, true>), dim3((unsigned)(tasks * nb)), dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
+    else hipLaunchKernelGGL((potrf_region_kernel<2, true>), dim3((unsigned)(tasks * nb)), dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
+  } else if (occ == 1) hipLaunchKernelGGL(potrf_region_kernel<1>, dim3((unsigned)(tasks * nb)), dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
   else hipLaunchKernelGGL(potrf_region_kernel<2>, dim3((unsigned)(tasks * nb)), dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
   if (tr) {
     (void)hipStreamSynchronize(st);

@@ -424,3 +424,42 @@ def test_per_batch_noise_gradient_fp32_mode(lmm):
     for l in range(m):
         for key in ("variance", "lengthscale", "mean"):
             assert G32["gps"][l][key] == pytest.approx(G64["gps"][l][key], rel=2e-3, abs=1e-2), (l, key)
+
+
+# ---------------------------------------------------------------------------------------------------
+# strict forward progress (lmm_set_strict_progress): tasks of the dataflow kernels by arrival ticket instead of blockIdx.x.  The tasks
+# are the same, only which workgroup runs which changes: values are bit-identical to the default mode on the one-launch region path
+# (n <= 1024) and agree to the default mode's own run-to-run noise (split-K atomics) on the region base case under the recursion
+# and the fused update launches (NODE_FUSE) of the panel path.
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,n", [(3, 200), (20, 552), (8, 1024), (8, 2048), (5, 3000), (16, 4096), (2, 6500)])
+def test_strict_progress_mode_gives_the_same_values(lmm, m, n):
+    from lmm_amd.workloads import synthetic_problem
+    p = m + 2
+    P = synthetic_problem(m, p, n, "matern52", True, s2=0.1, seed=7)
+    f = lmm.ILMM(_model(lmm, P["gps"]), lmm.Orthogonal(P["U"], P["S"]))
+    xin = lmm.MOInputIsotopicByOutputs(P["x"], p)
+    xs = lmm.MOInputIsotopicByOutputs(np.linspace(0.0, 1.0, 37) * float(np.max(P["x"])), p)
+
+    def run():
+        v = [lmm.logpdf(f(xin, 0.1), P["y"]) for _ in range(3)]
+        mu, var = lmm.mean_and_var(lmm.posterior(f(xin, 0.1), P["y"])(xs, 0.1))
+        return v, np.asarray(mu), np.asarray(var)
+
+    assert not lmm.get_strict_progress()
+    v0, mu0, var0 = run()
+    lmm.set_strict_progress(True)
+    try:
+        assert lmm.get_strict_progress()
+        v1, mu1, var1 = run()
+    finally:
+        lmm.set_strict_progress(False)
+    if n <= 1024:                        # one region launch per batch: no split-K atomics anywhere, bitwise reproducible in both modes
+        assert v0[0] == v0[1] == v0[2] and v1 == v0
+        np.testing.assert_allclose(mu1, mu0, rtol=1e-12, atol=1e-14)      # (the cross-solve behind the marginals combines partial products
+        np.testing.assert_allclose(var1, var0, rtol=1e-12, atol=1e-14)    #  with atomics in either mode)
+        assert v0[0] == pytest.approx(O.oilmm_logpdf(P["gps"], P["U"], P["S"], P["x"], 0.1, P["y"]), rel=1e-9)
+    else:                                # the update launches' split-K tails are combined with f64 atomics: run-to-run noise of the default mode
+        assert v1 == pytest.approx(v0, rel=1e-12)
+        np.testing.assert_allclose(mu1, mu0, rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(var1, var0, rtol=1e-9, atol=1e-11)
