@@ -34,20 +34,19 @@
  *   - process-global modes: the compute dtype (lmm_set_compute_dtype) and the projection dtype (lmm_set_projection_dtype) are state
  *     of the process's one context, NOT call arguments: they apply to every later call of every thread until changed (a posterior
  *     handle remembers the dtype it was built in and refuses the other one).
- *   - forward progress of the dataflow kernels (LMM_ERR_HIP "dependency wait timed out"): potrf_region_kernel and the fused update
- *     launches (NODE_FUSE) run cooperating workgroups that wait on flags written by other workgroups of the SAME launch.  A workgroup's
- *     task is its blockIdx.x, and the deadlock-freedom argument ASSUMES that the hardware starts the workgroups of a 1-D grid in index
- *     order -- what every AMD GPU to date does, but not something HIP promises: a task waits only for tasks with LOWER indices (already
- *     running or finished under that assumption), with one exception, the walker of a matrix, which waits for the helper of its current
- *     row -- a higher index -- only after it has published everything the lower-indexed helpers need to finish and free their slots.
- *     Under the assumption a launch completes with any number of resident workgroups.  Should a device ever dispatch out of order, the
- *     library does not hang and does not return a wrong value: every wait is bounded (4 s of the 100-MHz wall clock, or another
- *     workgroup's epoch-tagged abort word); the grid drains and the call returns LMM_ERR_HIP.
- *     lmm_set_strict_progress(1) (or LMM_STRICT_PROGRESS=1 in the environment at lmm_init) REMOVES the assumption: both kernels then
- *     take their task from an atomic ticket drawn at workgroup entry, so task t is the t-th workgroup to have STARTED and "waits only
- *     for tasks that are running or finished" holds in any dispatch order (same values -- the tasks are the same, only who runs them
- *     changes: bit-identical logpdf on the one-launch path, the default mode's own split-K noise elsewhere).  Its cost -- one atomic round trip at the head of every workgroup and, in the fused update launches, the
- *     loss of the blockIdx-based XCD tile mapping -- is stated in DESIGN.md section 4.5; the default stays off.
+ *   - forward progress of the dataflow kernels: potrf_region_kernel runs cooperating workgroups that wait on flags written by other
+ *     workgroups of the SAME launch; its deadlock-freedom argument needs "a task waits only for tasks with LOWER indices, which are
+ *     running or finished" (one exception: the walker of a matrix waits for the helper of its current row -- a higher index -- only
+ *     after it has published everything the lower-indexed helpers need to finish and free their slots).  HIP does not promise that
+ *     workgroups start in index order, so by DEFAULT (round 5) a workgroup does not take its task index from blockIdx.x: it takes its
+ *     TURN -- a per-matrix counter hands the indices out in order to workgroups that have started; a workgroup whose turn does not
+ *     come within 200 us (a lower-indexed workgroup has not started: the device did not dispatch in order) takes the next free index
+ *     instead.  The argument then holds in ANY dispatch order, and while the device does dispatch in order every workgroup runs exactly
+ *     the task it would have had (values identical; cost 0.1-0.7 % of an evaluation).
+ *     lmm_set_strict_progress(0) (LMM_STRICT_PROGRESS=0 at lmm_init) restores the round-4 behaviour: task = blockIdx.x, and the fused
+ *     update launches (NODE_FUSE, off by default anyway) allowed -- correct under in-order dispatch, which every AMD GPU to date does.
+ *     In both modes every wait is bounded (4 s of the 100-MHz wall clock, or another workgroup's epoch-tagged abort word): should a
+ *     launch ever stall, the grid drains and the call returns LMM_ERR_HIP -- no hang, no wrong value.
  */
 #ifndef LMM_HIP_H
 #define LMM_HIP_H
@@ -119,8 +118,8 @@ int lmm_release_cached_memory(void);      /* return the caching device-memory po
 typedef enum { LMM_F64 = 0, LMM_F32 = 1 } lmm_dtype;
 int lmm_set_compute_dtype(int dtype);
 int lmm_get_compute_dtype(void);
-/* Strict forward progress of the dataflow kernels (conventions above): 1 = tasks by arrival ticket, 0 (default) = by blockIdx.x.
- * Process-global like the dtype modes. */
+/* Strict forward progress of the dataflow kernels (conventions above): 1 (default) = task indices handed out in turn to workgroups
+ * that have started, 0 = task = blockIdx.x (relies on in-order dispatch).  Process-global like the dtype modes. */
 int lmm_set_strict_progress(int on);
 int lmm_get_strict_progress(void);
 

@@ -194,8 +194,9 @@ def get_compute_dtype() -> str:
 
 
 def set_strict_progress(on: bool) -> None:
-    """Dataflow kernels take their task from an arrival ticket instead of blockIdx.x: forward progress in any dispatch order
-    (include/lmm_hip.h, conventions).  Same values; default off."""
+    """True (the default): the dataflow kernel's workgroups take their task index in turn from a counter, so its deadlock-freedom
+    argument holds in any dispatch order; False: task = blockIdx.x, which relies on in-order dispatch (include/lmm_hip.h,
+    conventions).  Same values either way."""
     check(load().lmm_set_strict_progress(C.c_int(1 if on else 0)))
 
 

@@ -485,7 +485,7 @@ void potrf_batch(const Batch& B, int ld, int NR, int NC, int n_real, hipStream_t
   nfl.min_k = fuse_min_k; nfl.max_k = fuse_max_k;
   nfl.rows_real = rows_real;
   nfl.region_cols = region_here ? region_cols : 0;
-  if (fuse_bulk && !region_here && NC > 128) {
+  if (fuse_bulk && !g_strict_progress && !region_here && NC > 128) {
     nfl.stride = (int)node_flag_ints(NR);
     const size_t ints = (size_t)nfl.stride * B.nb;
     nfl.p = reinterpret_cast<int*>(call_scratch((ints + 1) / 2));

@@ -77,7 +77,6 @@ struct NodeArgs {
   int* nflags; int nf_stride, epoch;
   int strip_n, strip0;    // column tiles of the ragged last 64 rows run as work items of this launch (0: none / separate launch); their first item
   int Mb, MTb, bulk0;     // rows / 128-row tiles the bulk items cover (a ragged last 64 rows included); index of the first bulk item
-  unsigned* ticket; unsigned ticket_base;     // strict-progress build (lmm_set_strict_progress): work item = arrival ticket - base
 };
 // Arguments of potrf_region_kernel (lmm_kernels.hip K2d): the columns [c0, c0 + 128 P) of every matrix of the batch, rows c0 .. c0 + M - 1.
 struct RegionArgs {
@@ -90,12 +89,13 @@ struct RegionArgs {
   int ntasks;             // workgroups per matrix (trace layout)
   int n128;               // the first n128 row tiles below the square are 128 rows high, the following ones 64
   long long* trace;       // optional (LMM_REGION_TRACE=1, tools/region_trace.py): start / end wall-clock ticks of every workgroup
-  unsigned* ticket; unsigned ticket_base;     // strict-progress build (lmm_set_strict_progress): task = arrival ticket - base
+  unsigned* claim; unsigned* claim_next;      // strict-progress build: this launch's claim counters, and the set it zeroes for the next one
 };
-// Strict forward progress (lmm_set_strict_progress): the dataflow kernels take their task from an atomic ticket drawn at workgroup
-// entry instead of blockIdx.x, so "a task waits only for tasks that have started" holds in ANY dispatch order.
+// Strict forward progress (lmm_set_strict_progress, default on): potrf_region_kernel's workgroups claim their task at entry instead of
+// reading it from blockIdx.x, and the fused update launches (NODE_FUSE: bulk items that wait for earlier items of the same launch)
+// are not used -- no kernel then relies on the order in which workgroups are dispatched.
 extern int g_strict_progress;
-void strict_ticket_reset();               // drop the arrival counters (after an error drained the device; at shutdown)
+void strict_ticket_reset();               // drop the claim counters (after an error drained the device; at shutdown)
 #define LMM_REGION_MAX_PANELS 8
 #define LMM_REGION_ASST_MIN_C 4           // a helper's product for column block c >= this is split with its row's assistant
 #define LMM_REGION_ASST_MIN_R (LMM_REGION_ASST_MIN_C + 2)

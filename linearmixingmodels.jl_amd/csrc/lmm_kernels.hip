@@ -1632,13 +1632,44 @@ __device__ __forceinline__ void wg_mm64(const double* __restrict__ As, int sai, 
 // hundreds of bulk workgroups of a fused node launch poll the same few words and use 16 (~0.5 us), or they slow the leaf they wait for.
 // The abort word is epoch-tagged like every other flag (epoch * 32 + 1): a word raised by an EARLIER launch on the same slice of the
 // persistent flag array never matches, so a timeout in one launch cannot make a later launch leave its waits early.
-// Strict-progress builds: the workgroup's task index is the order of its ARRIVAL (an atomic ticket minus the counter's value at launch
-// time, which the host tracks: launches that share a counter are serialised by their stream), not its blockIdx.x.
-__device__ __forceinline__ int take_ticket(unsigned* ctr, unsigned base) {
-  __shared__ unsigned tk_sh;
-  if (threadIdx.x == 0) tk_sh = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - base;
+// Strict-progress build of potrf_region_kernel.  HIP promises no dispatch order, and the deadlock-freedom argument of the dataflow
+// needs one: "task (b, idx) waits only for tasks (b, idx' < idx), which are running or finished" (the walker excepted, see the kernel).
+// So a workgroup does not TAKE its task index from blockIdx.x, it takes its TURN with it: claim[b] counts the tasks of matrix b
+// (b = blockIdx.x % nb) that have been handed out, in index order, to workgroups that have STARTED.
+//   * Normally: workgroup (b, i = blockIdx.x / nb) waits until claim[b] == i and moves it to i + 1 (one compare-and-swap when it is
+//     already its turn -- every workgroup but those of the first burst, which sort themselves in ~1-2 us per index while the
+//     walker, index 0, goes at once).  It then runs exactly the task it has in the index-order build, on the same CU at the same time:
+//     that matters, because the hardware refills freed CU slots strictly in workgroup order (one shader engine after the other, the
+//     queue's head waiting for ITS engine: profiles/r05/strict_progress_cost.txt), so WHICH first-burst workgroup runs which role
+//     decides when the later ones get in -- arrival-order claims scramble the roles and cost configs[1] 10 %, a rank's share 2 %.
+//   * Should its turn not come within LMM_CLAIM_TURN_TICKS (a workgroup with a lower index has not started: the hardware did NOT
+//     dispatch in order), or has its index been handed out already, it takes the next free index instead (atomic add).  Either way
+//     indices go out in order to started workgroups -- the argument holds in any dispatch order; only the speed assumed one.
+// The counters come in two sets used by alternate launches of a stream: the workgroup that claims task (0, 0) zeroes the OTHER set
+// for the next launch (which cannot start before this one has ended, nor while the launch before, the other set's last user, is
+// running) -- no memset between launches, nothing for the host to track but the parity.
+#define LMM_CLAIM_INTS LMM_MAX_BATCH
+#define LMM_CLAIM_TURN_TICKS 20000LL          // 200 us of the 100-MHz wall clock
+__device__ __forceinline__ bool region_claim(unsigned* claim, unsigned* claim_next, int nb, int ntasks, int b, int& idx) {
+  __shared__ unsigned claim_sh;
+  if (threadIdx.x == 0) {
+    const unsigned own = (unsigned)idx;
+    unsigned* c = claim + b;
+    unsigned got = 0xffffffffu;
+    const long long t0 = wall_clock64();
+    for (;;) {
+      unsigned v = own;
+      if (__hip_atomic_compare_exchange_strong(c, &v, own + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { got = own; break; }
+      if (v > own || wall_clock64() - t0 > LMM_CLAIM_TURN_TICKS) { got = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    claim_sh = got;
+  }
   __syncthreads();
-  return __builtin_amdgcn_readfirstlane((int)tk_sh);
+  const unsigned c = (unsigned)__builtin_amdgcn_readfirstlane((int)claim_sh);
+  idx = (int)c;
+  if (b == 0 && c == 0u && threadIdx.x < LMM_CLAIM_INTS) __hip_atomic_store(claim_next + threadIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return c < (unsigned)ntasks;
 }
 __device__ __forceinline__ bool region_aborted(const int* abort_word, int epoch) {
   const int v = __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1890,8 +1921,7 @@ __device__ __forceinline__ void pipe64_accumulate(d4 (&acc)[2][4], double* __res
 
 // FUSE: the NODE_FUSE work items exist (their waits and write-through stores cost the hot loop 3-4 spilled registers: 0.3 % on the
 // K >= 4096 launches, which is why it is a template parameter and the long launches run without it)
-// STRICT: the work item is the workgroup's arrival ticket (take_ticket) -- the strict-progress build of the fused launches
-template <int DEPTH, bool FUSE = false, bool STRICT = false>
+template <int DEPTH, bool FUSE = false>
 __global__ __launch_bounds__(256, 2) void potrf_node_kernel(NodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) double node_lds[];
   __shared__ int dflags[3];                                        // two-wave diagonal-block factorisation of the leaf (zero before its first barrier)
@@ -1916,11 +1946,7 @@ __global__ __launch_bounds__(256, 2) void potrf_node_kernel(NodeArgs a) {
   bool bulk = false, col0 = false;
   constexpr bool fuse = FUSE;
   {
-    const int item = STRICT ? take_ticket(a.ticket, a.ticket_base) : (int)blockIdx.x;
-    if (STRICT && (unsigned)item >= gridDim.x) {          // host and device counters disagree (never expected): report, do nothing
-      if (threadIdx.x == 0) atomicCAS(a.info.p[0], 0, LMM_INFO_SYNC_TIMEOUT);
-      return;
-    }
+    const int item = blockIdx.x;
     if (a.mode & NODE_UPDATE) {
       const int n0 = a.nb * a.MT;
       if (item < n0) { ti = item / a.nb; bidx = item - ti * a.nb; col0 = true; }
@@ -2666,18 +2692,20 @@ __device__ __forceinline__ void potrf_region_row_thin(const RegionArgs& a, doubl
 // published everything the helpers of rows < r need to finish (they never wait beyond wk = r - 1), so they complete and free their
 // slots however few workgroups are resident, helper r gets dispatched and runs.  One workgroup per CU (414 registers per lane).
 // OCC 1: one workgroup per CU (no register spills in the walker); 2: two (the row streams' natural occupancy)
-// STRICT: the task is the workgroup's arrival ticket, so "dispatched before it" in the argument above holds in any dispatch order
+// STRICT: the task's index is CLAIMED at entry (region_claim), so "dispatched before it" in the argument above reads "started before
+// it" and holds in any dispatch order
 template <int OCC, bool STRICT = false>
 __global__ __launch_bounds__(256, OCC) void potrf_region_kernel(RegionArgs a) {
   extern __shared__ __attribute__((aligned(16))) double node_lds[];
   __shared__ int dflags[3];                  // the walker's two-wave diagonal-block factorisation (zero before the walker's first barrier)
   if (threadIdx.x == 0) { dflags[0] = 0; dflags[1] = 0; dflags[2] = 0; }
-  const int task = STRICT ? take_ticket(a.ticket, a.ticket_base) : (int)blockIdx.x;
-  if (STRICT && (unsigned)task >= gridDim.x) {            // host and device counters disagree (never expected): report, do nothing
+  const int b = blockIdx.x % a.nb;
+  int idx = blockIdx.x / a.nb;
+  if (STRICT && !region_claim(a.claim, a.claim_next, a.nb, a.ntasks, b, idx)) {      // counters out of step (never expected): report, do nothing
     if (threadIdx.x == 0) atomicCAS(a.info.p[0], 0, LMM_INFO_SYNC_TIMEOUT);
     return;
   }
-  const int b = task % a.nb, idx = task / a.nb;
+  const int task = idx * a.nb + b;
   double* Am = a.A.p[b];
   const int Q = 2 * a.P;
   if (a.trace && threadIdx.x == 0) a.trace[2 * task] = wall_clock64();
@@ -3640,37 +3668,34 @@ static void node_lds_attr() {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_node_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_region_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_region_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_node_kernel<1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_node_kernel<2, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_region_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_region_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   done = true;
 }
-// Strict-progress mode: one arrival counter per stream (launches of a stream are serialised, so the counter's value when a launch
-// starts is what the host has handed out so far: `base`; unsigned arithmetic makes the wrap-around harmless).
-int g_strict_progress = 0;
-static std::mutex g_ticket_mu;
-static std::map<hipStream_t, std::pair<unsigned*, unsigned>> g_ticket_ctrs;
-// after an error drained the device (lmm_api.hip's drain_after_error: a launch that never ran took no tickets) and at lmm_shutdown
-// (the streams the counters are keyed by go away): drop the counters; the next strict launch of a stream makes a fresh one
+// Strict-progress mode (default): two sets of claim counters per stream, used by alternate region launches of that stream (region_claim).
+int g_strict_progress = 1;
+static std::mutex g_claim_mu;
+struct ClaimSets { unsigned* dev; int parity; };
+static std::map<hipStream_t, ClaimSets> g_claims;
+// after an error drained the device (lmm_api.hip's drain_after_error: a launch that never ran zeroed nothing) and at lmm_shutdown (the
+// streams the counters are keyed by go away): drop the counters; the next strict launch of a stream makes fresh ones
 void strict_ticket_reset() {
-  std::lock_guard<std::mutex> lock(g_ticket_mu);
-  for (auto& kv : g_ticket_ctrs) (void)hipFree(kv.second.first);       // (the caller has synchronised the device)
-  g_ticket_ctrs.clear();
+  std::lock_guard<std::mutex> lock(g_claim_mu);
+  for (auto& kv : g_claims) (void)hipFree(kv.second.dev);              // (the caller has synchronised the device)
+  g_claims.clear();
 }
-static bool strict_ticket(hipStream_t st, unsigned count, unsigned** ctr, unsigned* base) {
-  std::mutex& mu = g_ticket_mu;
-  auto& ctrs = g_ticket_ctrs;
-  std::lock_guard<std::mutex> lock(mu);
-  auto it = ctrs.find(st);
-  if (it == ctrs.end()) {
+static bool strict_claim_sets(hipStream_t st, unsigned** cur, unsigned** next) {
+  std::lock_guard<std::mutex> lock(g_claim_mu);
+  auto it = g_claims.find(st);
+  if (it == g_claims.end()) {
     unsigned* d = nullptr;
-    if (hipMalloc((void**)&d, sizeof(unsigned)) != hipSuccess) return false;
-    (void)hipMemsetAsync(d, 0, sizeof(unsigned), st);        // on the stream whose launches use it: ordered before the first of them
-    it = ctrs.emplace(st, std::make_pair(d, 0u)).first;
+    if (hipMalloc((void**)&d, 2 * LMM_CLAIM_INTS * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); return false; }
+    (void)hipMemsetAsync(d, 0, 2 * LMM_CLAIM_INTS * sizeof(unsigned), st);      // on the stream whose launches use it: ordered before the first
+    it = g_claims.emplace(st, ClaimSets{d, 0}).first;
   }
-  *ctr = it->second.first; *base = it->second.second;
-  it->second.second += count;
+  *cur = it->second.dev + LMM_CLAIM_INTS * it->second.parity;
+  *next = it->second.dev + LMM_CLAIM_INTS * (it->second.parity ^ 1);
+  it->second.parity ^= 1;
   return true;
 }
 void launch_leaf128(const BatchPtr& A, size_t offD, int ld, const BatchPtr& W, size_t offW, const BatchPtr& W2, size_t offW2,
@@ -3782,10 +3807,7 @@ bool launch_update_leaf(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2
     items += (long long)nb * (MTb - 1);
   }
   const dim3 grid((unsigned)items);
-  if (fuse && g_strict_progress && strict_ticket(st, grid.x, &a.ticket, &a.ticket_base)) {
-    if (h >= 1024) hipLaunchKernelGGL((potrf_node_kernel<2, true, true>), grid, dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
-    else hipLaunchKernelGGL((potrf_node_kernel<1, true, true>), grid, dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
-  } else if (fuse) {
+  if (fuse) {
     if (h >= 1024) hipLaunchKernelGGL((potrf_node_kernel<2, true>), grid, dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
     else hipLaunchKernelGGL((potrf_node_kernel<1, true>), grid, dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
   } else {
@@ -3908,7 +3930,7 @@ void launch_region(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2, con
   long long* tr = nullptr;
   if (trace_env) { if (hipMalloc((void**)&tr, ((size_t)tasks * nb * 2 + 64 * (size_t)nb) * sizeof(long long)) != hipSuccess) tr = nullptr; }
   a.trace = tr; a.ntasks = (int)tasks;
-  if (g_strict_progress && strict_ticket(st, (unsigned)(tasks * nb), &a.ticket, &a.ticket_base)) {
+  if (g_strict_progress && strict_claim_sets(st, &a.claim, &a.claim_next)) {
     if (occ == 1) hipLaunchKernelGGL((potrf_region_kernel<1, true>), dim3((unsigned)(tasks * nb)), dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
     else hipLaunchKernelGGL((potrf_region_kernel<2, true>), dim3((unsigned)(tasks * nb)), dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
   } else if (occ == 1) hipLaunchKernelGGL(potrf_region_kernel<1>, dim3((unsigned)(tasks * nb)), dim3(256), LEAF_LDS_DOUBLES * 8, st, a);

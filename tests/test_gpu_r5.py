@@ -427,10 +427,10 @@ def test_per_batch_noise_gradient_fp32_mode(lmm):
 
 
 # ---------------------------------------------------------------------------------------------------
-# strict forward progress (lmm_set_strict_progress): tasks of the dataflow kernels by arrival ticket instead of blockIdx.x.  The tasks
-# are the same, only which workgroup runs which changes: values are bit-identical to the default mode on the one-launch region path
-# (n <= 1024) and agree to the default mode's own run-to-run noise (split-K atomics) on the region base case under the recursion
-# and the fused update launches (NODE_FUSE) of the panel path.
+# strict forward progress (lmm_set_strict_progress, default ON): potrf_region_kernel's workgroups claim their task at entry instead of
+# reading it from blockIdx.x (and the fused update launches are not used).  The tasks are the same, only which workgroup runs which
+# changes: logpdf is bit-identical to the index-order mode on the one-launch region path (n <= 1024) and agrees to that mode's own
+# run-to-run noise (split-K atomics) under the recursion.  Batch sizes: 3, 5, 20 take the global ticket; 2, 8, 16 the per-XCD claim.
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("m,n", [(3, 200), (20, 552), (8, 1024), (8, 2048), (5, 3000), (16, 4096), (2, 6500)])
 def test_strict_progress_mode_gives_the_same_values(lmm, m, n):
@@ -446,18 +446,18 @@ def test_strict_progress_mode_gives_the_same_values(lmm, m, n):
         mu, var = lmm.mean_and_var(lmm.posterior(f(xin, 0.1), P["y"])(xs, 0.1))
         return v, np.asarray(mu), np.asarray(var)
 
-    assert not lmm.get_strict_progress()
-    v0, mu0, var0 = run()
-    lmm.set_strict_progress(True)
+    assert lmm.get_strict_progress()                   # the default
+    v1, mu1, var1 = run()
+    lmm.set_strict_progress(False)
     try:
-        assert lmm.get_strict_progress()
-        v1, mu1, var1 = run()
+        assert not lmm.get_strict_progress()
+        v0, mu0, var0 = run()
     finally:
-        lmm.set_strict_progress(False)
+        lmm.set_strict_progress(True)
     if n <= 1024:                        # one region launch per batch: no split-K atomics anywhere, bitwise reproducible in both modes
         assert v0[0] == v0[1] == v0[2] and v1 == v0
-        np.testing.assert_allclose(mu1, mu0, rtol=1e-12, atol=1e-14)      # (the cross-solve behind the marginals combines partial products
-        np.testing.assert_allclose(var1, var0, rtol=1e-12, atol=1e-14)    #  with atomics in either mode)
+        np.testing.assert_allclose(mu1, mu0, rtol=1e-11, atol=1e-12)      # (the cross-solve behind the marginals combines partial products
+        np.testing.assert_allclose(var1, var0, rtol=1e-11, atol=1e-12)    #  with atomics in either mode)
         assert v0[0] == pytest.approx(O.oilmm_logpdf(P["gps"], P["U"], P["S"], P["x"], 0.1, P["y"]), rel=1e-9)
     else:                                # the update launches' split-K tails are combined with f64 atomics: run-to-run noise of the default mode
         assert v1 == pytest.approx(v0, rel=1e-12)
