@@ -413,6 +413,11 @@ int lmm_dev_region_plan(int P, int nb, int rows_below, int rows_real, int cus, i
 /* Test hook of the dataflow kernels' dependency flags: they carry a 26-bit launch epoch and are never reset; when the epoch wraps,
  * every persistent flag word is cleared.  *old_epoch (may be NULL) = the current epoch; set_to >= 0 replaces it (-1: read only). */
 int lmm_dev_flag_epoch(int set_to, int* old_epoch);
+/* Test hook of the strict-progress region kernel: on != 0 makes every workgroup ask for the task index a REVERSED dispatch order would
+ * give it (the stand-in for a device that does not start workgroups in index order): small launches then run with all roles on the
+ * "wrong" workgroups, launches larger than the device go through the 200-us time-out and take the next free index.  Values must not
+ * change (tests/test_gpu_r5.py). */
+int lmm_dev_claim_scramble(int on);
 /* C[MxN] -= A[MxK] * B[NxK]^T (column-major, device). lower != 0: only tiles on/below the diagonal. */
 int lmm_dev_gemm_nt_sub(double* C, int ldc, const double* A, int lda, const double* B, int ldb,
                         int M, int N, int K, int lower);

@@ -1127,6 +1127,12 @@ int lmm_set_strict_progress(int on) {
   return LMM_OK;
 }
 int lmm_get_strict_progress(void) { return g_strict_progress; }
+// test hook: the strict build's workgroups ask for their task indices in reverse order (include/lmm_hip.h)
+int lmm_dev_claim_scramble(int on) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_claim_scramble = on ? 1 : 0;
+  return LMM_OK;
+}
 
 int lmm_set_projection_dtype(int dtype) {
   std::lock_guard<std::mutex> lk(g_mu);

@@ -90,11 +90,13 @@ struct RegionArgs {
   int n128;               // the first n128 row tiles below the square are 128 rows high, the following ones 64
   long long* trace;       // optional (LMM_REGION_TRACE=1, tools/region_trace.py): start / end wall-clock ticks of every workgroup
   unsigned* claim; unsigned* claim_next;      // strict-progress build: this launch's claim counters, and the set it zeroes for the next one
+  int claim_scramble;     // test hook (lmm_dev_claim_scramble): workgroups ask for the indices in REVERSE order, as if dispatched last-first
 };
 // Strict forward progress (lmm_set_strict_progress, default on): potrf_region_kernel's workgroups claim their task at entry instead of
 // reading it from blockIdx.x, and the fused update launches (NODE_FUSE: bulk items that wait for earlier items of the same launch)
 // are not used -- no kernel then relies on the order in which workgroups are dispatched.
 extern int g_strict_progress;
+extern int g_claim_scramble;              // test hook: see RegionArgs.claim_scramble
 void strict_ticket_reset();               // drop the claim counters (after an error drained the device; at shutdown)
 #define LMM_REGION_MAX_PANELS 8
 #define LMM_REGION_ASST_MIN_C 4           // a helper's product for column block c >= this is split with its row's assistant

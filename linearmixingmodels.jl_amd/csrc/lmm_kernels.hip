@@ -1650,10 +1650,12 @@ __device__ __forceinline__ void wg_mm64(const double* __restrict__ As, int sai, 
 // running) -- no memset between launches, nothing for the host to track but the parity.
 #define LMM_CLAIM_INTS LMM_MAX_BATCH
 #define LMM_CLAIM_TURN_TICKS 20000LL          // 200 us of the 100-MHz wall clock
-__device__ __forceinline__ bool region_claim(unsigned* claim, unsigned* claim_next, int nb, int ntasks, int b, int& idx) {
+__device__ __forceinline__ bool region_claim(unsigned* claim, unsigned* claim_next, int nb, int ntasks, int b, int& idx, int scramble) {
   __shared__ unsigned claim_sh;
   if (threadIdx.x == 0) {
-    const unsigned own = (unsigned)idx;
+    // (scramble: the test hook's stand-in for a device that starts the LAST workgroups first -- every index is then asked for by the
+    // wrong workgroup, and launches larger than the device go through the time-out path)
+    const unsigned own = scramble ? (unsigned)(ntasks - 1 - idx) : (unsigned)idx;
     unsigned* c = claim + b;
     unsigned got = 0xffffffffu;
     const long long t0 = wall_clock64();
@@ -2701,7 +2703,7 @@ __global__ __launch_bounds__(256, OCC) void potrf_region_kernel(RegionArgs a) {
   if (threadIdx.x == 0) { dflags[0] = 0; dflags[1] = 0; dflags[2] = 0; }
   const int b = blockIdx.x % a.nb;
   int idx = blockIdx.x / a.nb;
-  if (STRICT && !region_claim(a.claim, a.claim_next, a.nb, a.ntasks, b, idx)) {      // counters out of step (never expected): report, do nothing
+  if (STRICT && !region_claim(a.claim, a.claim_next, a.nb, a.ntasks, b, idx, a.claim_scramble)) {      // counters out of step (never expected): report, do nothing
     if (threadIdx.x == 0) atomicCAS(a.info.p[0], 0, LMM_INFO_SYNC_TIMEOUT);
     return;
   }
@@ -3674,6 +3676,7 @@ static void node_lds_attr() {
 }
 // Strict-progress mode (default): two sets of claim counters per stream, used by alternate region launches of that stream (region_claim).
 int g_strict_progress = 1;
+int g_claim_scramble = 0;
 static std::mutex g_claim_mu;
 struct ClaimSets { unsigned* dev; int parity; };
 static std::map<hipStream_t, ClaimSets> g_claims;
@@ -3930,6 +3933,7 @@ void launch_region(const BatchPtr& A, const BatchPtr& W, const BatchPtr& W2, con
   long long* tr = nullptr;
   if (trace_env) { if (hipMalloc((void**)&tr, ((size_t)tasks * nb * 2 + 64 * (size_t)nb) * sizeof(long long)) != hipSuccess) tr = nullptr; }
   a.trace = tr; a.ntasks = (int)tasks;
+  a.claim_scramble = g_claim_scramble;
   if (g_strict_progress && strict_claim_sets(st, &a.claim, &a.claim_next)) {
     if (occ == 1) hipLaunchKernelGGL((potrf_region_kernel<1, true>), dim3((unsigned)(tasks * nb)), dim3(256), LEAF_LDS_DOUBLES * 8, st, a);
     else hipLaunchKernelGGL((potrf_region_kernel<2, true>), dim3((unsigned)(tasks * nb)), dim3(256), LEAF_LDS_DOUBLES * 8, st, a);

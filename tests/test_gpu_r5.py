@@ -463,3 +463,27 @@ def test_strict_progress_mode_gives_the_same_values(lmm, m, n):
         assert v1 == pytest.approx(v0, rel=1e-12)
         np.testing.assert_allclose(mu1, mu0, rtol=1e-9, atol=1e-11)
         np.testing.assert_allclose(var1, var0, rtol=1e-9, atol=1e-11)
+
+
+@pytest.mark.parametrize("m,n", [(3, 200), (20, 552), (32, 1024), (8, 2048), (16, 4096), (4, 9000)])
+def test_region_kernel_completes_when_workgroups_start_in_the_wrong_order(lmm, m, n):
+    """lmm_dev_claim_scramble: every workgroup of the strict-progress region kernel asks for the task index that a REVERSED dispatch order
+    would give it.  Launches that fit the device run with every role on the 'wrong' workgroup; larger ones (32 x 1024: 32 x 30 workgroups,
+    16 x 4096, 4 x 9000) start with all slots held by workgroups whose turn cannot come, which time out after 200 us and take the next
+    free index.  The evaluation must complete (no LMM_ERR_HIP) with the same value."""
+    from lmm_amd.workloads import synthetic_problem
+    lib = lmm.load()
+    p = m + 1
+    P = synthetic_problem(m, p, n, "matern52", True, s2=0.1, seed=11)
+    fx = lmm.ILMM(_model(lmm, P["gps"]), lmm.Orthogonal(P["U"], P["S"]))(lmm.MOInputIsotopicByOutputs(P["x"], p), 0.1)
+    v0 = lmm.logpdf(fx, P["y"])
+    assert lib.lmm_dev_claim_scramble(1) == 0
+    try:
+        v1 = [lmm.logpdf(fx, P["y"]) for _ in range(3)]
+    finally:
+        assert lib.lmm_dev_claim_scramble(0) == 0
+    v2 = lmm.logpdf(fx, P["y"])
+    if n <= 1024:
+        assert v1 == [v0, v0, v0] and v2 == v0
+    else:
+        assert v1 == pytest.approx([v0] * 3, rel=1e-12) and v2 == pytest.approx(v0, rel=1e-12)
