@@ -644,6 +644,8 @@ end
 # ---- modes -------------------------------------------------------------------------------------------------------------
 # compute dtype of the per-latent matrices: :f64 (parity mode) | :f32 (BASELINE configs[4])
 set_compute_dtype(d::Symbol) = check(ccall((:lmm_set_compute_dtype, liblmm), Cint, (Cint,), d === :f32 ? 1 : 0))
+# the region kernel's task hand-out: true (default) = in turn to started workgroups (no reliance on dispatch order), false = task = blockIdx.x
+set_strict_progress(on::Bool) = check(ccall((:lmm_set_strict_progress, liblmm), Cint, (Cint,), on ? 1 : 0))
 # dtype of the H unprojection of predictive marginals (reference src/oilmm.jl:69-72): :native | :bf16 (BASELINE configs[3]:
 # v_mfma_f32_16x16x32_bf16, tolerance 2^-7 Σ_l |H||M_lat|) | :bf16x2 (hi + lo split, <= 2^-15 Σ_l |H||M_lat|, include/lmm_hip.h)
 set_projection_dtype(d::Symbol) =
