@@ -227,6 +227,17 @@ int lmm_ilmm_post_logpdf_grad_seq(const double* x, int d, int n, const int* batc
                                   double* grad_ys, double* grad_batch_sigma2, double* grad_sigma2_s, double* grad_H,
                                   lmm_gp_grad_t* grad_gps);
 
+/* The same for the LATENT view of a dense-H posterior: logpdf(get_latent_gp(posterior(...))(xs, sigma2_s), zs), zs = ns x m by outputs over
+ * the m latent processes (reference src/ilmm.jl:39 on the posterior ILMM of :196-197: the coupled PosteriorGP of the IndependentMOGP,
+ * whose logpdf Zygote differentiates like any other).  Joint density of the conditioning batches (observed through H) and the latent
+ * test block (observed through [I_m; 0], noise sigma2_s I) minus the marginal of the batches.  grad_zs: ns x m; grad_H: through the
+ * conditioning batches.  m <= p.  Posteriors conditioned ON latent observations are not served. */
+int lmm_ilmm_post_latent_logpdf_grad_seq(const double* x, int d, int n, const int* batch_n, const double* batch_sigma2, int nbatch,
+                                         const double* y, const double* xs, int ns, const double* zs, int p, const double* H, int m,
+                                         double sigma2_s, const lmm_gp_t* gps, const lmm_jitters_t* jit, double* out_logpdf,
+                                         double* grad_y, double* grad_zs, double* grad_batch_sigma2, double* grad_sigma2_s,
+                                         double* grad_H, lmm_gp_grad_t* grad_gps);
+
 /* logpdf(fx, Y::AbstractMatrix): one value per column of Y ((n p) x ncol, column-major) from ONE factorisation per latent
  * (the extra columns ride the factorisation as rider rows).  The reference does not overload this (it falls to AbstractGPs'
  * dense generic path); AbstractGPs.TestUtils calls it.  out: ncol values. */

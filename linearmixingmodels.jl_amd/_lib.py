@@ -21,7 +21,7 @@ SYMBOLS = [
     "lmm_init", "lmm_shutdown", "lmm_last_error_string", "lmm_last_error_detail", "lmm_device_synchronize", "lmm_release_cached_memory",
     "lmm_stream_wait_caller", "lmm_set_compute_dtype", "lmm_get_compute_dtype", "lmm_set_projection_dtype", "lmm_get_projection_dtype", "lmm_comm_get_unique_id", "lmm_comm_init_rank", "lmm_comm_info", "lmm_allreduce_sum_f64", "lmm_allreduce_max_f64",
     "lmm_comm_destroy",
-    "lmm_set_strict_progress", "lmm_get_strict_progress", "lmm_dev_claim_scramble", "lmm_orthogonal_validate", "lmm_oilmm_logpdf", "lmm_oilmm_logpdf_grad", "lmm_oilmm_post_logpdf_grad", "lmm_oilmm_post_logpdf_grad_seq", "lmm_ilmm_logpdf_grad", "lmm_ilmm_post_logpdf_grad", "lmm_ilmm_post_logpdf_grad_seq", "lmm_oilmm_logpdf_multi", "lmm_reorder", "lmm_ilmm_logpdf", "lmm_ilmm_logpdf_ex", "lmm_ilmm_logpdf_multi", "lmm_mogp_logpdf", "lmm_mogp_logpdf_diag",
+    "lmm_set_strict_progress", "lmm_get_strict_progress", "lmm_dev_claim_scramble", "lmm_orthogonal_validate", "lmm_oilmm_logpdf", "lmm_oilmm_logpdf_grad", "lmm_oilmm_post_logpdf_grad", "lmm_oilmm_post_logpdf_grad_seq", "lmm_ilmm_logpdf_grad", "lmm_ilmm_post_logpdf_grad", "lmm_ilmm_post_logpdf_grad_seq", "lmm_ilmm_post_latent_logpdf_grad_seq", "lmm_oilmm_logpdf_multi", "lmm_reorder", "lmm_ilmm_logpdf", "lmm_ilmm_logpdf_ex", "lmm_ilmm_logpdf_multi", "lmm_mogp_logpdf", "lmm_mogp_logpdf_diag",
     "lmm_oilmm_posterior_create", "lmm_mogp_posterior_create", "lmm_post_condition", "lmm_ilmm_posterior_create", "lmm_post_destroy", "lmm_ilmm_post_latent_view", "lmm_ilmm_post_mean_and_var", "lmm_ilmm_post_mean_and_cov", "lmm_ilmm_post_condition", "lmm_ilmm_post_logpdf", "lmm_ilmm_post_rand",
     "lmm_latent_marginals", "lmm_oilmm_mean_and_var", "lmm_lmm_mean_and_cov", "lmm_mogp_cross_cov", "lmm_oilmm_post_logpdf", "lmm_lmm_rand", "lmm_lmm_rand_multi", "lmm_normals",
     "lmm_profile_begin", "lmm_profile_end",

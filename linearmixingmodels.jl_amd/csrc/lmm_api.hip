@@ -1872,8 +1872,10 @@ struct IlmmGrad {            // host results of ilmm_grad_core
 // noise NB.s2[b].  x (d x n), y (n x p by outputs) are DEVICE pointers; gy_dev (n x p, device) may be null.  The multi-block form
 // exists for the posterior's predictive density: log p(y* | y) = log p(y, y*) - log p(y)   (T y is sufficient for the latents,
 // so the reference's projected posterior, src/ilmm.jl:184-198, is the exact conditional), one block per conditioning batch.
+// Hblk (optional): block b is observed through the mixing matrix Hblk[b] (p x m, host) instead of H -- the latent view of a posterior
+// (lmm_ilmm_post_latent_logpdf_grad_seq) observes its test block through [I_m; 0]; G.gH collects the blocks observed through H itself.
 int ilmm_grad_core(const double* xd, int d, int n, const NoiseBlocks& NB, const double* yd, int p, const double* H, int m,
-                   const lmm_gp_t* gps, const lmm_jitters_t* jit, IlmmGrad& G, double* gy_dev) {
+                   const lmm_gp_t* gps, const lmm_jitters_t* jit, IlmmGrad& G, double* gy_dev, const double* const* Hblk = nullptr) {
   if ((long long)m * n > 46000) return fail(LMM_ERR_UNSUPPORTED, "m*n too large for the dense gradient (explicit (mn)^2 inverse)");
   hipStream_t st0 = g.streams[0];
   constexpr int KB = LMM_MAX_NOISE_BLOCKS;
@@ -1881,23 +1883,24 @@ int ilmm_grad_core(const double* xd, int d, int n, const NoiseBlocks& NB, const 
   int bi0[KB] = {}, bn[KB] = {};
   double s2[KB] = {};
   for (int b = 0; b < nblk; ++b) { bi0[b] = NB.off[b]; bn[b] = NB.count(b); s2[b] = NB.s2[b]; }
+  const double* Hq[KB] = {};                       // the mixing matrix block b is observed through
+  for (int b = 0; b < nblk; ++b) Hq[b] = (Hblk && Hblk[b]) ? Hblk[b] : H;
   std::vector<double> T[KB], ST[KB];
   double logdetST[KB] = {};
   for (int b = 0; b < nblk; ++b)
-    if (int rc = project_dense(H, p, m, s2[b], jit->project_jitter, T[b], ST[b], &logdetST[b])) return rc;
-  // host copies in the layouts the kernels read: Tt = T' (p x m), Ht = H' (m x p); the blocks' T and T' back to back
-  std::vector<double> Hv(H, H + (size_t)p * m), Ht((size_t)m * p), means(m), STall, Tall, Ttall;
+    if (int rc = project_dense(Hq[b], p, m, s2[b], jit->project_jitter, T[b], ST[b], &logdetST[b])) return rc;
+  // host copies in the layouts the kernels read: Tt = T' (p x m), Ht = H' (m x p); the blocks' T, T', H and H' back to back
+  std::vector<double> Hv, Ht, means(m), STall, Tall, Ttall;
   for (int b = 0; b < nblk; ++b) {
-    std::vector<double> Ttb((size_t)p * m);
-    for (int l = 0; l < m; ++l) for (int o = 0; o < p; ++o) Ttb[o + (size_t)l * p] = T[b][l + (size_t)o * m];
+    std::vector<double> Ttb((size_t)p * m), Htb((size_t)m * p);
+    for (int l = 0; l < m; ++l) for (int o = 0; o < p; ++o) { Ttb[o + (size_t)l * p] = T[b][l + (size_t)o * m]; Htb[l + (size_t)o * m] = Hq[b][o + (size_t)l * p]; }
     STall.insert(STall.end(), ST[b].begin(), ST[b].end());
     Tall.insert(Tall.end(), T[b].begin(), T[b].end());
     Ttall.insert(Ttall.end(), Ttb.begin(), Ttb.end());
+    Hv.insert(Hv.end(), Hq[b], Hq[b] + (size_t)p * m);
+    Ht.insert(Ht.end(), Htb.begin(), Htb.end());
   }
-  for (int l = 0; l < m; ++l) {
-    means[l] = gps[l].mean;
-    for (int o = 0; o < p; ++o) Ht[l + (size_t)o * m] = H[o + (size_t)l * p];
-  }
+  for (int l = 0; l < m; ++l) means[l] = gps[l].mean;
   std::vector<LatentDev> lat(m);
   for (int l = 0; l < m; ++l) lat[l] = to_dev(gps[l]);
   std::vector<int> sidx(n);
@@ -1906,7 +1909,12 @@ int ilmm_grad_core(const double* xd, int d, int n, const NoiseBlocks& NB, const 
   Uploaded Tdall(Tall, st0), STd(STall, st0), Hd(Hv, st0), Ttdall(Ttall, st0), Htd(Ht, st0), meansd(means, st0);
   const double* Tdv[KB] = {};
   const double* Ttdv[KB] = {};
-  for (int b = 0; b < nblk; ++b) { Tdv[b] = Tdall.buf.p + (size_t)b * m * p; Ttdv[b] = Ttdall.buf.p + (size_t)b * m * p; }
+  const double* Hdv[KB] = {};
+  const double* Htdv[KB] = {};
+  for (int b = 0; b < nblk; ++b) {
+    Tdv[b] = Tdall.buf.p + (size_t)b * m * p; Ttdv[b] = Ttdall.buf.p + (size_t)b * m * p;
+    Hdv[b] = Hd.buf.p + (size_t)b * m * p; Htdv[b] = Htd.buf.p + (size_t)b * m * p;
+  }
   Buf<LatentDev> latd(m);
   Buf<int> sidxd(n);
   HIPCHK(hipMemcpyAsync(latd.p, lat.data(), m * sizeof(LatentDev), hipMemcpyHostToDevice, st0));
@@ -1918,7 +1926,7 @@ int ilmm_grad_core(const double* xd, int d, int n, const NoiseBlocks& NB, const 
     launch_tall_skinny(yd + i0, n, nb_, p, Tdv[b], m, m, Ty.p + i0, n, nullptr, nullptr, 0, nullptr, 0, st0);
     launch_tall_skinny(yd + i0, n, nb_, p, Tdv[b], m, m, delta.p + i0, n, meansd.buf.p, nullptr, 0, nullptr, 0, st0);
     // reference src/ilmm.jl:171-181: |Y - H T Y|_F^2 of the block
-    launch_tall_skinny(Ty.p + i0, n, nb_, m, Hd.buf.p, p, p, nullptr, 0, nullptr, yd + i0, n, partial.p, 1, st0);
+    launch_tall_skinny(Ty.p + i0, n, nb_, m, Hdv[b], p, p, nullptr, 0, nullptr, yd + i0, n, partial.p, 1, st0);
     launch_sum_partials(partial.p, tall_skinny_partials(nb_, p), resid_dev.p + b, st0);
   }
   Dims D(N, 1);
@@ -1945,9 +1953,11 @@ int ilmm_grad_core(const double* xd, int d, int n, const NoiseBlocks& NB, const 
                        lat[l], gpart.p, red.p + (size_t)NGR * l, st0);
   // regulariser pieces: Rm = Y - (T Y)' H' (n x p), RH = Rm H (n x m), per block Rm' Ty (p x m), RH' Y (m x p)
   Buf<double> HTY((size_t)n * p), Rm((size_t)n * p), RH((size_t)N), RtTy(KB * mp), RHtY(KB * mp);
-  launch_tall_skinny(Ty.p, n, n, m, Hd.buf.p, p, p, HTY.p, n, nullptr, nullptr, 0, nullptr, 0, st0);
+  for (int b = 0; b < nblk; ++b)
+    launch_tall_skinny(Ty.p + bi0[b], n, bn[b], m, Hdv[b], p, p, HTY.p + bi0[b], n, nullptr, nullptr, 0, nullptr, 0, st0);
   launch_vec_lin(yd, HTY.p, -1.0, n * p, Rm.p, st0);
-  launch_tall_skinny(Rm.p, n, n, p, Htd.buf.p, m, m, RH.p, n, nullptr, nullptr, 0, nullptr, 0, st0);
+  for (int b = 0; b < nblk; ++b)
+    launch_tall_skinny(Rm.p + bi0[b], n, bn[b], p, Htdv[b], m, m, RH.p + bi0[b], n, nullptr, nullptr, 0, nullptr, 0, st0);
   for (int b = 0; b < nblk; ++b) {
     const int i0 = bi0[b], nb_ = bn[b];
     launch_block_trace(A.p, D.ld, n, m, i0, i0 + nb_, Btr.p + b * mm, st0);
@@ -1982,14 +1992,16 @@ int ilmm_grad_core(const double* xd, int d, int n, const NoiseBlocks& NB, const 
     G.ggps[l].variance = (r[7] + 0.5 * gps[l].variance * (r[2] - r[1])) / gps[l].variance;     // K_ii = variance
     G.ggps[l].mean = r[4];
   }
-  std::vector<double> Hb((size_t)p * m, 0.0), HtH(mm, 0.0);
-  for (int aI = 0; aI < m; ++aI)
-    for (int bb = 0; bb < m; ++bb) {
-      double acc = 0.0;
-      for (int o = 0; o < p; ++o) acc += H[o + (size_t)aI * p] * H[o + (size_t)bb * p];
-      HtH[aI + (size_t)bb * m] = acc;
-    }
+  std::vector<double> Hacc((size_t)p * m, 0.0), HtH(mm, 0.0);
   for (int b = 0; b < nblk; ++b) {
+    const double* H = Hq[b];                        // (shadows the argument: everything below differentiates through THIS block's mixing matrix)
+    std::vector<double> Hb((size_t)p * m, 0.0);     // its cotangent; kept only for the blocks observed through the model's H
+    for (int aI = 0; aI < m; ++aI)
+      for (int bb = 0; bb < m; ++bb) {
+        double acc = 0.0;
+        for (int o = 0; o < p; ++o) acc += H[o + (size_t)aI * p] * H[o + (size_t)bb * p];
+        HtH[aI + (size_t)bb * m] = acc;
+      }
     const double sigma2 = s2[b], s = 1.0 / sigma2;
     const std::vector<double>& Tq = T[b];
     const double* bAY = &hAY[b * mp]; const double* bRHtY = &hRHtY[b * mp]; const double* bRtTy = &hRtTy[b * mp];
@@ -2058,8 +2070,9 @@ int ilmm_grad_core(const double* xd, int d, int n, const NoiseBlocks& NB, const 
     for (int aI = 0; aI < m; ++aI) for (int bb = 0; bb < m; ++bb) sb += Pb[aI + (size_t)bb * m] * HtH[aI + (size_t)bb * m];
     s2g += -sb * s * s;
     G.gs2[b] = s2g;
+    if (!(Hblk && Hblk[b])) for (size_t q = 0; q < Hacc.size(); ++q) Hacc[q] += Hb[q];
   }
-  G.gH = Hb;
+  G.gH = Hacc;
   if (gy_dev) {
     // dL/dY (n x p) = -((alpha - RH / sigma2_i) T_i) - Rm / sigma2_i     (alpha as the n x m matrix [point][latent])
     Buf<double> Z((size_t)N), ZT((size_t)n * p);
@@ -2111,36 +2124,50 @@ int lmm_ilmm_logpdf_grad(const double* x, int d, int n, const double* y, int p, 
 // Zygote.gradient(logpdf, pi, y_test) differentiates in reference test/ilmm.jl:32 -- as the joint prior density of (y, ys) under
 // per-block noise minus the prior density of y.  Does not shard.  _seq: sequentially conditioned posterior (src/ilmm.jl:184-198
 // applied to its own result), one noise block per conditioning batch; x, y as in lmm_oilmm_post_logpdf_grad_seq.
-int lmm_ilmm_post_logpdf_grad_seq(const double* x, int d, int n, const int* batch_n, const double* batch_sigma2, int nbatch,
-                                  const double* y, const double* xs, int ns, const double* ys, int p, const double* H, int m,
-                                  double sigma2_s, const lmm_gp_t* gps, const lmm_jitters_t* jit, double* out_logpdf, double* grad_y,
-                                  double* grad_ys, double* grad_batch_sigma2, double* grad_sigma2_s, double* grad_H,
-                                  lmm_gp_grad_t* grad_gps) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  REQUIRE_INIT();
-  LMM_TRY
+}  // extern "C"
+
+namespace {
+// latent_test: the test block observes the LATENT processes (ys is ns x m): get_latent_gp(posterior)(xs, sigma2_s)
+int ilmm_post_logpdf_grad_impl(bool latent_test, const double* x, int d, int n, const int* batch_n, const double* batch_sigma2, int nbatch,
+                               const double* y, const double* xs, int ns, const double* ys, int p, const double* H, int m,
+                               double sigma2_s, const lmm_gp_t* gps, const lmm_jitters_t* jit, double* out_logpdf, double* grad_y,
+                               double* grad_ys, double* grad_batch_sigma2, double* grad_sigma2_s, double* grad_H,
+                               lmm_gp_grad_t* grad_gps) {
   if (!x || !y || !xs || !ys || !H || !out_logpdf || d <= 0 || n <= 0 || ns <= 0 || p <= 0 || m <= 0) return fail(LMM_ERR_ARG, "bad arguments");
+  if (latent_test && m > p) return fail(LMM_ERR_DIM, "out dim of x != out dim of f.");
   if (int rc = check_gps(gps, m)) return rc;
   if (int rc = check_batches(batch_n, batch_sigma2, nbatch, n)) return rc;
   if (!(sigma2_s > 0.0)) return fail(LMM_ERR_ARG, "sigma2 must be > 0");
   if (!jit) jit = &kDefaultJit;
   hipStream_t st0 = g.streams[0];
-  const int N = n + ns;
-  DevIn xd(x, (size_t)d * n, st0), yd(y, (size_t)n * p, st0), xsd(xs, (size_t)d * ns, st0), ysd(ys, (size_t)ns * p, st0);
+  const int N = n + ns, pt = latent_test ? m : p;          // columns of ys
+  DevIn xd(x, (size_t)d * n, st0), yd(y, (size_t)n * p, st0), xsd(xs, (size_t)d * ns, st0), ysd(ys, (size_t)ns * pt, st0);
   Buf<double> xj((size_t)d * N), yj((size_t)N * p), gj((size_t)N * p), gm((size_t)n * p);
   HIPCHK(hipMemcpyAsync(xj.p, xd.p, (size_t)d * n * sizeof(double), hipMemcpyDeviceToDevice, st0));
   HIPCHK(hipMemcpyAsync(xj.p + (size_t)d * n, xsd.p, (size_t)d * ns * sizeof(double), hipMemcpyDeviceToDevice, st0));
+  if (pt < p) HIPCHK(hipMemsetAsync(yj.p, 0, (size_t)N * p * sizeof(double), st0));        // the test block's columns m .. p-1 stay 0
   HIPCHK(hipMemcpy2DAsync(yj.p, (size_t)N * sizeof(double), yd.p, (size_t)n * sizeof(double), (size_t)n * sizeof(double), p, hipMemcpyDeviceToDevice, st0));
-  HIPCHK(hipMemcpy2DAsync(yj.p + n, (size_t)N * sizeof(double), ysd.p, (size_t)ns * sizeof(double), (size_t)ns * sizeof(double), p, hipMemcpyDeviceToDevice, st0));
+  HIPCHK(hipMemcpy2DAsync(yj.p + n, (size_t)N * sizeof(double), ysd.p, (size_t)ns * sizeof(double), (size_t)ns * sizeof(double), pt, hipMemcpyDeviceToDevice, st0));
+  // The latent view observes its test points through H* = [I_m; 0] (p x m): z embedded in the first m of p output columns.  project(H*,
+  // s) gives T = [I 0], SigmaT = s I (src/ilmm.jl:61-68) -- the latent FiniteGP's own noise -- and a residual of 0; what the p - m
+  // padded columns add to the regulariser, -ns (p - m) log(2 pi s) / 2, is taken out again below.
+  std::vector<double> Hlat;
+  const double* Hblk[LMM_MAX_NOISE_BLOCKS] = {};
+  if (latent_test) {
+    Hlat.assign((size_t)p * m, 0.0);
+    for (int l = 0; l < m; ++l) Hlat[l + (size_t)l * p] = 1.0;
+    Hblk[nbatch] = Hlat.data();
+  }
   const bool want_gy = grad_y != nullptr || grad_ys != nullptr;
   IlmmGrad GJ, GM;
   if (int rc = ilmm_grad_core(xj.p, d, N, batch_noise_blocks(batch_n, batch_sigma2, nbatch, ns, sigma2_s), yj.p, p, H, m, gps, jit, GJ,
-                              want_gy ? gj.p : nullptr)) return rc;
+                              want_gy ? gj.p : nullptr, latent_test ? Hblk : nullptr)) return rc;
   if (int rc = ilmm_grad_core(xd.p, d, n, batch_noise_blocks(batch_n, batch_sigma2, nbatch, 0, 0.0), yd.p, p, H, m, gps, jit, GM,
                               grad_y ? gm.p : nullptr)) return rc;
-  *out_logpdf = GJ.value - GM.value;
+  const double pad = latent_test ? 0.5 * (double)ns * (double)(p - m) : 0.0;
+  *out_logpdf = GJ.value - GM.value + pad * (kLog2Pi + std::log(sigma2_s));
   if (grad_batch_sigma2) for (int b = 0; b < nbatch; ++b) grad_batch_sigma2[b] = GJ.gs2[b] - GM.gs2[b];
-  if (grad_sigma2_s) *grad_sigma2_s = GJ.gs2[nbatch];
+  if (grad_sigma2_s) *grad_sigma2_s = GJ.gs2[nbatch] + pad / sigma2_s;
   if (grad_H) for (size_t q = 0; q < (size_t)p * m; ++q) grad_H[q] = GJ.gH[q] - GM.gH[q];
   if (grad_gps)
     for (int l = 0; l < m; ++l) {
@@ -2157,12 +2184,43 @@ int lmm_ilmm_post_logpdf_grad_seq(const double* x, int d, int n, const int* batc
     HIPCHK(hipStreamSynchronize(st0));
   }
   if (grad_ys) {
-    DevOut gys(grad_ys, (size_t)ns * p);
-    HIPCHK(hipMemcpy2DAsync(gys.p, (size_t)ns * sizeof(double), gj.p + n, (size_t)N * sizeof(double), (size_t)ns * sizeof(double), p, hipMemcpyDeviceToDevice, st0));
+    DevOut gys(grad_ys, (size_t)ns * pt);
+    HIPCHK(hipMemcpy2DAsync(gys.p, (size_t)ns * sizeof(double), gj.p + n, (size_t)N * sizeof(double), (size_t)ns * sizeof(double), pt, hipMemcpyDeviceToDevice, st0));
     gys.finish(st0);
     HIPCHK(hipStreamSynchronize(st0));
   }
   return LMM_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int lmm_ilmm_post_logpdf_grad_seq(const double* x, int d, int n, const int* batch_n, const double* batch_sigma2, int nbatch,
+                                  const double* y, const double* xs, int ns, const double* ys, int p, const double* H, int m,
+                                  double sigma2_s, const lmm_gp_t* gps, const lmm_jitters_t* jit, double* out_logpdf, double* grad_y,
+                                  double* grad_ys, double* grad_batch_sigma2, double* grad_sigma2_s, double* grad_H,
+                                  lmm_gp_grad_t* grad_gps) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  REQUIRE_INIT();
+  LMM_TRY
+  return ilmm_post_logpdf_grad_impl(false, x, d, n, batch_n, batch_sigma2, nbatch, y, xs, ns, ys, p, H, m, sigma2_s, gps, jit, out_logpdf,
+                                    grad_y, grad_ys, grad_batch_sigma2, grad_sigma2_s, grad_H, grad_gps);
+  LMM_CATCH
+}
+
+// The same for the LATENT view of the posterior: logpdf(get_latent_gp(posterior(...))(xs, sigma2_s), zs) with zs (ns x m, by outputs over
+// the m latents) -- reference src/ilmm.jl:39 on the posterior ILMM of :196-197, whose latent GP is the coupled PosteriorGP of the
+// IndependentMOGP; Zygote differentiates its logpdf like any other.  grad_ys: ns x m.  grad_H: through the conditioning batches only.
+int lmm_ilmm_post_latent_logpdf_grad_seq(const double* x, int d, int n, const int* batch_n, const double* batch_sigma2, int nbatch,
+                                         const double* y, const double* xs, int ns, const double* zs, int p, const double* H, int m,
+                                         double sigma2_s, const lmm_gp_t* gps, const lmm_jitters_t* jit, double* out_logpdf, double* grad_y,
+                                         double* grad_zs, double* grad_batch_sigma2, double* grad_sigma2_s, double* grad_H,
+                                         lmm_gp_grad_t* grad_gps) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  REQUIRE_INIT();
+  LMM_TRY
+  return ilmm_post_logpdf_grad_impl(true, x, d, n, batch_n, batch_sigma2, nbatch, y, xs, ns, zs, p, H, m, sigma2_s, gps, jit, out_logpdf,
+                                    grad_y, grad_zs, grad_batch_sigma2, grad_sigma2_s, grad_H, grad_gps);
   LMM_CATCH
 }
 

@@ -70,8 +70,9 @@ mutable struct HIPMOGP{Tfs<:Vector{<:AbstractGP}} <: AbstractGPs.AbstractGP
     # filled by the posterior logpdf rrule: the total-derivative cotangents of the predictive logpdf w.r.t. the training data and
     # training noise, (y_train = ..., sigma2_train = ...), which the pullback itself cannot route anywhere (see the rrule)
     last_train_cotangents::Base.RefValue{Any}
-    function HIPMOGP(fs::Tfs, h::Ptr{Cvoid}=C_NULL, train=nothing) where {Tfs<:Vector{<:AbstractGP}}
-        obj = new{Tfs}(fs, h, train, Ref{Any}(nothing))
+    mix::Any                 # latent view of a dense-H posterior only: the H (p x m) its conditioning batches were observed through
+    function HIPMOGP(fs::Tfs, h::Ptr{Cvoid}=C_NULL, train=nothing, mix=nothing) where {Tfs<:Vector{<:AbstractGP}}
+        obj = new{Tfs}(fs, h, train, Ref{Any}(nothing), mix)
         h == C_NULL || finalizer(o -> ccall((:lmm_post_destroy, liblmm), Cint, (Ptr{Cvoid},), o.handle), obj)
         return obj
     end
@@ -275,7 +276,8 @@ function AbstractGPs.posterior(fx::ByOutputsFill{HIPDenseILMM}, y::AbstractVecto
         GC.@preserve X yv check(ccall((:lmm_ilmm_post_condition, liblmm), Cint,
             (Ptr{Cvoid}, Cdouble, Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Ptr{LmmJitters}, Ref{Ptr{Cvoid}}),
             f.handle, σ², X, d, n, yv, C_NULL, h))
-        return ILMM(HIPMOGP(f.fs, h[], _push_train(f.train, X, σ², yv)), H)
+        # (a latent view conditioned ON latent observations keeps no training record: its batches were observed through different H's)
+        return ILMM(HIPMOGP(f.fs, h[], f.mix === nothing ? _push_train(f.train, X, σ², yv) : nothing), H)
     end
     gps = _gps(f.fs); Hm = Matrix{Float64}(H)
     GC.@preserve X yv Hm gps check(ccall((:lmm_ilmm_posterior_create, liblmm), Cint,
@@ -619,8 +621,22 @@ function ChainRulesCore.rrule(::typeof(AbstractGPs.logpdf), fx::ByOutputsFill{HI
     X = _xmat(x); d, n = size(X); p, m = size(H); gps = _gps(f.fs); Hm = Matrix{Float64}(H); yv = Vector{Float64}(y)
     val = Ref{Cdouble}(0.0); gσ = Ref{Cdouble}(0.0)
     gy = Vector{Float64}(undef, n * p); gH = Matrix{Float64}(undef, p, m); gg = Vector{LmmGpGrad}(undef, m)
-    if isposterior(f)
-        f.train === nothing && error("this posterior does not carry its training data (the latent view of a dense-H posterior)")
+    if isposterior(f) && f.mix !== nothing
+        # the latent view of a dense-H posterior (latent_view; reference src/ilmm.jl:39 on :196-197): here H = I_m, p = m, y = latent
+        # observations; the conditioning batches were observed through f.mix.  d/d(mix) and the training cotangents have no slot in
+        # this model's tangent (its H is the constant I): they are left in last_train_cotangents.
+        f.train === nothing && error("gradient of the latent view after conditioning ON latent observations is not built")
+        Hp = f.mix::Matrix{Float64}; pp = size(Hp, 1)
+        X0, bn, bs, y0 = _merged_train(f.train, pp); n0 = size(X0, 2); gy0 = Vector{Float64}(undef, n0 * pp); gb = similar(bs)
+        gHp = Matrix{Float64}(undef, pp, m)
+        GC.@preserve X0 bn bs y0 X yv Hp gps gy0 gy gb gHp gg check(ccall((:lmm_ilmm_post_latent_logpdf_grad_seq, liblmm), Cint,
+            (Ptr{Cdouble}, Cint, Cint, Ptr{Cint}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Cint,
+             Cdouble, Ptr{LmmGp}, Ptr{LmmJitters}, Ref{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Cdouble}, Ptr{Cdouble}, Ptr{LmmGpGrad}),
+            X0, d, n0, bn, bs, length(bn), y0, X, n, yv, pp, Hp, m, σ², gps, C_NULL, val, gy0, gy, gb, gσ, gHp, gg))
+        f.last_train_cotangents[] = merge(_split_train(gy0, gb, bn, pp), (H_train=gHp,))
+        fill!(gH, 0.0)
+    elseif isposterior(f)
+        f.train === nothing && error("this posterior does not carry its training data")
         X0, bn, bs, y0 = _merged_train(f.train, p); n0 = size(X0, 2); gy0 = Vector{Float64}(undef, n0 * p); gb = similar(bs)
         GC.@preserve X0 bn bs y0 X yv Hm gps gy0 gy gb gH gg check(ccall((:lmm_ilmm_post_logpdf_grad_seq, liblmm), Cint,
             (Ptr{Cdouble}, Cint, Cint, Ptr{Cint}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Cint,
@@ -658,7 +674,8 @@ function latent_view(f::ILMM{<:HIPMOGP,<:Matrix})
     isposterior(f.f) || return f.f
     h = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:lmm_ilmm_post_latent_view, liblmm), Cint, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}), f.f.handle, h))
-    return ILMM(HIPMOGP(f.f.fs, h[], nothing), Matrix{Float64}(I, length(f.f.fs), length(f.f.fs)))
+    # (train and mix ride along for the gradient of the view's logpdf: lmm_ilmm_post_latent_logpdf_grad_seq)
+    return ILMM(HIPMOGP(f.f.fs, h[], f.f.train, Matrix{Float64}(f.H)), Matrix{Float64}(I, length(f.f.fs), length(f.f.fs)))
 end
 
 # ---- multi-GPU: one Julia process per GPU; the collective lives in the library (RCCL over xGMI) ----------------------------

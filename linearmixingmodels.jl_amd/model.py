@@ -196,8 +196,9 @@ class _PostHandle:
     """Owns an lmm_post_t* (device-resident posterior state); freed with the Python object, as the Julia
     shim does with a finalizer."""
 
-    def __init__(self, ptr: C.c_void_p, l0: int, l1: int, dense: bool = False, train=None, latent: bool = False, parent=None):
+    def __init__(self, ptr: C.c_void_p, l0: int, l1: int, dense: bool = False, train=None, latent: bool = False, parent=None, mix=None):
         self.ptr, self.l0, self.l1, self.dense = ptr, l0, l1, dense      # dense: coupled (mn) x (mn) state of a dense-H ILMM
+        self.mix = mix                # dense only: the H (p x m) the conditioning batches were observed through (gradient of the latent view)
         # the conditioning batches [(x, sigma2, y), ...] the posterior was built from (references, no copies): the gradient of the
         # predictive logpdf is a total derivative through the posterior and needs them (one entry per posterior(...) call)
         self.train = train if (train is None or isinstance(train, list)) else [train]
@@ -471,7 +472,29 @@ def logpdf_and_gradient(fx: FiniteGP, y, with_regulariser: bool = True) -> dict:
     if not mogp and not isinstance(f, ILMM):
         raise TypeError("logpdf_and_gradient needs an ILMM / OILMM / IndependentMOGP FiniteGP")
     if mogp and post is not None and post.dense:
-        raise NotImplementedError("gradient of the logpdf of the coupled latent PosteriorGP of a dense-H posterior is not built")
+        # logpdf(get_latent_gp(posterior(ilmm(x, s2), y))(xs, s2s), zs): the coupled latent PosteriorGP of a dense-H posterior (reference
+        # src/ilmm.jl:39 on the ILMM of :196-197).  Joint density of the conditioning batches (observed through H) and the latent test
+        # block (observed through [I; 0]) minus the marginal of the batches: lmm_ilmm_post_latent_logpdf_grad_seq.
+        if post.latent or post.mix is None:
+            raise NotImplementedError("gradient of the latent view after conditioning ON latent observations is not built")
+        m = len(f.fs)
+        if x.out_dim != m:
+            raise RuntimeError("out dim of x != out dim of f.")
+        Ha, _, p, _m = _H_args(post.mix)
+        n = x.n
+        x0, s2b, y0, sizes = _merged_train(post.train, p)
+        bn, bs, gb = _batch_args(s2b, sizes)
+        val, gs2 = C.c_double(), C.c_double()
+        gy, gH = _alloc_like(y if L._is_torch(y) else x.x, n * m), np.empty(p * m)
+        gy0 = _alloc_like(y0 if L._is_torch(y0) else x0.x, x0.n * p)
+        gg = (L.GpGradT * m)()
+        L.check(lib.lmm_ilmm_post_latent_logpdf_grad_seq(x0.carr().ptr, x0.dim, x0.n, bn, bs, len(sizes), L.Arr(y0).ptr, x.carr().ptr, n,
+                                                         L.Arr(y).ptr, p, Ha.ptr, m, C.c_double(s2), L.gps_array([g.desc() for g in f.fs]),
+                                                         None, C.byref(val), L.Arr(gy0, True).ptr, L.Arr(gy, True).ptr, gb, C.byref(gs2),
+                                                         L.Arr(gH, True).ptr, gg))
+        return {"value": val.value, "y": gy, "y_train": _split_train_grad(gy0, sizes, p), "sigma2": gs2.value,
+                "sigma2_train": _train_noise_grad(gb, s2b), "H": gH.reshape(m, p).T.copy(),
+                "gps": [{"variance": gg[l].variance, "lengthscale": gg[l].lengthscale, "mean": gg[l].mean} for l in range(m)]}
     if not mogp and not f.is_oilmm:
         unpack(fx)
         Ha, _, p, m = _H_args(f.H)
@@ -608,7 +631,8 @@ def posterior(fx: FiniteGP, y):
     if f.f._post is not None:          # sequential conditioning of a posterior OILMM (same H: reference src/oilmm.jl:133)
         if not f.is_oilmm:         # dense-H posterior: both projected data sets condition the prior (reference src/ilmm.jl:184-198)
             L.check(lib.lmm_ilmm_post_condition(f.f._post.ptr, C.c_double(s2), xa.ptr, x.dim, x.n, ya.ptr, None, C.byref(handle)))
-            return ILMM(IndependentMOGP(f.f.fs, _PostHandle(handle, l0, l1, dense=True, train=_more_train(f.f._post, x, s2, y))), f.H, shard=f.shard)
+            return ILMM(IndependentMOGP(f.f.fs, _PostHandle(handle, l0, l1, dense=True, train=_more_train(f.f._post, x, s2, y), mix=f.H)), f.H,
+                        shard=f.shard)
         L.check(lib.lmm_post_condition(f.f._post.ptr, Ua.ptr, Sa.ptr, p, m, C.c_double(s2), xa.ptr, x.dim, x.n, ya.ptr,
                                        C.byref(handle)))
         return ILMM(IndependentMOGP(f.f.fs, _PostHandle(handle, l0, l1, train=_more_train(f.f._post, x, s2, y))), f.H, shard=f.shard)
@@ -619,7 +643,8 @@ def posterior(fx: FiniteGP, y):
     else:
         L.check(lib.lmm_ilmm_posterior_create(xa.ptr, x.dim, x.n, ya.ptr, p, Ua.ptr, m, C.c_double(s2), gps, None,
                                               C.byref(handle)))
-    return ILMM(IndependentMOGP(f.f.fs, _PostHandle(handle, l0, l1, dense=not f.is_oilmm, train=(x, s2, y))), f.H, shard=f.shard)
+    return ILMM(IndependentMOGP(f.f.fs, _PostHandle(handle, l0, l1, dense=not f.is_oilmm, train=(x, s2, y), mix=None if f.is_oilmm else f.H)),
+                f.H, shard=f.shard)
 
 
 def mean_and_var(fx: FiniteGP, add_noise: bool = True):

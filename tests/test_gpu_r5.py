@@ -487,3 +487,68 @@ def test_region_kernel_completes_when_workgroups_start_in_the_wrong_order(lmm, m
         assert v1 == [v0, v0, v0] and v2 == v0
     else:
         assert v1 == pytest.approx([v0] * 3, rel=1e-12) and v2 == pytest.approx(v0, rel=1e-12)
+
+
+# ---------------------------------------------------------------------------------------------------
+# gradient of logpdf(get_latent_gp(posterior(dense-H ILMM ...))(xs, s2s), zs): the coupled latent PosteriorGP of a dense-H posterior
+# (reference src/ilmm.jl:39 on the ILMM of :196-197) -- lmm_ilmm_post_latent_logpdf_grad_seq.  Oracle: the generic Gaussian on
+# O._ilmm_latent_joint of O.ilmm_posterior / ilmm_posterior_condition, central finite differences.
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("sizes,noises", [((70,), (0.1,)), ((40, 33), (0.3, 0.12))])
+def test_gradient_of_the_latent_view_of_a_dense_posterior(lmm, sizes, noises):
+    rng = np.random.default_rng(601 + len(sizes))
+    ns, p, m = 9, 5, 3
+    xb = [np.sort(rng.uniform(0, 6, nb)) for nb in sizes]
+    xs = np.sort(rng.uniform(0, 6, ns))
+    gps = _gps(m, rng)
+    H = rng.uniform(0.2, 1.0, size=(p, m))
+    yb = [rng.standard_normal(nb * p) for nb in sizes]
+    zs = rng.standard_normal(ns * m)
+    s2s = 0.07
+
+    def F(gps=gps, H=H, s2b=noises, s2s=s2s, ybs=yb, zs=zs):
+        post = O.ilmm_posterior(gps, H, xb[0], s2b[0], ybs[0])
+        for x_, s_, y_ in zip(xb[1:], s2b[1:], ybs[1:]):
+            post = O.ilmm_posterior_condition(post, H, x_, s_, y_)
+        mo, Co = O._ilmm_latent_joint(post, xs)
+        return O.gaussian_logpdf(mo, Co + s2s * np.eye(m * ns), zs)
+
+    po = lmm.ILMM(_model(lmm, gps), H)
+    for x_, s_, y_ in zip(xb, noises, yb):
+        po = lmm.posterior(po(lmm.MOInputIsotopicByOutputs(x_, p), s_), y_)
+    flx = lmm.get_latent_gp(po)(lmm.MOInputIsotopicByOutputs(xs, m), s2s)
+    G = lmm.logpdf_and_gradient(flx, zs)
+    assert G["value"] == pytest.approx(F(), rel=1e-7)
+    assert G["value"] == pytest.approx(lmm.logpdf(flx, zs), rel=1e-7)
+    assert G["sigma2"] == pytest.approx(_fd(lambda t: F(s2s=s2s + t)), rel=5e-5, abs=1e-5)
+    per_batch = []
+    for b in range(len(sizes)):
+        def Fs(t, b=b):
+            s = list(noises); s[b] += t
+            return F(s2b=s)
+        per_batch.append(_fd(Fs))
+    got = G["sigma2_train"] if isinstance(G["sigma2_train"], list) else [G["sigma2_train"]]
+    assert got == pytest.approx(per_batch, rel=5e-5, abs=1e-5)
+    for k in [0, ns + 4, ns * m - 1]:
+        e = np.zeros(ns * m); e[k] = 1.0
+        assert G["y"][k] == pytest.approx(_fd(lambda t: F(zs=zs + t * e)), rel=5e-5, abs=1e-5)
+    ytr = G["y_train"] if isinstance(G["y_train"], list) else [G["y_train"]]
+    for b, yv in enumerate(yb):
+        for k in [2, len(yv) - 3]:
+            e = np.zeros(len(yv)); e[k] = 1.0
+            def Fb(t, b=b, e=e):
+                yy = [np.array(v) for v in yb]; yy[b] = yy[b] + t * e
+                return F(ybs=yy)
+            assert np.asarray(ytr[b])[k] == pytest.approx(_fd(Fb), rel=5e-5, abs=1e-5), (b, k)
+    for l in range(m):
+        for key in ("variance", "lengthscale", "mean"):
+            def f1(t, l=l, key=key):
+                g2 = [dict(g) for g in gps]; g2[l][key] += t
+                return F(gps=g2)
+            assert G["gps"][l][key] == pytest.approx(_fd(f1), rel=5e-5, abs=1e-5), (l, key)
+    for (o, l) in [(1, 2), (4, 0)]:
+        E = np.zeros((p, m)); E[o, l] = 1.0
+        assert G["H"][o, l] == pytest.approx(_fd(lambda t: F(H=H + t * E)), rel=5e-5, abs=1e-5)
+    # conditioned ON latent observations: refused
+    with pytest.raises(NotImplementedError):
+        lmm.logpdf_and_gradient(lmm.posterior(flx, zs)(lmm.MOInputIsotopicByOutputs(xs, m), s2s), zs)
