@@ -122,7 +122,7 @@ def test_shim_covers_the_reference_method_families():
                 "lmm_mogp_posterior_create", "lmm_ilmm_posterior_create", "lmm_post_condition", "lmm_ilmm_post_condition",
                 "lmm_oilmm_mean_and_var", "lmm_ilmm_post_mean_and_var", "lmm_latent_marginals", "lmm_lmm_mean_and_cov",
                 "lmm_ilmm_post_mean_and_cov", "lmm_lmm_rand_multi", "lmm_ilmm_post_rand", "lmm_oilmm_logpdf_grad",
-                "lmm_oilmm_post_logpdf_grad_seq", "lmm_ilmm_logpdf_grad", "lmm_ilmm_post_logpdf_grad_seq", "lmm_reorder",
+                "lmm_oilmm_post_logpdf_grad_seq", "lmm_ilmm_logpdf_grad", "lmm_ilmm_post_logpdf_grad_seq", "lmm_ilmm_post_latent_logpdf_grad_seq", "lmm_reorder",
                 "lmm_ilmm_post_latent_view", "lmm_post_destroy", "lmm_mogp_cross_cov"]:
         assert sym in used, sym
     assert "Distributions._rand!" in src
