@@ -92,8 +92,8 @@ struct RegionArgs {
   unsigned* claim; unsigned* claim_next;      // strict-progress build: this launch's claim counters, and the set it zeroes for the next one
   int claim_scramble;     // test hook (lmm_dev_claim_scramble): workgroups ask for the indices in REVERSE order, as if dispatched last-first
 };
-// Strict forward progress (lmm_set_strict_progress, default on): potrf_region_kernel's workgroups claim their task at entry instead of
-// reading it from blockIdx.x, and the fused update launches (NODE_FUSE: bulk items that wait for earlier items of the same launch)
+// Strict forward progress (lmm_set_strict_progress, default on): potrf_region_kernel's workgroups take their task INDEX in turn from a
+// per-matrix counter (region_claim) instead of reading it from blockIdx.x, and the fused update launches (NODE_FUSE: bulk items that wait for earlier items of the same launch)
 // are not used -- no kernel then relies on the order in which workgroups are dispatched.
 extern int g_strict_progress;
 extern int g_claim_scramble;              // test hook: see RegionArgs.claim_scramble
